@@ -1,0 +1,37 @@
+"""Transcription check for tests/golden/node_rs_kats.json.
+
+Run in the build container (where /root/reference exists): every requirement string and every
+model string of the fixture must appear verbatim in the reference test module it cites.  The GPU box
+has no /root/reference, so this is a container-only integrity check, not a run-time dependency.
+"""
+import json
+import os
+import sys
+
+REF = "/root/reference/crates/shared/src/models/node.rs"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main() -> int:
+    if not os.path.exists(REF):
+        print("reference not present; nothing to check")
+        return 0
+    src = open(REF).read()
+    kats = json.load(open(os.path.join(HERE, "node_rs_kats.json")))
+    bad = 0
+    for sec in ("parser", "parser_errors", "meets"):
+        for k in kats[sec]:
+            if f'"{k["req"]}"' not in src:
+                print(f"[{sec}] {k['name']}: requirement string not found verbatim: {k['req']!r}")
+                bad += 1
+            m = k.get("specs", [None, None])[1]
+            if m is not None and f'"{m}"' not in src:
+                print(f"[{sec}] {k['name']}: model string not found verbatim: {m!r}")
+                bad += 1
+    n = sum(len(kats[s]) for s in ("parser", "parser_errors", "meets"))
+    print(f"checked {n} vectors, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
