@@ -1,0 +1,287 @@
+/*
+ * pm_engine.h — C ABI of the MI355X job-to-worker matching engine (libpm_engine.so).
+ *
+ * This is the drop-in boundary for the allocation hot path of the PrimeIntellect-ai/protocol
+ * orchestrator.  The reference has no FFI today; each entry point below names the Rust item whose
+ * work it takes over (paths relative to /root/reference/crates) and INTEGRATION.md shows the
+ * `GpuMatchPlugin` variant + `extern "C"` block a maintainer would add next to
+ * orchestrator/src/plugins/mod.rs:60-79.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every call returns PM_OK (0) or a negative PM_E* code and never throws/aborts across the ABI;
+ *     pm_last_error() returns a thread-local message for the last failing call on this thread;
+ *   - inputs are borrowed SoA column views, valid only for the duration of the call (the engine
+ *     copies them to HBM); outputs are caller-allocated;
+ *   - rows are identified by index: worker index = position in the caller's `get_nodes()` order
+ *     (orchestrator/src/store/domains/node_store.rs:163-209 — the order is significant, it is the
+ *     reference's tie-break), task index = position in `get_all_tasks()` order
+ *     (store/domains/task_store.rs:57-82), config index = position in the configuration list given
+ *     to pm_set_configs;
+ *   - the engine needs a gfx950 device and fails with PM_ENODEV without one.  There is no CPU
+ *     fallback.
+ *
+ * Threading (orchestrator/src/plugins/mod.rs:66-78 is called concurrently from actix workers):
+ *   pm_lookup_* are wait-free reads of the last published assignment table and may be called from
+ *   any thread at any time; every other call takes the engine's single-writer mutex.
+ */
+#ifndef PM_ENGINE_H
+#define PM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_ABI_VERSION 1
+
+enum {
+  PM_OK = 0,
+  PM_EINVAL = -1,   /* bad argument / invalid configuration (the reference constructor panics,
+                       node_groups/mod.rs:142-147) */
+  PM_ENODEV = -2,   /* no usable gfx950 device / HIP runtime error */
+  PM_ENOMEM = -3,
+  PM_ESTATE = -4,   /* call order violated (e.g. tick before tables were uploaded) */
+  PM_ERANGE = -5,   /* index out of range / caller buffer too small */
+  PM_EPARSE = -6,   /* ComputeRequirements::from_str returned Err */
+  PM_EPANIC = -7    /* the reference would panic on this input (e.g. shared/models/node.rs:251) */
+};
+
+#define PM_NONE 0xFFFFFFFFu /* "no task" / "no worker" / "no group" */
+#define PM_MAX_CONFIGS 64   /* one bit per NodeGroupConfiguration in the u64 masks */
+
+typedef struct pm_engine pm_engine;
+
+/* ------------------------------------------------------------------ worker table
+ * Projection of OrchestratorNode (orchestrator/src/models/node.rs:11-37) + ComputeSpecs
+ * (shared/src/models/node.rs:25-35,72-78,153-157) + NodeLocation (:543-550).  Option<T> fields
+ * become a flag bit + a value column. */
+enum {
+  PM_W_HAS_SPECS = 1u << 0,  /* compute_specs.is_some() */
+  PM_W_HAS_GPU = 1u << 1,    /* compute_specs.gpu.is_some() */
+  PM_W_GPU_COUNT = 1u << 2,  /* gpu.count.is_some() */
+  PM_W_GPU_MEM = 1u << 3,    /* gpu.memory_mb.is_some() */
+  PM_W_GPU_MODEL = 1u << 4,  /* gpu.model.is_some() -> gpu_model_class valid */
+  PM_W_HAS_CPU = 1u << 5,    /* compute_specs.cpu.is_some() */
+  PM_W_CPU_CORES = 1u << 6,  /* cpu.cores.is_some() */
+  PM_W_RAM = 1u << 7,        /* ram_mb.is_some() */
+  PM_W_STORAGE = 1u << 8,    /* storage_gb.is_some() */
+  PM_W_HEALTHY = 1u << 9,    /* status == NodeStatus::Healthy (models/node.rs:75-85) */
+  PM_W_HAS_P2P = 1u << 10,   /* p2p_id.is_some() */
+  PM_W_HAS_LOC = 1u << 11    /* location.is_some() */
+};
+
+typedef struct {
+  uint32_t n;
+  const uint32_t* flags;           /* PM_W_* */
+  const uint32_t* gpu_count;
+  const uint32_t* gpu_mem_mb;
+  const uint32_t* gpu_model_class; /* index of the interned gpu.model string (pm_set_model_table) */
+  const uint32_t* cpu_cores;
+  const uint32_t* ram_mb;
+  const uint32_t* storage_gb;
+  const uint32_t* price;           /* extension column; NULL or all-zero in every parity run */
+  const uint32_t* addr_rank;       /* rank of address.to_string() in byte order: GROUP_INDEX is the
+                                      rank inside the group's BTreeSet<String> (node_groups/mod.rs:
+                                      424-434). NULL => worker index order */
+  const double* lat;               /* NodeLocation.latitude  (read only when PM_W_HAS_LOC) */
+  const double* lon;               /* NodeLocation.longitude */
+} pm_worker_soa;
+
+/* ------------------------------------------------------------------ configuration table
+ * NodeGroupConfiguration (node_groups/mod.rs:30-37) + ComputeRequirements / GpuRequirements
+ * (shared/src/models/node.rs:49-70). */
+enum {
+  PM_R_HAS_REQ = 1u << 0,   /* compute_requirements.is_some() */
+  PM_R_CPU = 1u << 1,       /* requirements.cpu.is_some() */
+  PM_R_CPU_CORES = 1u << 2, /* requirements.cpu.cores.is_some() */
+  PM_R_RAM = 1u << 3,
+  PM_R_STORAGE = 1u << 4
+};
+typedef struct {
+  uint32_t flags; /* PM_R_* */
+  uint32_t cpu_cores, ram_mb, storage_gb;
+  uint32_t alt_begin, alt_count; /* GPU alternatives (OR) in the pm_gpu_alt_row table */
+  uint32_t min_group_size, max_group_size;
+} pm_config_row; /* 32 B */
+
+enum {
+  PM_G_COUNT = 1u << 0,
+  PM_G_MODEL = 1u << 1,
+  PM_G_MEM = 1u << 2,
+  PM_G_MEM_MIN = 1u << 3,
+  PM_G_MEM_MAX = 1u << 4,
+  PM_G_TOT_MIN = 1u << 5,
+  PM_G_TOT_MAX = 1u << 6
+};
+typedef struct {
+  uint32_t flags; /* PM_G_* */
+  uint32_t count, memory_mb, memory_mb_min, memory_mb_max, total_memory_min, total_memory_max;
+  uint32_t model_row; /* row of the model bit table (valid when PM_G_MODEL) */
+} pm_gpu_alt_row; /* 32 B */
+
+/* ------------------------------------------------------------------ task table
+ * Projection of Task (shared/src/models/task.rs:162-184) to what the path reads. */
+typedef struct {
+  uint32_t n;
+  const uint64_t* topo_mask; /* bit c set iff allowed_topologies contains config c's name; ~0ull when
+                                any Option on the way is None (scheduler_impl.rs:44-59) */
+  const int64_t* created_at;
+  const uint64_t* uid;       /* stable task identity across uploads (e.g. low 64 bits of the UUID);
+                                NULL => identity = index */
+} pm_task_soa;
+
+/* ------------------------------------------------------------------ engine */
+enum { PM_CHOOSE_FIRST = 0, PM_CHOOSE_SEEDED = 1 };
+
+typedef struct {
+  uint32_t abi_version;          /* PM_ABI_VERSION */
+  int32_t device;                /* HIP device ordinal (LOCAL_RANK) */
+  uint32_t proximity_enabled;    /* ProximityOptimizationPolicy.enabled (mod.rs:85-88, default 1) */
+  uint32_t switching_enabled;    /* TaskSwitchingPolicy.enabled        (mod.rs:90-97, default 1) */
+  uint32_t prefer_larger_groups; /* TaskSwitchingPolicy.prefer_larger_groups (default 1) */
+  uint32_t chooser;              /* replaces rand::rng().choose (scheduler_impl.rs:66-70, mod.rs:1175) */
+  uint64_t chooser_seed;
+  uint64_t group_id_seed;        /* replaces generate_group_id (mod.rs:1489-1493): ids are the
+                                    splitmix64 stream of this seed */
+  uint32_t debug_uncertain_every; /* test hook: treat every n-th carve step as a near-tie so the
+                                     exact host resolve path runs (0 = off) */
+  uint32_t sweep_variant;        /* pair-sweep kernel: 0 = default (best), 1 = scalar reference kernel */
+} pm_engine_config;
+
+void pm_engine_config_default(pm_engine_config*);
+
+/* NodeGroupsPlugin::new / Scheduler::new (node_groups/mod.rs:113-175, scheduler/mod.rs:14-24) */
+int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out);
+void pm_engine_destroy(pm_engine*);
+const char* pm_last_error(void);
+
+/* Configuration templates in caller order; the engine applies the constructor sort
+ * (mod.rs:150-164) and validity checks (:138-147 -> PM_EINVAL) itself.  n_cfgs <= PM_MAX_CONFIGS;
+ * min_group_size == 0 is rejected (the reference would create empty groups forever). */
+int32_t pm_set_configs(pm_engine*, const pm_config_row* cfgs, uint32_t n_cfgs,
+                       const pm_gpu_alt_row* alts, uint32_t n_alts);
+/* Host-evaluated model rule (shared/src/models/node.rs:463-484): bits[row * words + (cls >> 5)]
+ * bit (cls & 31) = requirement row `row` matches interned spec model string `cls`;
+ * words = (n_classes + 31) / 32.  pm_host_build_model_table() produces it. */
+int32_t pm_set_model_table(pm_engine*, const uint32_t* bits, uint32_t n_rows, uint32_t n_classes);
+/* "available_node_group_configs" (mod.rs:399-418, :1328-1348): bit c = config c enabled. */
+int32_t pm_set_enabled_mask(pm_engine*, uint64_t enabled);
+
+/* NodeStore::get_nodes snapshot (order significant). Resets group state iff keep_groups == 0. */
+int32_t pm_upload_workers(pm_engine*, const pm_worker_soa* workers, uint32_t keep_groups);
+/* Churn: overwrite rows idx[0..rows->n) (discovery sync / status updater deltas).  A row that
+ * loses PM_W_HEALTHY is NOT dissolved here; call pm_on_worker_status for Dead/LowBalance. */
+int32_t pm_update_workers(pm_engine*, const uint32_t* idx, const pm_worker_soa* rows);
+/* TaskStore::get_all_tasks snapshot. Groups whose claimed task uid disappeared are dissolved
+ * (on_task_deleted, mod.rs:1245-1288). */
+int32_t pm_upload_tasks(pm_engine*, const pm_task_soa* tasks);
+
+/* StatusUpdatePlugin::handle_status_change (status_update_impl.rs:8-39): dead != 0 means the new
+ * status is Dead or LowBalance => dissolve the worker's whole group. */
+int32_t pm_on_worker_status(pm_engine*, uint32_t worker, uint32_t flags_new, uint32_t dead);
+/* dissolve_group (mod.rs:1423-1487) by group slot. */
+int32_t pm_dissolve_group(pm_engine*, uint32_t group_slot);
+/* Drop all groups (bench: cold start of a full-swarm match). */
+int32_t pm_reset_groups(pm_engine*);
+
+/* Phase A — is_node_compatible_with_config x ComputeSpecs::meets over W x C
+ * (mod.rs:206-215, shared/src/models/node.rs:377-541).  mask_out (W entries) may be NULL. */
+int32_t pm_compat_masks(pm_engine*, uint64_t* mask_out);
+
+/* try_form_new_groups (mod.rs:478-628) / try_merge_solo_groups (:631-971). */
+int32_t pm_form_groups(pm_engine*, uint32_t* n_formed);
+int32_t pm_merge_solo_groups(pm_engine*, uint32_t* n_merged);
+
+typedef struct {
+  uint64_t id;          /* generate_group_id stream */
+  uint32_t config;      /* configuration index */
+  uint32_t n_members;
+  uint32_t member_begin; /* offset into the members array returned alongside */
+  uint32_t task;        /* claimed task index (group_task:<id>) or PM_NONE */
+} pm_group;
+
+/* get_all_groups (mod.rs:1006-1044) in slot (creation) order.  group_of_worker (W entries, slot in
+ * the returned array or -1), groups (cap_groups) and members (cap_members, BTreeSet order) may be
+ * NULL to query counts only. */
+int32_t pm_get_groups(pm_engine*, int32_t* group_of_worker, pm_group* groups, uint32_t cap_groups,
+                      uint32_t* n_groups, uint32_t* members, uint32_t cap_members, uint32_t* n_members);
+
+/* Phase B, reference orientation — NodeGroupsPlugin::filter_tasks (scheduler_impl.rs:11-110) for
+ * EVERY worker at once: the T x W topology sweep, the chooser and the per-group claim (SETNX :74).
+ * task_of_worker[w] = task index or PM_NONE; applicable_count[w] = number of applicable tasks the
+ * sweep found for w's group (0 for workers outside groups).  Either output may be NULL. */
+int32_t pm_match(pm_engine*, uint32_t* task_of_worker, uint32_t* applicable_count);
+
+/* Phase B, north_star orientation — for every task the best bid among eligible compatible
+ * workers: eligible = Healthy & p2p & unassigned (mod.rs:492-497), compatible = some config in
+ * topo_mask[t] & enabled with compat bit set; best = min (price, worker index).
+ * best_worker[t] = index or PM_NONE; candidate_count[t] = number of such workers. */
+int32_t pm_match_per_task(pm_engine*, uint32_t* best_worker, uint32_t* candidate_count);
+
+/* NewestTaskPlugin::filter_tasks (newest_task/mod.rs:8-19): argmax created_at, last max wins. */
+int32_t pm_newest_task(pm_engine*, uint32_t* task_idx);
+
+typedef struct {
+  /* GPU time per phase of the last pm_tick, from hipEvents on the engine's stream (ms) */
+  float ms_compat, ms_carve, ms_merge, ms_sweep, ms_publish, ms_total;
+  /* kernel-only durations (hipEvents recorded immediately around the launches, summed over relaunches) */
+  float ms_compat_kernel, ms_carve_kernel, ms_sweep_kernel;
+  uint32_t n_groups, n_formed, n_merged;
+  uint32_t carve_steps;         /* groups carved + merge selections done on the GPU */
+  uint32_t host_resolved_steps; /* carve steps whose near-tie was settled by the exact host path */
+  uint32_t carve_launches;
+  uint64_t pair_evals;          /* T x W of the sweep */
+  uint64_t carve_cand_sum;      /* sum over carve steps of the remaining candidates scanned (roofline bytes) */
+} pm_stats;
+
+/* One full-swarm match: compat masks -> form groups -> merge solo groups -> pair sweep + claim ->
+ * publish the assignment table (run_group_management_loop body, mod.rs:180-203, plus one
+ * get_task_for_node per worker, scheduler/mod.rs:26-36). */
+int32_t pm_tick(pm_engine*, pm_stats* stats);
+/* Stats of the last pm_tick / pm_form_groups / pm_merge_solo_groups call. */
+int32_t pm_last_stats(pm_engine*, pm_stats* stats);
+
+typedef struct {
+  uint32_t task;        /* task index or PM_NONE */
+  uint32_t group_slot;  /* PM_NONE when the worker is in no group */
+  uint32_t group_index; /* GROUP_INDEX (mod.rs:424-434) */
+  uint32_t group_size;  /* GROUP_SIZE */
+  uint32_t next_worker; /* worker whose p2p id is NEXT_P2P_ADDRESS (scheduler_impl.rs:115-128) */
+  uint64_t group_id;    /* GROUP_ID */
+} pm_assignment;
+
+/* Scheduler::get_task_for_node (scheduler/mod.rs:26-36) served from the table published by the last
+ * pm_tick / pm_match: wait-free, no HIP call. */
+int32_t pm_lookup_task_for_worker(pm_engine*, uint32_t worker, pm_assignment* out);
+
+/* Device-resident view of the last published per-worker task column (u32 task index or PM_NONE, W
+ * entries) for device-side consumers — e.g. the cross-shard RCCL all-gather of table shards.  The
+ * pointer stays valid until the next worker upload; contents are rewritten by pm_tick / pm_match. */
+int32_t pm_device_task_column(pm_engine*, uint64_t* device_ptr, uint32_t* n);
+
+/* ------------------------------------------------------------------ host helpers (no GPU needed)
+ * ComputeRequirements::from_str (shared/src/models/node.rs:180-374).  Fills cfg->flags/cpu/ram/
+ * storage/alt_count (alt_begin, min/max sizes untouched) and up to alt_cap alternatives; model
+ * strings are returned as offsets: alts[i].model_row = byte offset into models_out of a
+ * NUL-terminated copy.  Returns PM_OK, PM_EPARSE, PM_EPANIC or PM_ERANGE. */
+int32_t pm_host_parse_requirements(const char* s, pm_config_row* cfg, pm_gpu_alt_row* alts,
+                                   uint32_t alt_cap, char* models_out, size_t models_cap);
+/* GpuSpecs::meets model rule (shared/src/models/node.rs:463-484) for one string pair. */
+int32_t pm_host_model_matches(const char* spec_model, const char* req_model);
+/* Bit table for pm_set_model_table: req_models[n_rows] x spec_models[n_classes]. */
+int32_t pm_host_build_model_table(const char* const* req_models, uint32_t n_rows,
+                                  const char* const* spec_models, uint32_t n_classes, uint32_t* bits_out);
+/* Constructor sort (mod.rs:150-164) + runtime filter/sort (:399-418): writes the carve order of the
+ * enabled configurations, returns their count in *n_out. */
+int32_t pm_host_config_order(const pm_config_row* cfgs, uint32_t n_cfgs, uint64_t enabled,
+                             uint32_t* order_out, uint32_t* n_out);
+
+uint32_t pm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

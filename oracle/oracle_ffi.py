@@ -321,3 +321,56 @@ class State:
         a, b = C.c_uint64(0), C.c_uint64(0)
         lib().orc_counters(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+
+# ------------------------------------------------------------------ swarm -> oracle AoS rows
+
+def from_swarm(sw):
+    """protocol_amd.swarm.Swarm (string-level data) -> (nodes, cfgs, tasks, enabled) oracle tables."""
+    W, T = sw.W, sw.T
+    nodes = np.zeros(W, dtype=node_dt)
+    nodes["address"] = np.array([("0x%040d" % int(v)).encode() for v in sw.address], dtype=f"S{ADDR_LEN}") \
+        if W else np.zeros(0, dtype=f"S{ADDR_LEN}")
+    nodes["status"] = sw.status
+    nodes["has_p2p"] = sw.has_p2p
+    nodes["has_specs"] = sw.has_specs
+    nodes["has_location"] = sw.has_loc
+    nodes["latitude"] = sw.lat
+    nodes["longitude"] = sw.lon
+    sp = nodes["specs"]
+    f = np.zeros(W, dtype=np.uint32)
+    gpu, cpu = sw.has_gpu, sw.has_cpu
+    f |= np.where(gpu, S_GPU, 0).astype(np.uint32)
+    f |= np.where(gpu & sw.gpu_count_some, S_G_COUNT, 0).astype(np.uint32)
+    f |= np.where(gpu & sw.gpu_model_some, S_G_MODEL, 0).astype(np.uint32)
+    f |= np.where(gpu & sw.gpu_mem_some, S_G_MEM, 0).astype(np.uint32)
+    f |= np.where(cpu, S_CPU, 0).astype(np.uint32)
+    f |= np.where(cpu & sw.cpu_cores_some, S_CPU_CORES, 0).astype(np.uint32)
+    f |= np.where(sw.ram_some, S_RAM, 0).astype(np.uint32)
+    f |= np.where(sw.storage_some, S_STORAGE, 0).astype(np.uint32)
+    sp["flags"] = f
+    sp["gpu_count"] = sw.gpu_count
+    sp["gpu_memory_mb"] = sw.gpu_mem_mb
+    sp["cpu_cores"] = sw.cpu_cores
+    sp["ram_mb"] = sw.ram_mb
+    sp["storage_gb"] = sw.storage_gb
+    names = np.array([m.encode() for m in sw.model_names], dtype=f"S{MODEL_LEN}")
+    sp["gpu_model"] = names[sw.gpu_model_id] if W else names[:0]
+    nodes["specs"] = sp
+
+    cfgs = np.concatenate([make_config(n, mn, mx, r) for (n, mn, mx, r) in sw.configs]) \
+        if sw.configs else np.zeros(0, dtype=config_dt)
+
+    tasks = np.zeros(T, dtype=task_dt)
+    tasks["created_at"] = sw.created_at
+    tasks["restricted"] = sw.restricted
+    tasks["n_topologies"] = sw.n_topo
+    cname = np.array([c[0].encode() for c in sw.configs] + [b"ghost-topology", b""], dtype=f"S{NAME_LEN}")
+    topo = sw.topo.astype(np.int64)
+    topo = np.where(topo == -1, len(sw.configs), np.where(topo == -2, len(sw.configs) + 1, topo))
+    tp = np.zeros((T, MAX_TOPO), dtype=f"S{NAME_LEN}")
+    if T:
+        tp[:, :topo.shape[1]] = cname[topo]
+    tasks["topologies"] = tp
+    enabled = np.array([(sw.enabled_mask() >> i) & 1 for i in range(len(sw.configs))], dtype=np.uint8)
+    return nodes, cfgs, tasks, enabled

@@ -1,0 +1,112 @@
+// pm_device.h — argument blocks shared by the kernels (pm_kernels.hip) and the engine (pm_engine.cpp).
+#ifndef PM_DEVICE_H
+#define PM_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pm_engine.h"
+
+namespace pm {
+
+static constexpr double PM_RAD = 3.14159265358979323846 / 180.0;  // f64::to_radians factor
+static constexpr uint64_t PM_KEY_NOLOC = 0x7FEFFFFFFFFFFFFFull;   // bits of f64::MAX (mod.rs:244,249)
+static constexpr double PM_TIE_BAND = 1.0 / 68719476736.0;        // 2^-36, see carve_kernel
+static constexpr double PM_A_MAX_SAFE = 1.0 - 1.0 / 1048576.0;    // near-antipodal => settle on host
+static constexpr size_t PM_CARVE_MAX_LDS = 144 * 1024;
+
+struct CompatArgs {
+  uint32_t W, n_cfgs, model_words;
+  const uint32_t *flags, *gpu_count, *gpu_mem, *gpu_cls, *cpu_cores, *ram, *storage;
+  const pm_config_row* cfgs;
+  const pm_gpu_alt_row* alts;
+  const uint32_t* model_bits;
+  uint64_t* compat;
+};
+
+struct ClaimArgs {
+  uint32_t W;
+  const int32_t* group_of;
+  const uint32_t *g_n, *g_off, *g_task;
+  const uint64_t* g_id;
+  uint32_t* g_task_next;
+  const uint32_t* chosen;
+  const uint32_t* rank_in_group;  // per worker
+  const uint32_t* by_rank;        // per member slot: worker of that rank
+  pm_assignment* table;
+  uint32_t* task_col;  // compact per-worker task column (device-side consumers)
+};
+
+enum { CARVE_MODE_FORM = 0, CARVE_MODE_MERGE = 1 };
+enum { CARVE_STATE_RUNNING = 0, CARVE_STATE_DONE = 1, CARVE_STATE_UNCERTAIN = 2, CARVE_STATE_OVERFLOW = 3 };
+
+struct CarveStatus {
+  uint32_t state;
+  uint32_t stop_ci;      // configuration (position in the carve order) to resume at
+  uint32_t n_groups;     // records written so far (in/out)
+  uint32_t n_members;    // member slots used so far (in/out)
+  uint32_t steps_total;  // committed steps over all launches of this tick
+  uint32_t stop_seed;    // worker index of the seed of the uncertain step (diagnostic)
+  uint32_t n_eligible;   // compacted candidate count of the last launch
+  uint32_t _pad;
+  unsigned long long cand_sum;  // sum over committed steps of the candidates scanned
+};
+
+struct CarveArgs {
+  uint32_t mode;  // CARVE_MODE_*
+  uint32_t W;
+  uint32_t proximity;
+  uint32_t debug_uncertain_every;
+  // worker columns
+  const uint32_t* wflags;
+  const double *lat, *lon, *coslat;
+  const uint64_t* compat;
+  int32_t* group_of;  // FORM: read (eligibility) and written (commit)
+  // ordered candidate list: FORM -> written by the kernel (eligible rows in input order);
+  // MERGE -> supplied by the engine (nodes of the compatible solo groups in group-id order)
+  uint32_t* order;
+  uint32_t n_order;
+  // compacted scratch (capacity W each)
+  double *c_lat, *c_lon, *c_cos;
+  uint64_t* c_compat;
+  uint64_t* keys;
+  uint64_t* bits_scratch;  // 3 * bits_stride words when the bitmaps do not fit in LDS
+  uint32_t bits_stride;
+  uint32_t bits_in_lds;
+  // configurations in carve order (get_available_configurations, mod.rs:399-418)
+  uint32_t n_avail, start_ci;
+  uint32_t avail_cfg[PM_MAX_CONFIGS];
+  uint32_t min_size[PM_MAX_CONFIGS];
+  uint32_t max_size[PM_MAX_CONFIGS];
+  // output group records (slots n_groups.. are appended)
+  uint32_t *g_cfg, *g_n, *g_off, *members;
+  uint32_t cap_groups, cap_members;
+  CarveStatus* status;
+};
+
+void launch_compat(const CompatArgs& a, hipStream_t s);
+void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s);
+void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t W, uint64_t* sel, hipStream_t s);
+void launch_eligible_selector(const uint32_t* wflags, const int32_t* group_of, const uint64_t* compat,
+                              uint64_t enabled, uint32_t W, uint64_t* sel, hipStream_t s);
+void launch_chooser_rank(const int32_t* group_of, const uint64_t* g_id, const uint32_t* count, uint32_t W,
+                         uint64_t seed, uint32_t* rank, hipStream_t s);
+void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint32_t* g_off, const uint32_t* members,
+                       const uint32_t* addr_rank, uint32_t W, uint32_t* rank_in_group, uint32_t* by_rank,
+                       hipStream_t s);
+void launch_claim_publish(const ClaimArgs& a, hipStream_t s);
+void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t n_planes, uint64_t* planes,
+                         hipStream_t s);
+uint32_t pair_sweep_scratch_chunks(int variant, uint32_t R, uint32_t n_cols, uint32_t n_planes);
+void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
+                       const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, uint32_t* scratch,
+                       uint32_t max_chunks, uint32_t* first, uint32_t* count, hipStream_t s);
+void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
+                        const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, const uint32_t* rank,
+                        uint32_t* out, hipStream_t s);
+void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block, long long* val_by_block,
+                   uint32_t n_blocks, hipStream_t s);
+hipError_t launch_carve(const CarveArgs& a, size_t lds_bytes, hipStream_t s);
+
+}  // namespace pm
+#endif

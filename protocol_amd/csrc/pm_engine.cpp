@@ -1,0 +1,1350 @@
+// pm_engine.cpp — host side of libpm_engine.so: owns the HBM-resident SoA tables, drives the kernels of
+// pm_kernels.hip on one HIP stream and implements the C ABI of include/pm_engine.h.
+//
+// Reference behaviour mirrored here (paths relative to /root/reference/crates/orchestrator/src):
+//   plugins/node_groups/mod.rs:113-175   constructor checks + config sort      -> pm_set_configs
+//   plugins/node_groups/mod.rs:478-628   try_form_new_groups                   -> pm_form_groups
+//   plugins/node_groups/mod.rs:631-971   try_merge_solo_groups                 -> pm_merge_solo_groups
+//   plugins/node_groups/mod.rs:1423-1487 dissolve_group                        -> pm_dissolve_group
+//   plugins/node_groups/scheduler_impl.rs:11-110  filter_tasks (all workers)   -> pm_match
+//   plugins/node_groups/status_update_impl.rs:8-39 handle_status_change        -> pm_on_worker_status
+//   plugins/newest_task/mod.rs:8-19                                            -> pm_newest_task
+//   scheduler/mod.rs:26-36               get_task_for_node                     -> pm_lookup_task_for_worker
+// There is no CPU fallback: without a gfx950 device pm_engine_create fails with PM_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "pm_device.h"
+#include "pm_engine.h"
+#include "pm_internal.h"
+
+namespace pm {
+
+static thread_local std::string g_last_error;
+
+int32_t set_error(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return set_error(PM_ENODEV, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Group {
+  uint64_t id;
+  uint32_t cfg;
+  uint32_t task;      // index into the current task table or PM_NONE
+  uint64_t task_uid;  // identity of the claimed task across uploads
+  std::vector<uint32_t> members;  // carve order; BTreeSet order is derived from addr_rank
+};
+
+using Table = std::vector<pm_assignment>;
+
+}  // namespace pm
+
+using namespace pm;
+
+struct pm_engine {
+  pm_engine_config cfg{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6]{};
+  hipEvent_t kev[6]{};  // kernel-only brackets: compat, carve, sweep
+  float k_ms_compat = 0, k_ms_carve = 0, k_ms_sweep = 0;
+  bool k_sweep_recorded = false, k_compat_recorded = false;
+  uint64_t tick_cand_sum = 0;
+  std::mutex mu;
+
+  // ---- configuration tables
+  std::vector<pm_config_row> cfgs;
+  std::vector<pm_gpu_alt_row> alts;
+  std::vector<uint32_t> model_bits;
+  uint32_t model_rows = 0, model_classes = 0;
+  uint64_t enabled = ~0ull;
+  DevBuf<pm_config_row> d_cfgs;
+  DevBuf<pm_gpu_alt_row> d_alts;
+  DevBuf<uint32_t> d_model_bits;
+  bool have_cfgs = false;
+
+  // ---- worker table (host mirror + HBM columns)
+  uint32_t W = 0;
+  bool have_workers = false;
+  std::vector<uint32_t> h_flags, h_gpu_count, h_gpu_mem, h_gpu_cls, h_cpu_cores, h_ram, h_storage, h_price,
+      h_addr_rank;
+  std::vector<double> h_lat, h_lon;
+  DevBuf<uint32_t> d_flags, d_gpu_count, d_gpu_mem, d_gpu_cls, d_cpu_cores, d_ram, d_storage, d_addr_rank;
+  DevBuf<double> d_lat, d_lon, d_coslat;
+  DevBuf<uint64_t> d_compat;
+  bool compat_dirty = true;
+  std::vector<uint64_t> h_compat;
+  bool h_compat_valid = false;
+  bool any_price = false;
+  std::vector<uint32_t> price_perm;  // workers sorted by (price, index)
+
+  // ---- task table
+  uint32_t T = 0;
+  bool have_tasks = false;
+  std::vector<uint64_t> h_tmask, h_tuid;
+  std::vector<int64_t> h_created;
+  bool tasks_have_uid = false;
+  DevBuf<uint64_t> d_tmask, d_tplanes;
+  DevBuf<int64_t> d_created;
+  bool tplanes_dirty = true;
+
+  // ---- groups: the host vector is the source of truth between calls; device arrays mirror it
+  std::vector<Group> groups;
+  std::vector<int32_t> h_group_of;
+  uint64_t id_rng = 0;
+  bool groups_dirty = true;
+  DevBuf<int32_t> d_group_of;
+  DevBuf<uint32_t> d_g_cfg, d_g_n, d_g_off, d_g_task, d_g_task_next, d_members, d_by_rank, d_rank_in_group;
+  DevBuf<uint64_t> d_g_id;
+  uint32_t d_n_groups = 0, d_n_members = 0;
+
+  // ---- carve scratch
+  DevBuf<uint32_t> d_order;
+  DevBuf<double> d_c_lat, d_c_lon, d_c_cos;
+  DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
+  DevBuf<CarveStatus> d_status;
+  DevBuf<uint32_t> d_m_cfg, d_m_n, d_m_off, d_m_members;  // MERGE batches
+
+  // ---- sweep scratch
+  DevBuf<uint64_t> d_sel, d_wplanes, d_sel_perm;
+  DevBuf<uint32_t> d_scratch, d_first, d_count, d_rank, d_chosen, d_perm;
+  DevBuf<pm_assignment> d_table;
+  DevBuf<uint32_t> d_task_col;
+  pm_assignment* h_table_pinned = nullptr;
+  size_t h_table_cap = 0;
+  DevBuf<uint32_t> d_nb_idx;
+  DevBuf<long long> d_nb_val;
+
+  std::shared_ptr<const Table> published;
+  pm_stats last_stats{};
+  uint32_t tick_host_resolved = 0, tick_carve_launches = 0, tick_carve_steps = 0;
+};
+
+namespace pm {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+
+template <typename T>
+static int32_t upload(DevBuf<T>& d, const T* src, size_t n, hipStream_t s) {
+  HIPCHK(d.ensure(n ? n : 1));
+  if (n) HIPCHK(hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+  return PM_OK;
+}
+
+static void reset_groups_locked(pm_engine* e) {
+  e->groups.clear();
+  e->h_group_of.assign(e->W, -1);
+  e->id_rng = e->cfg.group_id_seed;
+  e->groups_dirty = true;
+}
+
+static void dissolve_locked(pm_engine* e, uint32_t slot) {  // dissolve_group, mod.rs:1423-1487
+  if (slot >= e->groups.size()) return;
+  e->groups.erase(e->groups.begin() + slot);
+  std::fill(e->h_group_of.begin(), e->h_group_of.end(), -1);
+  for (size_t g = 0; g < e->groups.size(); ++g)
+    for (uint32_t w : e->groups[g].members) e->h_group_of[w] = int32_t(g);
+  e->groups_dirty = true;
+}
+
+// Mirror the host group list into HBM (packed member pool, slot = index).
+static int32_t push_groups(pm_engine* e) {
+  if (!e->groups_dirty) return PM_OK;
+  const size_t G = e->groups.size();
+  std::vector<uint32_t> g_cfg(G), g_n(G), g_off(G), g_task(G), members;
+  std::vector<uint64_t> g_id(G);
+  members.reserve(e->W);
+  for (size_t g = 0; g < G; ++g) {
+    const Group& gr = e->groups[g];
+    g_cfg[g] = gr.cfg;
+    g_n[g] = uint32_t(gr.members.size());
+    g_off[g] = uint32_t(members.size());
+    g_task[g] = gr.task;
+    g_id[g] = gr.id;
+    members.insert(members.end(), gr.members.begin(), gr.members.end());
+  }
+  const size_t capG = std::max<size_t>(e->W, 1), capM = std::max<size_t>(e->W, 1);
+  HIPCHK(e->d_g_cfg.ensure(capG));
+  HIPCHK(e->d_g_n.ensure(capG));
+  HIPCHK(e->d_g_off.ensure(capG));
+  HIPCHK(e->d_g_task.ensure(capG));
+  HIPCHK(e->d_g_task_next.ensure(capG));
+  HIPCHK(e->d_g_id.ensure(capG));
+  HIPCHK(e->d_members.ensure(capM));
+  HIPCHK(e->d_by_rank.ensure(capM));
+  HIPCHK(e->d_rank_in_group.ensure(capM));
+  HIPCHK(e->d_group_of.ensure(capM));
+  if (G) {
+    HIPCHK(hipMemcpyAsync(e->d_g_cfg.p, g_cfg.data(), G * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_g_n.p, g_n.data(), G * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_g_off.p, g_off.data(), G * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_g_task.p, g_task.data(), G * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_g_id.p, g_id.data(), G * 8, hipMemcpyHostToDevice, e->stream));
+  }
+  if (!members.empty())
+    HIPCHK(hipMemcpyAsync(e->d_members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice, e->stream));
+  if (e->W)
+    HIPCHK(hipMemcpyAsync(e->d_group_of.p, e->h_group_of.data(), size_t(e->W) * 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));  // the staging vectors die here
+  e->d_n_groups = uint32_t(G);
+  e->d_n_members = uint32_t(members.size());
+  e->groups_dirty = false;
+  return PM_OK;
+}
+
+static int32_t ensure_compat(pm_engine* e) {
+  if (!e->have_cfgs || !e->have_workers) return set_error(PM_ESTATE, "configs and workers must be uploaded first");
+  if (!e->compat_dirty) return PM_OK;
+  for (const pm_gpu_alt_row& a : e->alts)
+    if ((a.flags & PM_G_MODEL) && a.model_row >= e->model_rows)
+      return set_error(PM_ESTATE, "a GPU alternative names a model row but pm_set_model_table was not called");
+  if (e->model_rows)
+    for (uint32_t w = 0; w < e->W; ++w)
+      if ((e->h_flags[w] & PM_W_GPU_MODEL) && e->h_gpu_cls[w] >= e->model_classes)
+        return set_error(PM_ERANGE, "worker gpu_model_class outside the model table");
+  HIPCHK(e->d_compat.ensure(std::max<size_t>(e->W, 1)));
+  CompatArgs a{};
+  a.W = e->W;
+  a.n_cfgs = uint32_t(e->cfgs.size());
+  a.model_words = (e->model_classes + 31u) / 32u;
+  a.flags = e->d_flags.p;
+  a.gpu_count = e->d_gpu_count.p;
+  a.gpu_mem = e->d_gpu_mem.p;
+  a.gpu_cls = e->d_gpu_cls.p;
+  a.cpu_cores = e->d_cpu_cores.p;
+  a.ram = e->d_ram.p;
+  a.storage = e->d_storage.p;
+  a.cfgs = e->d_cfgs.p;
+  a.alts = e->d_alts.p;
+  a.model_bits = e->d_model_bits.p;
+  a.compat = e->d_compat.p;
+  HIPCHK(hipEventRecord(e->kev[0], e->stream));
+  launch_compat(a, e->stream);
+  HIPCHK(hipEventRecord(e->kev[1], e->stream));
+  HIPCHK(hipGetLastError());
+  e->k_compat_recorded = true;
+  e->compat_dirty = false;
+  e->h_compat_valid = false;
+  return PM_OK;
+}
+
+static int32_t pull_compat(pm_engine* e) {
+  if (e->h_compat_valid) return PM_OK;
+  e->h_compat.resize(e->W);
+  if (e->W) {
+    HIPCHK(hipMemcpyAsync(e->h_compat.data(), e->d_compat.p, size_t(e->W) * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  e->h_compat_valid = true;
+  return PM_OK;
+}
+
+// Haversine exactly as the reference evaluates it (mod.rs:218-231) with the host libm.  Used only by
+// the exact-resolve path for steps the GPU certificate could not prove (see carve_kernel).
+static double host_distance(double lat1, double lon1, double lat2, double lon2) {
+  const double R = 6371.0;
+  const double lat1r = lat1 * PM_RAD, lat2r = lat2 * PM_RAD;
+  const double dlat = (lat2 - lat1) * PM_RAD, dlon = (lon2 - lon1) * PM_RAD;
+  const double s1 = std::sin(dlat / 2.0), s2 = std::sin(dlon / 2.0);
+  const double a = s1 * s1 + std::cos(lat1r) * std::cos(lat2r) * (s2 * s2);
+  const double c = 2.0 * std::atan2(std::sqrt(a), std::sqrt(1.0 - a));
+  return R * c;
+}
+
+struct CarvePlan {
+  std::vector<uint32_t> avail;  // configuration indices in carve order
+};
+
+static size_t carve_lds_bytes(uint32_t stride_words, bool* in_lds) {
+  const size_t need = size_t(stride_words) * 3 * sizeof(uint64_t);
+  *in_lds = need <= PM_CARVE_MAX_LDS - 1024;
+  return *in_lds ? need : 0;
+}
+
+static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32_t n_order) {
+  const size_t cap = std::max<size_t>(e->W, 1);
+  HIPCHK(e->d_order.ensure(cap));
+  HIPCHK(e->d_c_lat.ensure(cap));
+  HIPCHK(e->d_c_lon.ensure(cap));
+  HIPCHK(e->d_c_cos.ensure(cap));
+  HIPCHK(e->d_c_compat.ensure(cap));
+  HIPCHK(e->d_keys.ensure(cap));
+  HIPCHK(e->d_status.ensure(1));
+  const uint32_t stride = uint32_t((cap + 63) / 64);
+  bool in_lds = false;
+  (void)carve_lds_bytes(stride, &in_lds);
+  HIPCHK(e->d_bits.ensure(size_t(stride) * 3));
+  std::memset(a, 0, sizeof(*a));
+  a->mode = mode;
+  a->W = e->W;
+  a->proximity = e->cfg.proximity_enabled;
+  a->debug_uncertain_every = e->cfg.debug_uncertain_every;
+  a->wflags = e->d_flags.p;
+  a->lat = e->d_lat.p;
+  a->lon = e->d_lon.p;
+  a->coslat = e->d_coslat.p;
+  a->compat = e->d_compat.p;
+  a->group_of = e->d_group_of.p;
+  a->order = e->d_order.p;
+  a->n_order = n_order;
+  a->c_lat = e->d_c_lat.p;
+  a->c_lon = e->d_c_lon.p;
+  a->c_cos = e->d_c_cos.p;
+  a->c_compat = e->d_c_compat.p;
+  a->keys = e->d_keys.p;
+  a->bits_scratch = e->d_bits.p;
+  a->bits_stride = stride;
+  a->bits_in_lds = in_lds ? 1u : 0u;
+  a->status = e->d_status.p;
+  return PM_OK;
+}
+
+// One exact carve step on the host for configuration `cfg` (FORM mode): the same rule as
+// mod.rs:511-551 with glibc distances and a stable sort.  Appends the group to the device arrays.
+static int32_t host_resolve_form_step(pm_engine* e, uint32_t cfg, CarveStatus* st) {
+  int32_t rc = pull_compat(e);
+  if (rc) return rc;
+  std::vector<int32_t> group_of(e->W);
+  if (e->W) {
+    HIPCHK(hipMemcpyAsync(group_of.data(), e->d_group_of.p, size_t(e->W) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  const pm_config_row& c = e->cfgs[cfg];
+  std::vector<uint32_t> compat;
+  size_t total_available = 0;
+  for (uint32_t w = 0; w < e->W; ++w) {
+    const uint32_t f = e->h_flags[w];
+    if (!((f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && group_of[w] < 0)) continue;
+    ++total_available;
+    if ((e->h_compat[w] >> cfg) & 1ull) compat.push_back(w);
+  }
+  if (total_available < c.min_group_size || compat.size() < c.min_group_size || compat.empty())
+    return set_error(PM_ESTATE, "host resolve: nothing to carve (state mismatch)");
+  uint32_t seed = compat[0];
+  bool seed_loc = false;
+  for (uint32_t w : compat)
+    if (e->h_flags[w] & PM_W_HAS_LOC) {
+      seed = w;
+      seed_loc = true;
+      break;
+    }
+  std::vector<uint32_t> rest;
+  for (uint32_t w : compat)
+    if (w != seed) rest.push_back(w);
+  if (seed_loc && e->cfg.proximity_enabled) {
+    std::vector<double> d(e->W, 0.0);
+    for (uint32_t w : rest)
+      d[w] = (e->h_flags[w] & PM_W_HAS_LOC) ? host_distance(e->h_lat[seed], e->h_lon[seed], e->h_lat[w], e->h_lon[w])
+                                            : 1.7976931348623157e308;
+    std::stable_sort(rest.begin(), rest.end(), [&](uint32_t a, uint32_t b) { return d[a] < d[b]; });
+  }
+  std::vector<uint32_t> members{seed};
+  for (uint32_t w : rest) {
+    if (members.size() >= c.max_group_size) break;
+    members.push_back(w);
+  }
+  if (members.size() < c.min_group_size) return set_error(PM_ESTATE, "host resolve: group below min size");
+  const uint32_t g = st->n_groups, off = st->n_members, n = uint32_t(members.size());
+  if (g >= e->d_g_cfg.cap || off + n > e->d_members.cap) return set_error(PM_ENOMEM, "group arrays overflow");
+  HIPCHK(hipMemcpyAsync(e->d_g_cfg.p + g, &cfg, 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_g_n.p + g, &n, 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_g_off.p + g, &off, 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_members.p + off, members.data(), size_t(n) * 4, hipMemcpyHostToDevice, e->stream));
+  for (uint32_t w : members) group_of[w] = int32_t(g);
+  HIPCHK(hipMemcpyAsync(e->d_group_of.p, group_of.data(), size_t(e->W) * 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  st->n_groups += 1;
+  st->n_members += n;
+  st->steps_total += 1;
+  return PM_OK;
+}
+
+// Run the persistent carve kernel until it reports DONE, settling UNCERTAIN steps on the host.
+static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
+  int32_t rc = ensure_compat(e);
+  if (rc) return rc;
+  rc = push_groups(e);
+  if (rc) return rc;
+  std::vector<uint32_t> avail;
+  available_order(e->cfgs.data(), uint32_t(e->cfgs.size()), e->enabled, &avail);
+  const uint32_t g0 = e->d_n_groups, m0 = e->d_n_members;
+  if (n_formed) *n_formed = 0;
+  if (avail.empty() || e->W == 0) return PM_OK;
+
+  CarveArgs a;
+  rc = fill_carve_args(e, &a, CARVE_MODE_FORM, 0);
+  if (rc) return rc;
+  a.n_avail = uint32_t(avail.size());
+  for (size_t i = 0; i < avail.size(); ++i) {
+    a.avail_cfg[i] = avail[i];
+    a.min_size[i] = e->cfgs[avail[i]].min_group_size;
+    a.max_size[i] = e->cfgs[avail[i]].max_group_size;
+  }
+  a.g_cfg = e->d_g_cfg.p;
+  a.g_n = e->d_g_n.p;
+  a.g_off = e->d_g_off.p;
+  a.members = e->d_members.p;
+  a.cap_groups = uint32_t(std::min<size_t>(e->d_g_cfg.cap, 0xFFFFFFFFu));
+  a.cap_members = uint32_t(std::min<size_t>(e->d_members.cap, 0xFFFFFFFFu));
+  bool in_lds;
+  const size_t lds = carve_lds_bytes(a.bits_stride, &in_lds);
+
+  CarveStatus st{};
+  st.state = CARVE_STATE_RUNNING;
+  st.n_groups = g0;
+  st.n_members = m0;
+  a.start_ci = 0;
+  for (;;) {
+    HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->kev[2], e->stream));
+    HIPCHK(launch_carve(a, lds, e->stream));
+    HIPCHK(hipEventRecord(e->kev[3], e->stream));
+    e->tick_carve_launches++;
+    HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
+      e->k_ms_carve += ms;
+    }
+    if (st.state == CARVE_STATE_DONE) break;
+    if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
+    if (st.state != CARVE_STATE_UNCERTAIN) return set_error(PM_ENODEV, "carve kernel did not complete");
+    rc = host_resolve_form_step(e, avail[st.stop_ci], &st);
+    if (rc) return rc;
+    e->tick_host_resolved++;
+    a.start_ci = st.stop_ci;
+    st.state = CARVE_STATE_RUNNING;
+  }
+  e->tick_carve_steps += st.steps_total;
+  e->tick_cand_sum += st.cand_sum;
+
+  // pull the new group records into the host list and give them ids (generate_group_id stream)
+  const uint32_t g1 = st.n_groups, m1 = st.n_members;
+  if (g1 > g0) {
+    const uint32_t ng = g1 - g0;
+    std::vector<uint32_t> g_cfg(ng), g_n(ng), g_off(ng), members(m1 - m0);
+    HIPCHK(hipMemcpyAsync(g_cfg.data(), e->d_g_cfg.p + g0, ng * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(g_n.data(), e->d_g_n.p + g0, ng * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(g_off.data(), e->d_g_off.p + g0, ng * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(members.data(), e->d_members.p + m0, size_t(m1 - m0) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<uint64_t> ids(ng);
+    std::vector<uint32_t> none(ng, PM_NONE);
+    for (uint32_t k = 0; k < ng; ++k) {
+      Group gr;
+      gr.id = splitmix64_next(&e->id_rng);
+      gr.cfg = g_cfg[k];
+      gr.task = PM_NONE;
+      gr.task_uid = 0;
+      gr.members.assign(members.begin() + (g_off[k] - m0), members.begin() + (g_off[k] - m0) + g_n[k]);
+      for (uint32_t w : gr.members) e->h_group_of[w] = int32_t(g0 + k);
+      ids[k] = gr.id;
+      e->groups.push_back(std::move(gr));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_g_id.p + g0, ids.data(), size_t(ng) * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_g_task.p + g0, none.data(), size_t(ng) * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->d_n_groups = g1;
+    e->d_n_members = m1;
+  }
+  if (n_formed) *n_formed = g1 - g0;
+  return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair sweep plumbing
+
+static int32_t ensure_task_planes(pm_engine* e) {
+  if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
+  if (!e->tplanes_dirty) return PM_OK;
+  const uint32_t n_planes = uint32_t(e->cfgs.size());
+  const size_t n_words = (size_t(e->T) + 63) / 64;
+  HIPCHK(e->d_tplanes.ensure(std::max<size_t>(n_words * n_planes, 1)));
+  launch_build_planes(e->d_tmask.p, e->T, n_planes, e->d_tplanes.p, e->stream);
+  HIPCHK(hipGetLastError());
+  e->tplanes_dirty = false;
+  return PM_OK;
+}
+
+static int32_t ensure_sweep_scratch(pm_engine* e, uint32_t R, uint32_t n_cols, uint32_t* max_chunks) {
+  const int variant = int(e->cfg.sweep_variant);
+  const uint32_t chunks = pair_sweep_scratch_chunks(variant, R, n_cols, uint32_t(e->cfgs.size()));
+  HIPCHK(e->d_scratch.ensure(size_t(2) * chunks * std::max<uint32_t>(R, 1)));
+  HIPCHK(e->d_first.ensure(std::max<uint32_t>(R, 1)));
+  HIPCHK(e->d_count.ensure(std::max<uint32_t>(R, 1)));
+  HIPCHK(e->d_rank.ensure(std::max<uint32_t>(R, 1)));
+  HIPCHK(e->d_chosen.ensure(std::max<uint32_t>(R, 1)));
+  *max_chunks = chunks;
+  return PM_OK;
+}
+
+// rank-th applicable task for one configuration bit (merge path: find_best_task_for_group,
+// mod.rs:1122-1189).  Returns PM_NONE if no task is applicable.
+static int32_t pick_task_for_config(pm_engine* e, uint32_t cfg, uint64_t group_id, uint32_t* task_out) {
+  *task_out = PM_NONE;
+  if (!e->have_tasks || e->T == 0) return PM_OK;
+  // The applicable list depends only on the configuration bit: evaluate it on the host mirror — this is
+  // a T-length scan on a rare path (a merge actually happened), not the pair sweep.
+  const uint64_t bit = 1ull << cfg;
+  uint32_t n_app = 0;
+  for (uint32_t t = 0; t < e->T; ++t) n_app += (e->h_tmask[t] & bit) != 0;
+  if (!n_app) return PM_OK;
+  uint32_t r = 0;
+  if (e->cfg.chooser == PM_CHOOSE_SEEDED) r = uint32_t(splitmix64_mix(e->cfg.chooser_seed ^ group_id) % n_app);
+  for (uint32_t t = 0; t < e->T; ++t)
+    if (e->h_tmask[t] & bit) {
+      if (r == 0) {
+        *task_out = t;
+        return PM_OK;
+      }
+      --r;
+    }
+  return PM_OK;
+}
+
+static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* count_out) {
+  if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
+    return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
+  int32_t rc = push_groups(e);
+  if (rc) return rc;
+  const int variant = int(e->cfg.sweep_variant);
+  if (variant != 1) {
+    rc = ensure_task_planes(e);
+    if (rc) return rc;
+  }
+  uint32_t max_chunks = 0;
+  rc = ensure_sweep_scratch(e, e->W, e->T, &max_chunks);
+  if (rc) return rc;
+  HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
+  HIPCHK(e->d_table.ensure(std::max<uint32_t>(e->W, 1)));
+  HIPCHK(e->d_task_col.ensure(std::max<uint32_t>(e->W, 1)));
+  if (e->W == 0) return PM_OK;
+  const uint32_t n_planes = uint32_t(e->cfgs.size());
+
+  launch_worker_selector(e->d_group_of.p, e->d_g_cfg.p, e->W, e->d_sel.p, e->stream);
+  HIPCHK(hipEventRecord(e->kev[4], e->stream));
+  launch_pair_sweep(variant, e->d_sel.p, e->W, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_scratch.p,
+                    max_chunks, e->d_first.p, e->d_count.p, e->stream);
+  HIPCHK(hipEventRecord(e->kev[5], e->stream));
+  e->k_sweep_recorded = true;
+  const uint32_t* chosen = e->d_first.p;  // PM_CHOOSE_FIRST: the first applicable task
+  if (e->cfg.chooser == PM_CHOOSE_SEEDED) {
+    launch_chooser_rank(e->d_group_of.p, e->d_g_id.p, e->d_count.p, e->W, e->cfg.chooser_seed, e->d_rank.p,
+                        e->stream);
+    launch_pair_select(variant, e->d_sel.p, e->W, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_rank.p,
+                       e->d_chosen.p, e->stream);
+    chosen = e->d_chosen.p;
+  }
+  launch_group_rank(e->d_group_of.p, e->d_g_n.p, e->d_g_off.p, e->d_members.p, e->d_addr_rank.p, e->W,
+                    e->d_rank_in_group.p, e->d_by_rank.p, e->stream);
+  const size_t G = e->groups.size();
+  if (G) HIPCHK(hipMemcpyAsync(e->d_g_task_next.p, e->d_g_task.p, G * 4, hipMemcpyDeviceToDevice, e->stream));
+  ClaimArgs c{};
+  c.W = e->W;
+  c.group_of = e->d_group_of.p;
+  c.g_n = e->d_g_n.p;
+  c.g_off = e->d_g_off.p;
+  c.g_task = e->d_g_task.p;
+  c.g_id = e->d_g_id.p;
+  c.g_task_next = e->d_g_task_next.p;
+  c.chosen = chosen;
+  c.rank_in_group = e->d_rank_in_group.p;
+  c.by_rank = e->d_by_rank.p;
+  c.table = e->d_table.p;
+  c.task_col = e->d_task_col.p;
+  launch_claim_publish(c, e->stream);
+  HIPCHK(hipGetLastError());
+  if (want_count && count_out) {
+    count_out->resize(e->W);
+    HIPCHK(hipMemcpyAsync(count_out->data(), e->d_count.p, size_t(e->W) * 4, hipMemcpyDeviceToHost, e->stream));
+  }
+  return PM_OK;
+}
+
+// D2H of the assignment table + the group task words, then swap in the new published snapshot.
+static int32_t publish(pm_engine* e) {
+  const size_t G = e->groups.size();
+  if (e->h_table_cap < e->W) {
+    if (e->h_table_pinned) (void)hipHostFree(e->h_table_pinned);
+    e->h_table_pinned = nullptr;
+    e->h_table_cap = 0;
+    HIPCHK(hipHostMalloc((void**)&e->h_table_pinned, sizeof(pm_assignment) * std::max<uint32_t>(e->W, 1)));
+    e->h_table_cap = e->W;
+  }
+  std::vector<uint32_t> g_task(G);
+  if (e->W)
+    HIPCHK(hipMemcpyAsync(e->h_table_pinned, e->d_table.p, sizeof(pm_assignment) * e->W, hipMemcpyDeviceToHost,
+                          e->stream));
+  if (G) HIPCHK(hipMemcpyAsync(g_task.data(), e->d_g_task_next.p, G * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (size_t g = 0; g < G; ++g) {
+    e->groups[g].task = g_task[g];
+    e->groups[g].task_uid = (g_task[g] != PM_NONE && e->tasks_have_uid) ? e->h_tuid[g_task[g]] : g_task[g];
+  }
+  std::swap(e->d_g_task, e->d_g_task_next);
+  auto t = std::make_shared<Table>(e->h_table_pinned, e->h_table_pinned + e->W);
+  std::atomic_store_explicit(&e->published, std::shared_ptr<const Table>(std::move(t)), std::memory_order_release);
+  return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge (try_merge_solo_groups, mod.rs:631-971)
+
+// get_all_groups order: by id formatted "{:x}" compared as strings (mod.rs:1040).
+static bool hex_id_less(uint64_t a, uint64_t b) {
+  auto len = [](uint64_t x) {
+    int n = 1;
+    while (x >>= 4) ++n;
+    return n;
+  };
+  const int la = len(a), lb = len(b);
+  const uint64_t aa = a << (4 * (16 - la)), bb = b << (4 * (16 - lb));  // left-align the digit strings
+  if (aa != bb) return aa < bb;
+  return la < lb;  // a proper prefix sorts first
+}
+
+// Exact host version of one attempt_group_merge selection (mod.rs:752-860) over `rem` (workers of the
+// remaining compatible solo groups in get_all_groups order).
+static void host_merge_select(pm_engine* e, const std::vector<uint32_t>& rem, const pm_config_row& c,
+                              std::vector<uint32_t>* batch) {
+  batch->clear();
+  if (e->cfg.proximity_enabled) {
+    size_t seed_pos = rem.size();
+    for (size_t i = 0; i < rem.size(); ++i)
+      if (e->h_flags[rem[i]] & PM_W_HAS_LOC) {
+        seed_pos = i;
+        break;
+      }
+    if (seed_pos < rem.size()) {
+      const uint32_t seed = rem[seed_pos];
+      batch->push_back(seed);
+      std::vector<std::pair<double, uint32_t>> others;
+      for (size_t i = 0; i < rem.size(); ++i)
+        if (i != seed_pos && (e->h_flags[rem[i]] & PM_W_HAS_LOC))
+          others.emplace_back(host_distance(e->h_lat[seed], e->h_lon[seed], e->h_lat[rem[i]], e->h_lon[rem[i]]), rem[i]);
+      std::stable_sort(others.begin(), others.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      for (const auto& o : others)
+        if (batch->size() + 1 <= c.max_group_size) {
+          batch->push_back(o.second);
+          if (batch->size() >= c.max_group_size) break;
+        }
+    }
+  }
+  if (batch->empty() || (batch->size() < c.max_group_size && batch->size() < c.min_group_size)) {
+    if (batch->size() < c.min_group_size) batch->clear();
+    for (uint32_t w : rem) {
+      if (std::find(batch->begin(), batch->end(), w) != batch->end()) continue;
+      if (batch->size() + 1 <= c.max_group_size) {
+        batch->push_back(w);
+        if (batch->size() >= c.max_group_size) break;
+      }
+    }
+  }
+}
+
+static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
+  if (n_merged) *n_merged = 0;
+  if (!e->have_cfgs || !e->have_workers) return set_error(PM_ESTATE, "configs and workers must be uploaded first");
+  size_t solo = 0;
+  for (const Group& g : e->groups) solo += g.members.size() == 1;
+  if (solo < 2) return PM_OK;  // mod.rs:641-644
+  int32_t rc = ensure_compat(e);
+  if (rc) return rc;
+  rc = pull_compat(e);
+  if (rc) return rc;
+  std::vector<uint32_t> avail;
+  available_order(e->cfgs.data(), uint32_t(e->cfgs.size()), e->enabled, &avail);
+  uint32_t merged = 0;
+  for (uint32_t cfg : avail) {  // mod.rs:654
+    const pm_config_row& c = e->cfgs[cfg];
+    // get_all_groups (sorted by id string) -> find_compatible_solo_groups (mod.rs:712-734)
+    std::vector<uint32_t> slots;
+    for (uint32_t s = 0; s < e->groups.size(); ++s)
+      if (e->groups[s].members.size() == 1 && ((e->h_compat[e->groups[s].members[0]] >> cfg) & 1ull)) slots.push_back(s);
+    std::sort(slots.begin(), slots.end(),
+              [&](uint32_t a, uint32_t b) { return hex_id_less(e->groups[a].id, e->groups[b].id); });
+    if (slots.size() < c.min_group_size) continue;  // mod.rs:688-691
+    std::vector<uint32_t> rem;
+    for (uint32_t s : slots) rem.push_back(e->groups[s].members[0]);
+
+    // ---- selection of all batches for this configuration on the GPU (carve kernel, MERGE mode)
+    std::vector<std::vector<uint32_t>> batches;
+    {
+      rc = push_groups(e);
+      if (rc) return rc;
+      std::vector<uint32_t> order = rem;
+      const size_t cap = std::max<size_t>(e->W, 1);
+      HIPCHK(e->d_m_cfg.ensure(cap));
+      HIPCHK(e->d_m_n.ensure(cap));
+      HIPCHK(e->d_m_off.ensure(cap));
+      HIPCHK(e->d_m_members.ensure(cap));
+      for (;;) {
+        CarveArgs a;
+        rc = fill_carve_args(e, &a, CARVE_MODE_MERGE, uint32_t(order.size()));
+        if (rc) return rc;
+        a.n_avail = 1;
+        a.avail_cfg[0] = cfg;
+        a.min_size[0] = c.min_group_size;
+        a.max_size[0] = c.max_group_size;
+        a.g_cfg = e->d_m_cfg.p;
+        a.g_n = e->d_m_n.p;
+        a.g_off = e->d_m_off.p;
+        a.members = e->d_m_members.p;
+        a.cap_groups = uint32_t(cap);
+        a.cap_members = uint32_t(cap);
+        bool in_lds;
+        const size_t lds = carve_lds_bytes(a.bits_stride, &in_lds);
+        CarveStatus st{};
+        st.state = CARVE_STATE_RUNNING;
+        st.steps_total = e->tick_carve_steps;
+        if (!order.empty())
+          HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(launch_carve(a, lds, e->stream));
+        e->tick_carve_launches++;
+        HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "merge: batch arrays overflow");
+        if (st.state != CARVE_STATE_DONE && st.state != CARVE_STATE_UNCERTAIN)
+          return set_error(PM_ENODEV, "merge kernel did not complete");
+        const uint32_t nb = st.n_groups;
+        if (nb) {
+          std::vector<uint32_t> b_n(nb), b_off(nb), mem(st.n_members);
+          HIPCHK(hipMemcpyAsync(b_n.data(), e->d_m_n.p, nb * 4, hipMemcpyDeviceToHost, e->stream));
+          HIPCHK(hipMemcpyAsync(b_off.data(), e->d_m_off.p, nb * 4, hipMemcpyDeviceToHost, e->stream));
+          HIPCHK(hipMemcpyAsync(mem.data(), e->d_m_members.p, size_t(st.n_members) * 4, hipMemcpyDeviceToHost, e->stream));
+          HIPCHK(hipStreamSynchronize(e->stream));
+          for (uint32_t k = 0; k < nb; ++k)
+            batches.emplace_back(mem.begin() + b_off[k], mem.begin() + b_off[k] + b_n[k]);
+        }
+        e->tick_carve_steps = st.steps_total;
+        auto drop_used = [&](const std::vector<uint32_t>& used) {
+          order.erase(std::remove_if(order.begin(), order.end(),
+                                     [&](uint32_t w) { return std::find(used.begin(), used.end(), w) != used.end(); }),
+                      order.end());
+        };
+        order = rem;
+        for (const auto& b : batches) drop_used(b);
+        if (st.state == CARVE_STATE_DONE) break;
+        // UNCERTAIN: settle exactly this selection on the host, then let the kernel continue
+        if (order.size() < c.min_group_size) break;
+        std::vector<uint32_t> b;
+        host_merge_select(e, order, c, &b);
+        e->tick_host_resolved++;
+        e->tick_carve_steps++;
+        if (b.size() < 2) break;
+        batches.push_back(b);
+        drop_used(b);
+        if (order.size() < c.min_group_size) break;
+      }
+    }
+
+    // ---- apply the batches in order (is_merge_beneficial / should_switch_tasks / execute_group_merge)
+    for (const auto& b : batches) {
+      if (b.size() < 2) break;                 // mod.rs:868-870
+      if (!e->cfg.switching_enabled) break;    // mod.rs:263-265
+      bool blocked = false;
+      if (!e->cfg.prefer_larger_groups)        // mod.rs:277-287
+        for (uint32_t w : b)
+          if (e->groups[e->h_group_of[w]].task != PM_NONE) blocked = true;
+      if (blocked) break;
+      Group gr;
+      gr.id = splitmix64_next(&e->id_rng);  // mod.rs:886
+      gr.cfg = cfg;
+      gr.members = b;
+      gr.task = PM_NONE;
+      gr.task_uid = 0;
+      rc = pick_task_for_config(e, cfg, gr.id, &gr.task);  // find_best_task_for_group, mod.rs:896
+      if (rc) return rc;
+      if (gr.task != PM_NONE) gr.task_uid = e->tasks_have_uid ? e->h_tuid[gr.task] : gr.task;
+      std::vector<uint32_t> old_slots;
+      for (uint32_t w : b) old_slots.push_back(uint32_t(e->h_group_of[w]));
+      std::sort(old_slots.rbegin(), old_slots.rend());
+      for (uint32_t s : old_slots) e->groups.erase(e->groups.begin() + s);  // mod.rs:903-921
+      e->groups.push_back(std::move(gr));                                    // mod.rs:924-942
+      std::fill(e->h_group_of.begin(), e->h_group_of.end(), -1);
+      for (size_t g = 0; g < e->groups.size(); ++g)
+        for (uint32_t w : e->groups[g].members) e->h_group_of[w] = int32_t(g);
+      e->groups_dirty = true;
+      ++merged;
+    }
+  }
+  if (n_merged) *n_merged = merged;
+  return PM_OK;
+}
+
+}  // namespace pm
+
+// ================================================================================================
+// C ABI
+
+extern "C" {
+
+const char* pm_last_error(void) { return pm::g_last_error.c_str(); }
+
+void pm_engine_config_default(pm_engine_config* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->abi_version = PM_ABI_VERSION;
+  c->device = 0;
+  c->proximity_enabled = 1;
+  c->switching_enabled = 1;
+  c->prefer_larger_groups = 1;
+  c->chooser = PM_CHOOSE_FIRST;
+  c->group_id_seed = 1;
+}
+
+int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
+  if (!cfg || !out) return set_error(PM_EINVAL, "null argument");
+  if (cfg->abi_version != PM_ABI_VERSION) return set_error(PM_EINVAL, "ABI version mismatch");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return set_error(PM_ENODEV, "no HIP device visible: the matching engine needs an MI355X (gfx950); there is no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= n_dev) return set_error(PM_EINVAL, "device ordinal out of range");
+  HIPCHK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(PM_ENODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  pm_engine* e = new (std::nothrow) pm_engine();
+  if (!e) return set_error(PM_ENOMEM, "out of host memory");
+  e->cfg = *cfg;
+  e->id_rng = cfg->group_id_seed;
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete e;
+    return set_error(PM_ENODEV, "hipStreamCreate failed");
+  }
+  for (auto& ev : e->ev)
+    if (hipEventCreate(&ev) != hipSuccess) {
+      delete e;
+      return set_error(PM_ENODEV, "hipEventCreate failed");
+    }
+  for (auto& ev : e->kev)
+    if (hipEventCreate(&ev) != hipSuccess) {
+      delete e;
+      return set_error(PM_ENODEV, "hipEventCreate failed");
+    }
+  *out = e;
+  return PM_OK;
+}
+
+void pm_engine_destroy(pm_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipStreamSynchronize(e->stream);
+  e->d_cfgs.release(); e->d_alts.release(); e->d_model_bits.release();
+  e->d_flags.release(); e->d_gpu_count.release(); e->d_gpu_mem.release(); e->d_gpu_cls.release();
+  e->d_cpu_cores.release(); e->d_ram.release(); e->d_storage.release(); e->d_addr_rank.release();
+  e->d_lat.release(); e->d_lon.release(); e->d_coslat.release(); e->d_compat.release();
+  e->d_tmask.release(); e->d_tplanes.release(); e->d_created.release();
+  e->d_group_of.release(); e->d_g_cfg.release(); e->d_g_n.release(); e->d_g_off.release();
+  e->d_g_task.release(); e->d_g_task_next.release(); e->d_members.release(); e->d_by_rank.release();
+  e->d_rank_in_group.release(); e->d_g_id.release();
+  e->d_order.release(); e->d_c_lat.release(); e->d_c_lon.release(); e->d_c_cos.release();
+  e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release();
+  e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
+  e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release(); e->d_scratch.release();
+  e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
+  e->d_table.release(); e->d_task_col.release(); e->d_nb_idx.release(); e->d_nb_val.release();
+  if (e->h_table_pinned) (void)hipHostFree(e->h_table_pinned);
+  for (auto& ev : e->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->kev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int32_t pm_set_configs(pm_engine* e, const pm_config_row* cfgs, uint32_t n_cfgs, const pm_gpu_alt_row* alts,
+                       uint32_t n_alts) {
+  if (!e || (n_cfgs && !cfgs) || (n_alts && !alts)) return set_error(PM_EINVAL, "null argument");
+  if (n_cfgs > PM_MAX_CONFIGS) return set_error(PM_EINVAL, "more than PM_MAX_CONFIGS configurations");
+  for (uint32_t i = 0; i < n_cfgs; ++i) {
+    if (cfgs[i].max_group_size < cfgs[i].min_group_size)
+      return set_error(PM_EINVAL, "Plugin configuration is invalid (max_group_size < min_group_size)");  // mod.rs:145
+    if (cfgs[i].min_group_size == 0)
+      return set_error(PM_EINVAL, "min_group_size == 0 is rejected (the reference would form empty groups forever)");
+    if (uint64_t(cfgs[i].alt_begin) + cfgs[i].alt_count > n_alts)
+      return set_error(PM_ERANGE, "alternative range outside the alt table");
+  }
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->cfgs.assign(cfgs, cfgs + n_cfgs);
+  e->alts.assign(alts, alts + n_alts);
+  int32_t rc = upload(e->d_cfgs, e->cfgs.data(), e->cfgs.size(), e->stream);
+  if (rc) return rc;
+  rc = upload(e->d_alts, e->alts.data(), e->alts.size(), e->stream);
+  if (rc) return rc;
+  HIPCHK(e->d_model_bits.ensure(1));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->have_cfgs = true;
+  e->compat_dirty = true;
+  e->tplanes_dirty = true;
+  return PM_OK;
+}
+
+int32_t pm_set_model_table(pm_engine* e, const uint32_t* bits, uint32_t n_rows, uint32_t n_classes) {
+  if (!e || (n_rows && n_classes && !bits)) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const size_t words = size_t(n_rows) * ((n_classes + 31u) / 32u);
+  e->model_bits.assign(bits, bits + words);
+  e->model_rows = n_rows;
+  e->model_classes = n_classes;
+  int32_t rc = upload(e->d_model_bits, e->model_bits.data(), words, e->stream);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->compat_dirty = true;
+  return PM_OK;
+}
+
+int32_t pm_set_enabled_mask(pm_engine* e, uint64_t enabled) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->enabled = enabled;
+  return PM_OK;
+}
+
+static int32_t upload_worker_columns(pm_engine* e) {
+  const size_t W = e->W;
+  int32_t rc;
+  if ((rc = upload(e->d_flags, e->h_flags.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_gpu_count, e->h_gpu_count.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_gpu_mem, e->h_gpu_mem.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_gpu_cls, e->h_gpu_cls.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_cpu_cores, e->h_cpu_cores.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_ram, e->h_ram.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_storage, e->h_storage.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_addr_rank, e->h_addr_rank.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_lat, e->h_lat.data(), W, e->stream))) return rc;
+  if ((rc = upload(e->d_lon, e->h_lon.data(), W, e->stream))) return rc;
+  HIPCHK(e->d_coslat.ensure(W ? W : 1));
+  launch_coslat(e->d_lat.p, e->d_coslat.p, uint32_t(W), e->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->any_price = std::any_of(e->h_price.begin(), e->h_price.end(), [](uint32_t p) { return p != 0; });
+  e->price_perm.clear();
+  if (e->any_price) {
+    e->price_perm.resize(W);
+    for (uint32_t i = 0; i < W; ++i) e->price_perm[i] = i;
+    std::stable_sort(e->price_perm.begin(), e->price_perm.end(),
+                     [&](uint32_t a, uint32_t b) { return e->h_price[a] < e->h_price[b]; });
+  }
+  e->compat_dirty = true;
+  return PM_OK;
+}
+
+int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_groups) {
+  if (!e || !w) return set_error(PM_EINVAL, "null argument");
+  const uint32_t n = w->n;
+  if (n && (!w->flags || !w->gpu_count || !w->gpu_mem_mb || !w->gpu_model_class || !w->cpu_cores || !w->ram_mb ||
+            !w->storage_gb || !w->lat || !w->lon))
+    return set_error(PM_EINVAL, "null worker column");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (keep_groups && e->have_workers && n != e->W)
+    return set_error(PM_EINVAL, "keep_groups requires an unchanged worker count");
+  e->W = n;
+  e->h_flags.assign(w->flags, w->flags + n);
+  e->h_gpu_count.assign(w->gpu_count, w->gpu_count + n);
+  e->h_gpu_mem.assign(w->gpu_mem_mb, w->gpu_mem_mb + n);
+  e->h_gpu_cls.assign(w->gpu_model_class, w->gpu_model_class + n);
+  e->h_cpu_cores.assign(w->cpu_cores, w->cpu_cores + n);
+  e->h_ram.assign(w->ram_mb, w->ram_mb + n);
+  e->h_storage.assign(w->storage_gb, w->storage_gb + n);
+  if (w->price) e->h_price.assign(w->price, w->price + n); else e->h_price.assign(n, 0);
+  if (w->addr_rank) {
+    e->h_addr_rank.assign(w->addr_rank, w->addr_rank + n);
+  } else {
+    e->h_addr_rank.resize(n);
+    for (uint32_t i = 0; i < n; ++i) e->h_addr_rank[i] = i;
+  }
+  e->h_lat.assign(w->lat, w->lat + n);
+  e->h_lon.assign(w->lon, w->lon + n);
+  int32_t rc = upload_worker_columns(e);
+  if (rc) return rc;
+  e->have_workers = true;
+  if (!keep_groups || e->h_group_of.size() != n) reset_groups_locked(e);
+  e->groups_dirty = true;
+  return PM_OK;
+}
+
+int32_t pm_update_workers(pm_engine* e, const uint32_t* idx, const pm_worker_soa* rows) {
+  if (!e || !rows || (rows->n && !idx)) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->have_workers) return set_error(PM_ESTATE, "workers must be uploaded first");
+  if (rows->n && (!rows->flags || !rows->gpu_count || !rows->gpu_mem_mb || !rows->gpu_model_class ||
+                  !rows->cpu_cores || !rows->ram_mb || !rows->storage_gb || !rows->lat || !rows->lon))
+    return set_error(PM_EINVAL, "null worker column");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  for (uint32_t k = 0; k < rows->n; ++k)
+    if (idx[k] >= e->W) return set_error(PM_ERANGE, "worker index out of range");
+  for (uint32_t k = 0; k < rows->n; ++k) {
+    const uint32_t w = idx[k];
+    e->h_flags[w] = rows->flags[k];
+    e->h_gpu_count[w] = rows->gpu_count[k];
+    e->h_gpu_mem[w] = rows->gpu_mem_mb[k];
+    e->h_gpu_cls[w] = rows->gpu_model_class[k];
+    e->h_cpu_cores[w] = rows->cpu_cores[k];
+    e->h_ram[w] = rows->ram_mb[k];
+    e->h_storage[w] = rows->storage_gb[k];
+    if (rows->price) e->h_price[w] = rows->price[k];
+    if (rows->addr_rank) e->h_addr_rank[w] = rows->addr_rank[k];
+    e->h_lat[w] = rows->lat[k];
+    e->h_lon[w] = rows->lon[k];
+  }
+  return upload_worker_columns(e);
+}
+
+int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
+  if (!e || !t) return set_error(PM_EINVAL, "null argument");
+  if (t->n && (!t->topo_mask || !t->created_at)) return set_error(PM_EINVAL, "null task column");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->T = t->n;
+  e->h_tmask.assign(t->topo_mask, t->topo_mask + t->n);
+  e->h_created.assign(t->created_at, t->created_at + t->n);
+  e->tasks_have_uid = t->uid != nullptr;
+  if (t->uid) e->h_tuid.assign(t->uid, t->uid + t->n); else e->h_tuid.clear();
+  int32_t rc = upload(e->d_tmask, e->h_tmask.data(), e->T, e->stream);
+  if (rc) return rc;
+  rc = upload(e->d_created, e->h_created.data(), e->T, e->stream);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->have_tasks = true;
+  e->tplanes_dirty = true;
+  // re-bind claimed tasks by identity; groups whose task vanished are dissolved (on_task_deleted,
+  // mod.rs:1259-1288)
+  bool any_claim = false;
+  for (const Group& g : e->groups) any_claim |= g.task != PM_NONE;
+  if (any_claim) {
+    std::unordered_map<uint64_t, uint32_t> by_uid;
+    if (e->tasks_have_uid) {
+      by_uid.reserve(e->T * 2);
+      for (uint32_t i = 0; i < e->T; ++i) by_uid.emplace(e->h_tuid[i], i);
+    }
+    for (size_t g = e->groups.size(); g-- > 0;) {
+      Group& gr = e->groups[g];
+      if (gr.task == PM_NONE) continue;
+      uint32_t ni = PM_NONE;
+      if (e->tasks_have_uid) {
+        auto it = by_uid.find(gr.task_uid);
+        if (it != by_uid.end()) ni = it->second;
+      } else if (gr.task_uid < e->T) {
+        ni = uint32_t(gr.task_uid);
+      }
+      if (ni == PM_NONE) {
+        dissolve_locked(e, uint32_t(g));
+      } else if (ni != gr.task) {
+        gr.task = ni;
+        e->groups_dirty = true;
+      }
+    }
+  }
+  return PM_OK;
+}
+
+int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, uint32_t dead) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->have_workers || worker >= e->W) return set_error(PM_ERANGE, "worker index out of range");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->h_flags[worker] = flags_new;
+  HIPCHK(hipMemcpyAsync(e->d_flags.p + worker, &e->h_flags[worker], 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->compat_dirty = true;  // HAS_SPECS etc. may have changed with the row
+  if (dead && e->h_group_of[worker] >= 0) dissolve_locked(e, uint32_t(e->h_group_of[worker]));  // status_update_impl.rs:17-29
+  return PM_OK;
+}
+
+int32_t pm_dissolve_group(pm_engine* e, uint32_t slot) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (slot >= e->groups.size()) return set_error(PM_ERANGE, "group slot out of range");
+  dissolve_locked(e, slot);
+  return PM_OK;
+}
+
+int32_t pm_reset_groups(pm_engine* e) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  reset_groups_locked(e);
+  return PM_OK;
+}
+
+int32_t pm_compat_masks(pm_engine* e, uint64_t* mask_out) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int32_t rc = ensure_compat(e);
+  if (rc) return rc;
+  if (mask_out && e->W) {
+    HIPCHK(hipMemcpyAsync(mask_out, e->d_compat.p, size_t(e->W) * 8, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PM_OK;
+}
+
+int32_t pm_form_groups(pm_engine* e, uint32_t* n_formed) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
+  int32_t rc = run_form(e, n_formed);
+  e->last_stats.host_resolved_steps = e->tick_host_resolved;
+  e->last_stats.carve_launches = e->tick_carve_launches;
+  e->last_stats.carve_steps = e->tick_carve_steps;
+  return rc;
+}
+
+int32_t pm_merge_solo_groups(pm_engine* e, uint32_t* n_merged) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
+  int32_t rc = run_merge(e, n_merged);
+  e->last_stats.host_resolved_steps = e->tick_host_resolved;
+  e->last_stats.carve_launches = e->tick_carve_launches;
+  e->last_stats.carve_steps = e->tick_carve_steps;
+  return rc;
+}
+
+int32_t pm_get_groups(pm_engine* e, int32_t* group_of_worker, pm_group* groups, uint32_t cap_groups,
+                      uint32_t* n_groups, uint32_t* members, uint32_t cap_members, uint32_t* n_members) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  const uint32_t G = uint32_t(e->groups.size());
+  uint32_t M = 0;
+  for (const Group& g : e->groups) M += uint32_t(g.members.size());
+  if (n_groups) *n_groups = G;
+  if (n_members) *n_members = M;
+  if (group_of_worker) std::copy(e->h_group_of.begin(), e->h_group_of.end(), group_of_worker);
+  if (groups && cap_groups < G) return set_error(PM_ERANGE, "groups buffer too small");
+  if (members && cap_members < M) return set_error(PM_ERANGE, "members buffer too small");
+  uint32_t off = 0;
+  for (uint32_t g = 0; g < G; ++g) {
+    const Group& gr = e->groups[g];
+    if (groups) {
+      groups[g].id = gr.id;
+      groups[g].config = gr.cfg;
+      groups[g].n_members = uint32_t(gr.members.size());
+      groups[g].member_begin = off;
+      groups[g].task = gr.task;
+    }
+    if (members) {
+      std::vector<uint32_t> m = gr.members;  // BTreeSet<String> order = address rank
+      std::sort(m.begin(), m.end(), [&](uint32_t a, uint32_t b) { return e->h_addr_rank[a] < e->h_addr_rank[b]; });
+      std::copy(m.begin(), m.end(), members + off);
+    }
+    off += uint32_t(gr.members.size());
+  }
+  return PM_OK;
+}
+
+int32_t pm_match(pm_engine* e, uint32_t* task_of_worker, uint32_t* applicable_count) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  std::vector<uint32_t> cnt;
+  int32_t rc = run_match(e, applicable_count != nullptr, &cnt);
+  if (rc) return rc;
+  rc = publish(e);
+  if (rc) return rc;
+  if (task_of_worker)
+    for (uint32_t w = 0; w < e->W; ++w) task_of_worker[w] = e->h_table_pinned[w].task;
+  if (applicable_count) std::copy(cnt.begin(), cnt.end(), applicable_count);
+  return PM_OK;
+}
+
+int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candidate_count) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
+  int32_t rc = ensure_compat(e);
+  if (rc) return rc;
+  rc = push_groups(e);
+  if (rc) return rc;
+  const int variant = int(e->cfg.sweep_variant);
+  const uint32_t n_planes = uint32_t(e->cfgs.size());
+  uint32_t max_chunks = 0;
+  rc = ensure_sweep_scratch(e, e->T, e->W, &max_chunks);
+  if (rc) return rc;
+  HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
+  launch_eligible_selector(e->d_flags.p, e->d_group_of.p, e->d_compat.p, e->enabled, e->W, e->d_sel.p, e->stream);
+  const uint64_t* cols = e->d_sel.p;
+  if (e->any_price) {  // order the swept axis by (price, index) so "first hit" is the best bid
+    HIPCHK(e->d_perm.ensure(e->W));
+    HIPCHK(e->d_sel_perm.ensure(e->W));
+    std::vector<uint64_t> sel(e->W), selp(e->W);
+    HIPCHK(hipMemcpyAsync(sel.data(), e->d_sel.p, size_t(e->W) * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (uint32_t i = 0; i < e->W; ++i) selp[i] = sel[e->price_perm[i]];
+    HIPCHK(hipMemcpyAsync(e->d_sel_perm.p, selp.data(), size_t(e->W) * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    cols = e->d_sel_perm.p;
+  }
+  if (variant != 1) {
+    const size_t n_words = (size_t(e->W) + 63) / 64;
+    HIPCHK(e->d_wplanes.ensure(std::max<size_t>(n_words * n_planes, 1)));
+    launch_build_planes(cols, e->W, n_planes, e->d_wplanes.p, e->stream);
+  }
+  launch_pair_sweep(variant, e->d_tmask.p, e->T, cols, e->d_wplanes.p, e->W, n_planes, e->d_scratch.p, max_chunks,
+                    e->d_first.p, e->d_count.p, e->stream);
+  HIPCHK(hipGetLastError());
+  if (best_worker && e->T)
+    HIPCHK(hipMemcpyAsync(best_worker, e->d_first.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
+  if (candidate_count && e->T)
+    HIPCHK(hipMemcpyAsync(candidate_count, e->d_count.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (best_worker && e->any_price)
+    for (uint32_t t = 0; t < e->T; ++t)
+      if (best_worker[t] != PM_NONE) best_worker[t] = e->price_perm[best_worker[t]];
+  return PM_OK;
+}
+
+int32_t pm_newest_task(pm_engine* e, uint32_t* task_idx) {
+  if (!e || !task_idx) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
+  *task_idx = PM_NONE;
+  if (e->T == 0) return PM_OK;
+  const uint32_t nb = std::min<uint32_t>(1024, (e->T + 255u) / 256u);
+  HIPCHK(e->d_nb_idx.ensure(nb));
+  HIPCHK(e->d_nb_val.ensure(nb));
+  launch_newest(e->d_created.p, e->T, e->d_nb_idx.p, e->d_nb_val.p, nb, e->stream);
+  HIPCHK(hipGetLastError());
+  std::vector<uint32_t> bi(nb);
+  std::vector<long long> bv(nb);
+  HIPCHK(hipMemcpyAsync(bi.data(), e->d_nb_idx.p, nb * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(bv.data(), e->d_nb_val.p, nb * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  uint32_t best = PM_NONE;
+  long long bval = 0;
+  for (uint32_t k = 0; k < nb; ++k) {
+    if (bi[k] == PM_NONE) continue;
+    if (best == PM_NONE || bv[k] > bval || (bv[k] == bval && bi[k] > best)) {
+      best = bi[k];
+      bval = bv[k];
+    }
+  }
+  *task_idx = best;
+  return PM_OK;
+}
+
+int32_t pm_tick(pm_engine* e, pm_stats* stats) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
+    return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
+  e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
+  e->tick_cand_sum = 0;
+  e->k_ms_compat = e->k_ms_carve = e->k_ms_sweep = 0;
+  e->k_sweep_recorded = e->k_compat_recorded = false;
+  uint32_t n_formed = 0, n_merged = 0;
+  HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  int32_t rc = ensure_compat(e);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev[1], e->stream));
+  rc = run_form(e, &n_formed);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev[2], e->stream));
+  rc = run_merge(e, &n_merged);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev[3], e->stream));
+  rc = run_match(e, false, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev[4], e->stream));
+  rc = publish(e);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev[5], e->stream));
+  HIPCHK(hipEventSynchronize(e->ev[5]));
+  pm_stats s{};
+  HIPCHK(hipEventElapsedTime(&s.ms_compat, e->ev[0], e->ev[1]));
+  HIPCHK(hipEventElapsedTime(&s.ms_carve, e->ev[1], e->ev[2]));
+  HIPCHK(hipEventElapsedTime(&s.ms_merge, e->ev[2], e->ev[3]));
+  HIPCHK(hipEventElapsedTime(&s.ms_sweep, e->ev[3], e->ev[4]));
+  HIPCHK(hipEventElapsedTime(&s.ms_publish, e->ev[4], e->ev[5]));
+  HIPCHK(hipEventElapsedTime(&s.ms_total, e->ev[0], e->ev[5]));
+  if (e->k_compat_recorded) HIPCHK(hipEventElapsedTime(&s.ms_compat_kernel, e->kev[0], e->kev[1]));
+  if (e->k_sweep_recorded) HIPCHK(hipEventElapsedTime(&s.ms_sweep_kernel, e->kev[4], e->kev[5]));
+  s.ms_carve_kernel = e->k_ms_carve;
+  s.carve_cand_sum = e->tick_cand_sum;
+  s.n_groups = uint32_t(e->groups.size());
+  s.n_formed = n_formed;
+  s.n_merged = n_merged;
+  s.carve_steps = e->tick_carve_steps;
+  s.host_resolved_steps = e->tick_host_resolved;
+  s.carve_launches = e->tick_carve_launches;
+  s.pair_evals = uint64_t(e->T) * uint64_t(e->W);
+  e->last_stats = s;
+  if (stats) *stats = s;
+  return PM_OK;
+}
+
+int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t worker, pm_assignment* out) {
+  if (!e || !out) return set_error(PM_EINVAL, "null argument");
+  std::shared_ptr<const Table> t = std::atomic_load_explicit(&e->published, std::memory_order_acquire);
+  if (!t) return set_error(PM_ESTATE, "no assignment table published yet");
+  if (worker >= t->size()) return set_error(PM_ERANGE, "worker index out of range");
+  *out = (*t)[worker];
+  return PM_OK;
+}
+
+int32_t pm_device_task_column(pm_engine* e, uint64_t* device_ptr, uint32_t* n) {
+  if (!e || !device_ptr || !n) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->d_task_col.p) return set_error(PM_ESTATE, "no assignment table computed yet");
+  *device_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_task_col.p));
+  *n = e->W;
+  return PM_OK;
+}
+
+int32_t pm_last_stats(pm_engine* e, pm_stats* stats) {
+  if (!e || !stats) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  *stats = e->last_stats;
+  return PM_OK;
+}
+
+}  // extern "C"

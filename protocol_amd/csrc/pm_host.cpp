@@ -1,0 +1,270 @@
+// pm_host.cpp — host-side mirror of the reference's configuration front end (no GPU needed):
+//   ComputeRequirements::from_str      crates/shared/src/models/node.rs:180-374
+//   GpuSpecs::meets model-string rule  crates/shared/src/models/node.rs:463-484
+//   config priority order              crates/orchestrator/src/plugins/node_groups/mod.rs:150-164, :399-418
+// This is product code: it shares nothing with oracle/, which restates the same rules separately so
+// the two can be checked against each other and against the reference's known-answer tests.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "pm_engine.h"
+#include "pm_internal.h"
+
+namespace pm {
+
+namespace {
+
+constexpr std::string_view kWs = " \t\n\v\f\r";  // ASCII subset of char::is_whitespace (str::trim)
+
+std::string_view trim(std::string_view s) {
+  const size_t b = s.find_first_not_of(kWs);
+  if (b == std::string_view::npos) return {};
+  const size_t e = s.find_last_not_of(kWs);
+  return s.substr(b, e - b + 1);
+}
+
+// <u32 as FromStr>: optional '+', at least one ASCII digit, no overflow.
+bool parse_u32(std::string_view s, uint32_t* out) {
+  if (!s.empty() && s.front() == '+') s.remove_prefix(1);
+  if (s.empty()) return false;
+  uint64_t v = 0;
+  for (char c : s) {
+    if (c < '0' || c > '9') return false;
+    v = v * 10 + uint64_t(c - '0');
+    if (v > 0xFFFFFFFFull) return false;
+  }
+  *out = uint32_t(v);
+  return true;
+}
+
+std::string normalize_model(std::string_view s) {  // to_lowercase().replace(' ', "_"), ASCII
+  std::string o(s);
+  for (char& c : o) {
+    if (c >= 'A' && c <= 'Z') c = char(c - 'A' + 'a');
+    if (c == ' ') c = '_';
+  }
+  return o;
+}
+std::string drop_underscores(const std::string& s) {
+  std::string o;
+  o.reserve(s.size());
+  for (char c : s)
+    if (c != '_') o.push_back(c);
+  return o;
+}
+bool contains(const std::string& hay, const std::string& needle) { return hay.find(needle) != std::string::npos; }
+
+}  // namespace
+
+bool model_matches(std::string_view spec_model, std::string_view req_model) {
+  const std::string ns = normalize_model(spec_model);  // node.rs:465
+  const std::string ns_nu = drop_underscores(ns);      // :473
+  size_t pos = 0;
+  for (;;) {  // req_model.split(',') — an empty string still yields one (empty) part
+    const size_t comma = req_model.find(',', pos);
+    const std::string_view part =
+        req_model.substr(pos, comma == std::string_view::npos ? std::string_view::npos : comma - pos);
+    const std::string nr = normalize_model(trim(part));  // :468-470
+    const std::string nr_nu = drop_underscores(nr);      // :474
+    if (contains(ns, nr) || contains(nr, ns) || contains(ns_nu, nr_nu) || contains(nr_nu, ns_nu)) return true;
+    if (comma == std::string_view::npos) break;
+    pos = comma + 1;
+  }
+  return false;
+}
+
+// Parsed requirement with owned model strings.
+int32_t parse_requirements(std::string_view s, ParsedRequirements* out) {
+  out->flags = 0;
+  out->cpu_cores = out->ram_mb = out->storage_gb = 0;
+  out->alts.clear();
+  out->models.clear();
+  pm_gpu_alt_row cur{};
+  std::string cur_model;
+  bool started = false;  // gpu_spec_started, node.rs:185
+  auto push_cur = [&]() {
+    out->alts.push_back(cur);
+    out->models.push_back(cur_model);
+    cur = pm_gpu_alt_row{};
+    cur_model.clear();
+  };
+  size_t pos = 0;
+  for (;;) {
+    const size_t semi = s.find(';', pos);
+    std::string_view part = trim(s.substr(pos, semi == std::string_view::npos ? std::string_view::npos : semi - pos));
+    if (!part.empty()) {
+      const size_t eq = part.find('=');  // splitn(2, '=')
+      if (eq == std::string_view::npos) return set_error(PM_EPARSE, "Invalid key-value pair format");
+      const std::string_view key = trim(part.substr(0, eq));
+      const std::string_view value = trim(part.substr(eq + 1));
+      uint32_t v = 0;
+      const bool num = parse_u32(value, &v);
+      if (key == "gpu:count") {  // :203-216
+        if (started && (cur.flags & PM_G_COUNT)) push_cur();
+        started = true;
+        if (!num) return set_error(PM_EPARSE, "Invalid gpu:count value");
+        cur.flags |= PM_G_COUNT;
+        cur.count = v;
+      } else if (key == "gpu:model") {  // :217-222
+        started = true;
+        cur.flags |= PM_G_MODEL;
+        cur_model.assign(value);
+      } else if (key == "gpu:memory_mb") {  // :223-238
+        started = true;
+        if (cur.flags & (PM_G_MEM_MIN | PM_G_MEM_MAX))
+          return set_error(PM_EPARSE, "Cannot specify both exact memory and min/max memory");
+        if (!num) return set_error(PM_EPARSE, "Invalid gpu:memory_mb value");
+        cur.flags |= PM_G_MEM;
+        cur.memory_mb = v;
+      } else if (key == "gpu:memory_mb_min") {  // :239-262
+        started = true;
+        if (cur.flags & PM_G_MEM) return set_error(PM_EPARSE, "Cannot specify both exact memory and min/max memory");
+        if (cur.flags & PM_G_MEM_MAX) {
+          if (!num) return set_error(PM_EPANIC, "reference panics: unwrap on non-numeric gpu:memory_mb_min");
+          if (cur.memory_mb_max < v) return set_error(PM_EPARSE, "min value is greater than max value");
+        }
+        if (!num) return set_error(PM_EPARSE, "Invalid gpu:memory_mb_min value");
+        cur.flags |= PM_G_MEM_MIN;
+        cur.memory_mb_min = v;
+      } else if (key == "gpu:memory_mb_max") {  // :263-288
+        started = true;
+        if (cur.flags & PM_G_MEM) return set_error(PM_EPARSE, "Cannot specify both exact memory and min/max memory");
+        if (cur.flags & PM_G_MEM_MIN) {
+          if (!num) return set_error(PM_EPANIC, "reference panics: unwrap on non-numeric gpu:memory_mb_max");
+          if (cur.memory_mb_min > v) return set_error(PM_EPARSE, "max value is less than min value");
+        }
+        if (!num) return set_error(PM_EPARSE, "Invalid gpu:memory_mb_max value");
+        cur.flags |= PM_G_MEM_MAX;
+        cur.memory_mb_max = v;
+      } else if (key == "gpu:total_memory_min") {  // :290-310
+        started = true;
+        if (cur.flags & PM_G_TOT_MAX) {
+          if (!num) return set_error(PM_EPANIC, "reference panics: unwrap on non-numeric gpu:total_memory_min");
+          if (cur.total_memory_max < v) return set_error(PM_EPARSE, "min value is greater than max value");
+        }
+        if (!num) return set_error(PM_EPARSE, "Invalid gpu:total_memory_min value");
+        cur.flags |= PM_G_TOT_MIN;
+        cur.total_memory_min = v;
+      } else if (key == "gpu:total_memory_max") {  // :311-331
+        started = true;
+        if (cur.flags & PM_G_TOT_MIN) {
+          if (!num) return set_error(PM_EPANIC, "reference panics: unwrap on non-numeric gpu:total_memory_max");
+          if (cur.total_memory_min > v) return set_error(PM_EPARSE, "max value is less than min value");
+        }
+        if (!num) return set_error(PM_EPARSE, "Invalid gpu:total_memory_max value");
+        cur.flags |= PM_G_TOT_MAX;
+        cur.total_memory_max = v;
+      } else if (key == "cpu:cores") {  // :333-341
+        if (!num) return set_error(PM_EPARSE, "Invalid cpu:cores value");
+        out->flags |= PM_R_CPU | PM_R_CPU_CORES;
+        out->cpu_cores = v;
+      } else if (key == "ram_mb") {  // :344-350
+        if (!num) return set_error(PM_EPARSE, "Invalid ram_mb value");
+        out->flags |= PM_R_RAM;
+        out->ram_mb = v;
+      } else if (key == "storage_gb") {  // :351-357
+        if (!num) return set_error(PM_EPARSE, "Invalid storage_gb value");
+        out->flags |= PM_R_STORAGE;
+        out->storage_gb = v;
+      } else {
+        return set_error(PM_EPARSE, "Unknown requirement key");  // :358
+      }
+    }
+    if (semi == std::string_view::npos) break;
+    pos = semi + 1;
+  }
+  if (started && cur.flags != 0) push_cur();  // :360-370
+  return PM_OK;
+}
+
+// Constructor sort (mod.rs:150-164): min_group_size desc, then with-requirements first; stable.
+void template_order(const pm_config_row* cfgs, uint32_t n, std::vector<uint32_t>* order) {
+  order->resize(n);
+  for (uint32_t i = 0; i < n; ++i) (*order)[i] = i;
+  std::stable_sort(order->begin(), order->end(), [&](uint32_t a, uint32_t b) {
+    if (cfgs[a].min_group_size != cfgs[b].min_group_size) return cfgs[a].min_group_size > cfgs[b].min_group_size;
+    return (cfgs[a].flags & PM_R_HAS_REQ) && !(cfgs[b].flags & PM_R_HAS_REQ);
+  });
+}
+
+// get_available_configurations (mod.rs:399-418): enabled filter, then stable min_group_size desc.
+void available_order(const pm_config_row* cfgs, uint32_t n, uint64_t enabled, std::vector<uint32_t>* out) {
+  std::vector<uint32_t> tmpl;
+  template_order(cfgs, n, &tmpl);
+  out->clear();
+  for (uint32_t c : tmpl)
+    if ((enabled >> c) & 1ull) out->push_back(c);
+  std::stable_sort(out->begin(), out->end(),
+                   [&](uint32_t a, uint32_t b) { return cfgs[a].min_group_size > cfgs[b].min_group_size; });
+}
+
+}  // namespace pm
+
+extern "C" {
+
+int32_t pm_host_parse_requirements(const char* s, pm_config_row* cfg, pm_gpu_alt_row* alts, uint32_t alt_cap,
+                                   char* models_out, size_t models_cap) {
+  if (!s || !cfg) return pm::set_error(PM_EINVAL, "null argument");
+  pm::ParsedRequirements pr;
+  const int32_t rc = pm::parse_requirements(s, &pr);
+  if (rc != PM_OK) return rc;
+  if (pr.alts.size() > alt_cap) return pm::set_error(PM_ERANGE, "too many GPU alternatives for the caller buffer");
+  cfg->flags = (cfg->flags & ~uint32_t(PM_R_CPU | PM_R_CPU_CORES | PM_R_RAM | PM_R_STORAGE)) | pr.flags | PM_R_HAS_REQ;
+  cfg->cpu_cores = pr.cpu_cores;
+  cfg->ram_mb = pr.ram_mb;
+  cfg->storage_gb = pr.storage_gb;
+  cfg->alt_count = uint32_t(pr.alts.size());
+  size_t off = 0;
+  for (size_t i = 0; i < pr.alts.size(); ++i) {
+    pm_gpu_alt_row a = pr.alts[i];
+    a.model_row = 0;
+    if (a.flags & PM_G_MODEL) {
+      const std::string& m = pr.models[i];
+      if (!models_out || off + m.size() + 1 > models_cap)
+        return pm::set_error(PM_ERANGE, "model string buffer too small");
+      std::memcpy(models_out + off, m.c_str(), m.size() + 1);
+      a.model_row = uint32_t(off);
+      off += m.size() + 1;
+    }
+    if (alts) alts[i] = a;
+  }
+  return PM_OK;
+}
+
+int32_t pm_host_model_matches(const char* spec_model, const char* req_model) {
+  if (!spec_model || !req_model) return pm::set_error(PM_EINVAL, "null argument");
+  return pm::model_matches(spec_model, req_model) ? 1 : 0;
+}
+
+int32_t pm_host_build_model_table(const char* const* req_models, uint32_t n_rows, const char* const* spec_models,
+                                  uint32_t n_classes, uint32_t* bits_out) {
+  if ((n_rows && !req_models) || (n_classes && !spec_models) || !bits_out)
+    return pm::set_error(PM_EINVAL, "null argument");
+  const uint32_t words = (n_classes + 31u) / 32u;
+  std::memset(bits_out, 0, sizeof(uint32_t) * size_t(n_rows) * words);
+  for (uint32_t r = 0; r < n_rows; ++r)
+    for (uint32_t c = 0; c < n_classes; ++c)
+      if (pm::model_matches(spec_models[c], req_models[r])) bits_out[size_t(r) * words + (c >> 5)] |= 1u << (c & 31u);
+  return PM_OK;
+}
+
+int32_t pm_host_config_order(const pm_config_row* cfgs, uint32_t n_cfgs, uint64_t enabled, uint32_t* order_out,
+                             uint32_t* n_out) {
+  if ((n_cfgs && !cfgs) || !order_out || !n_out) return pm::set_error(PM_EINVAL, "null argument");
+  if (n_cfgs > PM_MAX_CONFIGS) return pm::set_error(PM_EINVAL, "more than PM_MAX_CONFIGS configurations");
+  for (uint32_t i = 0; i < n_cfgs; ++i)
+    if (cfgs[i].max_group_size < cfgs[i].min_group_size)
+      return pm::set_error(PM_EINVAL, "Plugin configuration is invalid (max_group_size < min_group_size)");
+  std::vector<uint32_t> o;
+  pm::available_order(cfgs, n_cfgs, enabled, &o);
+  for (size_t i = 0; i < o.size(); ++i) order_out[i] = o[i];
+  *n_out = uint32_t(o.size());
+  return PM_OK;
+}
+
+uint32_t pm_abi_version(void) { return PM_ABI_VERSION; }
+
+}  // extern "C"

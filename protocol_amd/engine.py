@@ -1,0 +1,318 @@
+"""ctypes binding of include/pm_engine.h (libpm_engine.so).
+
+This is plumbing for tests and bench.py: every call goes straight through the C ABI.  Loading fails
+loudly if the library has not been built, and Engine() fails with PM_ENODEV when no MI355X is
+visible — there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+PM_NONE = 0xFFFFFFFF
+PM_MAX_CONFIGS = 64
+PM_OK, PM_EINVAL, PM_ENODEV, PM_ENOMEM, PM_ESTATE, PM_ERANGE, PM_EPARSE, PM_EPANIC = 0, -1, -2, -3, -4, -5, -6, -7
+CHOOSE_FIRST, CHOOSE_SEEDED = 0, 1
+
+# worker flag bits
+(W_HAS_SPECS, W_HAS_GPU, W_GPU_COUNT, W_GPU_MEM, W_GPU_MODEL, W_HAS_CPU, W_CPU_CORES, W_RAM, W_STORAGE,
+ W_HEALTHY, W_HAS_P2P, W_HAS_LOC) = (1 << i for i in range(12))
+R_HAS_REQ, R_CPU, R_CPU_CORES, R_RAM, R_STORAGE = (1 << i for i in range(5))
+G_COUNT, G_MODEL, G_MEM, G_MEM_MIN, G_MEM_MAX, G_TOT_MIN, G_TOT_MAX = (1 << i for i in range(7))
+
+config_row_dt = np.dtype([("flags", "<u4"), ("cpu_cores", "<u4"), ("ram_mb", "<u4"), ("storage_gb", "<u4"),
+                          ("alt_begin", "<u4"), ("alt_count", "<u4"), ("min_group_size", "<u4"),
+                          ("max_group_size", "<u4")], align=True)
+alt_row_dt = np.dtype([("flags", "<u4"), ("count", "<u4"), ("memory_mb", "<u4"), ("memory_mb_min", "<u4"),
+                       ("memory_mb_max", "<u4"), ("total_memory_min", "<u4"), ("total_memory_max", "<u4"),
+                       ("model_row", "<u4")], align=True)
+group_dt = np.dtype([("id", "<u8"), ("config", "<u4"), ("n_members", "<u4"), ("member_begin", "<u4"),
+                     ("task", "<u4")], align=True)
+assignment_dt = np.dtype([("task", "<u4"), ("group_slot", "<u4"), ("group_index", "<u4"), ("group_size", "<u4"),
+                          ("next_worker", "<u4"), ("group_id", "<u8")], align=True)
+assert config_row_dt.itemsize == 32 and alt_row_dt.itemsize == 32 and assignment_dt.itemsize == 32
+
+
+class WorkerSoa(C.Structure):
+    _fields_ = [("n", C.c_uint32)] + [(k, C.c_void_p) for k in
+                                      ("flags", "gpu_count", "gpu_mem_mb", "gpu_model_class", "cpu_cores", "ram_mb",
+                                       "storage_gb", "price", "addr_rank", "lat", "lon")]
+
+
+class TaskSoa(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("topo_mask", C.c_void_p), ("created_at", C.c_void_p), ("uid", C.c_void_p)]
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("proximity_enabled", C.c_uint32),
+                ("switching_enabled", C.c_uint32), ("prefer_larger_groups", C.c_uint32), ("chooser", C.c_uint32),
+                ("chooser_seed", C.c_uint64), ("group_id_seed", C.c_uint64), ("debug_uncertain_every", C.c_uint32),
+                ("sweep_variant", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_compat", C.c_float), ("ms_carve", C.c_float), ("ms_merge", C.c_float), ("ms_sweep", C.c_float),
+                ("ms_publish", C.c_float), ("ms_total", C.c_float), ("ms_compat_kernel", C.c_float),
+                ("ms_carve_kernel", C.c_float), ("ms_sweep_kernel", C.c_float), ("n_groups", C.c_uint32),
+                ("n_formed", C.c_uint32), ("n_merged", C.c_uint32), ("carve_steps", C.c_uint32),
+                ("host_resolved_steps", C.c_uint32), ("carve_launches", C.c_uint32), ("pair_evals", C.c_uint64),
+                ("carve_cand_sum", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Assignment(C.Structure):
+    _fields_ = [("task", C.c_uint32), ("group_slot", C.c_uint32), ("group_index", C.c_uint32),
+                ("group_size", C.c_uint32), ("next_worker", C.c_uint32), ("group_id", C.c_uint64)]
+
+
+# every symbol include/pm_engine.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "pm_engine_config_default", "pm_engine_create", "pm_engine_destroy", "pm_last_error", "pm_set_configs",
+    "pm_set_model_table", "pm_set_enabled_mask", "pm_upload_workers", "pm_update_workers", "pm_upload_tasks",
+    "pm_on_worker_status", "pm_dissolve_group", "pm_reset_groups", "pm_compat_masks", "pm_form_groups",
+    "pm_merge_solo_groups", "pm_get_groups", "pm_match", "pm_match_per_task", "pm_newest_task", "pm_tick",
+    "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
+    "pm_host_build_model_table", "pm_host_config_order", "pm_abi_version",
+]
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pm_engine error {code}: {msg}")
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Load libpm_engine.so (building it in-tree first if the sources are newer)."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB_PATH
+        if _build.needs_build():
+            path = _build.build()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m protocol_amd.build` (needs hipcc)")
+        L = C.CDLL(path)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+        L.pm_last_error.restype = C.c_char_p
+        L.pm_abi_version.restype = u32
+        L.pm_engine_config_default.argtypes = [C.POINTER(EngineConfig)]
+        L.pm_engine_create.argtypes = [C.POINTER(EngineConfig), C.POINTER(vp)]
+        L.pm_engine_destroy.argtypes = [vp]
+        L.pm_engine_destroy.restype = None
+        L.pm_set_configs.argtypes = [vp, vp, u32, vp, u32]
+        L.pm_set_model_table.argtypes = [vp, vp, u32, u32]
+        L.pm_set_enabled_mask.argtypes = [vp, u64]
+        L.pm_upload_workers.argtypes = [vp, C.POINTER(WorkerSoa), u32]
+        L.pm_update_workers.argtypes = [vp, vp, C.POINTER(WorkerSoa)]
+        L.pm_upload_tasks.argtypes = [vp, C.POINTER(TaskSoa)]
+        L.pm_on_worker_status.argtypes = [vp, u32, u32, u32]
+        L.pm_dissolve_group.argtypes = [vp, u32]
+        L.pm_reset_groups.argtypes = [vp]
+        L.pm_compat_masks.argtypes = [vp, vp]
+        L.pm_form_groups.argtypes = [vp, C.POINTER(u32)]
+        L.pm_merge_solo_groups.argtypes = [vp, C.POINTER(u32)]
+        L.pm_get_groups.argtypes = [vp, vp, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32)]
+        L.pm_match.argtypes = [vp, vp, vp]
+        L.pm_match_per_task.argtypes = [vp, vp, vp]
+        L.pm_newest_task.argtypes = [vp, C.POINTER(u32)]
+        L.pm_tick.argtypes = [vp, C.POINTER(Stats)]
+        L.pm_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.pm_lookup_task_for_worker.argtypes = [vp, u32, C.POINTER(Assignment)]
+        L.pm_device_task_column.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+        L.pm_host_parse_requirements.argtypes = [C.c_char_p, vp, vp, u32, C.c_char_p, C.c_size_t]
+        L.pm_host_model_matches.argtypes = [C.c_char_p, C.c_char_p]
+        L.pm_host_build_model_table.argtypes = [C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, vp]
+        L.pm_host_config_order.argtypes = [vp, u32, u64, vp, C.POINTER(u32)]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if name not in ("pm_last_error", "pm_abi_version", "pm_engine_destroy", "pm_engine_config_default"):
+                fn.restype = i32
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise EngineError(rc, lib().pm_last_error().decode(errors="replace"))
+    return rc
+
+
+def _arr(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine:
+    """Owns a pm_engine*.  Keeps nothing but the handle: all state lives behind the C ABI."""
+
+    def __init__(self, *, device: int = 0, proximity=True, switching=True, prefer_larger=True,
+                 chooser=CHOOSE_FIRST, chooser_seed=0, group_id_seed=1, debug_uncertain_every=0, sweep_variant=0):
+        L = lib()
+        cfg = EngineConfig()
+        L.pm_engine_config_default(C.byref(cfg))
+        cfg.device = device
+        cfg.proximity_enabled = int(proximity)
+        cfg.switching_enabled = int(switching)
+        cfg.prefer_larger_groups = int(prefer_larger)
+        cfg.chooser = chooser
+        cfg.chooser_seed = chooser_seed
+        cfg.group_id_seed = group_id_seed
+        cfg.debug_uncertain_every = debug_uncertain_every
+        cfg.sweep_variant = sweep_variant
+        self._h = C.c_void_p()
+        check(L.pm_engine_create(C.byref(cfg), C.byref(self._h)))
+        self.W = 0
+        self.T = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pm_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables
+    def set_configs(self, cfg_rows: np.ndarray, alt_rows: np.ndarray):
+        cfg_rows = _arr(cfg_rows, config_row_dt)
+        alt_rows = _arr(alt_rows, alt_row_dt)
+        check(lib().pm_set_configs(self._h, cfg_rows.ctypes.data, len(cfg_rows),
+                                   alt_rows.ctypes.data if len(alt_rows) else None, len(alt_rows)))
+        self.C = len(cfg_rows)
+
+    def set_model_table(self, bits: np.ndarray, n_rows: int, n_classes: int):
+        bits = _arr(bits, np.uint32)
+        check(lib().pm_set_model_table(self._h, bits.ctypes.data if bits.size else None, n_rows, n_classes))
+
+    def set_enabled_mask(self, mask: int):
+        check(lib().pm_set_enabled_mask(self._h, mask & 0xFFFFFFFFFFFFFFFF))
+
+    @staticmethod
+    def _worker_soa(cols: dict):
+        keep = {}
+        soa = WorkerSoa()
+        n = len(cols["flags"])
+        soa.n = n
+        for k, dt in (("flags", np.uint32), ("gpu_count", np.uint32), ("gpu_mem_mb", np.uint32),
+                      ("gpu_model_class", np.uint32), ("cpu_cores", np.uint32), ("ram_mb", np.uint32),
+                      ("storage_gb", np.uint32), ("price", np.uint32), ("addr_rank", np.uint32),
+                      ("lat", np.float64), ("lon", np.float64)):
+            v = cols.get(k)
+            if v is None:
+                setattr(soa, k, None)
+            else:
+                keep[k] = _arr(v, dt)
+                assert len(keep[k]) == n, k
+                setattr(soa, k, keep[k].ctypes.data)
+        return soa, keep
+
+    def upload_workers(self, cols: dict, keep_groups: bool = False):
+        soa, keep = self._worker_soa(cols)
+        check(lib().pm_upload_workers(self._h, C.byref(soa), int(keep_groups)))
+        self.W = soa.n
+
+    def update_workers(self, idx, cols: dict):
+        idx = _arr(idx, np.uint32)
+        soa, keep = self._worker_soa(cols)
+        assert soa.n == len(idx)
+        check(lib().pm_update_workers(self._h, idx.ctypes.data, C.byref(soa)))
+
+    def upload_tasks(self, topo_mask, created_at, uid=None):
+        tm, ca = _arr(topo_mask, np.uint64), _arr(created_at, np.int64)
+        soa = TaskSoa()
+        soa.n = len(tm)
+        soa.topo_mask = tm.ctypes.data
+        soa.created_at = ca.ctypes.data
+        u = None
+        if uid is not None:
+            u = _arr(uid, np.uint64)
+            soa.uid = u.ctypes.data
+        check(lib().pm_upload_tasks(self._h, C.byref(soa)))
+        self.T = soa.n
+
+    # ---- events
+    def on_worker_status(self, worker: int, flags_new: int, dead: bool):
+        check(lib().pm_on_worker_status(self._h, worker, flags_new, int(dead)))
+
+    def dissolve_group(self, slot: int):
+        check(lib().pm_dissolve_group(self._h, slot))
+
+    def reset_groups(self):
+        check(lib().pm_reset_groups(self._h))
+
+    # ---- phases
+    def compat_masks(self) -> np.ndarray:
+        out = np.zeros(self.W, dtype=np.uint64)
+        check(lib().pm_compat_masks(self._h, out.ctypes.data if self.W else None))
+        return out
+
+    def form_groups(self) -> int:
+        n = C.c_uint32(0)
+        check(lib().pm_form_groups(self._h, C.byref(n)))
+        return n.value
+
+    def merge_solo_groups(self) -> int:
+        n = C.c_uint32(0)
+        check(lib().pm_merge_solo_groups(self._h, C.byref(n)))
+        return n.value
+
+    def get_groups(self):
+        """-> (group_of_worker int32[W], groups structured array, members uint32[] in BTreeSet order)"""
+        ng, nm = C.c_uint32(0), C.c_uint32(0)
+        check(lib().pm_get_groups(self._h, None, None, 0, C.byref(ng), None, 0, C.byref(nm)))
+        gow = np.zeros(self.W, dtype=np.int32)
+        groups = np.zeros(ng.value, dtype=group_dt)
+        members = np.zeros(nm.value, dtype=np.uint32)
+        check(lib().pm_get_groups(self._h, gow.ctypes.data if self.W else None,
+                                  groups.ctypes.data if ng.value else None, ng.value, C.byref(ng),
+                                  members.ctypes.data if nm.value else None, nm.value, C.byref(nm)))
+        return gow, groups, members
+
+    def match(self):
+        task = np.zeros(self.W, dtype=np.uint32)
+        count = np.zeros(self.W, dtype=np.uint32)
+        check(lib().pm_match(self._h, task.ctypes.data if self.W else None, count.ctypes.data if self.W else None))
+        return task, count
+
+    def match_per_task(self):
+        best = np.zeros(self.T, dtype=np.uint32)
+        count = np.zeros(self.T, dtype=np.uint32)
+        check(lib().pm_match_per_task(self._h, best.ctypes.data if self.T else None,
+                                      count.ctypes.data if self.T else None))
+        return best, count
+
+    def newest_task(self) -> int:
+        t = C.c_uint32(0)
+        check(lib().pm_newest_task(self._h, C.byref(t)))
+        return t.value
+
+    def tick(self) -> dict:
+        s = Stats()
+        check(lib().pm_tick(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def last_stats(self) -> dict:
+        s = Stats()
+        check(lib().pm_last_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def device_task_column(self):
+        """(device pointer, n) of the published per-worker task column — for device-side consumers."""
+        p, n = C.c_uint64(0), C.c_uint32(0)
+        check(lib().pm_device_task_column(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def lookup(self, worker: int) -> Assignment:
+        a = Assignment()
+        check(lib().pm_lookup_task_for_worker(self._h, worker, C.byref(a)))
+        return a

@@ -34,3 +34,25 @@ def tasks_of(*rows) -> np.ndarray:
 
 def group_sizes(state) -> list:
     return sorted(len(g[3]) for g in state.groups())
+
+
+# ------------------------------------------------------------------ engine <-> oracle adapters
+
+def engine_groups(eng):
+    """[(id, config, members in BTreeSet order, task or -1)] in creation order, like State.groups()[1:]"""
+    _, groups, members = eng.get_groups()
+    out = []
+    for g in groups:
+        b, n = int(g["member_begin"]), int(g["n_members"])
+        t = int(g["task"])
+        out.append((int(g["id"]), int(g["config"]), members[b:b + n].tolist(), -1 if t == 0xFFFFFFFF else t))
+    return out
+
+
+def oracle_groups(state):
+    return [(gid, cfg, mem, task) for (_slot, gid, cfg, mem, task) in state.groups()]
+
+
+def oracle_state_for(sw, **kw):
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    return orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, **kw)

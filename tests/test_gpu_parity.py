@@ -1,0 +1,339 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs,
+plus the reference's known-answer vectors pushed through the GPU predicate.  Bit-exact throughout
+(integer / index work; the proximity order is proven equal or settled exactly on the host)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ffi as orc
+from protocol_amd import engine as E
+from protocol_amd import host
+from protocol_amd.swarm import GPU_MODELS, Swarm, baseline_config, make_swarm
+from helpers import engine_groups, oracle_groups, oracle_state_for
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "node_rs_kats.json")))
+NONE = 0xFFFFFFFF
+
+
+def _one_worker_cols(gc, gm, gmem, cores, ram, sto, model_class):
+    f = E.W_HAS_SPECS | E.W_HEALTHY | E.W_HAS_P2P
+    if gc is not None or gm is not None or gmem is not None:
+        f |= E.W_HAS_GPU
+    if gc is not None:
+        f |= E.W_GPU_COUNT
+    if gm is not None:
+        f |= E.W_GPU_MODEL
+    if gmem is not None:
+        f |= E.W_GPU_MEM
+    if cores is not None:
+        f |= E.W_HAS_CPU | E.W_CPU_CORES
+    if ram is not None:
+        f |= E.W_RAM
+    if sto is not None:
+        f |= E.W_STORAGE
+    z = lambda v: np.array([v or 0], dtype=np.uint32)
+    return dict(flags=np.array([f], dtype=np.uint32), gpu_count=z(gc), gpu_mem_mb=z(gmem),
+                gpu_model_class=z(model_class), cpu_cores=z(cores), ram_mb=z(ram), storage_gb=z(sto),
+                lat=np.zeros(1), lon=np.zeros(1))
+
+
+def test_meets_kats_through_the_gpu_predicate():
+    """crates/shared/src/models/node.rs:740-1227 — all 29 `meets` vectors, one launch per vector."""
+    eng = E.Engine()
+    for kat in KATS["meets"]:
+        gc, gm, gmem, cores, ram, sto = kat["specs"]
+        cfg_rows, alt_rows, req_models = host.pack_configs([("k", 1, 1, kat["req"])])
+        spec_models = [gm] if gm is not None else ["unused"]
+        eng.set_configs(cfg_rows, alt_rows)
+        eng.set_model_table(host.build_model_table(req_models, spec_models), len(req_models), len(spec_models))
+        eng.upload_workers(_one_worker_cols(gc, gm, gmem, cores, ram, sto, 0))
+        assert bool(eng.compat_masks()[0] & 1) is kat["expect"], kat["name"]
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_compat_masks_bit_exact(cfg, seed):
+    sw = baseline_config(cfg, seed=seed)
+    nodes, cfgs, _, _ = orc.from_swarm(sw)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    assert np.array_equal(eng.compat_masks(), orc.compat_masks(nodes, cfgs))
+    eng.close()
+
+
+def test_compat_masks_edge_rows():
+    # (None req, _) => true; (Some req, None specs) => false; empty tables
+    sw = make_swarm(9, 10, 300)
+    sw.has_specs[:100] = False
+    nodes, cfgs, _, _ = orc.from_swarm(sw)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    assert np.array_equal(eng.compat_masks(), orc.compat_masks(nodes, cfgs))
+    empty = make_swarm(9, 0, 0)
+    host.load_swarm(eng, empty)
+    assert eng.compat_masks().shape == (0,)
+    eng.close()
+
+
+def _form_both(sw, **kw):
+    st = oracle_state_for(sw, reference_shaped=(sw.W <= 2048), **{k: v for k, v in kw.items()
+                                                                   if k in ("proximity", "group_id_seed")})
+    eng = E.Engine(**kw)
+    host.load_swarm(eng, sw)
+    return st, eng
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_form_groups_cfg1_bit_exact(seed):
+    sw = baseline_config(0, seed=seed)
+    st, eng = _form_both(sw, group_id_seed=seed)
+    n_o, n_e = st.try_form_new_groups(), eng.form_groups()
+    assert n_o == n_e and oracle_groups(st) == engine_groups(eng)
+    assert np.array_equal(eng.get_groups()[0] >= 0, st.node_to_group >= 0)
+    assert eng.last_stats()["host_resolved_steps"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_form_groups_cfg2_bit_exact(seed):
+    sw = baseline_config(1, seed=seed)
+    st, eng = _form_both(sw, group_id_seed=seed)
+    n_o, n_e = st.try_form_new_groups(), eng.form_groups()
+    assert n_o == n_e
+    assert oracle_groups(st) == engine_groups(eng)
+    assert eng.last_stats()["host_resolved_steps"] == 0
+    eng.close()
+
+
+def test_form_groups_without_proximity_and_with_partial_enable():
+    sw = make_swarm(11, 500, 3000)
+    for kw, enabled in ((dict(proximity=False), None), (dict(), 0b1010_1010_0110_0101_0011_0001)):
+        st = oracle_state_for(sw, **kw)
+        eng = E.Engine(**kw)
+        host.load_swarm(eng, sw, enabled=enabled)
+        if enabled is not None:
+            st.set_enabled(np.array([(enabled >> i) & 1 for i in range(len(sw.configs))], dtype=np.uint8))
+        st.try_form_new_groups()
+        eng.form_groups()
+        assert oracle_groups(st) == engine_groups(eng)
+        eng.close()
+
+
+def test_host_resolve_path_gives_identical_groups():
+    """debug_uncertain_every forces the exact host path (glibc distances) on every 3rd step."""
+    sw = make_swarm(4, 200, 1500)
+    st = oracle_state_for(sw)
+    st.try_form_new_groups()
+    eng = E.Engine(debug_uncertain_every=3)
+    host.load_swarm(eng, sw)
+    eng.form_groups()
+    stats = eng.last_stats()
+    assert stats["host_resolved_steps"] > 10 and stats["carve_launches"] == stats["host_resolved_steps"] + 1
+    assert oracle_groups(st) == engine_groups(eng)
+    eng.close()
+
+
+def test_incremental_ticks_and_death_reformation():
+    """The reference is incremental (Appendix A): existing groups are sticky, a dead node dissolves its
+    whole group (status_update_impl.rs:17-29) and survivors re-enter the next carve."""
+    sw = make_swarm(5, 300, 800)
+    late = np.arange(sw.W) % 7 == 0
+    status0 = sw.status.copy()
+    sw.status = np.where(late, 0, sw.status).astype(np.uint8)      # join later
+    st = oracle_state_for(sw)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    st.try_form_new_groups()
+    eng.form_groups()
+    assert oracle_groups(st) == engine_groups(eng)
+    flags = host.worker_flags(sw)
+    for w in np.nonzero(late & (status0 == 2))[0]:
+        st.set_node_status(int(w), 2)
+        eng.on_worker_status(int(w), int(flags[w]) | E.W_HEALTHY, False)
+    st.try_form_new_groups()
+    eng.form_groups()
+    assert oracle_groups(st) == engine_groups(eng)
+    victims = [int(g[2][0]) for g in engine_groups(eng)[::9]]
+    for w in victims:
+        st.set_node_status(w, 4)
+        eng.on_worker_status(w, int(flags[w]) & ~E.W_HEALTHY, True)
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    st.try_form_new_groups()
+    eng.form_groups()
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    eng.close()
+
+
+def _solo_scenario(seed, **kw):
+    """Nodes trickle in one per tick against (1, k) configurations => many solo groups, then merge."""
+    sw = make_swarm(seed, 50, 60, n_configs=24)
+    sw.configs = [("pairs-gpu8", 1, 2, "gpu:count=8"), ("trio", 1, 3, None), ("solo-only", 1, 1, "gpu:count=1")]
+    sw.topo = (sw.topo.astype(np.int64) % 3).astype(np.int16)
+    sw.topo[sw.n_topo[:, None] <= np.arange(3)[None, :]] = -2
+    sw.topo[~sw.restricted] = -2
+    status0 = sw.status.copy()
+    sw.status[:] = 0
+    st = oracle_state_for(sw, **{k: v for k, v in kw.items() if k in ("switching", "prefer_larger", "chooser", "chooser_seed")})
+    eng = E.Engine(**kw)
+    host.load_swarm(eng, sw)
+    flags = host.worker_flags(sw)
+    for w in range(sw.W):
+        if status0[w] != 2:
+            continue
+        st.set_node_status(w, 2)
+        eng.on_worker_status(w, int(flags[w]) | E.W_HEALTHY, False)
+        st.try_form_new_groups()
+        eng.form_groups()
+    return sw, st, eng
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_merge_solo_groups_bit_exact(seed):
+    sw, st, eng = _solo_scenario(seed)
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    assert sum(len(g[2]) == 1 for g in engine_groups(eng)) > 10
+    assert st.try_merge_solo_groups() == eng.merge_solo_groups() > 0
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    eng.close()
+
+
+def test_merge_policies_and_host_resolve():
+    sw, st, eng = _solo_scenario(2, switching=False)
+    assert st.try_merge_solo_groups() == eng.merge_solo_groups() == 0
+    eng.close()
+    sw, st, eng = _solo_scenario(2, prefer_larger=False)
+    t_o = [st.get_task_for_node(w) for w in range(0, sw.W, 5)]      # some groups claim tasks first
+    t_e, _ = eng.match()
+    assert t_o == [(-1 if t == NONE else int(t)) for t in t_e[::5]]
+    assert st.try_merge_solo_groups() == eng.merge_solo_groups()
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    eng.close()
+    sw, st, eng = _solo_scenario(3, debug_uncertain_every=2)
+    assert st.try_merge_solo_groups() == eng.merge_solo_groups() > 0
+    assert eng.last_stats()["host_resolved_steps"] > 0
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    eng.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("chooser", [E.CHOOSE_FIRST, E.CHOOSE_SEEDED])
+def test_match_reference_orientation_bit_exact(variant, chooser):
+    """NodeGroupsPlugin::filter_tasks for every worker (scheduler_impl.rs:11-110) incl. GROUP_INDEX,
+    GROUP_SIZE and the NEXT_P2P_ADDRESS worker, against one oracle call per node."""
+    sw = make_swarm(6, 20000, 3000)
+    kw = dict(chooser=chooser, chooser_seed=99)
+    st = oracle_state_for(sw, reference_shaped=False, **kw)
+    eng = E.Engine(sweep_variant=variant, **kw)
+    host.load_swarm(eng, sw)
+    st.try_form_new_groups()
+    eng.form_groups()
+    task, count = eng.match()
+    nodes, cfgs, tasks, _ = orc.from_swarm(sw)
+    cfg_of_node = np.full(sw.W, -1, dtype=np.int32)
+    for _, _, cfg, mem, _ in st.groups():
+        cfg_of_node[mem] = cfg
+    first_o, count_o = orc.pair_sweep_per_worker(tasks, cfgs, cfg_of_node)
+    assert np.array_equal(count, count_o)
+    for w in range(sw.W):
+        t, gi, gs, nxt = st.filter_tasks(w)
+        a = eng.lookup(w)
+        assert (-1 if a.task == NONE else a.task) == t == (-1 if task[w] == NONE else int(task[w])), w
+        if t >= 0:
+            assert (a.group_index, a.group_size, a.next_worker) == (gi, gs, nxt), w
+    if chooser == E.CHOOSE_FIRST:
+        assert np.array_equal(task, first_o)
+    # the claim is sticky (SETNX): a second match returns the same table
+    assert np.array_equal(eng.match()[0], task)
+    assert oracle_groups(st) == engine_groups(eng)
+    eng.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_match_per_task_orientation(variant):
+    """north_star orientation: per task, the first eligible compatible worker and the candidate count."""
+    sw = make_swarm(8, 5000, 4000)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    eng = E.Engine(sweep_variant=variant)
+    host.load_swarm(eng, sw)
+    masks = orc.compat_masks(nodes, cfgs)
+    elig = (sw.status == 2) & sw.has_p2p
+    col = np.where(elig, masks & np.uint64(sw.enabled_mask()), np.uint64(0))
+    tm = sw.task_masks()
+    best, count = eng.match_per_task()
+    for t in range(0, sw.T, 7):
+        hit = np.nonzero(col & tm[t])[0]
+        assert count[t] == len(hit) and best[t] == (hit[0] if len(hit) else NONE), t
+    # after carving, assigned workers stop being candidates (mod.rs:492-497)
+    eng.form_groups()
+    gow = eng.get_groups()[0]
+    col2 = np.where(gow < 0, col, np.uint64(0))
+    best2, count2 = eng.match_per_task()
+    for t in range(0, sw.T, 13):
+        hit = np.nonzero(col2 & tm[t])[0]
+        assert count2[t] == len(hit) and best2[t] == (hit[0] if len(hit) else NONE), t
+    eng.close()
+
+
+def test_newest_task_plugin():
+    eng = E.Engine()
+    sw = make_swarm(3, 100000, 16)
+    host.load_swarm(eng, sw)
+    nodes, cfgs, tasks, _ = orc.from_swarm(sw)
+    assert eng.newest_task() == orc.newest_task(tasks)
+    # unsorted input + duplicates of the maximum: the LAST maximum wins (Iterator::max_by_key)
+    ca = np.array([5, 9, 1, 9, 9, 3] * 1000, dtype=np.int64)
+    eng.upload_tasks(np.full(len(ca), 2 ** 64 - 1, dtype=np.uint64), ca)
+    assert eng.newest_task() == len(ca) - 2
+    eng.upload_tasks(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.int64))
+    assert eng.newest_task() == NONE
+    eng.close()
+
+
+def test_tick_publishes_table_and_tasks_follow_uid():
+    sw = make_swarm(12, 4000, 1500)
+    st = oracle_state_for(sw, reference_shaped=False)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    with pytest.raises(E.EngineError):
+        eng.lookup(0)                                   # nothing published yet
+    s = eng.tick()
+    st.try_form_new_groups()
+    st.try_merge_solo_groups()
+    want = [st.get_task_for_node(w) for w in range(sw.W)]
+    got = [(-1 if eng.lookup(w).task == NONE else eng.lookup(w).task) for w in range(sw.W)]
+    assert got == want and s["pair_evals"] == sw.T * sw.W and s["n_groups"] == st.n_groups
+    # a newer task is inserted at the front: claimed tasks keep their identity (uid), indices shift by one
+    eng.upload_tasks(np.concatenate([[np.uint64(2 ** 64 - 1)], sw.task_masks()]),
+                     np.concatenate([[sw.created_at[0] + 1], sw.created_at]),
+                     np.concatenate([[np.uint64(12345)], sw.task_uid]))
+    eng.tick()
+    got2 = [(-1 if eng.lookup(w).task == NONE else eng.lookup(w).task) for w in range(sw.W)]
+    assert got2 == [(t + 1 if t >= 0 else -1) for t in want]
+    # deleting a claimed task dissolves its groups (on_task_deleted, mod.rs:1259-1288)
+    victim = max(set(t for t in want if t >= 0), key=want.count)
+    keep = np.arange(sw.T) != victim
+    n_before = len(engine_groups(eng))
+    eng.upload_tasks(sw.task_masks()[keep], sw.created_at[keep], sw.task_uid[keep])
+    assert len(engine_groups(eng)) < n_before
+    eng.close()
+
+
+def test_engine_argument_errors():
+    eng = E.Engine()
+    with pytest.raises(E.EngineError) as ei:
+        eng.tick()
+    assert ei.value.code == E.PM_ESTATE
+    bad = np.zeros(1, dtype=E.config_row_dt)
+    bad["min_group_size"], bad["max_group_size"] = 3, 2
+    with pytest.raises(E.EngineError) as ei:
+        eng.set_configs(bad, np.zeros(0, dtype=E.alt_row_dt))          # mod.rs:145-147 panics
+    assert ei.value.code == E.PM_EINVAL
+    bad["min_group_size"], bad["max_group_size"] = 0, 2
+    with pytest.raises(E.EngineError):
+        eng.set_configs(bad, np.zeros(0, dtype=E.alt_row_dt))
+    eng.close()

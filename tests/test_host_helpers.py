@@ -1,0 +1,142 @@
+"""CPU-side checks of the product's host layer (no GPU): the C-ABI library loads and exports every
+symbol include/pm_engine.h declares, its parser / model rule / config order agree with the reference's
+known-answer vectors and with the oracle, and the engine refuses to run without an MI355X."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_ffi as orc
+from protocol_amd import engine as E
+from protocol_amd import host
+from protocol_amd.swarm import GPU_MODELS, MIXED_CONFIGS, UNIFORM_CONFIGS, make_swarm, mix64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "node_rs_kats.json")))
+
+ALT_FIELDS = [("count", E.G_COUNT), ("memory_mb", E.G_MEM), ("memory_mb_min", E.G_MEM_MIN),
+              ("memory_mb_max", E.G_MEM_MAX), ("total_memory_min", E.G_TOT_MIN), ("total_memory_max", E.G_TOT_MAX)]
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pm_engine.h")).read()
+    declared = set(re.findall(r"\b(pm_[a-z_]+)\s*\(", hdr))
+    L = E.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in pm_engine.h but not exported"
+    assert declared == set(E.EXPORTS)
+    assert L.pm_abi_version() == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="this check is for boxes without a GPU")
+def test_engine_fails_loudly_without_gpu():
+    with pytest.raises(E.EngineError) as ei:
+        E.Engine()
+    assert ei.value.code == E.PM_ENODEV and "no CPU fallback" in str(ei.value)
+
+
+def parsed_to_dict(cfg, alts, names):
+    gpus = []
+    for a, nm in zip(alts, names):
+        d = {k: int(a[k]) for k, bit in ALT_FIELDS if int(a["flags"]) & bit}
+        if nm is not None:
+            d["model"] = nm
+        gpus.append(d)
+    f = int(cfg["flags"])
+    return {"gpu": gpus,
+            "ram_mb": int(cfg["ram_mb"]) if f & E.R_RAM else None,
+            "storage_gb": int(cfg["storage_gb"]) if f & E.R_STORAGE else None,
+            "cpu": ({"cores": int(cfg["cpu_cores"])} if f & E.R_CPU_CORES else {}) if f & E.R_CPU else None}
+
+
+@pytest.mark.parametrize("kat", KATS["parser"], ids=lambda k: k["name"])
+def test_product_parser_kat(kat):
+    assert parsed_to_dict(*host.parse_requirements(kat["req"])) == kat["expect"]
+
+
+@pytest.mark.parametrize("kat", KATS["parser_errors"], ids=lambda k: k["name"])
+def test_product_parser_error_kat(kat):
+    with pytest.raises(E.EngineError) as ei:
+        host.parse_requirements(kat["req"])
+    assert ei.value.code == E.PM_EPARSE
+
+
+def test_product_parser_panic_and_grammar_match_oracle():
+    cases = ["gpu:memory_mb_max=5;gpu:memory_mb_min=x", "gpu:total_memory_min=5;gpu:total_memory_max=x",
+             "gpu:memory_mb_min=x", "ram_mb=+5", "ram_mb=-5", "ram_mb=4294967295", "ram_mb=4294967296",
+             "ram_mb=1 2", "gpu:model=H100;gpu:count=2", ";;;", "a", "=", "gpu:count=1;gpu:count=2;gpu:model=x",
+             "gpu:model=a;gpu:model=b", "cpu:cores=4;cpu:cores=8", " \t gpu:count\t=\t7 \n;"]
+    code_map = {0: E.PM_OK, 1: E.PM_EPARSE, 2: E.PM_EPANIC}
+    for s in cases + [c[3] for c in MIXED_CONFIGS + UNIFORM_CONFIGS if c[3]]:
+        ocode, orow, _ = orc.parse_requirements(s)
+        try:
+            got = parsed_to_dict(*host.parse_requirements(s))
+            pcode = E.PM_OK
+        except E.EngineError as ex:
+            pcode, got = ex.code, None
+        assert pcode == code_map[ocode], s
+        if ocode == 0:
+            from test_oracle_kats import req_to_dict
+            assert got == req_to_dict(orow), s
+
+
+def test_model_table_matches_oracle_rule():
+    req_models = sorted({a["model"] for k in KATS["parser"] for a in k["expect"]["gpu"] if "model" in a} |
+                        {"a100,h100,h200", "nvidia,rtx", "rtx4090,rtx_3090", "a6000,l40s", "v100", "mi300x", "", "zzz, ",
+                         "RTX_4090", "nvidia_a100_80gb_pcie"})
+    spec_models = GPU_MODELS + sorted({k["specs"][1] for k in KATS["meets"] if k["specs"][1]}) + ["", "_", "h 100"]
+    bits = host.build_model_table(req_models, spec_models)
+    words = (len(spec_models) + 31) // 32
+    for r, rm in enumerate(req_models):
+        for c, sm in enumerate(spec_models):
+            got = (int(bits[r * words + (c >> 5)]) >> (c & 31)) & 1
+            assert bool(got) == orc.model_matches(sm, rm) == host.model_matches(sm, rm), (sm, rm)
+
+
+def test_config_order_matches_oracle():
+    rng = np.random.default_rng(3)
+    for trial in range(50):
+        n = int(rng.integers(1, 24))
+        sel = rng.permutation(len(MIXED_CONFIGS))[:n]
+        cfgs = [MIXED_CONFIGS[i] for i in sel]
+        cfg_rows, _, _ = host.pack_configs(cfgs)
+        ocfgs = np.concatenate([orc.make_config(*c) for c in cfgs])
+        enabled = int(rng.integers(0, 1 << n))
+        code, tmpl = orc.sort_configs(ocfgs)
+        assert code == 0
+        en = np.array([(enabled >> i) & 1 for i in range(n)], dtype=np.uint8)
+        out = np.zeros(n, dtype=np.uint32)
+        m = orc.lib().orc_available_configs(ocfgs.ctypes.data, tmpl.ctypes.data, n, en.ctypes.data, out.ctypes.data)
+        assert host.config_order(cfg_rows, enabled) == out[:m].tolist()
+
+
+def test_swarm_generator_is_deterministic_and_in_spec():
+    a, b = make_swarm(7, 5000, 2000), make_swarm(7, 5000, 2000)
+    for k in ("address", "status", "gpu_count", "lat", "lon", "created_at", "topo", "task_uid"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert not np.array_equal(a.address, make_swarm(8, 5000, 2000).address)
+    assert len(np.unique(a.address)) == a.W
+    assert 0.95 < (a.status == 2).mean() < 0.99 and 0.97 < a.has_p2p.mean() <= 1.0
+    assert 0.85 < a.has_loc.mean() < 0.95
+    assert (a.lat >= 25).all() and (a.lat <= 60).all() and (a.lon >= -125).all() and (a.lon <= 40).all()
+    assert (a.gpu_count.astype(np.uint64) * a.gpu_mem_mb.astype(np.uint64) < 2 ** 32).all()
+    assert (np.diff(a.created_at) <= 0).all()                       # get_all_tasks order
+    assert (a.price == 0).all()
+    # splitmix64 here == the oracle's C implementation (and therefore the engine's)
+    assert np.array_equal(mix64(np.arange(5, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(42)),
+                          orc.splitmix64_stream(42, 5))
+
+
+def test_swarm_masks_agree_with_oracle_topology_predicate():
+    sw = make_swarm(2, 3000, 64)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    masks = sw.task_masks()
+    for c in range(len(cfgs)):
+        name = bytes(cfgs[c]["name"])
+        want = np.array([orc.lib().orc_task_applicable(tasks[t:t + 1].ctypes.data, name) for t in range(sw.T)])
+        got = ((masks >> np.uint64(c)) & np.uint64(1)).astype(np.int64)
+        assert np.array_equal(want, got), c
