@@ -1283,6 +1283,7 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   e->k_sweep_recorded = e->k_compat_recorded = false;
   uint32_t n_formed = 0, n_merged = 0;
   HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  e->compat_dirty = true;  // a full-swarm match re-evaluates the W x C predicate, like mod.rs:511-515
   int32_t rc = ensure_compat(e);
   if (rc) return rc;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
     }
     const uint64_t bl = __ballot(has_loc);
     const uint64_t ba = __ballot(i < n);
-    if (lane == 0) {
+    if (lane == 0 && (i >> 6) < n_words) {  // waves past the last word must not touch the bitmaps
       locb[i >> 6] = bl;
       alive[i >> 6] = ba;
     }
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
       bool c = false;
       if (i < n) c = bit_at(alive, i) && (p.mode == CARVE_MODE_MERGE || (p.c_compat[i] & cbit));
       const uint64_t bc = __ballot(c);
-      if (lane == 0) {
+      if (lane == 0 && (i >> 6) < n_words) {
         cand[i >> 6] = bc;
         my_cnt += __popcll(bc);
       }

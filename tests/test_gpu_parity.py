@@ -169,13 +169,18 @@ def test_incremental_ticks_and_death_reformation():
     eng.close()
 
 
-def _solo_scenario(seed, **kw):
+def _solo_scenario(seed, tasks_only_for=None, **kw):
     """Nodes trickle in one per tick against (1, k) configurations => many solo groups, then merge."""
     sw = make_swarm(seed, 50, 60, n_configs=24)
     sw.configs = [("pairs-gpu8", 1, 2, "gpu:count=8"), ("trio", 1, 3, None), ("solo-only", 1, 1, "gpu:count=1")]
     sw.topo = (sw.topo.astype(np.int64) % 3).astype(np.int16)
     sw.topo[sw.n_topo[:, None] <= np.arange(3)[None, :]] = -2
     sw.topo[~sw.restricted] = -2
+    if tasks_only_for is not None:      # every task names exactly one configuration
+        sw.restricted[:] = True
+        sw.n_topo[:] = 1
+        sw.topo[:, 0] = tasks_only_for
+        sw.topo[:, 1:] = -2
     status0 = sw.status.copy()
     sw.status[:] = 0
     st = oracle_state_for(sw, **{k: v for k, v in kw.items() if k in ("switching", "prefer_larger", "chooser", "chooser_seed")})
@@ -206,10 +211,12 @@ def test_merge_policies_and_host_resolve():
     sw, st, eng = _solo_scenario(2, switching=False)
     assert st.try_merge_solo_groups() == eng.merge_solo_groups() == 0
     eng.close()
-    sw, st, eng = _solo_scenario(2, prefer_larger=False)
-    t_o = [st.get_task_for_node(w) for w in range(0, sw.W, 5)]      # some groups claim tasks first
+    # prefer_larger_groups = false: a batch containing a group that already holds a task is refused
+    # (mod.rs:277-287).  Only "solo-only" groups can claim a task here, the others stay idle and merge.
+    sw, st, eng = _solo_scenario(2, tasks_only_for=2, prefer_larger=False)
+    t_o = [st.get_task_for_node(w) for w in range(sw.W)]
     t_e, _ = eng.match()
-    assert t_o == [(-1 if t == NONE else int(t)) for t in t_e[::5]]
+    assert t_o == [(-1 if t == NONE else int(t)) for t in t_e] and 0 < sum(t >= 0 for t in t_o) < sw.W
     assert st.try_merge_solo_groups() == eng.merge_solo_groups()
     assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
     eng.close()
