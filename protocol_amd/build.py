@@ -31,17 +31,18 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, defines=(), out: str | None = None) -> str:
+    out = out or LIB_PATH
+    if not force and out == LIB_PATH and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
+           "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result", *[f"-D{d}" for d in defines],
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

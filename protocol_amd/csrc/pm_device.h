@@ -11,9 +11,18 @@ namespace pm {
 
 static constexpr double PM_RAD = 3.14159265358979323846 / 180.0;  // f64::to_radians factor
 static constexpr uint64_t PM_KEY_NOLOC = 0x7FEFFFFFFFFFFFFFull;   // bits of f64::MAX (mod.rs:244,249)
-static constexpr double PM_TIE_BAND = 1.0 / 68719476736.0;        // 2^-36, see carve_kernel
 static constexpr double PM_A_MAX_SAFE = 1.0 - 1.0 / 1048576.0;    // near-antipodal => settle on host
-static constexpr size_t PM_CARVE_MAX_LDS = 144 * 1024;
+// carve kernel geometry
+static constexpr uint32_t PM_CARVE_SLOTS = 8192;       // candidate slots with positions/bitmaps in LDS, keys in VGPRs
+static constexpr uint32_t PM_CARVE_PART = 64;          // per-wave partial selection capacity (max_group_size - 1)
+static constexpr uint32_t PM_CARVE_SEL_CAP = 1024;     // selected slots staged in LDS before the member stores
+static constexpr uint32_t PM_CARVE_SLOT_BITS = 13;     // log2(PM_CARVE_SLOTS): low key bits that hold the slot
+static constexpr uint32_t PM_CARVE_SLOT_BITS_MEM = 21; // same for lists kept in HBM (up to 2M candidates)
+// certificate bands: 8x the truncation step of the packed key (2^-(52-bits)) — see carve_kernel
+static constexpr double PM_TIE_BAND = 1.0 / 68719476736.0;      // 2^-36
+static constexpr double PM_TIE_BAND_MEM = 1.0 / 268435456.0;    // 2^-28
+static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
+                                             size_t(PM_CARVE_SLOTS) * 4 + size_t(PM_CARVE_SEL_CAP) * 4 + 512;
 
 struct CompatArgs {
   uint32_t W, n_cfgs, model_words;
@@ -50,6 +59,7 @@ struct CarveStatus {
   uint32_t n_eligible;   // compacted candidate count of the last launch
   uint32_t _pad;
   unsigned long long cand_sum;  // sum over committed steps of the candidates scanned
+  unsigned long long prof[16];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
 struct CarveArgs {
@@ -66,13 +76,18 @@ struct CarveArgs {
   // MERGE -> supplied by the engine (nodes of the compatible solo groups in group-id order)
   uint32_t* order;
   uint32_t n_order;
-  // compacted scratch (capacity W each)
+  // scratch (capacity W each): columns indexed by position in the eligible list ...
   double *c_lat, *c_lon, *c_cos;
   uint64_t* c_compat;
-  uint64_t* keys;
-  uint64_t* bits_scratch;  // 3 * bits_stride words when the bitmaps do not fit in LDS
+  uint64_t *alive_g, *loc_g;  // bitmaps over positions (bits_stride words each)
+  // ... and by candidate slot of the current configuration
+  double *cc_lat, *cc_lon, *cc_cos;
+  uint64_t* keys;          // used when the candidate list does not fit in LDS
+  uint32_t* slot_pos;      // slot -> position (for the alive_g write-back)
+  uint32_t* slot_wid;      // slot -> worker id when the candidate list does not fit in LDS
+  uint64_t* bits_scratch;  // idem: 2 * bits_stride words (alive, loc)
   uint32_t bits_stride;
-  uint32_t bits_in_lds;
+  uint32_t _pad0;
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];

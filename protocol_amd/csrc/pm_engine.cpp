@@ -86,6 +86,7 @@ struct pm_engine {
   float k_ms_compat = 0, k_ms_carve = 0, k_ms_sweep = 0;
   bool k_sweep_recorded = false, k_compat_recorded = false;
   uint64_t tick_cand_sum = 0;
+  unsigned long long carve_prof[16]{};
   std::mutex mu;
 
   // ---- configuration tables
@@ -136,8 +137,9 @@ struct pm_engine {
 
   // ---- carve scratch
   DevBuf<uint32_t> d_order;
-  DevBuf<double> d_c_lat, d_c_lon, d_c_cos;
+  DevBuf<double> d_c_lat, d_c_lon, d_c_cos, d_cc_lat, d_cc_lon, d_cc_cos;
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
+  DevBuf<uint32_t> d_slot_pos, d_slot_wid;
   DevBuf<CarveStatus> d_status;
   DevBuf<uint32_t> d_m_cfg, d_m_n, d_m_off, d_m_members;  // MERGE batches
 
@@ -292,10 +294,9 @@ struct CarvePlan {
   std::vector<uint32_t> avail;  // configuration indices in carve order
 };
 
-static size_t carve_lds_bytes(uint32_t stride_words, bool* in_lds) {
-  const size_t need = size_t(stride_words) * 3 * sizeof(uint64_t);
-  *in_lds = need <= PM_CARVE_MAX_LDS - 1024;
-  return *in_lds ? need : 0;
+static size_t carve_lds_bytes(uint32_t /*stride_words*/, bool* in_lds) {
+  *in_lds = true;  // the kernel decides per configuration whether its candidate list fits in LDS
+  return PM_CARVE_LDS_BYTES;
 }
 
 static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32_t n_order) {
@@ -304,13 +305,16 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_c_lat.ensure(cap));
   HIPCHK(e->d_c_lon.ensure(cap));
   HIPCHK(e->d_c_cos.ensure(cap));
+  HIPCHK(e->d_cc_lat.ensure(cap));
+  HIPCHK(e->d_cc_lon.ensure(cap));
+  HIPCHK(e->d_cc_cos.ensure(cap));
   HIPCHK(e->d_c_compat.ensure(cap));
   HIPCHK(e->d_keys.ensure(cap));
+  HIPCHK(e->d_slot_pos.ensure(cap));
+  HIPCHK(e->d_slot_wid.ensure(cap));
   HIPCHK(e->d_status.ensure(1));
   const uint32_t stride = uint32_t((cap + 63) / 64);
-  bool in_lds = false;
-  (void)carve_lds_bytes(stride, &in_lds);
-  HIPCHK(e->d_bits.ensure(size_t(stride) * 3));
+  HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
   std::memset(a, 0, sizeof(*a));
   a->mode = mode;
   a->W = e->W;
@@ -328,10 +332,16 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->c_lon = e->d_c_lon.p;
   a->c_cos = e->d_c_cos.p;
   a->c_compat = e->d_c_compat.p;
+  a->alive_g = e->d_bits.p;
+  a->loc_g = e->d_bits.p + stride;
+  a->cc_lat = e->d_cc_lat.p;
+  a->cc_lon = e->d_cc_lon.p;
+  a->cc_cos = e->d_cc_cos.p;
   a->keys = e->d_keys.p;
-  a->bits_scratch = e->d_bits.p;
+  a->slot_pos = e->d_slot_pos.p;
+  a->slot_wid = e->d_slot_wid.p;
+  a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
   a->bits_stride = stride;
-  a->bits_in_lds = in_lds ? 1u : 0u;
   a->status = e->d_status.p;
   return PM_OK;
 }
@@ -455,6 +465,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
   }
   e->tick_carve_steps += st.steps_total;
   e->tick_cand_sum += st.cand_sum;
+  std::memcpy(e->carve_prof, st.prof, sizeof(st.prof));
 
   // pull the new group records into the host list and give them ids (generate_group_id stream)
   const uint32_t g1 = st.n_groups, m1 = st.n_members;
@@ -879,6 +890,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_g_task.release(); e->d_g_task_next.release(); e->d_members.release(); e->d_by_rank.release();
   e->d_rank_in_group.release(); e->d_g_id.release();
   e->d_order.release(); e->d_c_lat.release(); e->d_c_lon.release(); e->d_c_cos.release();
+  e->d_cc_lat.release(); e->d_cc_lon.release(); e->d_cc_cos.release(); e->d_slot_pos.release(); e->d_slot_wid.release();
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release(); e->d_scratch.release();
@@ -1338,6 +1350,14 @@ int32_t pm_device_task_column(pm_engine* e, uint64_t* device_ptr, uint32_t* n) {
   if (!e->d_task_col.p) return set_error(PM_ESTATE, "no assignment table computed yet");
   *device_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_task_col.p));
   *n = e->W;
+  return PM_OK;
+}
+
+// debug (not part of the public header): phase tick counters of the last carve (PM_CARVE_PROF builds)
+int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out16) {
+  if (!e || !out16) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  std::memcpy(out16, e->carve_prof, sizeof(e->carve_prof));
   return PM_OK;
 }
 

@@ -439,133 +439,571 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 #define CARVE_THREADS 1024
 #define CARVE_WAVES 16
 
+// ---- wave-wide unsigned min via DPP (no LDS traffic): row_shr 1,2,4,8 -> row_bcast15 -> row_bcast31,
+// result broadcast from lane 63 with readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_min_step(uint64_t v) {
+  const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
+  const uint32_t ohi =
+      (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+  const uint64_t o = ((uint64_t)ohi << 32) | olo;
+  return o < v ? o : v;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+  v = dpp_min_step<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_min_step<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_min_step<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_min_step<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_min_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_min_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
+  const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// barrier for exchanges that go through LDS only (no global-memory drain)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct BlockRed {
   uint32_t a[CARVE_WAVES];
   uint32_t b[CARVE_WAVES];
-  uint64_t k[2][CARVE_WAVES];
-  uint32_t i[2][CARVE_WAVES];
+  uint32_t part_n[CARVE_WAVES];
+  uint32_t flag[CARVE_WAVES];
 };
+
+// sin on [-pi/2, pi/2] as an odd Taylor polynomial to x^19 (|rel err| < 1e-15 there); larger arguments
+// (longitude differences beyond 180 degrees) take the OCML path.  The certificate band (2^-35) is four
+// orders of magnitude wider than this error.
+__device__ __forceinline__ double sin_band(double x) {
+  if (fabs(x) > 1.5707963267948966) return sin(x);
+  const double z = x * x;
+  double p = -8.2206352466243297e-18;               // -1/19!
+  p = fma(p, z, 2.8114572543455206e-15);            //  1/17!
+  p = fma(p, z, -7.6471637318198164e-13);           // -1/15!
+  p = fma(p, z, 1.6059043836821613e-10);            //  1/13!
+  p = fma(p, z, -2.5052108385441720e-08);           // -1/11!
+  p = fma(p, z, 2.7557319223985893e-06);            //  1/9!
+  p = fma(p, z, -1.9841269841269841e-04);           // -1/7!
+  p = fma(p, z, 8.3333333333333332e-03);            //  1/5!
+  p = fma(p, z, -1.6666666666666666e-01);           // -1/3!
+  return fma(x * z, p, x);
+}
 
 __device__ __forceinline__ double hav_a(double lat1, double lon1, double cos1, double lat2, double lon2,
                                         double cos2) {
   const double dlat = (lat2 - lat1) * PM_RAD;
   const double dlon = (lon2 - lon1) * PM_RAD;
-  const double s1 = sin(dlat * 0.5);
-  const double s2 = sin(dlon * 0.5);
+  const double s1 = sin_band(dlat * 0.5);
+  const double s2 = sin_band(dlon * 0.5);
   return s1 * s1 + cos1 * cos2 * (s2 * s2);
 }
 
 __device__ __forceinline__ bool bit_at(const uint64_t* b, uint32_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }
 
-struct SelResult {
-  uint32_t n_sel;
-  uint64_t last_k;
-  uint32_t last_i;
+// Ordering key of a candidate: the f64 bits of its Haversine term `a` with the low SLOT_BITS replaced by
+// the slot number (slot order == input order), so one u64 compare is the whole (distance, input order)
+// comparison.  Dropping SLOT_BITS mantissa bits is covered by the certificate band.
+__device__ __forceinline__ uint64_t pack_key(uint64_t key_bits, uint32_t slot, uint32_t slot_bits) {
+  return ((key_bits >> slot_bits) << slot_bits) | slot;
+}
+
+enum { STEP_CONTINUE = 0, STEP_BREAK = 1, STEP_UNCERTAIN = 2, STEP_OVERFLOW = 3 };
+
+#ifdef PM_CARVE_PROF
+#define PROF_DECL uint64_t prof_t0 = __builtin_amdgcn_s_memtime()
+#define PROF_MARK(slot)                                          \
+  do {                                                           \
+    const uint64_t t_ = __builtin_amdgcn_s_memtime();            \
+    if (threadIdx.x == 0) p.status->prof[slot] += t_ - prof_t0;  \
+    prof_t0 = t_;                                                \
+  } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(slot)
+#endif
+
+struct StepCtx {
+  uint32_t mode, proximity, min_s, max_s, cfg;
+  uint32_t n_list;       // slots of the current list
+  uint32_t n_cand;       // live slots
+  uint32_t n_groups, mem_off;
+  uint32_t total_available;
+  uint32_t steps;
+  unsigned long long cand_sum;
 };
 
-// Keys for every remaining candidate + top-`want` by (key, position).  located_only drops candidates
-// without a location (attempt_group_merge's filter_map, mod.rs:795-799); otherwise they sort last
-// with f64::MAX (sort_nodes_by_proximity, mod.rs:244,249).  Selected workers are written to
-// members[mem_base + 1 ...].  All control flow is workgroup-uniform.
-__device__ SelResult carve_select(const CarveArgs& p, BlockRed& red, uint32_t& parity, const uint64_t* cand,
-                                  const uint64_t* locb, uint32_t n, uint32_t seed, bool use_dist, bool located_only,
-                                  uint32_t want, uint32_t mem_base) {
+// LDS carve of one candidate list of at most E*1024 slots.  Per-lane state lives in registers for the
+// whole run: coordinates of the lane's E slots (slot = tid + j*1024), loaded once after a compaction;
+// packed keys are recomputed per step.  LDS holds the worker ids, the alive / loc bitmaps and the
+// per-wave partial selections.  Runs steps until the configuration is exhausted, a recompaction is due,
+// or a step cannot be certified.  Three LDS-only barriers per step.
+template <int E>
+__device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, const uint32_t* l_wid, uint64_t* l_alive,
+                             const uint64_t* l_loc, uint64_t* part, uint32_t* sel_out, uint32_t steps_before) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const double slat = p.c_lat[seed], slon = p.c_lon[seed], scos = p.c_cos[seed];
-  uint64_t lk = ~0ull;
-  uint32_t li = PM_NONE;
-  for (uint32_t i = tid; i < n; i += CARVE_THREADS) {
-    if (!bit_at(cand, i) || i == seed) continue;
-    uint64_t key = 0;
-    if (use_dist) {
-      if (bit_at(locb, i)) {
-        key = (uint64_t)__double_as_longlong(hav_a(slat, slon, scos, p.c_lat[i], p.c_lon[i], p.c_cos[i]));
-      } else {
-        if (located_only) continue;
-        key = PM_KEY_NOLOC;
-      }
-    }
-    p.keys[i] = key;
-    if (li == PM_NONE || ki_less(key, i, lk, li)) {
-      lk = key;
-      li = i;
-    }
-  }
-  SelResult r;
-  r.n_sel = 0;
-  r.last_k = 0;
-  r.last_i = PM_NONE;
-  while (r.n_sel < want) {
-    // wavefront argmin -> LDS -> every thread folds the 16 wave partials (one barrier per round)
-    KeyIdx v;
-    v.k = lk;
-    v.i = li;
-    v = wave_min_ki(v);
-    if (lane == 0) {
-      red.k[parity][wave] = v.k;
-      red.i[parity][wave] = v.i;
-    }
-    __syncthreads();
-    uint64_t bk = ~0ull;
-    uint32_t bi = PM_NONE;
+  constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
+  const uint32_t lw = (c.n_list + 63u) >> 6;
+  double clat[E], clon[E], ccos[E];
 #pragma unroll
-    for (uint32_t k = 0; k < CARVE_WAVES; ++k) {
-      const uint64_t ok = red.k[parity][k];
-      const uint32_t oi = red.i[parity][k];
-      if (oi != PM_NONE && (bi == PM_NONE || ki_less(ok, oi, bk, bi))) {
-        bk = ok;
-        bi = oi;
+  for (int j = 0; j < E; ++j) {
+    const uint32_t s = tid + (uint32_t)j * CARVE_THREADS;
+    const bool in = s < c.n_list;
+    clat[j] = in ? p.cc_lat[s] : 0.0;
+    clon[j] = in ? p.cc_lon[s] : 0.0;
+    ccos[j] = in ? p.cc_cos[s] : 0.0;
+  }
+
+  for (;;) {
+    // FORM: `while total_available >= min` (mod.rs:507) with `compatible < min => break` (:517-519).
+    // MERGE: `while remaining_groups.len() >= min` (mod.rs:695).
+    if (!((c.mode == CARVE_MODE_MERGE || c.total_available >= c.min_s) && c.n_cand >= c.min_s && c.n_cand > 0))
+      return STEP_BREAK;
+    PROF_DECL;
+    // ---- seed: first live slot with a location, else first live slot (mod.rs:526-530); every wave finds
+    // it redundantly from the bitmaps with one ballot per 64 words (no barrier, no shuffle tree)
+    uint32_t f_loc = PM_NONE, f_any = PM_NONE;
+    for (uint32_t j0 = 0; j0 < lw && (f_loc == PM_NONE || f_any == PM_NONE); j0 += 64u) {
+      const uint32_t j = j0 + lane;
+      const uint64_t al = j < lw ? l_alive[j] : 0ull;
+      const uint64_t ll = j < lw ? (al & l_loc[j]) : 0ull;
+      if (f_any == PM_NONE) {
+        const uint64_t nz = __ballot(al != 0ull);
+        if (nz) {
+          const int src = __builtin_ctzll(nz);
+          const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(al >> 32), src) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)al, src);
+          f_any = (j0 + src) * 64u + __builtin_ctzll(w);
+        }
       }
-    }
-    parity ^= 1u;
-    if (bi == PM_NONE) break;  // ran out of candidates
-    if (tid == 0 && mem_base + 1u + r.n_sel < p.cap_members) p.members[mem_base + 1u + r.n_sel] = p.order[bi];
-    r.last_k = bk;
-    r.last_i = bi;
-    ++r.n_sel;
-    if (li == bi) {  // the winning thread advances to its next-best element
-      lk = ~0ull;
-      li = PM_NONE;
-      for (uint32_t i = tid; i < n; i += CARVE_THREADS) {
-        if (!bit_at(cand, i) || i == seed) continue;
-        if (use_dist && located_only && !bit_at(locb, i)) continue;
-        const uint64_t key = p.keys[i];
-        if (!ki_less(bk, bi, key, i)) continue;  // only elements after (bk, bi)
-        if (li == PM_NONE || ki_less(key, i, lk, li)) {
-          lk = key;
-          li = i;
+      if (f_loc == PM_NONE) {
+        const uint64_t nz = __ballot(ll != 0ull);
+        if (nz) {
+          const int src = __builtin_ctzll(nz);
+          const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ll >> 32), src) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ll, src);
+          f_loc = (j0 + src) * 64u + __builtin_ctzll(w);
         }
       }
     }
+    PROF_MARK(0);
+
+    const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // fill to max (mod.rs:545-551)
+    uint64_t rk[E];
+    uint32_t seed = f_any;
+    bool use_dist = false, located_only = false;
+    uint64_t last = 0;
+    uint32_t n_sel = 0, total = 0;
+
+    // attempt 0: FORM, or MERGE with proximity (mod.rs:762-821); attempt 1: MERGE first-come (:824-848)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (c.mode == CARVE_MODE_FORM) {
+        if (attempt == 1) break;
+        seed = f_any;
+        use_dist = false;
+        if (c.proximity && f_loc != PM_NONE) {  // seed = first WITH a location
+          seed = f_loc;
+          use_dist = true;
+        }  // else first-come (:553-561), or a seed without location makes the sort a no-op (:238)
+        located_only = false;
+      } else if (attempt == 0) {
+        if (!(c.proximity && f_loc != PM_NONE)) continue;
+        seed = f_loc;
+        use_dist = true;
+        located_only = true;
+      } else {
+        if (!(total == 0 || (total < c.max_s && total < c.min_s))) break;
+        seed = f_any;
+        use_dist = false;
+        located_only = false;
+      }
+
+      // ---- keys (registers only; the seed's coordinates are one uniform load each)
+      const double slat = p.cc_lat[seed], slon = p.cc_lon[seed], scos = p.cc_cos[seed];
+      uint64_t lmin = ~0ull;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const uint32_t s = tid + (uint32_t)j * CARVE_THREADS;
+        uint64_t k = ~0ull;
+        if (s < c.n_list && s != seed && bit_at(l_alive, s)) {
+          if (!use_dist) {
+            k = s;
+          } else if (bit_at(l_loc, s)) {
+            k = pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, clat[j], clon[j], ccos[j])), s, SB);
+          } else if (!located_only) {
+            k = pack_key(PM_KEY_NOLOC, s, SB);
+          }
+        }
+        rk[j] = k;
+        lmin = k < lmin ? k : lmin;
+      }
+      PROF_MARK(1);
+      n_sel = 0;
+      last = 0;
+      if (want > 0) {
+        if (want <= PM_CARVE_PART) {
+          // ---- level 1: this wave's `want` smallest, DPP argmin rounds, no barrier
+          uint32_t cnt = 0;
+          while (cnt < want) {
+            const uint64_t v = wave_min_u64(lmin);
+            if (v == ~0ull) break;
+            if (lane == 0) part[wave * PM_CARVE_PART + cnt] = v;
+            ++cnt;
+            if (lmin == v) {  // the owning lane advances to its next element (keys are unique)
+              uint64_t m = ~0ull;
+#pragma unroll
+              for (int j = 0; j < E; ++j) m = (rk[j] > v && rk[j] < m) ? rk[j] : m;
+              lmin = m;
+            }
+          }
+          if (lane == 0) red.part_n[wave] = cnt;
+          PROF_MARK(2);
+          lds_barrier();
+          PROF_MARK(3);
+          // ---- level 2: 16-way merge of the sorted partial lists, redundantly in every wave
+          uint32_t ptr = 0;
+          const uint32_t my_n = lane < CARVE_WAVES ? red.part_n[lane] : 0u;
+          uint64_t head = my_n ? part[lane * PM_CARVE_PART] : ~0ull;
+          uint64_t mine = ~0ull;
+          while (n_sel < want) {
+            const uint64_t v = wave_min_u64(head);
+            if (v == ~0ull) break;
+            if (lane == n_sel) mine = v;
+            last = v;
+            ++n_sel;
+            if (head == v) {
+              ++ptr;
+              head = ptr < my_n ? part[lane * PM_CARVE_PART + ptr] : ~0ull;
+            }
+          }
+          if (wave == 0 && lane < n_sel) sel_out[lane] = (uint32_t)(mine & ((1ull << SB) - 1ull));
+          PROF_MARK(4);
+        } else {
+          // ---- wide groups: one workgroup-wide round per member (wave argmin -> LDS -> fold)
+          while (n_sel < want) {
+            const uint64_t v = wave_min_u64(lmin);
+            if (lane == 0) part[wave] = v;
+            lds_barrier();
+            uint64_t b = ~0ull;
+#pragma unroll
+            for (uint32_t k = 0; k < CARVE_WAVES; ++k) b = part[k] < b ? part[k] : b;
+            lds_barrier();
+            if (b == ~0ull) break;
+            const uint32_t bs = (uint32_t)(b & ((1ull << SB) - 1ull));
+            if (tid == 0) {
+              if (n_sel < PM_CARVE_SEL_CAP)
+                sel_out[n_sel] = bs;
+              else if (c.mem_off + 1u + n_sel < p.cap_members)
+                p.members[c.mem_off + 1u + n_sel] = l_wid[bs];
+            }
+            last = b;
+            ++n_sel;
+            if (lmin == b) {
+              uint64_t m = ~0ull;
+#pragma unroll
+              for (int j = 0; j < E; ++j) m = (rk[j] > b && rk[j] < m) ? rk[j] : m;
+              lmin = m;
+            }
+          }
+        }
+      }
+      total = 1u + n_sel;
+      if (c.mode == CARVE_MODE_FORM) break;
+      if (attempt == 0 && want > 0 && want <= PM_CARVE_PART) lds_barrier();  // part/part_n reused by attempt 1
+    }
+    if (total == 0) return STEP_BREAK;                                   // MERGE: nothing selectable
+    if (c.mode == CARVE_MODE_FORM && total < c.min_s) return STEP_BREAK;  // mod.rs:564-566
+    if (c.mode == CARVE_MODE_MERGE && total < 2u) return STEP_BREAK;      // is_merge_beneficial (mod.rs:868-870)
+
+    // ---- exactness certificate for a distance-ordered selection (see the comment above carve_kernel)
+    int uncertain = p.debug_uncertain_every && use_dist &&
+                    ((steps_before + c.steps + 1u) % p.debug_uncertain_every) == 0u;
+    const uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
+    const uint64_t last_key = (last >> SB) << SB;
+    if (use_dist && n_sel > 0 && last_key != noloc_key) {
+      const uint32_t ls = (uint32_t)(last & ((1ull << SB) - 1ull));
+      const double a_m = __longlong_as_double((long long)last_key);
+      const double band = a_m * PM_TIE_BAND + 1e-300;
+      const double mlat = p.cc_lat[ls], mlon = p.cc_lon[ls];  // uniform loads
+      if (a_m > PM_A_MAX_SAFE) uncertain = 1;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const uint64_t kb = (rk[j] >> SB) << SB;
+        const double a = __longlong_as_double((long long)kb);
+        const bool near = rk[j] != ~0ull && kb != noloc_key && fabs(a - a_m) <= band;
+        if (near && (clat[j] != mlat || clon[j] != mlon)) uncertain = 1;
+      }
+    }
+    const uint64_t ub = __ballot(uncertain != 0);
+    if (lane == 0) red.flag[wave] = ub != 0ull;
+    PROF_MARK(5);
+    lds_barrier();
+    PROF_MARK(6);
+    uint32_t any = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CARVE_WAVES; ++k) any |= red.flag[k];
+    if (any) {
+      if (tid == 0) p.status->stop_seed = l_wid[seed];
+      return STEP_UNCERTAIN;
+    }
+    if (c.n_groups >= p.cap_groups || c.mem_off + total > p.cap_members) return STEP_OVERFLOW;
+
+    // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): selected slots =
+    // seed + every key <= last.  Each wave owns whole bitmap words (slot>>6 == j*16 + wave): ballot writes them.
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const uint32_t s = tid + (uint32_t)j * CARVE_THREADS;
+      const uint32_t wj = (uint32_t)j * CARVE_WAVES + wave;
+      if (wj < lw) {  // wave-uniform
+        const bool was = bit_at(l_alive, s);
+        const bool sel = was && (s == seed || (n_sel > 0 && rk[j] <= last));
+        const uint64_t nw = __ballot(was && !sel);
+        if (lane == 0) l_alive[wj] = nw;
+      }
+    }
+    if (wave == 0) {  // group record + members: LDS -> fire-and-forget global stores
+      if (lane == 0) {
+        p.members[c.mem_off] = l_wid[seed];
+        p.g_cfg[c.n_groups] = c.cfg;
+        p.g_n[c.n_groups] = total;
+        p.g_off[c.n_groups] = c.mem_off;
+      }
+      const uint32_t lim = n_sel < PM_CARVE_SEL_CAP ? n_sel : PM_CARVE_SEL_CAP;
+      for (uint32_t r = lane; r < lim; r += 64u) p.members[c.mem_off + 1u + r] = l_wid[sel_out[r]];
+    }
+    PROF_MARK(7);
+    lds_barrier();
+    PROF_MARK(8);
+    c.n_groups += 1;
+    c.mem_off += total;
+    c.cand_sum += c.n_cand;
+    c.n_cand -= total;
+    c.total_available -= total;  // mod.rs:586
+    c.steps += 1;
+    // drop dead slots once more than half of the list is gone
+    if (c.n_cand * 2u < c.n_list && c.n_list > CARVE_THREADS) return STEP_CONTINUE;
   }
-  return r;
 }
 
-// Exactness certificate for a distance-ordered selection (see the comment above carve_kernel).
-__device__ int carve_uncertain(const CarveArgs& p, const uint64_t* cand, const uint64_t* locb, uint32_t n,
-                               uint32_t seed, const SelResult& r) {
-  if (r.n_sel == 0 || r.last_k == PM_KEY_NOLOC) return 0;
-  const double a_m = __longlong_as_double((long long)r.last_k);
-  const double band = a_m * PM_TIE_BAND + 1e-300;
-  const double mlat = p.c_lat[r.last_i], mlon = p.c_lon[r.last_i];
-  int u = a_m > PM_A_MAX_SAFE;
-  for (uint32_t i = threadIdx.x; i < n; i += CARVE_THREADS) {
-    if (!bit_at(cand, i) || i == seed || !bit_at(locb, i)) continue;
-    const double a = __longlong_as_double((long long)p.keys[i]);
-    if (fabs(a - a_m) <= band && (p.c_lat[i] != mlat || p.c_lon[i] != mlon)) u = 1;
+// ---- generic path for candidate lists that do not fit the LDS/register scheme (> PM_CARVE_SLOTS):
+// packed keys, positions and bitmaps live in HBM/L2; one workgroup-wide argmin round per member.
+__device__ int carve_step_mem(const CarveArgs& p, BlockRed& red, StepCtx& c, uint64_t* part, uint64_t* key,
+                              const uint32_t* wid, uint64_t* alive, const uint64_t* loc, uint32_t steps_before) {
+  if (!((c.mode == CARVE_MODE_MERGE || c.total_available >= c.min_s) && c.n_cand >= c.min_s && c.n_cand > 0))
+    return STEP_BREAK;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  constexpr uint32_t SB = PM_CARVE_SLOT_BITS_MEM;
+  const uint32_t lw = (c.n_list + 63u) >> 6;
+  uint32_t f_loc = PM_NONE, f_any = PM_NONE;
+  for (uint32_t j = tid; j < lw; j += CARVE_THREADS) {
+    const uint64_t al = alive[j];
+    if (al && f_any == PM_NONE) f_any = j * 64u + __builtin_ctzll(al);
+    const uint64_t ll = al & loc[j];
+    if (ll && f_loc == PM_NONE) f_loc = j * 64u + __builtin_ctzll(ll);
   }
-  return u;
+  f_loc = wave_min(f_loc);
+  f_any = wave_min(f_any);
+  if (lane == 0) {
+    red.a[wave] = f_loc;
+    red.b[wave] = f_any;
+  }
+  __syncthreads();
+  f_loc = PM_NONE;
+  f_any = PM_NONE;
+  for (uint32_t k = 0; k < CARVE_WAVES; ++k) {
+    f_loc = min(f_loc, red.a[k]);
+    f_any = min(f_any, red.b[k]);
+  }
+  __syncthreads();
+  const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;
+  uint32_t seed = f_any;
+  bool use_dist = false, located_only = false;
+  uint64_t last = 0;
+  uint32_t n_sel = 0, total = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (c.mode == CARVE_MODE_FORM) {
+      if (attempt == 1) break;
+      seed = f_any;
+      use_dist = false;
+      if (c.proximity && f_loc != PM_NONE) {
+        seed = f_loc;
+        use_dist = true;
+      }
+      located_only = false;
+    } else if (attempt == 0) {
+      if (!(c.proximity && f_loc != PM_NONE)) continue;
+      seed = f_loc;
+      use_dist = true;
+      located_only = true;
+    } else {
+      if (!(total == 0 || (total < c.max_s && total < c.min_s))) break;
+      seed = f_any;
+      use_dist = false;
+      located_only = false;
+    }
+    const double slat = p.cc_lat[seed], slon = p.cc_lon[seed], scos = p.cc_cos[seed];
+    uint64_t lmin = ~0ull;
+    for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+      uint64_t k = ~0ull;
+      if (s != seed && bit_at(alive, s)) {
+        if (!use_dist) {
+          k = s;
+        } else if (bit_at(loc, s)) {
+          k = pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, p.cc_lat[s], p.cc_lon[s], p.cc_cos[s])), s, SB);
+        } else if (!located_only) {
+          k = pack_key(PM_KEY_NOLOC, s, SB);
+        }
+      }
+      key[s] = k;
+      lmin = k < lmin ? k : lmin;
+    }
+    n_sel = 0;
+    last = 0;
+    while (n_sel < want) {
+      const uint64_t v = wave_min_u64(lmin);
+      if (lane == 0) part[wave] = v;
+      __syncthreads();
+      uint64_t b = ~0ull;
+      for (uint32_t k = 0; k < CARVE_WAVES; ++k) b = part[k] < b ? part[k] : b;
+      __syncthreads();
+      if (b == ~0ull) break;
+      if (tid == 0 && c.mem_off + 1u + n_sel < p.cap_members)
+        p.members[c.mem_off + 1u + n_sel] = wid[(uint32_t)(b & ((1ull << SB) - 1ull))];
+      last = b;
+      ++n_sel;
+      if (lmin == b) {
+        uint64_t m = ~0ull;
+        for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+          const uint64_t k = key[s];
+          m = (k > b && k < m) ? k : m;
+        }
+        lmin = m;
+      }
+    }
+    total = 1u + n_sel;
+    if (c.mode == CARVE_MODE_FORM) break;
+  }
+  if (total == 0) return STEP_BREAK;
+  if (c.mode == CARVE_MODE_FORM && total < c.min_s) return STEP_BREAK;
+  if (c.mode == CARVE_MODE_MERGE && total < 2u) return STEP_BREAK;
+
+  int uncertain = p.debug_uncertain_every && use_dist &&
+                  ((steps_before + c.steps + 1u) % p.debug_uncertain_every) == 0u;
+  const uint64_t last_key = (last >> SB) << SB;
+  if (use_dist && n_sel > 0 && last_key != ((PM_KEY_NOLOC >> SB) << SB)) {
+    const uint32_t ls = (uint32_t)(last & ((1ull << SB) - 1ull));
+    const double a_m = __longlong_as_double((long long)last_key);
+    const double band = a_m * PM_TIE_BAND_MEM + 1e-300;
+    const double mlat = p.cc_lat[ls], mlon = p.cc_lon[ls];
+    if (a_m > PM_A_MAX_SAFE) uncertain = 1;
+    for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+      const uint64_t k = key[s];
+      if (k == ~0ull || s == ls) continue;
+      const uint64_t kb = (k >> SB) << SB;
+      if (kb == ((PM_KEY_NOLOC >> SB) << SB)) continue;
+      const double a = __longlong_as_double((long long)kb);
+      if (fabs(a - a_m) <= band && (p.cc_lat[s] != mlat || p.cc_lon[s] != mlon)) uncertain = 1;
+    }
+  }
+  if (__syncthreads_or(uncertain)) {
+    if (tid == 0) p.status->stop_seed = wid[seed];
+    return STEP_UNCERTAIN;
+  }
+  if (c.n_groups >= p.cap_groups || c.mem_off + total > p.cap_members) return STEP_OVERFLOW;
+  for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+    if (!bit_at(alive, s)) continue;
+    if (s == seed || (n_sel > 0 && key[s] <= last))
+      atomicAnd((unsigned long long*)&alive[s >> 6], ~(1ull << (s & 63u)));
+  }
+  if (tid == 0) {
+    p.members[c.mem_off] = wid[seed];
+    p.g_cfg[c.n_groups] = c.cfg;
+    p.g_n[c.n_groups] = total;
+    p.g_off[c.n_groups] = c.mem_off;
+  }
+  __syncthreads();
+  c.n_groups += 1;
+  c.mem_off += total;
+  c.cand_sum += c.n_cand;
+  c.n_cand -= total;
+  c.total_available -= total;
+  c.steps += 1;
+  return STEP_CONTINUE;
+}
+
+// Stable compaction of the live positions of this configuration into list slots: two passes over
+// contiguous per-wave ranges.  Returns the list length; red.a keeps the per-wave counts for the placement.
+__device__ uint32_t carve_compact_count(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t n_words = (n + 63u) >> 6;
+  const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
+  const uint32_t j0 = wave * wpw, j1 = min(n_words, j0 + wpw);
+  uint32_t cnt = 0;
+  for (uint32_t j = j0; j < j1; ++j) {
+    const uint32_t i = j * 64u + lane;
+    const bool c = i < n && bit_at(p.alive_g, i) && (p.mode == CARVE_MODE_MERGE || (p.c_compat[i] & cbit) != 0ull);
+    cnt += __popcll(__ballot(c));
+  }
+  __syncthreads();  // previous users of red.a are done
+  if (lane == 0) red.a[wave] = cnt;
+  __syncthreads();
+  uint32_t total = 0;
+  for (uint32_t k = 0; k < CARVE_WAVES; ++k) total += red.a[k];
+  return total;
+}
+
+__device__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit, uint32_t n_list,
+                                    uint32_t* wid, uint64_t* alive, uint64_t* loc) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_words = (n + 63u) >> 6;
+  const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
+  const uint32_t j0 = wave * wpw, j1 = min(n_words, j0 + wpw);
+  uint32_t off = 0;
+  for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
+  for (uint32_t j = j0; j < j1; ++j) {
+    const uint32_t i = j * 64u + lane;
+    const bool c = i < n && bit_at(p.alive_g, i) && (p.mode == CARVE_MODE_MERGE || (p.c_compat[i] & cbit) != 0ull);
+    const uint64_t bal = __ballot(c);
+    if (c) {
+      const uint32_t s = off + __popcll(bal & ((1ull << lane) - 1ull));
+      p.slot_pos[s] = i;
+      wid[s] = p.order[i];
+      p.cc_lat[s] = p.c_lat[i];
+      p.cc_lon[s] = p.c_lon[i];
+      p.cc_cos[s] = p.c_cos[i];
+    }
+    off += __popcll(bal);
+  }
+  __syncthreads();
+  const uint32_t lw = (n_list + 63u) >> 6;
+  for (uint32_t base = 0; base < lw * 64u; base += CARVE_THREADS) {
+    const uint32_t s = base + tid;
+    const bool in = s < n_list;
+    const bool hl = in && bit_at(p.loc_g, p.slot_pos[s]);
+    const uint64_t ba = __ballot(in), bl = __ballot(hl);
+    if (lane == 0 && (s >> 6) < lw) {
+      alive[s >> 6] = ba;
+      loc[s >> 6] = bl;
+    }
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
-  extern __shared__ uint64_t s_dyn[];  // [alive | cand | loc] bitmaps, bits_stride words each (if they fit)
-  __shared__ BlockRed red;
-  __shared__ uint32_t s_n;
+  // All LDS lives in the dynamic region, every carve offset a multiple of 16 B (a static __shared__ in
+  // front of it would shift the base and put every 64-bit DS access on the 64-cycle misaligned path).
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  uint64_t* part = reinterpret_cast<uint64_t*>(s_raw);                       // [16 * PART]
+  uint64_t* lds_alive = part + CARVE_WAVES * PM_CARVE_PART;                  // [SLOTS / 64]
+  uint64_t* lds_loc = lds_alive + PM_CARVE_SLOTS / 64;                       // [SLOTS / 64]
+  uint32_t* lds_wid = reinterpret_cast<uint32_t*>(lds_loc + PM_CARVE_SLOTS / 64);  // [SLOTS]
+  uint32_t* sel_out = lds_wid + PM_CARVE_SLOTS;                              // [SEL_CAP]
+  BlockRed& red = *reinterpret_cast<BlockRed*>(sel_out + PM_CARVE_SEL_CAP);
+  uint32_t& s_n = *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&red) + sizeof(BlockRed));
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   CarveStatus* st = p.status;
 
-  // ---- ordered candidate list.  FORM: compact the eligible rows (Healthy & p2p & unassigned,
+  // ---- ordered eligible list.  FORM: compact the eligible rows (Healthy & p2p & unassigned,
   // mod.rs:492-497) in input order.  MERGE: supplied by the engine.
   uint32_t n;
   if (p.mode == CARVE_MODE_FORM) {
@@ -597,11 +1035,8 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
     n = p.n_order;
   }
   const uint32_t n_words = (n + 63u) >> 6;
-  uint64_t* alive = p.bits_in_lds ? s_dyn : p.bits_scratch;
-  uint64_t* cand = alive + p.bits_stride;
-  uint64_t* locb = cand + p.bits_stride;
 
-  // compacted columns + alive / loc bitmaps
+  // position-indexed columns + alive / loc bitmaps (L2 resident)
   for (uint32_t base = 0; base < n_words * 64u; base += CARVE_THREADS) {
     const uint32_t i = base + tid;
     bool has_loc = false;
@@ -615,164 +1050,96 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
     }
     const uint64_t bl = __ballot(has_loc);
     const uint64_t ba = __ballot(i < n);
-    if (lane == 0 && (i >> 6) < n_words) {  // waves past the last word must not touch the bitmaps
-      locb[i >> 6] = bl;
-      alive[i >> 6] = ba;
+    if (lane == 0 && (i >> 6) < n_words) {
+      p.loc_g[i >> 6] = bl;
+      p.alive_g[i >> 6] = ba;
     }
   }
   __syncthreads();
 
-  uint32_t total_available = n;  // mod.rs:503
-  uint32_t n_groups = st->n_groups, mem_off = st->n_members;
   const uint32_t steps_before = st->steps_total;
-  uint32_t steps = 0, parity = 0;
-  unsigned long long cand_sum = 0;
+  StepCtx c;
+  c.mode = p.mode;
+  c.proximity = p.proximity;
+  c.n_groups = st->n_groups;
+  c.mem_off = st->n_members;
+  c.total_available = n;  // mod.rs:503
+  c.steps = 0;
+  c.cand_sum = 0;
+  uint32_t exit_state = CARVE_STATE_DONE, stop_ci = p.n_avail;
 
-  for (uint32_t ci = p.start_ci; ci < p.n_avail; ++ci) {  // mod.rs:505
-    const uint32_t cfg = p.avail_cfg[ci];
-    const uint32_t min_s = p.min_size[ci], max_s = p.max_size[ci];
-    const uint64_t cbit = 1ull << cfg;
+  for (uint32_t ci = p.start_ci; ci < p.n_avail && exit_state == CARVE_STATE_DONE; ++ci) {  // mod.rs:505
+    c.cfg = p.avail_cfg[ci];
+    c.min_s = p.min_size[ci];
+    c.max_s = p.max_size[ci];
+    const uint64_t cbit = 1ull << c.cfg;
+    if (p.mode == CARVE_MODE_FORM && c.total_available < c.min_s) continue;  // `while` of mod.rs:507 never entered
 
-    // candidate bitmap of this configuration (mod.rs:511-515 evaluated once; removals are applied to
-    // the bitmap instead of re-filtering).  MERGE: the list is already filtered.
-    uint32_t my_cnt = 0;
-    for (uint32_t base = 0; base < n_words * 64u; base += CARVE_THREADS) {
-      const uint32_t i = base + tid;
-      bool c = false;
-      if (i < n) c = bit_at(alive, i) && (p.mode == CARVE_MODE_MERGE || (p.c_compat[i] & cbit));
-      const uint64_t bc = __ballot(c);
-      if (lane == 0 && (i >> 6) < n_words) {
-        cand[i >> 6] = bc;
-        my_cnt += __popcll(bc);
-      }
-    }
-    if (lane == 0) red.a[wave] = my_cnt;
-    __syncthreads();
-    uint32_t n_cand = 0;
-    for (uint32_t k = 0; k < CARVE_WAVES; ++k) n_cand += red.a[k];
-    __syncthreads();
+    // candidate list of this configuration (mod.rs:511-515 evaluated once; removals are applied to the
+    // bitmaps instead of re-filtering).  MERGE: the list is already filtered by the engine.
+    for (;;) {
+      PROF_DECL;
+      c.n_list = carve_compact_count(p, red, n, cbit);
+      c.n_cand = c.n_list;
+      const bool in_lds = c.n_list <= PM_CARVE_SLOTS;
+      uint32_t* wid = in_lds ? lds_wid : p.slot_wid;
+      uint64_t* alive = in_lds ? lds_alive : p.bits_scratch;
+      uint64_t* loc = in_lds ? lds_loc : p.bits_scratch + p.bits_stride;
+      carve_compact_place(p, red, n, cbit, c.n_list, wid, alive, loc);
+      PROF_MARK(9);
 
-    // FORM: `while total_available >= min` (mod.rs:507) with `compatible < min => break` (:517-519).
-    // MERGE: `while remaining_groups.len() >= min` (mod.rs:695).
-    while ((p.mode == CARVE_MODE_MERGE || total_available >= min_s) && n_cand >= min_s && n_cand > 0) {
-      // ---- seed search over the bitmaps
-      uint32_t f_loc = PM_NONE, f_any = PM_NONE;
-      for (uint32_t j = tid; j < n_words; j += CARVE_THREADS) {
-        const uint64_t c = cand[j];
-        if (c && f_any == PM_NONE) f_any = j * 64u + __builtin_ctzll(c);
-        const uint64_t cl = c & locb[j];
-        if (cl && f_loc == PM_NONE) f_loc = j * 64u + __builtin_ctzll(cl);
-      }
-      f_loc = wave_min(f_loc);
-      f_any = wave_min(f_any);
-      if (lane == 0) {
-        red.a[wave] = f_loc;
-        red.b[wave] = f_any;
-      }
-      __syncthreads();
-      f_loc = PM_NONE;
-      f_any = PM_NONE;
-      for (uint32_t k = 0; k < CARVE_WAVES; ++k) {
-        f_loc = min(f_loc, red.a[k]);
-        f_any = min(f_any, red.b[k]);
-      }
-      __syncthreads();
-
-      const uint32_t want = max_s - 1u < n_cand - 1u ? max_s - 1u : n_cand - 1u;  // fill to max (mod.rs:545-551)
-      uint32_t seed = f_any;
-      bool use_dist = false, located_only = false;
-      SelResult r;
-      uint32_t total = 0;
-      if (p.mode == CARVE_MODE_FORM) {
-        if (p.proximity && f_loc != PM_NONE) {  // seed = first WITH a location (mod.rs:526-530)
-          seed = f_loc;
-          use_dist = true;
-        }  // else: first-come (:553-561) or seed without location => sort is a no-op (:238)
-        r = carve_select(p, red, parity, cand, locb, n, seed, use_dist, false, want, mem_off);
-        total = 1u + r.n_sel;
-        if (total < min_s) break;  // mod.rs:564-566
+      int rc;
+      if (!in_lds) {
+        do {
+          rc = carve_step_mem(p, red, c, part, p.keys, wid, alive, loc, steps_before);
+        } while (rc == STEP_CONTINUE && !(c.n_cand * 2u < c.n_list));
+      } else if (c.n_list <= 1u * CARVE_THREADS) {
+        rc = carve_run_lds<1>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
+      } else if (c.n_list <= 2u * CARVE_THREADS) {
+        rc = carve_run_lds<2>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
+      } else if (c.n_list <= 4u * CARVE_THREADS) {
+        rc = carve_run_lds<4>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
       } else {
-        if (p.proximity && f_loc != PM_NONE) {  // mod.rs:762-821
-          seed = f_loc;
-          use_dist = true;
-          located_only = true;
-          r = carve_select(p, red, parity, cand, locb, n, seed, true, true, want, mem_off);
-          total = 1u + r.n_sel;
-        }
-        if (total == 0 || (total < max_s && total < min_s)) {  // mod.rs:824-848: reset + first-come
-          seed = f_any;
-          use_dist = false;
-          located_only = false;
-          r = carve_select(p, red, parity, cand, locb, n, seed, false, false, want, mem_off);
-          total = 1u + r.n_sel;
-        }
-        if (total < 2u) break;  // is_merge_beneficial (mod.rs:868-870)
-      }
-
-      int uncertain = use_dist ? carve_uncertain(p, cand, locb, n, seed, r) : 0;
-      if (p.debug_uncertain_every && use_dist && ((steps_before + steps + 1u) % p.debug_uncertain_every) == 0u)
-        uncertain = 1;
-      uncertain = __syncthreads_or(uncertain);
-      if (uncertain) {
-        if (tid == 0) {
-          st->state = CARVE_STATE_UNCERTAIN;
-          st->stop_ci = ci;
-          st->n_groups = n_groups;
-          st->n_members = mem_off;
-          st->steps_total = steps_before + steps;
-          st->stop_seed = p.order[seed];
-          st->n_eligible = n;
-          st->cand_sum += cand_sum;
-        }
-        return;
-      }
-      if (n_groups >= p.cap_groups || mem_off + total > p.cap_members) {
-        if (tid == 0) {
-          st->state = CARVE_STATE_OVERFLOW;
-          st->n_groups = n_groups;
-          st->n_members = mem_off;
-          st->steps_total = steps_before + steps;
-        }
-        return;
-      }
-
-      // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
-      if (tid == 0) {
-        p.members[mem_off] = p.order[seed];
-        p.g_cfg[n_groups] = cfg;
-        p.g_n[n_groups] = total;
-        p.g_off[n_groups] = mem_off;
-      }
-      // selected positions = seed + every candidate with (key, pos) <= (last_k, last_i)
-      for (uint32_t i = tid; i < n; i += CARVE_THREADS) {
-        if (!bit_at(cand, i)) continue;
-        bool sel = (i == seed);
-        if (!sel && r.n_sel > 0 && !(use_dist && located_only && !bit_at(locb, i)))
-          sel = !ki_less(r.last_k, r.last_i, p.keys[i], i);
-        if (sel) {
-          const unsigned long long m = ~(1ull << (i & 63u));
-          atomicAnd((unsigned long long*)&cand[i >> 6], m);
-          atomicAnd((unsigned long long*)&alive[i >> 6], m);
-          if (p.mode == CARVE_MODE_FORM) p.group_of[p.order[i]] = (int32_t)n_groups;
-        }
+        rc = carve_run_lds<8>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
       }
       __syncthreads();
-      n_groups += 1;
-      mem_off += total;
-      total_available -= total;  // mod.rs:586
-      cand_sum += n_cand;
-      n_cand -= total;
-      ++steps;
+#ifdef PM_CARVE_PROF
+      prof_t0 = __builtin_amdgcn_s_memtime();
+#endif
+      // dead slots -> position bitmap, so the next compaction / configuration sees the removals
+      for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS)
+        if (!bit_at(alive, s)) {
+          const uint32_t i = p.slot_pos[s];
+          atomicAnd((unsigned long long*)&p.alive_g[i >> 6], ~(1ull << (i & 63u)));
+        }
+      __syncthreads();
+      PROF_MARK(10);
+      if (rc == STEP_UNCERTAIN || rc == STEP_OVERFLOW) {
+        exit_state = rc == STEP_UNCERTAIN ? CARVE_STATE_UNCERTAIN : CARVE_STATE_OVERFLOW;
+        stop_ci = ci;
+        break;
+      }
+      if (rc == STEP_BREAK) break;  // configuration exhausted; STEP_CONTINUE => recompact and go on
     }
   }
+
+  // group_of for everything carved by this launch (FORM), one parallel pass at the end
+  if (p.mode == CARVE_MODE_FORM) {
+    __syncthreads();
+    for (uint32_t g = st->n_groups + wave; g < c.n_groups; g += CARVE_WAVES) {
+      const uint32_t off = p.g_off[g], gn = p.g_n[g];
+      for (uint32_t k = lane; k < gn; k += 64u) p.group_of[p.members[off + k]] = (int32_t)g;
+    }
+  }
+  __syncthreads();
   if (tid == 0) {
-    st->state = CARVE_STATE_DONE;
-    st->n_groups = n_groups;
-    st->n_members = mem_off;
-    st->steps_total = steps_before + steps;
-    st->stop_ci = p.n_avail;
+    st->state = exit_state;
+    st->n_groups = c.n_groups;
+    st->n_members = c.mem_off;
+    st->steps_total = steps_before + c.steps;
+    st->stop_ci = stop_ci;
     st->n_eligible = n;
-    st->cand_sum += cand_sum;
+    st->cand_sum += c.cand_sum;
   }
 }
 
@@ -911,7 +1278,7 @@ hipError_t launch_carve(const CarveArgs& a, size_t lds_bytes, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)carve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PM_CARVE_MAX_LDS);
+                                       (int)PM_CARVE_LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }

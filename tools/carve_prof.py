@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the carve kernel: builds a PM_CARVE_PROF variant of the library (s_memtime ticks
+accumulated per phase by thread 0) and runs cold full-swarm matches on BASELINE configs[1]."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from protocol_amd import build as B
+
+prof_lib = os.path.join(ROOT, "protocol_amd", "libpm_engine_prof.so")
+B.build(force=True, defines=["PM_CARVE_PROF"], out=prof_lib)
+B.LIB_PATH = prof_lib
+B.needs_build = lambda: False
+from protocol_amd import engine as E, host
+from protocol_amd.swarm import make_swarm
+
+T, W = int(sys.argv[1]) if len(sys.argv) > 1 else 100000, int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+sw = make_swarm(1, T, W)
+eng = E.Engine()
+host.load_swarm(eng, sw)
+names = ["seed", "keys", "level1", "barrier1", "level2", "certificate", "barrier2", "commit", "barrier3",
+         "compaction", "flush"]
+for it in range(3):
+    eng.reset_groups()
+    s = eng.tick()
+out = (C.c_ulonglong * 16)()
+E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+E.lib().pm_debug_carve_prof(eng._h, out)
+tot = sum(out[:11])
+print(f"carve kernel {s['ms_carve_kernel']:.3f} ms, {s['carve_steps']} steps, {1e3 * s['ms_carve_kernel'] / s['carve_steps']:.2f} us/step")
+for i, nm in enumerate(names):
+    print(f"  {nm:12s} {out[i]:12d} ticks  {100.0 * out[i] / max(tot, 1):5.1f}%  {out[i] / max(s['carve_steps'], 1):8.1f} ticks/step")
+print(f"  total ticks {tot}; ticks per ms = {tot / s['ms_carve_kernel']:.0f}")
