@@ -149,6 +149,9 @@ typedef struct {
   uint32_t debug_uncertain_every; /* test hook: treat every n-th carve step as a near-tie so the
                                      exact host resolve path runs (0 = off) */
   uint32_t sweep_variant;        /* pair-sweep kernel: 0 = default (best), 1 = scalar reference kernel */
+  uint32_t carve_variant;        /* group formation: 0 = default (full-chip neighbour-list proposals + ordered
+                                    validation), 1 = single-workgroup sequential sweep only */
+  uint32_t _reserved;
 } pm_engine_config;
 
 void pm_engine_config_default(pm_engine_config*);
@@ -231,6 +234,7 @@ typedef struct {
   float ms_compat_kernel, ms_carve_kernel, ms_sweep_kernel;
   uint32_t n_groups, n_formed, n_merged;
   uint32_t carve_steps;         /* groups carved + merge selections done on the GPU */
+  uint32_t carve_fast_steps;    /* of which committed straight from a neighbour-list proposal */
   uint32_t host_resolved_steps; /* carve steps whose near-tie was settled by the exact host path */
   uint32_t carve_launches;
   uint64_t pair_evals;          /* T x W of the sweep */

@@ -15,14 +15,18 @@ static constexpr double PM_A_MAX_SAFE = 1.0 - 1.0 / 1048576.0;    // near-antipo
 // carve kernel geometry
 static constexpr uint32_t PM_CARVE_SLOTS = 8192;       // candidate slots with positions/bitmaps in LDS, keys in VGPRs
 static constexpr uint32_t PM_CARVE_PART = 64;          // per-wave partial selection capacity (max_group_size - 1)
-static constexpr uint32_t PM_CARVE_SEL_CAP = 1024;     // selected slots staged in LDS before the member stores
+static constexpr uint32_t PM_CARVE_SEL_CAP = 256;      // selected slots staged in LDS before the member stores
 static constexpr uint32_t PM_CARVE_SLOT_BITS = 13;     // log2(PM_CARVE_SLOTS): low key bits that hold the slot
 static constexpr uint32_t PM_CARVE_SLOT_BITS_MEM = 21; // same for lists kept in HBM (up to 2M candidates)
 // certificate bands: 8x the truncation step of the packed key (2^-(52-bits)) — see carve_kernel
 static constexpr double PM_TIE_BAND = 1.0 / 68719476736.0;      // 2^-36
 static constexpr double PM_TIE_BAND_MEM = 1.0 / 268435456.0;    // 2^-28
+static constexpr uint32_t PM_CARVE_CACHE_ROWS = 128;   // proposal rows staged in LDS (128 * 64 * 8 B = the key array)
+static constexpr uint32_t PM_PROP_ROW = 64;            // proposal row stride (entries)
+static constexpr uint32_t PM_PROP_RESERVE = 24;        // entries beyond max_group_size - 1
+static constexpr uint32_t PM_PROP_MAX_SEEDS = 16384;   // located slots that get a proposal per configuration
 static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
-                                             size_t(PM_CARVE_SLOTS) * 4 + size_t(PM_CARVE_SEL_CAP) * 4 + 512;
+                                             size_t(PM_CARVE_SLOTS) * 18 + size_t(PM_CARVE_SEL_CAP) * 4 + 2048;
 
 struct CompatArgs {
   uint32_t W, n_cfgs, model_words;
@@ -48,46 +52,71 @@ struct ClaimArgs {
 
 enum { CARVE_MODE_FORM = 0, CARVE_MODE_MERGE = 1 };
 enum { CARVE_STATE_RUNNING = 0, CARVE_STATE_DONE = 1, CARVE_STATE_UNCERTAIN = 2, CARVE_STATE_OVERFLOW = 3 };
+// launch flags of carve_kernel
+enum {
+  CARVE_F_INIT = 1u << 0,   // build the eligible list + position columns (first launch of a carve)
+  CARVE_F_RUN = 1u << 1,    // process the prepared configuration
+  CARVE_F_ALL = 1u << 2,    // keep going through every configuration in this launch (no proposals)
+  CARVE_F_PROPS = 1u << 3   // neighbour-list proposals of carve_propose_kernel are available
+};
 
+// Device-resident state of one carve (try_form_new_groups / one merge configuration); it persists across
+// the launches of the propose / validate sequence.
 struct CarveStatus {
   uint32_t state;
-  uint32_t stop_ci;      // configuration (position in the carve order) to resume at
+  uint32_t stop_ci;      // configuration (position in the carve order) to resume at after UNCERTAIN
   uint32_t n_groups;     // records written so far (in/out)
   uint32_t n_members;    // member slots used so far (in/out)
   uint32_t steps_total;  // committed steps over all launches of this tick
   uint32_t stop_seed;    // worker index of the seed of the uncertain step (diagnostic)
-  uint32_t n_eligible;   // compacted candidate count of the last launch
-  uint32_t _pad;
+  uint32_t n_eligible;   // length of the eligible list
+  uint32_t cur_ci;       // prepared configuration (position in the carve order); n_avail = none left
   unsigned long long cand_sum;  // sum over committed steps of the candidates scanned
+  uint32_t n_list;       // slots of the prepared candidate list
+  uint32_t prop_k;       // entries per proposal for the prepared configuration (0 = no proposals)
+  uint32_t prop_limit;   // proposals exist for located slots below this slot number
+  uint32_t total_available;
+  uint32_t fast_steps;   // steps committed from proposals
+  uint32_t slow_steps;   // steps that needed the full key sweep
   unsigned long long prof[16];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
 struct CarveArgs {
-  uint32_t mode;  // CARVE_MODE_*
+  uint32_t mode;   // CARVE_MODE_*
+  uint32_t _flags_unused;
   uint32_t W;
   uint32_t proximity;
   uint32_t debug_uncertain_every;
+  uint32_t _pad1;
   // worker columns
   const uint32_t* wflags;
   const double *lat, *lon, *coslat;
+  const uint32_t* site;  // equal (lat, lon) bit patterns <=> equal site id (host-interned)
   const uint64_t* compat;
   int32_t* group_of;  // FORM: read (eligibility) and written (commit)
-  // ordered candidate list: FORM -> written by the kernel (eligible rows in input order);
+  // ordered eligible list: FORM -> written by the kernel (eligible rows in input order);
   // MERGE -> supplied by the engine (nodes of the compatible solo groups in group-id order)
   uint32_t* order;
   uint32_t n_order;
+  uint32_t _pad2;
   // scratch (capacity W each): columns indexed by position in the eligible list ...
   double *c_lat, *c_lon, *c_cos;
+  uint32_t* c_site;
   uint64_t* c_compat;
   uint64_t *alive_g, *loc_g;  // bitmaps over positions (bits_stride words each)
-  // ... and by candidate slot of the current configuration
+  // ... and by candidate slot of the prepared configuration
   double *cc_lat, *cc_lon, *cc_cos;
-  uint64_t* keys;          // used when the candidate list does not fit in LDS
+  uint32_t* cc_site;
   uint32_t* slot_pos;      // slot -> position (for the alive_g write-back)
-  uint32_t* slot_wid;      // slot -> worker id when the candidate list does not fit in LDS
-  uint64_t* bits_scratch;  // idem: 2 * bits_stride words (alive, loc)
+  uint32_t* slot_wid;      // slot -> worker id
+  uint64_t* bits_scratch;  // slot bitmaps: alive, loc (bits_stride words each)
+  uint64_t* keys;          // packed keys when the candidate list does not fit in LDS
   uint32_t bits_stride;
   uint32_t _pad0;
+  // proposals: PM_PROP_ROW packed keys per slot, sorted ascending (carve_propose_kernel)
+  uint64_t* prop;
+  uint32_t* prop_n;        // low byte: entries; bit 31: the list holds every live candidate
+  uint32_t* same_next;     // next located slot at the same site (identical coordinates), PM_NONE = none
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];
@@ -121,7 +150,8 @@ void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const 
                         uint32_t* out, hipStream_t s);
 void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block, long long* val_by_block,
                    uint32_t n_blocks, hipStream_t s);
-hipError_t launch_carve(const CarveArgs& a, size_t lds_bytes, hipStream_t s);
+hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
+void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 
 }  // namespace pm
 #endif

@@ -106,6 +106,10 @@ struct pm_engine {
   std::vector<uint32_t> h_flags, h_gpu_count, h_gpu_mem, h_gpu_cls, h_cpu_cores, h_ram, h_storage, h_price,
       h_addr_rank;
   std::vector<double> h_lat, h_lon;
+  std::vector<uint32_t> h_site;  // equal (lat, lon) bit patterns <=> equal site id
+  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_prop_n, d_same_next;
+  DevBuf<uint64_t> d_prop;
+  uint32_t tick_fast_steps = 0;
   DevBuf<uint32_t> d_flags, d_gpu_count, d_gpu_mem, d_gpu_cls, d_cpu_cores, d_ram, d_storage, d_addr_rank;
   DevBuf<double> d_lat, d_lon, d_coslat;
   DevBuf<uint64_t> d_compat;
@@ -141,6 +145,7 @@ struct pm_engine {
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
   DevBuf<uint32_t> d_slot_pos, d_slot_wid;
   DevBuf<CarveStatus> d_status;
+  DevBuf<CarveArgs> d_carve_args;
   DevBuf<uint32_t> d_m_cfg, d_m_n, d_m_off, d_m_members;  // MERGE batches
 
   // ---- sweep scratch
@@ -312,7 +317,13 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_keys.ensure(cap));
   HIPCHK(e->d_slot_pos.ensure(cap));
   HIPCHK(e->d_slot_wid.ensure(cap));
+  HIPCHK(e->d_c_site.ensure(cap));
+  HIPCHK(e->d_cc_site.ensure(cap));
+  HIPCHK(e->d_prop_n.ensure(cap));
+  HIPCHK(e->d_same_next.ensure(cap));
+  HIPCHK(e->d_prop.ensure(cap * PM_PROP_ROW));
   HIPCHK(e->d_status.ensure(1));
+  HIPCHK(e->d_carve_args.ensure(1));
   const uint32_t stride = uint32_t((cap + 63) / 64);
   HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
   std::memset(a, 0, sizeof(*a));
@@ -340,6 +351,12 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->keys = e->d_keys.p;
   a->slot_pos = e->d_slot_pos.p;
   a->slot_wid = e->d_slot_wid.p;
+  a->site = e->d_site.p;
+  a->c_site = e->d_c_site.p;
+  a->cc_site = e->d_cc_site.p;
+  a->prop = e->d_prop.p;
+  a->prop_n = e->d_prop_n.p;
+  a->same_next = e->d_same_next.p;
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
   a->bits_stride = stride;
   a->status = e->d_status.p;
@@ -440,11 +457,24 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
   st.state = CARVE_STATE_RUNNING;
   st.n_groups = g0;
   st.n_members = m0;
-  a.start_ci = 0;
+  const bool use_props = e->cfg.carve_variant == 0 && e->cfg.proximity_enabled;
+  HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
+  uint32_t start_ci = 0;
   for (;;) {
     HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->kev[2], e->stream));
-    HIPCHK(launch_carve(a, lds, e->stream));
+    if (use_props) {
+      // prepare the first candidate list, then (propose, validate) pairs: one per configuration plus one
+      // per re-proposal round; launches queued behind a finished carve return immediately
+      HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, start_ci, lds, e->stream));
+      for (uint32_t k = 0; k < a.n_avail - start_ci + 8u; ++k) {
+        launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
+        e->tick_carve_launches += 2;
+      }
+    } else {
+      HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, start_ci, lds, e->stream));
+    }
     HIPCHK(hipEventRecord(e->kev[3], e->stream));
     e->tick_carve_launches++;
     HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
@@ -456,13 +486,30 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
     }
     if (st.state == CARVE_STATE_DONE) break;
     if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
+    while (st.state == CARVE_STATE_RUNNING && use_props) {  // more re-proposal rounds than were queued
+      HIPCHK(hipEventRecord(e->kev[2], e->stream));
+      for (uint32_t k = 0; k < 16u; ++k) {
+        launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
+        e->tick_carve_launches += 2;
+      }
+      HIPCHK(hipEventRecord(e->kev[3], e->stream));
+      HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
+      e->k_ms_carve += ms;
+    }
+    if (st.state == CARVE_STATE_DONE) break;
+    if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
     if (st.state != CARVE_STATE_UNCERTAIN) return set_error(PM_ENODEV, "carve kernel did not complete");
     rc = host_resolve_form_step(e, avail[st.stop_ci], &st);
     if (rc) return rc;
     e->tick_host_resolved++;
-    a.start_ci = st.stop_ci;
+    start_ci = st.stop_ci;
     st.state = CARVE_STATE_RUNNING;
   }
+  e->tick_fast_steps += st.fast_steps;
   e->tick_carve_steps += st.steps_total;
   e->tick_cand_sum += st.cand_sum;
   std::memcpy(e->carve_prof, st.prof, sizeof(st.prof));
@@ -749,7 +796,9 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
         if (!order.empty())
           HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
-        HIPCHK(launch_carve(a, lds, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, 0, lds, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));  // `a` is a stack object
         e->tick_carve_launches++;
         HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -891,7 +940,8 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_rank_in_group.release(); e->d_g_id.release();
   e->d_order.release(); e->d_c_lat.release(); e->d_c_lon.release(); e->d_c_cos.release();
   e->d_cc_lat.release(); e->d_cc_lon.release(); e->d_cc_cos.release(); e->d_slot_pos.release(); e->d_slot_wid.release();
-  e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release();
+  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop_n.release(); e->d_prop.release(); e->d_same_next.release();
+  e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release(); e->d_scratch.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
@@ -968,6 +1018,26 @@ static int32_t upload_worker_columns(pm_engine* e) {
   if ((rc = upload(e->d_addr_rank, e->h_addr_rank.data(), W, e->stream))) return rc;
   if ((rc = upload(e->d_lat, e->h_lat.data(), W, e->stream))) return rc;
   if ((rc = upload(e->d_lon, e->h_lon.data(), W, e->stream))) return rc;
+  {  // intern coordinates: the carve certificate needs "same place" as an exact integer compare
+    struct KeyHash {
+      size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
+        return size_t(splitmix64_mix(k.first ^ splitmix64_mix(k.second)));
+      }
+    };
+    std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> sites;
+    sites.reserve(W * 2);
+    e->h_site.resize(W);
+    for (size_t w = 0; w < W; ++w) {
+      uint64_t a, b;
+      std::memcpy(&a, &e->h_lat[w], 8);
+      std::memcpy(&b, &e->h_lon[w], 8);
+      if (e->h_lat[w] == 0.0) a = 0;  // +0.0 and -0.0 compare equal in the reference's f64 arithmetic
+      if (e->h_lon[w] == 0.0) b = 0;
+      auto it = sites.emplace(std::make_pair(a, b), uint32_t(sites.size())).first;
+      e->h_site[w] = it->second;
+    }
+  }
+  if ((rc = upload(e->d_site, e->h_site.data(), W, e->stream))) return rc;
   HIPCHK(e->d_coslat.ensure(W ? W : 1));
   launch_coslat(e->d_lat.p, e->d_coslat.p, uint32_t(W), e->stream);
   HIPCHK(hipGetLastError());
@@ -1140,7 +1210,9 @@ int32_t pm_form_groups(pm_engine* e, uint32_t* n_formed) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
   e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
+  e->tick_fast_steps = 0;
   int32_t rc = run_form(e, n_formed);
+  e->last_stats.carve_fast_steps = e->tick_fast_steps;
   e->last_stats.host_resolved_steps = e->tick_host_resolved;
   e->last_stats.carve_launches = e->tick_carve_launches;
   e->last_stats.carve_steps = e->tick_carve_steps;
@@ -1290,6 +1362,7 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
     return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
   e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
+  e->tick_fast_steps = 0;
   e->tick_cand_sum = 0;
   e->k_ms_compat = e->k_ms_carve = e->k_ms_sweep = 0;
   e->k_sweep_recorded = e->k_compat_recorded = false;
@@ -1327,6 +1400,7 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   s.n_formed = n_formed;
   s.n_merged = n_merged;
   s.carve_steps = e->tick_carve_steps;
+  s.carve_fast_steps = e->tick_fast_steps;
   s.host_resolved_steps = e->tick_host_resolved;
   s.carve_launches = e->tick_carve_launches;
   s.pair_evals = uint64_t(e->T) * uint64_t(e->W);

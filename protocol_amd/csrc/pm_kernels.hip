@@ -469,6 +469,13 @@ struct BlockRed {
   uint32_t b[CARVE_WAVES];
   uint32_t part_n[CARVE_WAVES];
   uint32_t flag[CARVE_WAVES];
+  // mailbox: wave 0 -> workgroup after a run of fast (proposal) steps
+  uint32_t f_action, f_n_cand, f_total_available, f_n_groups, f_mem_off, f_steps, f_fast, f_pad;
+  unsigned long long f_cand_sum;
+  // proposal rows staged in LDS (they alias the slow path's key array): slot and prop_n word per row
+  uint32_t cache_n, cache_pad;
+  uint32_t cache_slot[PM_CARVE_CACHE_ROWS];
+  uint32_t cache_meta[PM_CARVE_CACHE_ROWS];
 };
 
 // sin on [-pi/2, pi/2] as an odd Taylor polynomial to x^19 (|rel err| < 1e-15 there); larger arguments
@@ -528,32 +535,289 @@ struct StepCtx {
   uint32_t n_cand;       // live slots
   uint32_t n_groups, mem_off;
   uint32_t total_available;
-  uint32_t steps;
+  uint32_t steps, fast_steps;
   unsigned long long cand_sum;
+  // proposals (0 = none)
+  uint32_t prop_k, prop_limit;
+  bool use_props;
 };
 
-// LDS carve of one candidate list of at most E*1024 slots.  Per-lane state lives in registers for the
-// whole run: coordinates of the lane's E slots (slot = tid + j*1024), loaded once after a compaction;
-// packed keys are recomputed per step.  LDS holds the worker ids, the alive / loc bitmaps and the
-// per-wave partial selections.  Runs steps until the configuration is exhausted, a recompaction is due,
-// or a step cannot be certified.  Three LDS-only barriers per step.
-template <int E>
-__device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, const uint32_t* l_wid, uint64_t* l_alive,
-                             const uint64_t* l_loc, uint64_t* part, uint32_t* sel_out, uint32_t steps_before) {
+enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3 };
+
+// Fast steps, executed by wave 0 alone while the other waves are parked at a barrier: the expensive
+// part of a step (keys for every live candidate + top-k) was done for every possible seed by
+// carve_propose_kernel against the live set at the start of the configuration.  Because candidates are
+// only ever REMOVED, the reference's sorted remaining list is the proposal list minus the dead entries,
+// as long as the proposal still holds enough live entries and the boundary can be certified; otherwise
+// the step is handed to the exact full sweep (FAST_SLOW).
+#ifdef PM_CARVE_PROF
+#define PROF_COUNT(slot) do { if (lane == 0) p.status->prof[slot] += 1; } while (0)
+#else
+#define PROF_COUNT(slot)
+#endif
+#define FAST_RETURN(code) do { c_ref = c; return (code); } while (0)
+
+__device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed& red, StepCtx& c_ref,
+                                             const uint32_t* l_wid, const uint32_t* l_site, const uint16_t* l_next,
+                                             const uint64_t* l_rows, uint64_t* l_alive, const uint64_t* l_loc,
+                                             uint32_t steps_before) {
+  StepCtx c = c_ref;  // registers for the whole run (the reference lives in the caller's scratch frame)
+  const uint32_t lane = threadIdx.x & 63u;
+  constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
+  constexpr uint64_t SLOT_MASK = (1ull << SB) - 1ull;
+  const uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
+  const uint32_t lw = (c.n_list + 63u) >> 6;
+  uint32_t row_ptr = 0;  // staged rows are in ascending slot order, and so are the seeds
+  const uint32_t cache_n = red.cache_n;
+  for (;;) {
+    if (!(c.total_available >= c.min_s && c.n_cand >= c.min_s && c.n_cand > 0)) FAST_RETURN(FAST_DONE);
+    // ---- seed (mod.rs:526-530)
+    uint32_t f_loc = PM_NONE;
+    if (c.proximity) {
+      for (uint32_t j0 = 0; j0 < lw; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        const uint64_t ll = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
+        const uint64_t nz = __ballot(ll != 0ull);
+        if (nz) {
+          const int src = __builtin_ctzll(nz);
+          const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ll >> 32), src) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ll, src);
+          f_loc = (j0 + src) * 64u + __builtin_ctzll(w);
+          break;
+        }
+      }
+    }
+    const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // mod.rs:545-551
+    if (c.n_groups >= p.cap_groups || c.mem_off + want + 1u > p.cap_members) FAST_RETURN(FAST_OVERFLOW);
+
+    if (f_loc == PM_NONE) {
+      // no located candidate (or proximity off): the group is the first `want + 1` live slots in input
+      // order (mod.rs:553-561; a seed without location makes the sort a no-op, :238)
+      uint32_t cnt = 0;
+      const uint32_t need = want + 1u;
+      for (uint32_t j = 0; j < lw && cnt < need; ++j) {
+        uint64_t w = l_alive[j];
+        if (!w) continue;
+        // take the lowest (need - cnt) set bits of w
+        const uint32_t pc = __popcll(w);
+        uint64_t take = w;
+        if (pc > need - cnt) {
+          uint64_t keep = w;
+          for (uint32_t k = 0; k < need - cnt; ++k) keep &= keep - 1ull;
+          take = w & ~keep;
+        }
+        const bool mine = (take >> lane) & 1ull;
+        if (mine) p.members[c.mem_off + cnt + __popcll(take & ((1ull << lane) - 1ull))] = l_wid[j * 64u + lane];
+        if (lane == 0) l_alive[j] = w & ~take;
+        cnt += __popcll(take);
+      }
+      if (lane == 0) {
+        p.g_cfg[c.n_groups] = c.cfg;
+        p.g_n[c.n_groups] = cnt;
+        p.g_off[c.n_groups] = c.mem_off;
+      }
+      c.n_groups += 1;
+      c.mem_off += cnt;
+      c.cand_sum += c.n_cand;
+      c.n_cand -= cnt;
+      c.total_available -= cnt;
+      c.steps += 1;
+      c.fast_steps += 1;
+      continue;
+    }
+
+    const uint32_t seed = f_loc;
+    if (c.prop_k == 0 || seed >= c.prop_limit) {  FAST_RETURN(FAST_SLOW); }
+    if (p.debug_uncertain_every && ((steps_before + c.steps + 1u) % p.debug_uncertain_every) == 0u) FAST_RETURN(FAST_SLOW);
+
+    // ---- same-site shortcut: candidates with the seed's exact coordinates are at distance 0 — ahead of
+    // everybody else, in input (slot) order.  If `want` of them are still alive they ARE the group.
+    if (want > 0 && l_next[seed] != 0xFFFFu) {
+      uint32_t cnt = 0;
+      uint32_t t = l_next[seed];
+      uint32_t mine_slot = PM_NONE;
+      while (t != 0xFFFFu && cnt < want) {
+        if (bit_at(l_alive, t)) {
+          if (lane == cnt) mine_slot = t;
+          ++cnt;
+        }
+        t = l_next[t];
+      }
+      if (cnt == want && want <= 64u) {
+        if (lane < want) {
+          atomicAnd((unsigned long long*)&l_alive[mine_slot >> 6], ~(1ull << (mine_slot & 63u)));
+          p.members[c.mem_off + 1u + lane] = l_wid[mine_slot];
+        }
+        if (lane == 0) {
+          atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
+          p.members[c.mem_off] = l_wid[seed];
+          p.g_cfg[c.n_groups] = c.cfg;
+          p.g_n[c.n_groups] = want + 1u;
+          p.g_off[c.n_groups] = c.mem_off;
+        }
+        c.n_groups += 1;
+        c.mem_off += want + 1u;
+        c.cand_sum += c.n_cand;
+        c.n_cand -= want + 1u;
+        c.total_available -= want + 1u;
+        c.steps += 1;
+        c.fast_steps += 1;
+        continue;
+      }
+    }
+
+    // ---- the seed's neighbour list (staged in LDS): one packed key per lane, sorted ascending
+    while (row_ptr < cache_n && red.cache_slot[row_ptr] < seed) ++row_ptr;
+    if (row_ptr >= cache_n || red.cache_slot[row_ptr] != seed) FAST_RETURN(FAST_REFILL);
+    const uint32_t nk_word = red.cache_meta[row_ptr];
+    const uint32_t n_k = nk_word & 0xFFu;
+    const bool complete = (nk_word >> 31) != 0u;
+    const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
+    const uint64_t e = lane < n_k ? l_rows[row_ptr * PM_PROP_ROW + lane] : ~0ull;
+    const uint32_t slot = (uint32_t)(e & SLOT_MASK);
+    const bool alive = lane < n_k && bit_at(l_alive, slot);
+    const uint64_t am = __ballot(alive);
+    const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
+    if ((uint32_t)__popcll(am) < want) {  FAST_RETURN(FAST_SLOW); }  // list exhausted by earlier groups
+    const bool sel = alive && rank < want;
+    if (want > 0) {
+      const uint64_t lm = __ballot(sel && rank == want - 1u);
+      const int lane_m = __builtin_ctzll(lm);
+      const uint64_t e_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), lane_m) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, lane_m);
+      const uint64_t kb_m = (e_m >> SB) << SB;
+      if (kb_m != noloc_key) {
+        // exactness certificate: every live unselected candidate within the band of the last selected one
+        // must sit at the same site (then the reference's distances tie exactly and slot order decides)
+        const double a_m = __longlong_as_double((long long)kb_m);
+        const double band = a_m * PM_TIE_BAND + 1e-300;
+        if (a_m > PM_A_MAX_SAFE) FAST_RETURN(FAST_SLOW);
+        const uint32_t site_m = l_site[(uint32_t)(e_m & SLOT_MASK)];
+        const uint64_t kb = (e >> SB) << SB;
+        const bool near = alive && !sel && kb != noloc_key && (__longlong_as_double((long long)kb) - a_m) <= band;
+        if (__ballot(near && l_site[slot] != site_m)) {  FAST_RETURN(FAST_SLOW); }
+        if (!complete) {
+          // candidates beyond the list are >= its last entry: either that entry clears the band, or it sits
+          // at e_m's site and the proposer verified (tail_ok) that everything unlisted within the band of
+          // the last entry is at that site too (then those tie exactly and have larger slots)
+          const int last_l = (int)n_k - 1;
+          const uint64_t e_l = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), last_l) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, last_l);
+          const uint64_t kb_l = (e_l >> SB) << SB;
+          if (kb_l != noloc_key && (__longlong_as_double((long long)kb_l) - a_m) <= band) {
+            if (!(tail_ok && l_site[(uint32_t)(e_l & SLOT_MASK)] == site_m)) FAST_RETURN(FAST_SLOW);
+          }
+        }
+      }
+    }
+    // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
+    if (sel) {
+      atomicAnd((unsigned long long*)&l_alive[slot >> 6], ~(1ull << (slot & 63u)));
+      p.members[c.mem_off + 1u + rank] = l_wid[slot];
+    }
+    if (lane == 0) {
+      atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
+      p.members[c.mem_off] = l_wid[seed];
+      p.g_cfg[c.n_groups] = c.cfg;
+      p.g_n[c.n_groups] = want + 1u;
+      p.g_off[c.n_groups] = c.mem_off;
+    }
+    c.n_groups += 1;
+    c.mem_off += want + 1u;
+    c.cand_sum += c.n_cand;
+    c.n_cand -= want + 1u;
+    c.total_available -= want + 1u;
+    c.steps += 1;
+    c.fast_steps += 1;
+  }
+}
+
+// LDS carve of one candidate list of at most PM_CARVE_SLOTS slots: worker ids, site ids, packed keys,
+// the alive / loc bitmaps and the per-wave partial selections all live in LDS (slot s is owned by thread
+// s % 1024).  Fast steps come from the proposals; a slow step is the exact full sweep: keys for every
+// live candidate, two-level selection (DPP argmin rounds per wave, 16-way merge), certificate, commit —
+// three LDS-only barriers.  Runs until the configuration is exhausted, a recompaction is due, or a step
+// cannot be certified.
+__device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, const uint32_t* l_wid,
+                                          const uint32_t* l_site, const uint16_t* l_next, uint64_t* l_key,
+                                          uint64_t* l_alive,
+                                          const uint64_t* l_loc, uint64_t* part, uint32_t* sel_out,
+                                          uint32_t steps_before) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
   const uint32_t lw = (c.n_list + 63u) >> 6;
-  double clat[E], clon[E], ccos[E];
-#pragma unroll
-  for (int j = 0; j < E; ++j) {
-    const uint32_t s = tid + (uint32_t)j * CARVE_THREADS;
-    const bool in = s < c.n_list;
-    clat[j] = in ? p.cc_lat[s] : 0.0;
-    clon[j] = in ? p.cc_lon[s] : 0.0;
-    ccos[j] = in ? p.cc_cos[s] : 0.0;
-  }
-
+  const bool have_props = c.mode == CARVE_MODE_FORM && c.use_props;
+  bool cache_valid = false;
   for (;;) {
+    if (have_props) {
+      if (!cache_valid && c.prop_k) {
+        // ---- stage the proposal rows of the next PM_CARVE_CACHE_ROWS live located slots in LDS (they
+        // alias l_key, which only the slow sweep uses): wave 0 lists the slots, all waves copy the rows
+        if (wave == 0) {
+          uint32_t base = 0;
+          for (uint32_t j0 = 0; j0 < lw && base < PM_CARVE_CACHE_ROWS; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            uint64_t w = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
+            const uint32_t cnt = __popcll(w);
+            uint32_t incl = cnt;  // inclusive prefix sum over the 64 lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const uint32_t up = __shfl_up(incl, o, 64);
+              if ((int)lane >= o) incl += up;
+            }
+            uint32_t r = base + incl - cnt;
+            while (w && r < PM_CARVE_CACHE_ROWS) {
+              red.cache_slot[r++] = j * 64u + __builtin_ctzll(w);
+              w &= w - 1ull;
+            }
+            base += __shfl(incl, 63, 64);
+          }
+          if (lane == 0) red.cache_n = base < PM_CARVE_CACHE_ROWS ? base : PM_CARVE_CACHE_ROWS;
+        }
+        lds_barrier();
+        const uint32_t rows = red.cache_n;
+        for (uint32_t r = wave; r < rows; r += CARVE_WAVES) {
+          const uint32_t sl = red.cache_slot[r];
+          l_key[r * PM_PROP_ROW + lane] = p.prop[(size_t)sl * PM_PROP_ROW + lane];
+          if (lane == 0) red.cache_meta[r] = p.prop_n[sl];
+        }
+        lds_barrier();
+        cache_valid = true;
+      }
+      // wave 0 commits as many steps as the proposals allow; everyone else waits at the barrier
+      if (wave == 0) {
+        PROF_DECL;
+        const int act = carve_fast_steps(p, red, c, l_wid, l_site, l_next, l_key, l_alive, l_loc, steps_before);
+        if (lane == 0) {
+          red.f_action = (uint32_t)act;
+          red.f_n_cand = c.n_cand;
+          red.f_total_available = c.total_available;
+          red.f_n_groups = c.n_groups;
+          red.f_mem_off = c.mem_off;
+          red.f_steps = c.steps;
+          red.f_fast = c.fast_steps;
+          red.f_cand_sum = c.cand_sum;
+        }
+        PROF_MARK(11);
+      }
+      lds_barrier();
+      const uint32_t act = red.f_action;
+      c.n_cand = red.f_n_cand;
+      c.total_available = red.f_total_available;
+      c.n_groups = red.f_n_groups;
+      c.mem_off = red.f_mem_off;
+      c.steps = red.f_steps;
+      c.fast_steps = red.f_fast;
+      c.cand_sum = red.f_cand_sum;
+      lds_barrier();  // the mailbox is rewritten after the next slow step
+      if (act == FAST_DONE) return STEP_BREAK;
+      if (act == FAST_OVERFLOW) return STEP_OVERFLOW;
+      if (act == FAST_REFILL) {
+        cache_valid = false;
+        continue;
+      }
+      cache_valid = false;  // the slow sweep below overwrites l_key
+    }
     // FORM: `while total_available >= min` (mod.rs:507) with `compatible < min => break` (:517-519).
     // MERGE: `while remaining_groups.len() >= min` (mod.rs:695).
     if (!((c.mode == CARVE_MODE_MERGE || c.total_available >= c.min_s) && c.n_cand >= c.min_s && c.n_cand > 0))
@@ -588,7 +852,6 @@ __device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, cons
     PROF_MARK(0);
 
     const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // fill to max (mod.rs:545-551)
-    uint64_t rk[E];
     uint32_t seed = f_any;
     bool use_dist = false, located_only = false;
     uint64_t last = 0;
@@ -620,20 +883,19 @@ __device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, cons
       // ---- keys (registers only; the seed's coordinates are one uniform load each)
       const double slat = p.cc_lat[seed], slon = p.cc_lon[seed], scos = p.cc_cos[seed];
       uint64_t lmin = ~0ull;
-#pragma unroll
-      for (int j = 0; j < E; ++j) {
-        const uint32_t s = tid + (uint32_t)j * CARVE_THREADS;
+      for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
         uint64_t k = ~0ull;
-        if (s < c.n_list && s != seed && bit_at(l_alive, s)) {
+        if (s != seed && bit_at(l_alive, s)) {
           if (!use_dist) {
             k = s;
           } else if (bit_at(l_loc, s)) {
-            k = pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, clat[j], clon[j], ccos[j])), s, SB);
+            k = pack_key((uint64_t)__double_as_longlong(
+                             hav_a(slat, slon, scos, p.cc_lat[s], p.cc_lon[s], p.cc_cos[s])), s, SB);
           } else if (!located_only) {
             k = pack_key(PM_KEY_NOLOC, s, SB);
           }
         }
-        rk[j] = k;
+        l_key[s] = k;
         lmin = k < lmin ? k : lmin;
       }
       PROF_MARK(1);
@@ -650,8 +912,10 @@ __device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, cons
             ++cnt;
             if (lmin == v) {  // the owning lane advances to its next element (keys are unique)
               uint64_t m = ~0ull;
-#pragma unroll
-              for (int j = 0; j < E; ++j) m = (rk[j] > v && rk[j] < m) ? rk[j] : m;
+              for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+                const uint64_t k = l_key[s];
+                m = (k > v && k < m) ? k : m;
+              }
               lmin = m;
             }
           }
@@ -699,8 +963,10 @@ __device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, cons
             ++n_sel;
             if (lmin == b) {
               uint64_t m = ~0ull;
-#pragma unroll
-              for (int j = 0; j < E; ++j) m = (rk[j] > b && rk[j] < m) ? rk[j] : m;
+              for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+                const uint64_t k = l_key[s];
+                m = (k > b && k < m) ? k : m;
+              }
               lmin = m;
             }
           }
@@ -725,12 +991,12 @@ __device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, cons
       const double band = a_m * PM_TIE_BAND + 1e-300;
       const double mlat = p.cc_lat[ls], mlon = p.cc_lon[ls];  // uniform loads
       if (a_m > PM_A_MAX_SAFE) uncertain = 1;
-#pragma unroll
-      for (int j = 0; j < E; ++j) {
-        const uint64_t kb = (rk[j] >> SB) << SB;
+      for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+        const uint64_t k = l_key[s];
+        const uint64_t kb = (k >> SB) << SB;
         const double a = __longlong_as_double((long long)kb);
-        const bool near = rk[j] != ~0ull && kb != noloc_key && fabs(a - a_m) <= band;
-        if (near && (clat[j] != mlat || clon[j] != mlon)) uncertain = 1;
+        const bool near = k != ~0ull && kb != noloc_key && fabs(a - a_m) <= band;
+        if (near && (p.cc_lat[s] != mlat || p.cc_lon[s] != mlon)) uncertain = 1;
       }
     }
     const uint64_t ub = __ballot(uncertain != 0);
@@ -749,16 +1015,12 @@ __device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, cons
 
     // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): selected slots =
     // seed + every key <= last.  Each wave owns whole bitmap words (slot>>6 == j*16 + wave): ballot writes them.
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-      const uint32_t s = tid + (uint32_t)j * CARVE_THREADS;
-      const uint32_t wj = (uint32_t)j * CARVE_WAVES + wave;
-      if (wj < lw) {  // wave-uniform
-        const bool was = bit_at(l_alive, s);
-        const bool sel = was && (s == seed || (n_sel > 0 && rk[j] <= last));
-        const uint64_t nw = __ballot(was && !sel);
-        if (lane == 0) l_alive[wj] = nw;
-      }
+    for (uint32_t wj = wave; wj < lw; wj += CARVE_WAVES) {  // wave-uniform
+      const uint32_t s = wj * 64u + lane;
+      const bool was = bit_at(l_alive, s);
+      const bool sel = was && (s == seed || (n_sel > 0 && l_key[s] <= last));
+      const uint64_t nw = __ballot(was && !sel);
+      if (lane == 0) l_alive[wj] = nw;
     }
     if (wave == 0) {  // group record + members: LDS -> fire-and-forget global stores
       if (lane == 0) {
@@ -779,14 +1041,15 @@ __device__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, cons
     c.n_cand -= total;
     c.total_available -= total;  // mod.rs:586
     c.steps += 1;
-    // drop dead slots once more than half of the list is gone
-    if (c.n_cand * 2u < c.n_list && c.n_list > CARVE_THREADS) return STEP_CONTINUE;
+    // drop dead slots once more than half of the list is gone.  With proposals this also ends the launch:
+    // the list is re-prepared and the next propose / validate pair continues with fresh neighbour lists.
+    if (c.n_cand * 2u < c.n_list && c.n_list > (have_props ? 256u : CARVE_THREADS)) return STEP_CONTINUE;
   }
 }
 
 // ---- generic path for candidate lists that do not fit the LDS/register scheme (> PM_CARVE_SLOTS):
 // packed keys, positions and bitmaps live in HBM/L2; one workgroup-wide argmin round per member.
-__device__ int carve_step_mem(const CarveArgs& p, BlockRed& red, StepCtx& c, uint64_t* part, uint64_t* key,
+__device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, StepCtx& c, uint64_t* part, uint64_t* key,
                               const uint32_t* wid, uint64_t* alive, const uint64_t* loc, uint32_t steps_before) {
   if (!((c.mode == CARVE_MODE_MERGE || c.total_available >= c.min_s) && c.n_cand >= c.min_s && c.n_cand > 0))
     return STEP_BREAK;
@@ -951,12 +1214,13 @@ __device__ uint32_t carve_compact_count(const CarveArgs& p, BlockRed& red, uint3
   return total;
 }
 
-__device__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit, uint32_t n_list,
-                                    uint32_t* wid, uint64_t* alive, uint64_t* loc) {
+__device__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit, uint32_t n_list) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n_words = (n + 63u) >> 6;
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
   const uint32_t j0 = wave * wpw, j1 = min(n_words, j0 + wpw);
+  uint64_t* alive = p.bits_scratch;
+  uint64_t* loc = p.bits_scratch + p.bits_stride;
   uint32_t off = 0;
   for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
   for (uint32_t j = j0; j < j1; ++j) {
@@ -966,10 +1230,11 @@ __device__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t 
     if (c) {
       const uint32_t s = off + __popcll(bal & ((1ull << lane) - 1ull));
       p.slot_pos[s] = i;
-      wid[s] = p.order[i];
+      p.slot_wid[s] = p.order[i];
       p.cc_lat[s] = p.c_lat[i];
       p.cc_lon[s] = p.c_lon[i];
       p.cc_cos[s] = p.c_cos[i];
+      p.cc_site[s] = p.c_site[i];
     }
     off += __popcll(bal);
   }
@@ -988,7 +1253,112 @@ __device__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
+// Proposal generator: one wave per located live slot of the prepared configuration.  The wave sweeps the
+// whole candidate list (coalesced 64-slot strides), every lane keeps its four smallest keys in registers,
+// and K rounds of DPP argmin pop the K nearest in (key, slot) order.  A lane whose four entries are all
+// consumed re-sweeps its own slots for keys beyond the last one popped.
+__device__ __forceinline__ void top4_insert(uint64_t k, uint64_t& r0, uint64_t& r1, uint64_t& r2, uint64_t& r3) {
+  if (k < r3) {
+    r3 = k;
+    if (r3 < r2) { const uint64_t t = r2; r2 = r3; r3 = t; }
+    if (r2 < r1) { const uint64_t t = r1; r1 = r2; r2 = t; }
+    if (r1 < r0) { const uint64_t t = r0; r0 = r1; r1 = t; }
+  }
+}
+
+__global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;  // argument block in device memory: read through the scalar cache, never copied
+  const CarveStatus* st = p.status;
+  if (st->state != CARVE_STATE_RUNNING || st->cur_ci >= p.n_avail) return;
+  const uint32_t K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
+  if (K == 0 || n_list > PM_CARVE_SLOTS) return;
+  constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave_g = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  const uint64_t* alive = p.bits_scratch;
+  const uint64_t* loc = p.bits_scratch + p.bits_stride;
+  const uint32_t lw = (n_list + 63u) >> 6;
+  for (uint32_t s = wave_g; s < limit; s += n_waves) {
+    if (!(bit_at(alive, s) && bit_at(loc, s))) continue;  // wave-uniform
+    const double slat = p.cc_lat[s], slon = p.cc_lon[s], scos = p.cc_cos[s];
+    const uint32_t ssite = p.cc_site[s];
+    uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull, r3 = ~0ull;
+    uint32_t n_mine = 0, same = PM_NONE;
+    for (uint32_t j = 0; j < lw; ++j) {
+      const uint32_t t = j * 64u + lane;
+      const uint64_t aw = alive[j], lwd = loc[j];
+      if (!((aw >> lane) & 1ull) || t == s) continue;
+      if (t > s && ((lwd >> lane) & 1ull) && same == PM_NONE && p.cc_site[t] == ssite) same = t;
+      const uint64_t k = ((lwd >> lane) & 1ull)
+                             ? pack_key((uint64_t)__double_as_longlong(
+                                            hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB)
+                             : pack_key(PM_KEY_NOLOC, t, SB);
+      top4_insert(k, r0, r1, r2, r3);
+      ++n_mine;
+    }
+    uint32_t popped = 0, n_k = 0;
+    uint64_t mine = ~0ull;
+    while (n_k < K) {
+      const uint64_t v = wave_min_u64(r0);
+      if (v == ~0ull) break;
+      if (lane == n_k) mine = v;
+      ++n_k;
+      if (r0 == v) {
+        r0 = r1; r1 = r2; r2 = r3; r3 = ~0ull;
+        ++popped;
+        if (r0 == ~0ull && popped < n_mine) {  // entries were dropped: re-sweep this lane's slots beyond v
+          for (uint32_t j = 0; j < lw; ++j) {
+            const uint32_t t = j * 64u + lane;
+            if (!((alive[j] >> lane) & 1ull) || t == s) continue;
+            const uint64_t k = ((loc[j] >> lane) & 1ull)
+                                   ? pack_key((uint64_t)__double_as_longlong(
+                                                  hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB)
+                                   : pack_key(PM_KEY_NOLOC, t, SB);
+            if (k > v) top4_insert(k, r0, r1, r2, r3);
+          }
+        }
+      }
+    }
+    same = wave_min(same);
+    // tail certificate: when the list is cut inside a run of exact ties (a whole site at one distance), check
+    // that every candidate NOT in the list whose key is within the band of the last entry sits at that
+    // entry's site — the validator may then take a prefix of the tie run
+    uint32_t tail_ok = 0;
+    if (n_k == K && K >= 2) {
+      const uint64_t e_last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 1) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 1);
+      const uint64_t e_prev = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 2) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 2);
+      const uint64_t kb_last = (e_last >> SB) << SB;
+      if (kb_last == ((e_prev >> SB) << SB) && kb_last != ((PM_KEY_NOLOC >> SB) << SB)) {
+        const uint32_t site_last = p.cc_site[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
+        const double a_last = __longlong_as_double((long long)kb_last);
+        const double band2 = a_last * (4.0 * PM_TIE_BAND) + 1e-300;
+        int bad = 0;
+        for (uint32_t j = 0; j < lw; ++j) {
+          const uint32_t t = j * 64u + lane;
+          if (!((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
+          const uint64_t k = pack_key((uint64_t)__double_as_longlong(
+                                          hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB);
+          if (k <= e_last) continue;  // listed
+          const double a = __longlong_as_double((long long)((k >> SB) << SB));
+          if (a - a_last <= band2 && p.cc_site[t] != site_last) bad = 1;
+        }
+        tail_ok = __ballot(bad) == 0ull;
+      }
+    }
+    p.prop[(size_t)s * PM_PROP_ROW + lane] = mine;
+    if (lane == 0) {
+      p.prop_n[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30);
+      p.same_next[s] = same;
+    }
+  }
+}
+
+__global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* __restrict__ pa, uint32_t flags_in,
+                                                              uint32_t start_ci) {
+  const CarveArgs& p = *pa;  // argument block in device memory (a by-value struct this large would be
+                             // copied to scratch as soon as a callee takes its address)
   // All LDS lives in the dynamic region, every carve offset a multiple of 16 B (a static __shared__ in
   // front of it would shift the base and put every 64-bit DS access on the 64-cycle misaligned path).
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -996,137 +1366,192 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
   uint64_t* lds_alive = part + CARVE_WAVES * PM_CARVE_PART;                  // [SLOTS / 64]
   uint64_t* lds_loc = lds_alive + PM_CARVE_SLOTS / 64;                       // [SLOTS / 64]
   uint32_t* lds_wid = reinterpret_cast<uint32_t*>(lds_loc + PM_CARVE_SLOTS / 64);  // [SLOTS]
-  uint32_t* sel_out = lds_wid + PM_CARVE_SLOTS;                              // [SEL_CAP]
-  BlockRed& red = *reinterpret_cast<BlockRed*>(sel_out + PM_CARVE_SEL_CAP);
+  uint32_t* lds_site = lds_wid + PM_CARVE_SLOTS;                             // [SLOTS]
+  uint64_t* lds_key = reinterpret_cast<uint64_t*>(lds_site + PM_CARVE_SLOTS);  // [SLOTS]
+  uint32_t* sel_out = reinterpret_cast<uint32_t*>(lds_key + PM_CARVE_SLOTS);  // [SEL_CAP]
+  uint16_t* lds_next = reinterpret_cast<uint16_t*>(sel_out + PM_CARVE_SEL_CAP);  // [SLOTS]
+  BlockRed& red = *reinterpret_cast<BlockRed*>(lds_next + PM_CARVE_SLOTS);
   uint32_t& s_n = *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&red) + sizeof(BlockRed));
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   CarveStatus* st = p.status;
+  uint32_t flags = flags_in;
+  if (!(flags & CARVE_F_INIT) && st->state != CARVE_STATE_RUNNING) return;  // queued behind a finished carve
 
-  // ---- ordered eligible list.  FORM: compact the eligible rows (Healthy & p2p & unassigned,
-  // mod.rs:492-497) in input order.  MERGE: supplied by the engine.
   uint32_t n;
-  if (p.mode == CARVE_MODE_FORM) {
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < p.W; base += CARVE_THREADS) {
-      const uint32_t w = base + tid;
-      bool e = false;
-      if (w < p.W) {
-        const uint32_t f = p.wflags[w];
-        e = (f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && p.group_of[w] < 0;
-      }
-      const uint64_t bal = __ballot(e);
-      if (lane == 0) red.a[wave] = __popcll(bal);
-      __syncthreads();
-      uint32_t off = s_n;
-      for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
-      if (e) p.order[off + __popcll(bal & ((1ull << lane) - 1ull))] = w;
-      __syncthreads();
-      if (tid == 0) {
-        uint32_t tot = 0;
-        for (uint32_t k = 0; k < CARVE_WAVES; ++k) tot += red.a[k];
-        s_n += tot;
-      }
-      __syncthreads();
-    }
-    n = s_n;
-  } else {
-    n = p.n_order;
-  }
-  const uint32_t n_words = (n + 63u) >> 6;
-
-  // position-indexed columns + alive / loc bitmaps (L2 resident)
-  for (uint32_t base = 0; base < n_words * 64u; base += CARVE_THREADS) {
-    const uint32_t i = base + tid;
-    bool has_loc = false;
-    if (i < n) {
-      const uint32_t w = p.order[i];
-      has_loc = (p.wflags[w] & PM_W_HAS_LOC) != 0;
-      p.c_lat[i] = p.lat[w];
-      p.c_lon[i] = p.lon[w];
-      p.c_cos[i] = p.coslat[w];
-      p.c_compat[i] = p.compat[w];
-    }
-    const uint64_t bl = __ballot(has_loc);
-    const uint64_t ba = __ballot(i < n);
-    if (lane == 0 && (i >> 6) < n_words) {
-      p.loc_g[i >> 6] = bl;
-      p.alive_g[i >> 6] = ba;
-    }
-  }
-  __syncthreads();
-
-  const uint32_t steps_before = st->steps_total;
   StepCtx c;
   c.mode = p.mode;
   c.proximity = p.proximity;
+  c.use_props = (flags_in & CARVE_F_PROPS) != 0u;
+  c.steps = 0;
+  c.fast_steps = 0;
+  c.cand_sum = 0;
+  uint32_t ci;          // configuration being prepared / run
+  bool prepared;
+  if (flags & CARVE_F_INIT) {
+    // ---- ordered eligible list.  FORM: compact the eligible rows (Healthy & p2p & unassigned,
+    // mod.rs:492-497) in input order.  MERGE: supplied by the engine.
+    if (p.mode == CARVE_MODE_FORM) {
+      if (tid == 0) s_n = 0;
+      __syncthreads();
+      for (uint32_t base = 0; base < p.W; base += CARVE_THREADS) {
+        const uint32_t w = base + tid;
+        bool e = false;
+        if (w < p.W) {
+          const uint32_t f = p.wflags[w];
+          e = (f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && p.group_of[w] < 0;
+        }
+        const uint64_t bal = __ballot(e);
+        if (lane == 0) red.a[wave] = __popcll(bal);
+        __syncthreads();
+        uint32_t off = s_n;
+        for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
+        if (e) p.order[off + __popcll(bal & ((1ull << lane) - 1ull))] = w;
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t tot = 0;
+          for (uint32_t k = 0; k < CARVE_WAVES; ++k) tot += red.a[k];
+          s_n += tot;
+        }
+        __syncthreads();
+      }
+      n = s_n;
+    } else {
+      n = p.n_order;
+    }
+    const uint32_t n_words = (n + 63u) >> 6;
+    // position-indexed columns + alive / loc bitmaps (L2 resident)
+    for (uint32_t base = 0; base < n_words * 64u; base += CARVE_THREADS) {
+      const uint32_t i = base + tid;
+      bool has_loc = false;
+      if (i < n) {
+        const uint32_t w = p.order[i];
+        has_loc = (p.wflags[w] & PM_W_HAS_LOC) != 0;
+        p.c_lat[i] = p.lat[w];
+        p.c_lon[i] = p.lon[w];
+        p.c_cos[i] = p.coslat[w];
+        p.c_site[i] = p.site[w];
+        p.c_compat[i] = p.compat[w];
+      }
+      const uint64_t bl = __ballot(has_loc);
+      const uint64_t ba = __ballot(i < n);
+      if (lane == 0 && (i >> 6) < n_words) {
+        p.loc_g[i >> 6] = bl;
+        p.alive_g[i >> 6] = ba;
+      }
+    }
+    __syncthreads();
+    c.total_available = n;  // mod.rs:503
+    ci = start_ci;
+    prepared = false;
+  } else {
+    n = st->n_eligible;
+    c.total_available = st->total_available;
+    ci = st->cur_ci;
+    prepared = true;
+    if (ci >= p.n_avail) return;
+  }
   c.n_groups = st->n_groups;
   c.mem_off = st->n_members;
-  c.total_available = n;  // mod.rs:503
-  c.steps = 0;
-  c.cand_sum = 0;
-  uint32_t exit_state = CARVE_STATE_DONE, stop_ci = p.n_avail;
+  const uint32_t groups_at_entry = c.n_groups;
+  const uint32_t steps_before = st->steps_total;
+  uint32_t exit_state = CARVE_STATE_RUNNING, stop_ci = p.n_avail;
+  uint32_t slow_before_cfg = 0;
 
-  for (uint32_t ci = p.start_ci; ci < p.n_avail && exit_state == CARVE_STATE_DONE; ++ci) {  // mod.rs:505
-    c.cfg = p.avail_cfg[ci];
-    c.min_s = p.min_size[ci];
-    c.max_s = p.max_size[ci];
-    const uint64_t cbit = 1ull << c.cfg;
-    if (p.mode == CARVE_MODE_FORM && c.total_available < c.min_s) continue;  // `while` of mod.rs:507 never entered
-
-    // candidate list of this configuration (mod.rs:511-515 evaluated once; removals are applied to the
-    // bitmaps instead of re-filtering).  MERGE: the list is already filtered by the engine.
-    for (;;) {
-      PROF_DECL;
-      c.n_list = carve_compact_count(p, red, n, cbit);
-      c.n_cand = c.n_list;
-      const bool in_lds = c.n_list <= PM_CARVE_SLOTS;
-      uint32_t* wid = in_lds ? lds_wid : p.slot_wid;
-      uint64_t* alive = in_lds ? lds_alive : p.bits_scratch;
-      uint64_t* loc = in_lds ? lds_loc : p.bits_scratch + p.bits_stride;
-      carve_compact_place(p, red, n, cbit, c.n_list, wid, alive, loc);
-      PROF_MARK(9);
-
-      int rc;
-      if (!in_lds) {
-        do {
-          rc = carve_step_mem(p, red, c, part, p.keys, wid, alive, loc, steps_before);
-        } while (rc == STEP_CONTINUE && !(c.n_cand * 2u < c.n_list));
-      } else if (c.n_list <= 1u * CARVE_THREADS) {
-        rc = carve_run_lds<1>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
-      } else if (c.n_list <= 2u * CARVE_THREADS) {
-        rc = carve_run_lds<2>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
-      } else if (c.n_list <= 4u * CARVE_THREADS) {
-        rc = carve_run_lds<4>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
-      } else {
-        rc = carve_run_lds<8>(p, red, c, wid, alive, loc, part, sel_out, steps_before);
-      }
-      __syncthreads();
-#ifdef PM_CARVE_PROF
-      prof_t0 = __builtin_amdgcn_s_memtime();
-#endif
-      // dead slots -> position bitmap, so the next compaction / configuration sees the removals
-      for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS)
-        if (!bit_at(alive, s)) {
-          const uint32_t i = p.slot_pos[s];
-          atomicAnd((unsigned long long*)&p.alive_g[i >> 6], ~(1ull << (i & 63u)));
-        }
-      __syncthreads();
-      PROF_MARK(10);
-      if (rc == STEP_UNCERTAIN || rc == STEP_OVERFLOW) {
-        exit_state = rc == STEP_UNCERTAIN ? CARVE_STATE_UNCERTAIN : CARVE_STATE_OVERFLOW;
-        stop_ci = ci;
+  for (;;) {
+    // ---- prepare: candidate list of the next configuration whose loop would be entered
+    // (mod.rs:505-519; the list is mod.rs:511-515 evaluated once, removals are applied to bitmaps)
+    if (!prepared) {
+      c.n_list = 0;
+      c.prop_k = 0;
+      c.prop_limit = 0;
+      for (; ci < p.n_avail; ++ci) {
+        c.min_s = p.min_size[ci];
+        c.max_s = p.max_size[ci];
+        if (p.mode == CARVE_MODE_FORM && c.total_available < c.min_s) continue;  // `while` never entered (:507)
+        const uint64_t cbit = 1ull << p.avail_cfg[ci];
+        c.n_list = carve_compact_count(p, red, n, cbit);
+        if (c.n_list < c.min_s || c.n_list == 0) continue;  // mod.rs:517-519
+        carve_compact_place(p, red, n, cbit, c.n_list);
         break;
       }
-      if (rc == STEP_BREAK) break;  // configuration exhausted; STEP_CONTINUE => recompact and go on
+      if (ci >= p.n_avail) {
+        exit_state = CARVE_STATE_DONE;
+        break;
+      }
+      // proposals: one neighbour list per located slot, K = (max - 1) + reserve entries
+      if ((flags & CARVE_F_PROPS) && p.proximity && c.n_list <= PM_CARVE_SLOTS && c.max_s - 1u < PM_PROP_ROW) {
+        const uint32_t k = c.max_s - 1u + PM_PROP_RESERVE;
+        c.prop_k = k < PM_PROP_ROW ? k : PM_PROP_ROW;
+        c.prop_limit = c.n_list;
+      }
+      prepared = true;
+      if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
+    } else {
+      c.n_list = st->n_list;
+      c.prop_k = st->prop_k;
+      c.prop_limit = st->prop_limit;
+      c.min_s = p.min_size[ci];
+      c.max_s = p.max_size[ci];
     }
+    c.cfg = p.avail_cfg[ci];
+    c.n_cand = c.n_list;
+
+    // ---- run the prepared configuration
+    const bool in_lds = c.n_list <= PM_CARVE_SLOTS;
+    const uint32_t lw = (c.n_list + 63u) >> 6;
+    uint64_t* g_alive = p.bits_scratch;
+    uint64_t* g_loc = p.bits_scratch + p.bits_stride;
+    if (in_lds) {
+      for (uint32_t j = tid; j < lw; j += CARVE_THREADS) {
+        lds_alive[j] = g_alive[j];
+        lds_loc[j] = g_loc[j];
+      }
+      for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) {
+        lds_wid[sl] = p.slot_wid[sl];
+        lds_site[sl] = p.cc_site[sl];
+        const uint32_t nx = (c.use_props && c.prop_k) ? p.same_next[sl] : PM_NONE;
+        lds_next[sl] = nx < c.n_list ? (uint16_t)nx : (uint16_t)0xFFFFu;
+      }
+      __syncthreads();
+    }
+    const uint32_t slow0 = c.steps - c.fast_steps;
+    int rc;
+    if (!in_lds) {
+      do {
+        rc = carve_step_mem(p, red, c, part, p.keys, p.slot_wid, g_alive, g_loc, steps_before);
+      } while (rc == STEP_CONTINUE && !(c.n_cand * 2u < c.n_list));
+    } else {
+      rc = carve_run_lds(p, red, c, lds_wid, lds_site, lds_next, lds_key, lds_alive, lds_loc, part, sel_out,
+                         steps_before);
+    }
+    (void)slow0;
+    (void)slow_before_cfg;
+    __syncthreads();
+    // dead slots -> position bitmap, so the next compaction / configuration sees the removals
+    {
+      const uint64_t* alive = in_lds ? lds_alive : g_alive;
+      for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS)
+        if (!bit_at(alive, sl)) {
+          const uint32_t i = p.slot_pos[sl];
+          atomicAnd((unsigned long long*)&p.alive_g[i >> 6], ~(1ull << (i & 63u)));
+        }
+    }
+    __syncthreads();
+    if (rc == STEP_UNCERTAIN || rc == STEP_OVERFLOW) {
+      exit_state = rc == STEP_UNCERTAIN ? CARVE_STATE_UNCERTAIN : CARVE_STATE_OVERFLOW;
+      stop_ci = ci;
+      break;
+    }
+    prepared = false;
+    if (rc == STEP_BREAK) ++ci;  // configuration exhausted; STEP_CONTINUE => re-prepare the same configuration
+    if (!(flags & CARVE_F_ALL)) flags &= ~CARVE_F_RUN;  // per-configuration launch: prepare the next list, leave
   }
 
   // group_of for everything carved by this launch (FORM), one parallel pass at the end
   if (p.mode == CARVE_MODE_FORM) {
     __syncthreads();
-    for (uint32_t g = st->n_groups + wave; g < c.n_groups; g += CARVE_WAVES) {
+    for (uint32_t g = groups_at_entry + wave; g < c.n_groups; g += CARVE_WAVES) {
       const uint32_t off = p.g_off[g], gn = p.g_n[g];
       for (uint32_t k = lane; k < gn; k += 64u) p.group_of[p.members[off + k]] = (int32_t)g;
     }
@@ -1140,6 +1565,13 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(CarveArgs p) {
     st->stop_ci = stop_ci;
     st->n_eligible = n;
     st->cand_sum += c.cand_sum;
+    st->cur_ci = exit_state == CARVE_STATE_DONE ? p.n_avail : ci;
+    st->n_list = c.n_list;
+    st->prop_k = c.prop_k;
+    st->prop_limit = c.prop_limit;
+    st->total_available = c.total_available;
+    st->fast_steps += c.fast_steps;
+    st->slow_steps += c.steps - c.fast_steps;
   }
 }
 
@@ -1274,7 +1706,15 @@ void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block
                      idx_by_block, val_by_block);
 }
 
-hipError_t launch_carve(const CarveArgs& a, size_t lds_bytes, hipStream_t s) {
+void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
+  // one wave per located slot, grid-stride; 2048 workgroups x 4 waves keep all 256 CUs busy
+  uint32_t blocks = (W + 3u) / 4u;
+  if (blocks > 2048u) blocks = 2048u;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(carve_propose_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+}
+
+hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)carve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1282,7 +1722,7 @@ hipError_t launch_carve(const CarveArgs& a, size_t lds_bytes, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(carve_kernel, dim3(1), dim3(CARVE_THREADS), lds_bytes, s, a);
+  hipLaunchKernelGGL(carve_kernel, dim3(1), dim3(CARVE_THREADS), lds_bytes, s, d_args, flags, start_ci);
   return hipGetLastError();
 }
 

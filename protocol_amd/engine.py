@@ -51,7 +51,7 @@ class EngineConfig(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("proximity_enabled", C.c_uint32),
                 ("switching_enabled", C.c_uint32), ("prefer_larger_groups", C.c_uint32), ("chooser", C.c_uint32),
                 ("chooser_seed", C.c_uint64), ("group_id_seed", C.c_uint64), ("debug_uncertain_every", C.c_uint32),
-                ("sweep_variant", C.c_uint32)]
+                ("sweep_variant", C.c_uint32), ("carve_variant", C.c_uint32), ("_reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -59,6 +59,7 @@ class Stats(C.Structure):
                 ("ms_publish", C.c_float), ("ms_total", C.c_float), ("ms_compat_kernel", C.c_float),
                 ("ms_carve_kernel", C.c_float), ("ms_sweep_kernel", C.c_float), ("n_groups", C.c_uint32),
                 ("n_formed", C.c_uint32), ("n_merged", C.c_uint32), ("carve_steps", C.c_uint32),
+                ("carve_fast_steps", C.c_uint32),
                 ("host_resolved_steps", C.c_uint32), ("carve_launches", C.c_uint32), ("pair_evals", C.c_uint64),
                 ("carve_cand_sum", C.c_uint64)]
 
@@ -153,7 +154,8 @@ class Engine:
     """Owns a pm_engine*.  Keeps nothing but the handle: all state lives behind the C ABI."""
 
     def __init__(self, *, device: int = 0, proximity=True, switching=True, prefer_larger=True,
-                 chooser=CHOOSE_FIRST, chooser_seed=0, group_id_seed=1, debug_uncertain_every=0, sweep_variant=0):
+                 chooser=CHOOSE_FIRST, chooser_seed=0, group_id_seed=1, debug_uncertain_every=0, sweep_variant=0,
+                 carve_variant=0):
         L = lib()
         cfg = EngineConfig()
         L.pm_engine_config_default(C.byref(cfg))
@@ -166,6 +168,7 @@ class Engine:
         cfg.group_id_seed = group_id_seed
         cfg.debug_uncertain_every = debug_uncertain_every
         cfg.sweep_variant = sweep_variant
+        cfg.carve_variant = carve_variant
         self._h = C.c_void_p()
         check(L.pm_engine_create(C.byref(cfg), C.byref(self._h)))
         self.W = 0

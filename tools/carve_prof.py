@@ -21,15 +21,17 @@ sw = make_swarm(1, T, W)
 eng = E.Engine()
 host.load_swarm(eng, sw)
 names = ["seed", "keys", "level1", "barrier1", "level2", "certificate", "barrier2", "commit", "barrier3",
-         "compaction", "flush"]
+         "compaction", "flush", "fast-path"]
 for it in range(3):
     eng.reset_groups()
     s = eng.tick()
 out = (C.c_ulonglong * 16)()
 E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 E.lib().pm_debug_carve_prof(eng._h, out)
-tot = sum(out[:11])
-print(f"carve kernel {s['ms_carve_kernel']:.3f} ms, {s['carve_steps']} steps, {1e3 * s['ms_carve_kernel'] / s['carve_steps']:.2f} us/step")
+tot = sum(out[:12])
+print(f"carve kernels {s['ms_carve_kernel']:.3f} ms, {s['carve_steps']} steps ({s['carve_fast_steps']} fast), "
+      f"{1e3 * s['ms_carve_kernel'] / s['carve_steps']:.2f} us/step")
 for i, nm in enumerate(names):
     print(f"  {nm:12s} {out[i]:12d} ticks  {100.0 * out[i] / max(tot, 1):5.1f}%  {out[i] / max(s['carve_steps'], 1):8.1f} ticks/step")
+print(f"  fast path split: seed-search={out[9]} same-site-chain={out[10]} proposal-load+filter={out[13]} certificate={out[14]} commit={out[15]}")
 print(f"  total ticks {tot}; ticks per ms = {tot / s['ms_carve_kernel']:.0f}")
