@@ -563,6 +563,14 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
                                              uint32_t steps_before) {
   StepCtx c = c_ref;  // registers for the whole run (the reference lives in the caller's scratch frame)
   const uint32_t lane = threadIdx.x & 63u;
+  // argument-block fields used per step, loaded once: the stores below go through flat pointers the compiler
+  // must assume may alias the block itself
+  uint32_t* __restrict__ const members = p.members;
+  uint32_t* __restrict__ const g_cfg = p.g_cfg;
+  uint32_t* __restrict__ const g_n = p.g_n;
+  uint32_t* __restrict__ const g_off = p.g_off;
+  const uint32_t cap_groups = p.cap_groups, cap_members = p.cap_members;
+  const uint32_t dbg_every = p.debug_uncertain_every;
   constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
   constexpr uint64_t SLOT_MASK = (1ull << SB) - 1ull;
   const uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
@@ -588,7 +596,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
       }
     }
     const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // mod.rs:545-551
-    if (c.n_groups >= p.cap_groups || c.mem_off + want + 1u > p.cap_members) FAST_RETURN(FAST_OVERFLOW);
+    if (c.n_groups >= cap_groups || c.mem_off + want + 1u > cap_members) FAST_RETURN(FAST_OVERFLOW);
 
     if (f_loc == PM_NONE) {
       // no located candidate (or proximity off): the group is the first `want + 1` live slots in input
@@ -607,14 +615,14 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
           take = w & ~keep;
         }
         const bool mine = (take >> lane) & 1ull;
-        if (mine) p.members[c.mem_off + cnt + __popcll(take & ((1ull << lane) - 1ull))] = l_wid[j * 64u + lane];
+        if (mine) members[c.mem_off + cnt + __popcll(take & ((1ull << lane) - 1ull))] = l_wid[j * 64u + lane];
         if (lane == 0) l_alive[j] = w & ~take;
         cnt += __popcll(take);
       }
       if (lane == 0) {
-        p.g_cfg[c.n_groups] = c.cfg;
-        p.g_n[c.n_groups] = cnt;
-        p.g_off[c.n_groups] = c.mem_off;
+        g_cfg[c.n_groups] = c.cfg;
+        g_n[c.n_groups] = cnt;
+        g_off[c.n_groups] = c.mem_off;
       }
       c.n_groups += 1;
       c.mem_off += cnt;
@@ -628,7 +636,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 
     const uint32_t seed = f_loc;
     if (c.prop_k == 0 || seed >= c.prop_limit) {  FAST_RETURN(FAST_SLOW); }
-    if (p.debug_uncertain_every && ((steps_before + c.steps + 1u) % p.debug_uncertain_every) == 0u) FAST_RETURN(FAST_SLOW);
+    if (dbg_every && ((steps_before + c.steps + 1u) % dbg_every) == 0u) FAST_RETURN(FAST_SLOW);
 
     // ---- same-site shortcut: candidates with the seed's exact coordinates are at distance 0 — ahead of
     // everybody else, in input (slot) order.  If `want` of them are still alive they ARE the group.
@@ -646,14 +654,14 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
       if (cnt == want && want <= 64u) {
         if (lane < want) {
           atomicAnd((unsigned long long*)&l_alive[mine_slot >> 6], ~(1ull << (mine_slot & 63u)));
-          p.members[c.mem_off + 1u + lane] = l_wid[mine_slot];
+          members[c.mem_off + 1u + lane] = l_wid[mine_slot];
         }
         if (lane == 0) {
           atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
-          p.members[c.mem_off] = l_wid[seed];
-          p.g_cfg[c.n_groups] = c.cfg;
-          p.g_n[c.n_groups] = want + 1u;
-          p.g_off[c.n_groups] = c.mem_off;
+          members[c.mem_off] = l_wid[seed];
+          g_cfg[c.n_groups] = c.cfg;
+          g_n[c.n_groups] = want + 1u;
+          g_off[c.n_groups] = c.mem_off;
         }
         c.n_groups += 1;
         c.mem_off += want + 1u;
@@ -667,8 +675,22 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     }
 
     // ---- the seed's neighbour list (staged in LDS): one packed key per lane, sorted ascending
-    while (row_ptr < cache_n && red.cache_slot[row_ptr] < seed) ++row_ptr;
-    if (row_ptr >= cache_n || red.cache_slot[row_ptr] != seed) FAST_RETURN(FAST_REFILL);
+    {  // rows are in ascending slot order: look 64 rows ahead with one LDS read per lane
+      bool found = false;
+      while (row_ptr < cache_n) {
+        const uint32_t r = row_ptr + lane;
+        const uint32_t cs = r < cache_n ? red.cache_slot[r] : PM_NONE;
+        const uint64_t ge = __ballot(cs >= seed);  // first staged slot >= seed (PM_NONE lanes count as >=)
+        if (ge) {
+          const int l = __builtin_ctzll(ge);
+          row_ptr += (uint32_t)l;
+          found = row_ptr < cache_n && (uint32_t)__builtin_amdgcn_readlane((int)cs, l) == seed;
+          break;
+        }
+        row_ptr += 64u;
+      }
+      if (!found) FAST_RETURN(FAST_REFILL);
+    }
     const uint32_t nk_word = red.cache_meta[row_ptr];
     const uint32_t n_k = nk_word & 0xFFu;
     const bool complete = (nk_word >> 31) != 0u;
@@ -713,14 +735,14 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
     if (sel) {
       atomicAnd((unsigned long long*)&l_alive[slot >> 6], ~(1ull << (slot & 63u)));
-      p.members[c.mem_off + 1u + rank] = l_wid[slot];
+      members[c.mem_off + 1u + rank] = l_wid[slot];
     }
     if (lane == 0) {
       atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
-      p.members[c.mem_off] = l_wid[seed];
-      p.g_cfg[c.n_groups] = c.cfg;
-      p.g_n[c.n_groups] = want + 1u;
-      p.g_off[c.n_groups] = c.mem_off;
+      members[c.mem_off] = l_wid[seed];
+      g_cfg[c.n_groups] = c.cfg;
+      g_n[c.n_groups] = want + 1u;
+      g_off[c.n_groups] = c.mem_off;
     }
     c.n_groups += 1;
     c.mem_off += want + 1u;
