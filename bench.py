@@ -41,12 +41,11 @@ VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/
 
 
 def shard_swarm(sw, rank: int, world: int):
-    """hash-shard the workers: shard = splitmix64(address) % world."""
-    from protocol_amd.swarm import mix64
+    """hash-shard the workers: shard = splitmix64(address) % world (protocol_amd/dist.py)."""
+    from protocol_amd.dist import shard_of
     if world == 1:
         return sw, np.arange(sw.W)
-    keep = (mix64(sw.address) % np.uint64(world)).astype(np.int64) == rank
-    idx = np.nonzero(keep)[0]
+    idx = np.nonzero(shard_of(sw.address, world) == rank)[0]
     import copy
     s = copy.copy(sw)
     for k in ("address", "status", "has_p2p", "has_specs", "has_gpu", "gpu_count_some", "gpu_mem_some",
@@ -95,6 +94,17 @@ def cpu_baseline(sw, budget_s: float = 30.0) -> dict:
     }
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per full-swarm match from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json,
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_match")
+    except Exception:
+        return None
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +113,7 @@ def main() -> int:
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index (default 1: 100k x 10k)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--sweep-variant", type=int, default=0)
+    ap.add_argument("--carve-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also verify the groups against the oracle (slow)")
     args = ap.parse_args()
@@ -133,7 +144,8 @@ def main() -> int:
         workload = f"BASELINE configs[{args.config}]"
     sw, shard_idx = shard_swarm(sw_global, rank, world)
 
-    eng = E.Engine(device=local_rank, sweep_variant=args.sweep_variant, group_id_seed=args.seed + rank)
+    eng = E.Engine(device=local_rank, sweep_variant=args.sweep_variant, carve_variant=args.carve_variant,
+                   group_id_seed=args.seed + rank)
     host.load_swarm(eng, sw)
     if world > 1:
         w_counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -197,7 +209,8 @@ def main() -> int:
                        "GB/s": sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None,
                        "pair_evals_per_s": T * sw.W / (sweep_ms * 1e-3) if sweep_ms > 0 else None},
         "carve_kernel": {"ms": carve_ms, "alg_bytes": carve_bytes, "GB/s": carve_gbs,
-                         "steps": med("carve_steps"), "us_per_step": 1e3 * carve_ms / max(med("carve_steps"), 1)},
+                         "steps": med("carve_steps"), "fast_steps": med("carve_fast_steps"),
+                         "us_per_step": 1e3 * carve_ms / max(med("carve_steps"), 1)},
     }
     out = {
         "metric": "task x worker pair-evals/sec (full-swarm match)", "value": value, "unit": "pair-evals/s",
@@ -205,13 +218,15 @@ def main() -> int:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload, "tasks": T, "workers_per_gpu": sw.W, "workers_total": sum(w_counts),
                    "configs": n_cfgs, "seed": args.seed, "sharding": "hash(address) % n_gpus" if world > 1 else "none",
-                   "sweep_variant": args.sweep_variant},
+                   "sweep_variant": args.sweep_variant, "carve_variant": args.carve_variant},
         "p50_match_latency_ms": statistics.median(ms),
         "match_latency_ms": {"min": min(ms), "p50": statistics.median(ms), "max": max(ms)},
         "phase_ms_p50": {k: med(k) for k in ("ms_compat", "ms_carve", "ms_merge", "ms_sweep", "ms_publish")},
         "groups": int(stats[-1]["n_groups"]), "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
-        "roofline": {"bound": "hbm", "kernel": "carve_kernel", "achieved": carve_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": carve_gbs / HBM_PEAK_GBS, "traffic": None},
+        "roofline": {"bound": "hbm", "kernel": "carve (carve_propose_kernel + carve_kernel launch sequence)",
+                     "achieved": carve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": carve_gbs / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("carve"),
+                     "note": "dependent chain of ~2k carve steps: latency-bound by construction, see DESIGN.md §6"},
         "kernels": kernels,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
