@@ -17,9 +17,12 @@ static constexpr uint32_t PM_CARVE_SLOTS = 8192;       // candidate slots with p
 static constexpr uint32_t PM_CARVE_PART = 64;          // per-wave partial selection capacity (max_group_size - 1)
 static constexpr uint32_t PM_CARVE_SEL_CAP = 256;      // selected slots staged in LDS before the member stores
 static constexpr uint32_t PM_CARVE_SLOT_BITS = 13;     // log2(PM_CARVE_SLOTS): low key bits that hold the slot
+static constexpr uint32_t PM_CARVE_BIG_SLOTS = 262144; // lists up to here keep their bitmaps + staged rows in LDS
+static constexpr uint32_t PM_CARVE_SLOT_BITS_BIG = 18; // log2(PM_CARVE_BIG_SLOTS)
 static constexpr uint32_t PM_CARVE_SLOT_BITS_MEM = 21; // same for lists kept in HBM (up to 2M candidates)
 // certificate bands: 8x the truncation step of the packed key (2^-(52-bits)) — see carve_kernel
 static constexpr double PM_TIE_BAND = 1.0 / 68719476736.0;      // 2^-36
+static constexpr double PM_TIE_BAND_BIG = 1.0 / 2147483648.0;   // 2^-31
 static constexpr double PM_TIE_BAND_MEM = 1.0 / 268435456.0;    // 2^-28
 static constexpr uint32_t PM_CARVE_CACHE_ROWS = 128;   // proposal rows staged in LDS (128 * 64 * 8 B = the key array)
 static constexpr uint32_t PM_PROP_ROW = 64;            // proposal row stride (entries)

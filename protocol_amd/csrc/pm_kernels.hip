@@ -436,8 +436,8 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 // kernel's (key, position) order), the selected SET is the reference's.  Otherwise the step is
 // reported as UNCERTAIN and the engine settles exactly that step on the host with glibc.
 
-#define CARVE_THREADS 1024
-#define CARVE_WAVES 16
+#define CARVE_THREADS 512
+#define CARVE_WAVES 8
 
 // ---- wave-wide unsigned min via DPP (no LDS traffic): row_shr 1,2,4,8 -> row_bcast15 -> row_bcast31,
 // result broadcast from lane 63 with readlane.
@@ -476,6 +476,7 @@ struct BlockRed {
   uint32_t cache_n, cache_pad;
   uint32_t cache_slot[PM_CARVE_CACHE_ROWS];
   uint32_t cache_meta[PM_CARVE_CACHE_ROWS];
+  uint32_t cache_next[PM_CARVE_CACHE_ROWS];  // same_next of the staged slot
 };
 
 // sin on [-pi/2, pi/2] as an odd Taylor polynomial to x^19 (|rel err| < 1e-15 there); larger arguments
@@ -518,11 +519,11 @@ enum { STEP_CONTINUE = 0, STEP_BREAK = 1, STEP_UNCERTAIN = 2, STEP_OVERFLOW = 3 
 
 #ifdef PM_CARVE_PROF
 #define PROF_DECL uint64_t prof_t0 = __builtin_amdgcn_s_memtime()
-#define PROF_MARK(slot)                                          \
-  do {                                                           \
-    const uint64_t t_ = __builtin_amdgcn_s_memtime();            \
-    if (threadIdx.x == 0) p.status->prof[slot] += t_ - prof_t0;  \
-    prof_t0 = t_;                                                \
+#define PROF_MARK(slot)                                                     \
+  do {                                                                      \
+    const uint64_t t_ = __builtin_amdgcn_s_memtime();                       \
+    if (threadIdx.x == 0 && (slot) >= 9) p.status->prof[slot] += t_ - prof_t0;  \
+    prof_t0 = t_;                                                           \
   } while (0)
 #else
 #define PROF_DECL
@@ -540,9 +541,19 @@ struct StepCtx {
   // proposals (0 = none)
   uint32_t prop_k, prop_limit;
   bool use_props;
+  // packed-key geometry of the current list: low slot_bits of a key hold the slot; certificate band
+  uint32_t slot_bits;
+  double band;
+  bool big;  // per-slot arrays live in HBM/L2 (list above PM_CARVE_SLOTS), bitmaps + staged rows in LDS
 };
 
-enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3 };
+__device__ __forceinline__ void ctx_set_geometry(StepCtx& c) {
+  c.big = c.n_list > PM_CARVE_SLOTS;
+  c.slot_bits = c.big ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
+  c.band = c.big ? PM_TIE_BAND_BIG : PM_TIE_BAND;
+}
+
+enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3, FAST_REPROPOSE = 4 };
 
 // Fast steps, executed by wave 0 alone while the other waves are parked at a barrier: the expensive
 // part of a step (keys for every live candidate + top-k) was done for every possible seed by
@@ -555,12 +566,22 @@ enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3 };
 #else
 #define PROF_COUNT(slot)
 #endif
-#define FAST_RETURN(code) do { c_ref = c; return (code); } while (0)
+#ifdef PM_CARVE_PROF
+#define FP_DECL uint64_t fp_t = __builtin_amdgcn_s_memtime(), fp_acc[6] = {0, 0, 0, 0, 0, 0}
+#define FP_MARK(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); fp_acc[i] += t_ - fp_t; fp_t = t_; } while (0)
+#define FP_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 6; ++i_) p.status->prof[i_] += fp_acc[i_]; } while (0)
+#else
+#define FP_DECL
+#define FP_MARK(i)
+#define FP_FLUSH()
+#endif
+#define FAST_RETURN(code) do { FP_FLUSH(); c_ref = c; return (code); } while (0)
 
+template <bool BIG>
 __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed& red, StepCtx& c_ref,
-                                             const uint32_t* l_wid, const uint32_t* l_site, const uint16_t* l_next,
-                                             const uint64_t* l_rows, uint64_t* l_alive, const uint64_t* l_loc,
-                                             uint32_t steps_before) {
+                                             const uint32_t* l_wid, const uint32_t* l_site, const uint16_t* l_next16,
+                                             const uint32_t* l_next32, const uint64_t* l_rows, uint64_t* l_alive,
+                                             const uint64_t* l_loc, uint32_t steps_before) {
   StepCtx c = c_ref;  // registers for the whole run (the reference lives in the caller's scratch frame)
   const uint32_t lane = threadIdx.x & 63u;
   // argument-block fields used per step, loaded once: the stores below go through flat pointers the compiler
@@ -571,30 +592,77 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
   uint32_t* __restrict__ const g_off = p.g_off;
   const uint32_t cap_groups = p.cap_groups, cap_members = p.cap_members;
   const uint32_t dbg_every = p.debug_uncertain_every;
-  constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
+  constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   constexpr uint64_t SLOT_MASK = (1ull << SB) - 1ull;
-  const uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
+  constexpr uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
+  constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
+  // big lists: members are recorded as SLOTS and translated to worker ids by one parallel pass after the run
+  // (a dependent HBM load per member would stall the single validating wave)
+  // (lambdas capture plain values: a by-reference capture of `c` would pin the whole context in scratch)
+  const uint32_t n_list_v = c.n_list;
+  auto wid_of = [l_wid](uint32_t sl) -> uint32_t { return BIG ? sl : l_wid[sl]; };
+  // next located slot at the same site: LDS u16 for small lists, HBM u32 for big ones
+  auto next_of = [l_next16, l_next32, n_list_v](uint32_t sl) -> uint32_t {
+    if (!BIG) {
+      const uint32_t v = l_next16[sl];
+      return v == 0xFFFFu ? PM_NONE : v;
+    }
+    const uint32_t v = l_next32[sl];
+    return v < n_list_v ? v : PM_NONE;
+  };
   const uint32_t lw = (c.n_list + 63u) >> 6;
   uint32_t row_ptr = 0;  // staged rows are in ascending slot order, and so are the seeds
   const uint32_t cache_n = red.cache_n;
+  FP_DECL;
   for (;;) {
+    FP_MARK(5);
     if (!(c.total_available >= c.min_s && c.n_cand >= c.min_s && c.n_cand > 0)) FAST_RETURN(FAST_DONE);
-    // ---- seed (mod.rs:526-530)
+    // ---- seed (mod.rs:526-530): the first live located slot.  The staged rows are exactly the live located
+    // slots in ascending order, so it is the first staged row whose slot is still alive.
     uint32_t f_loc = PM_NONE;
     if (c.proximity) {
-      for (uint32_t j0 = 0; j0 < lw; j0 += 64u) {
-        const uint32_t j = j0 + lane;
-        const uint64_t ll = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
-        const uint64_t nz = __ballot(ll != 0ull);
-        if (nz) {
-          const int src = __builtin_ctzll(nz);
-          const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ll >> 32), src) << 32) |
-                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ll, src);
-          f_loc = (j0 + src) * 64u + __builtin_ctzll(w);
-          break;
+      if (c.prop_k) {
+        while (row_ptr < cache_n) {
+          const uint32_t r = row_ptr + lane;
+          const uint32_t sl = r < cache_n ? red.cache_slot[r] : PM_NONE;
+          const bool al = sl != PM_NONE && bit_at(l_alive, sl);
+          const uint64_t m = __ballot(al);
+          if (m) {
+            const int l = __builtin_ctzll(m);
+            row_ptr += (uint32_t)l;
+            f_loc = (uint32_t)__builtin_amdgcn_readlane((int)sl, l);
+            break;
+          }
+          row_ptr += 64u;
+        }
+        if (f_loc == PM_NONE && cache_n == PM_CARVE_CACHE_ROWS) FAST_RETURN(FAST_REFILL);  // more may follow
+        if (f_loc == PM_NONE && c.prop_limit < c.n_list) {
+          // every proposed slot is used up; located candidates beyond the proposal batch need a new round
+          bool more = false;
+          for (uint32_t j0 = c.prop_limit >> 6; j0 < lw && !more; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            uint64_t ll = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
+            if (j == (c.prop_limit >> 6)) ll &= ~((1ull << (c.prop_limit & 63u)) - 1ull);
+            more = __ballot(ll != 0ull) != 0ull;
+          }
+          if (more) FAST_RETURN(FAST_REPROPOSE);
+        }
+      } else {
+        for (uint32_t j0 = 0; j0 < lw; j0 += 64u) {
+          const uint32_t j = j0 + lane;
+          const uint64_t ll = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
+          const uint64_t nz = __ballot(ll != 0ull);
+          if (nz) {
+            const int src = __builtin_ctzll(nz);
+            const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ll >> 32), src) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ll, src);
+            f_loc = (j0 + src) * 64u + __builtin_ctzll(w);
+            break;
+          }
         }
       }
     }
+    FP_MARK(0);
     const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // mod.rs:545-551
     if (c.n_groups >= cap_groups || c.mem_off + want + 1u > cap_members) FAST_RETURN(FAST_OVERFLOW);
 
@@ -615,7 +683,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
           take = w & ~keep;
         }
         const bool mine = (take >> lane) & 1ull;
-        if (mine) members[c.mem_off + cnt + __popcll(take & ((1ull << lane) - 1ull))] = l_wid[j * 64u + lane];
+        if (mine) members[c.mem_off + cnt + __popcll(take & ((1ull << lane) - 1ull))] = wid_of(j * 64u + lane);
         if (lane == 0) l_alive[j] = w & ~take;
         cnt += __popcll(take);
       }
@@ -640,25 +708,26 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 
     // ---- same-site shortcut: candidates with the seed's exact coordinates are at distance 0 — ahead of
     // everybody else, in input (slot) order.  If `want` of them are still alive they ARE the group.
-    if (want > 0 && l_next[seed] != 0xFFFFu) {
+    const uint32_t first_same = want > 0 ? red.cache_next[row_ptr] : PM_NONE;  // staged with the row
+    if (first_same != PM_NONE) {
       uint32_t cnt = 0;
-      uint32_t t = l_next[seed];
+      uint32_t t = first_same;
       uint32_t mine_slot = PM_NONE;
-      while (t != 0xFFFFu && cnt < want) {
+      while (t != PM_NONE && cnt < want) {
         if (bit_at(l_alive, t)) {
           if (lane == cnt) mine_slot = t;
           ++cnt;
         }
-        t = l_next[t];
+        t = next_of(t);
       }
       if (cnt == want && want <= 64u) {
         if (lane < want) {
           atomicAnd((unsigned long long*)&l_alive[mine_slot >> 6], ~(1ull << (mine_slot & 63u)));
-          members[c.mem_off + 1u + lane] = l_wid[mine_slot];
+          members[c.mem_off + 1u + lane] = wid_of(mine_slot);
         }
         if (lane == 0) {
           atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
-          members[c.mem_off] = l_wid[seed];
+          members[c.mem_off] = wid_of(seed);
           g_cfg[c.n_groups] = c.cfg;
           g_n[c.n_groups] = want + 1u;
           g_off[c.n_groups] = c.mem_off;
@@ -674,27 +743,14 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
       }
     }
 
-    // ---- the seed's neighbour list (staged in LDS): one packed key per lane, sorted ascending
-    {  // rows are in ascending slot order: look 64 rows ahead with one LDS read per lane
-      bool found = false;
-      while (row_ptr < cache_n) {
-        const uint32_t r = row_ptr + lane;
-        const uint32_t cs = r < cache_n ? red.cache_slot[r] : PM_NONE;
-        const uint64_t ge = __ballot(cs >= seed);  // first staged slot >= seed (PM_NONE lanes count as >=)
-        if (ge) {
-          const int l = __builtin_ctzll(ge);
-          row_ptr += (uint32_t)l;
-          found = row_ptr < cache_n && (uint32_t)__builtin_amdgcn_readlane((int)cs, l) == seed;
-          break;
-        }
-        row_ptr += 64u;
-      }
-      if (!found) FAST_RETURN(FAST_REFILL);
-    }
+    FP_MARK(1);
+    // ---- the seed's neighbour list (staged in LDS, row_ptr points at it): one packed key per lane, ascending
     const uint32_t nk_word = red.cache_meta[row_ptr];
     const uint32_t n_k = nk_word & 0xFFu;
     const bool complete = (nk_word >> 31) != 0u;
     const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
+    const bool row_clean = ((nk_word >> 29) & 1u) != 0u;
+    const bool tail_clear = ((nk_word >> 28) & 1u) != 0u;
     const uint64_t e = lane < n_k ? l_rows[row_ptr * PM_PROP_ROW + lane] : ~0ull;
     const uint32_t slot = (uint32_t)(e & SLOT_MASK);
     const bool alive = lane < n_k && bit_at(l_alive, slot);
@@ -702,7 +758,9 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
     if ((uint32_t)__popcll(am) < want) {  FAST_RETURN(FAST_SLOW); }  // list exhausted by earlier groups
     const bool sel = alive && rank < want;
-    if (want > 0) {
+    FP_MARK(2);
+    // the proposer certified the whole row (clean) and its tail (complete / tail_clear): nothing left to prove
+    if (want > 0 && !(row_clean && (complete || tail_clear))) {
       const uint64_t lm = __ballot(sel && rank == want - 1u);
       const int lane_m = __builtin_ctzll(lm);
       const uint64_t e_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), lane_m) << 32) |
@@ -712,7 +770,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         // exactness certificate: every live unselected candidate within the band of the last selected one
         // must sit at the same site (then the reference's distances tie exactly and slot order decides)
         const double a_m = __longlong_as_double((long long)kb_m);
-        const double band = a_m * PM_TIE_BAND + 1e-300;
+        const double band = a_m * band_rel + 1e-300;
         if (a_m > PM_A_MAX_SAFE) FAST_RETURN(FAST_SLOW);
         const uint32_t site_m = l_site[(uint32_t)(e_m & SLOT_MASK)];
         const uint64_t kb = (e >> SB) << SB;
@@ -732,14 +790,15 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         }
       }
     }
+    FP_MARK(3);
     // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
     if (sel) {
       atomicAnd((unsigned long long*)&l_alive[slot >> 6], ~(1ull << (slot & 63u)));
-      members[c.mem_off + 1u + rank] = l_wid[slot];
+      members[c.mem_off + 1u + rank] = wid_of(slot);
     }
     if (lane == 0) {
       atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
-      members[c.mem_off] = l_wid[seed];
+      members[c.mem_off] = wid_of(seed);
       g_cfg[c.n_groups] = c.cfg;
       g_n[c.n_groups] = want + 1u;
       g_off[c.n_groups] = c.mem_off;
@@ -751,6 +810,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     c.total_available -= want + 1u;
     c.steps += 1;
     c.fast_steps += 1;
+    FP_MARK(4);
   }
 }
 
@@ -760,15 +820,18 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 // live candidate, two-level selection (DPP argmin rounds per wave, 16-way merge), certificate, commit —
 // three LDS-only barriers.  Runs until the configuration is exhausted, a recompaction is due, or a step
 // cannot be certified.
+template <bool BIG>
 __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, const uint32_t* l_wid,
-                                          const uint32_t* l_site, const uint16_t* l_next, uint64_t* l_key,
-                                          uint64_t* l_alive,
+                                          const uint32_t* l_site, const uint16_t* l_next, const uint32_t* l_next32,
+                                          uint64_t* l_key, uint64_t* l_rows, uint64_t* l_alive,
                                           const uint64_t* l_loc, uint64_t* part, uint32_t* sel_out,
                                           uint32_t steps_before) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
+  constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
+  constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
   const uint32_t lw = (c.n_list + 63u) >> 6;
   const bool have_props = c.mode == CARVE_MODE_FORM && c.use_props;
+  auto wid_of = [l_wid](uint32_t sl) -> uint32_t { return BIG ? sl : l_wid[sl]; };  // big lists: translated after the run
   bool cache_valid = false;
   for (;;) {
     if (have_props) {
@@ -780,6 +843,9 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
           for (uint32_t j0 = 0; j0 < lw && base < PM_CARVE_CACHE_ROWS; j0 += 64u) {
             const uint32_t j = j0 + lane;
             uint64_t w = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
+            // proposals exist for slots below prop_limit only
+            if (j * 64u + 64u > c.prop_limit)
+              w = (j * 64u >= c.prop_limit) ? 0ull : (w & ((1ull << (c.prop_limit & 63u)) - 1ull));
             const uint32_t cnt = __popcll(w);
             uint32_t incl = cnt;  // inclusive prefix sum over the 64 lanes
 #pragma unroll
@@ -797,11 +863,33 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
           if (lane == 0) red.cache_n = base < PM_CARVE_CACHE_ROWS ? base : PM_CARVE_CACHE_ROWS;
         }
         lds_barrier();
+#ifdef PM_CARVE_PROF
+        if (tid == 0) p.status->prof[6] += 1;
+#endif
         const uint32_t rows = red.cache_n;
-        for (uint32_t r = wave; r < rows; r += CARVE_WAVES) {
-          const uint32_t sl = red.cache_slot[r];
-          l_key[r * PM_PROP_ROW + lane] = p.prop[(size_t)sl * PM_PROP_ROW + lane];
-          if (lane == 0) red.cache_meta[r] = p.prop_n[sl];
+        {  // all loads of a wave are issued before the first LDS store (rows: one u64 per lane; directory
+           // words: one staged row per thread)
+          uint64_t rowv[PM_CARVE_CACHE_ROWS / CARVE_WAVES];
+#pragma unroll
+          for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
+            const uint32_t r = wave + k * CARVE_WAVES;
+            rowv[k] = r < rows ? p.prop[(size_t)red.cache_slot[r] * PM_PROP_ROW + lane] : ~0ull;
+          }
+          uint32_t meta = 0, nx = PM_NONE;
+          if (tid < rows) {
+            const uint32_t sl = red.cache_slot[tid];
+            meta = p.prop_n[sl];
+            nx = p.same_next[sl];
+          }
+#pragma unroll
+          for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
+            const uint32_t r = wave + k * CARVE_WAVES;
+            if (r < rows) l_rows[r * PM_PROP_ROW + lane] = rowv[k];
+          }
+          if (tid < rows) {
+            red.cache_meta[tid] = meta;
+            red.cache_next[tid] = nx < c.n_list ? nx : PM_NONE;
+          }
         }
         lds_barrier();
         cache_valid = true;
@@ -809,7 +897,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
       // wave 0 commits as many steps as the proposals allow; everyone else waits at the barrier
       if (wave == 0) {
         PROF_DECL;
-        const int act = carve_fast_steps(p, red, c, l_wid, l_site, l_next, l_key, l_alive, l_loc, steps_before);
+        const int act = carve_fast_steps<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive, l_loc, steps_before);
         if (lane == 0) {
           red.f_action = (uint32_t)act;
           red.f_n_cand = c.n_cand;
@@ -838,7 +926,8 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         cache_valid = false;
         continue;
       }
-      cache_valid = false;  // the slow sweep below overwrites l_key
+      if (act == FAST_REPROPOSE) return STEP_CONTINUE;  // re-prepare: next proposal batch
+      if (l_rows == l_key) cache_valid = false;  // the slow sweep below overwrites the staged rows
     }
     // FORM: `while total_available >= min` (mod.rs:507) with `compatible < min => break` (:517-519).
     // MERGE: `while remaining_groups.len() >= min` (mod.rs:695).
@@ -979,7 +1068,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
               if (n_sel < PM_CARVE_SEL_CAP)
                 sel_out[n_sel] = bs;
               else if (c.mem_off + 1u + n_sel < p.cap_members)
-                p.members[c.mem_off + 1u + n_sel] = l_wid[bs];
+                p.members[c.mem_off + 1u + n_sel] = wid_of(bs);
             }
             last = b;
             ++n_sel;
@@ -1010,7 +1099,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
     if (use_dist && n_sel > 0 && last_key != noloc_key) {
       const uint32_t ls = (uint32_t)(last & ((1ull << SB) - 1ull));
       const double a_m = __longlong_as_double((long long)last_key);
-      const double band = a_m * PM_TIE_BAND + 1e-300;
+      const double band = a_m * band_rel + 1e-300;
       const double mlat = p.cc_lat[ls], mlon = p.cc_lon[ls];  // uniform loads
       if (a_m > PM_A_MAX_SAFE) uncertain = 1;
       for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
@@ -1046,13 +1135,13 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
     }
     if (wave == 0) {  // group record + members: LDS -> fire-and-forget global stores
       if (lane == 0) {
-        p.members[c.mem_off] = l_wid[seed];
+        p.members[c.mem_off] = wid_of(seed);
         p.g_cfg[c.n_groups] = c.cfg;
         p.g_n[c.n_groups] = total;
         p.g_off[c.n_groups] = c.mem_off;
       }
       const uint32_t lim = n_sel < PM_CARVE_SEL_CAP ? n_sel : PM_CARVE_SEL_CAP;
-      for (uint32_t r = lane; r < lim; r += 64u) p.members[c.mem_off + 1u + r] = l_wid[sel_out[r]];
+      for (uint32_t r = lane; r < lim; r += 64u) p.members[c.mem_off + 1u + r] = wid_of(sel_out[r]);
     }
     PROF_MARK(7);
     lds_barrier();
@@ -1217,7 +1306,7 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
 
 // Stable compaction of the live positions of this configuration into list slots: two passes over
 // contiguous per-wave ranges.  Returns the list length; red.a keeps the per-wave counts for the placement.
-__device__ uint32_t carve_compact_count(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit) {
+__device__ __noinline__ uint32_t carve_compact_count(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t n_words = (n + 63u) >> 6;
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
@@ -1236,7 +1325,7 @@ __device__ uint32_t carve_compact_count(const CarveArgs& p, BlockRed& red, uint3
   return total;
 }
 
-__device__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit, uint32_t n_list) {
+__device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit, uint32_t n_list) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n_words = (n + 63u) >> 6;
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
@@ -1293,8 +1382,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   const CarveStatus* st = p.status;
   if (st->state != CARVE_STATE_RUNNING || st->cur_ci >= p.n_avail) return;
   const uint32_t K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
-  if (K == 0 || n_list > PM_CARVE_SLOTS) return;
-  constexpr uint32_t SB = PM_CARVE_SLOT_BITS;
+  if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
+  const uint32_t SB = n_list > PM_CARVE_SLOTS ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
+  const double TIE_BAND = n_list > PM_CARVE_SLOTS ? PM_TIE_BAND_BIG : PM_TIE_BAND;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_g = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
   const uint64_t* alive = p.bits_scratch;
@@ -1319,10 +1409,14 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       ++n_mine;
     }
     uint32_t popped = 0, n_k = 0;
-    uint64_t mine = ~0ull;
-    while (n_k < K) {
+    uint64_t mine = ~0ull, beyond = ~0ull;  // beyond = the (K+1)-th key, if any
+    while (n_k <= K) {
       const uint64_t v = wave_min_u64(r0);
       if (v == ~0ull) break;
+      if (n_k == K) {
+        beyond = v;
+        break;
+      }
       if (lane == n_k) mine = v;
       ++n_k;
       if (r0 == v) {
@@ -1342,39 +1436,97 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       }
     }
     same = wave_min(same);
-    // tail certificate: when the list is cut inside a run of exact ties (a whole site at one distance), check
-    // that every candidate NOT in the list whose key is within the band of the last entry sits at that
-    // entry's site — the validator may then take a prefix of the tie run
-    uint32_t tail_ok = 0;
-    if (n_k == K && K >= 2) {
+    const uint64_t noloc_kb = (PM_KEY_NOLOC >> SB) << SB;
+    // row certificates the validator can rely on instead of re-deriving them at every step:
+    //  clean      — no two neighbouring entries within the band of each other sit at different sites (entries in
+    //               between are within the band too, so this covers every pair of the row)
+    //  tail_clear — the first candidate NOT in the row is further than the band from the last entry
+    //  tail_ok    — otherwise: everything unlisted within the band of the last entry sits at that entry's site
+    uint32_t clean = 1, tail_clear = 0, tail_ok = 0;
+    {
+      const uint64_t kb = (mine >> SB) << SB;
+      const uint32_t my_site = (lane < n_k && kb != noloc_kb) ? p.cc_site[(uint32_t)(mine & ((1ull << SB) - 1ull))] : 0u;
+      const uint64_t nkb_lo = __shfl_down((uint32_t)kb, 1, 64), nkb_hi = __shfl_down((uint32_t)(kb >> 32), 1, 64);
+      const uint64_t nkb = (nkb_hi << 32) | nkb_lo;
+      const uint32_t nsite = __shfl_down(my_site, 1, 64);
+      int bad = 0;
+      if (lane + 1u < n_k && kb != noloc_kb && nkb != noloc_kb) {
+        const double a0 = __longlong_as_double((long long)kb), a1 = __longlong_as_double((long long)nkb);
+        if (a1 - a0 <= a1 * (4.0 * TIE_BAND) + 1e-300 && nsite != my_site) bad = 1;
+      }
+      clean = __ballot(bad) == 0ull;
+    }
+    if (n_k == K) {
       const uint64_t e_last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 1) << 32) |
                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 1);
-      const uint64_t e_prev = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 2) << 32) |
-                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 2);
       const uint64_t kb_last = (e_last >> SB) << SB;
-      if (kb_last == ((e_prev >> SB) << SB) && kb_last != ((PM_KEY_NOLOC >> SB) << SB)) {
-        const uint32_t site_last = p.cc_site[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
+      const uint64_t kb_beyond = (beyond >> SB) << SB;
+      if (beyond == ~0ull || kb_last == noloc_kb) {
+        tail_clear = 1;  // nothing unlisted, or only location-less candidates (exact ties, larger slots)
+      } else if (kb_beyond == noloc_kb) {
+        tail_clear = 1;
+      } else {
         const double a_last = __longlong_as_double((long long)kb_last);
-        const double band2 = a_last * (4.0 * PM_TIE_BAND) + 1e-300;
-        int bad = 0;
-        for (uint32_t j = 0; j < lw; ++j) {
-          const uint32_t t = j * 64u + lane;
-          if (!((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
-          const uint64_t k = pack_key((uint64_t)__double_as_longlong(
-                                          hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB);
-          if (k <= e_last) continue;  // listed
-          const double a = __longlong_as_double((long long)((k >> SB) << SB));
-          if (a - a_last <= band2 && p.cc_site[t] != site_last) bad = 1;
+        const double a_b = __longlong_as_double((long long)kb_beyond);
+        if (a_b - a_last > a_b * (4.0 * TIE_BAND) + 1e-300) {
+          tail_clear = 1;
+        } else {
+          const uint32_t site_last = p.cc_site[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
+          const double band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
+          int bad = 0;
+          for (uint32_t j = 0; j < lw; ++j) {
+            const uint32_t t = j * 64u + lane;
+            if (!((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
+            const uint64_t k = pack_key((uint64_t)__double_as_longlong(
+                                            hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB);
+            if (k <= e_last) continue;  // listed
+            const double a = __longlong_as_double((long long)((k >> SB) << SB));
+            if (a - a_last <= band2 && p.cc_site[t] != site_last) bad = 1;
+          }
+          tail_ok = __ballot(bad) == 0ull;
         }
-        tail_ok = __ballot(bad) == 0ull;
       }
     }
     p.prop[(size_t)s * PM_PROP_ROW + lane] = mine;
     if (lane == 0) {
-      p.prop_n[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30);
+      p.prop_n[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
       p.same_next[s] = same;
     }
   }
+}
+
+// One proposal per located slot, at most PM_PROP_MAX_SEEDS per round: returns the slot after the word in
+// which the PM_PROP_MAX_SEEDS-th located slot falls (a later round covers the rest), or n_list.
+__device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& red, uint32_t n_list) {
+  if (n_list <= PM_PROP_MAX_SEEDS) return n_list;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    const uint64_t* g_al = p.bits_scratch;
+    const uint64_t* g_lc = p.bits_scratch + p.bits_stride;
+    const uint32_t lwp = (n_list + 63u) >> 6;
+    uint32_t acc = 0, limit = n_list;
+    for (uint32_t j0 = 0; j0 < lwp; j0 += 64u) {
+      const uint32_t j = j0 + lane;
+      const uint32_t cnt = j < lwp ? (uint32_t)__popcll(g_al[j] & g_lc[j]) : 0u;
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += up;
+      }
+      const uint64_t over = __ballot(acc + incl >= PM_PROP_MAX_SEEDS);
+      if (over) {
+        limit = (j0 + (uint32_t)__builtin_ctzll(over) + 1u) * 64u;
+        break;
+      }
+      acc += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) red.b[0] = limit < n_list ? limit : n_list;
+  }
+  __syncthreads();
+  const uint32_t r = red.b[0];
+  __syncthreads();
+  return r;
 }
 
 __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* __restrict__ pa, uint32_t flags_in,
@@ -1399,6 +1551,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   CarveStatus* st = p.status;
   uint32_t flags = flags_in;
   if (!(flags & CARVE_F_INIT) && st->state != CARVE_STATE_RUNNING) return;  // queued behind a finished carve
+  PROF_DECL;
 
   uint32_t n;
   StepCtx c;
@@ -1480,6 +1633,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   uint32_t exit_state = CARVE_STATE_RUNNING, stop_ci = p.n_avail;
   uint32_t slow_before_cfg = 0;
 
+  PROF_MARK(15);  // init / status load
   for (;;) {
     // ---- prepare: candidate list of the next configuration whose loop would be entered
     // (mod.rs:505-519; the list is mod.rs:511-515 evaluated once, removals are applied to bitmaps)
@@ -1502,12 +1656,18 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         break;
       }
       // proposals: one neighbour list per located slot, K = (max - 1) + reserve entries
-      if ((flags & CARVE_F_PROPS) && p.proximity && c.n_list <= PM_CARVE_SLOTS && c.max_s - 1u < PM_PROP_ROW) {
+      if ((flags & CARVE_F_PROPS) && p.proximity && c.n_list <= PM_CARVE_BIG_SLOTS && c.max_s - 1u < PM_PROP_ROW) {
         const uint32_t k = c.max_s - 1u + PM_PROP_RESERVE;
         c.prop_k = k < PM_PROP_ROW ? k : PM_PROP_ROW;
-        c.prop_limit = c.n_list;
+        // one proposal per located slot, at most PM_PROP_MAX_SEEDS per round: prop_limit = the slot after the
+        // PM_PROP_MAX_SEEDS-th located one (a later round covers the rest)
+        c.prop_limit = carve_prop_limit(p, red, c.n_list);
       }
       prepared = true;
+      PROF_MARK(9);
+#ifdef PM_CARVE_PROF
+      if (tid == 0) { p.status->prof[8] += 1; p.status->prof[7] += c.n_list; }
+#endif
       if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
     } else {
       c.n_list = st->n_list;
@@ -1519,40 +1679,60 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     c.cfg = p.avail_cfg[ci];
     c.n_cand = c.n_list;
 
-    // ---- run the prepared configuration
+    // ---- run the prepared configuration.  Three storage modes:
+    //   small (<= PM_CARVE_SLOTS slots):  every per-slot array in LDS
+    //   big   (<= PM_CARVE_BIG_SLOTS):    bitmaps + staged proposal rows in LDS, per-slot arrays in HBM/L2
+    //   mem   (larger):                   everything in HBM/L2, exact sweep only
+    ctx_set_geometry(c);
     const bool in_lds = c.n_list <= PM_CARVE_SLOTS;
+    const bool big = !in_lds && c.n_list <= PM_CARVE_BIG_SLOTS;
     const uint32_t lw = (c.n_list + 63u) >> 6;
     uint64_t* g_alive = p.bits_scratch;
     uint64_t* g_loc = p.bits_scratch + p.bits_stride;
-    if (in_lds) {
+    // big mode: the worker-id / site-id regions (32 KiB each) hold the bitmaps instead
+    uint64_t* r_alive = in_lds ? lds_alive : (big ? reinterpret_cast<uint64_t*>(lds_wid) : g_alive);
+    uint64_t* r_loc = in_lds ? lds_loc : (big ? reinterpret_cast<uint64_t*>(lds_site) : g_loc);
+    if (in_lds || big) {
       for (uint32_t j = tid; j < lw; j += CARVE_THREADS) {
-        lds_alive[j] = g_alive[j];
-        lds_loc[j] = g_loc[j];
+        r_alive[j] = g_alive[j];
+        r_loc[j] = g_loc[j];
       }
+    }
+    if (in_lds) {
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) {
         lds_wid[sl] = p.slot_wid[sl];
         lds_site[sl] = p.cc_site[sl];
         const uint32_t nx = (c.use_props && c.prop_k) ? p.same_next[sl] : PM_NONE;
         lds_next[sl] = nx < c.n_list ? (uint16_t)nx : (uint16_t)0xFFFFu;
       }
-      __syncthreads();
     }
+    __syncthreads();
+    PROF_MARK(10);
     const uint32_t slow0 = c.steps - c.fast_steps;
+    const uint32_t mem_before_run = c.mem_off;
     int rc;
-    if (!in_lds) {
+    if (in_lds) {
+      rc = carve_run_lds<false>(p, red, c, lds_wid, lds_site, lds_next, nullptr, lds_key, lds_key, r_alive, r_loc,
+                                part, sel_out, steps_before);
+    } else if (big) {
+      rc = carve_run_lds<true>(p, red, c, p.slot_wid, p.cc_site, nullptr, p.same_next, p.keys, lds_key, r_alive, r_loc,
+                               part, sel_out, steps_before);
+    } else {
       do {
         rc = carve_step_mem(p, red, c, part, p.keys, p.slot_wid, g_alive, g_loc, steps_before);
       } while (rc == STEP_CONTINUE && !(c.n_cand * 2u < c.n_list));
-    } else {
-      rc = carve_run_lds(p, red, c, lds_wid, lds_site, lds_next, lds_key, lds_alive, lds_loc, part, sel_out,
-                         steps_before);
     }
     (void)slow0;
     (void)slow_before_cfg;
     __syncthreads();
+    if (big) {  // slots -> worker ids for everything this run appended
+      for (uint32_t k = mem_before_run + tid; k < c.mem_off; k += CARVE_THREADS) p.members[k] = p.slot_wid[p.members[k]];
+      __syncthreads();
+    }
+    PROF_MARK(13);
     // dead slots -> position bitmap, so the next compaction / configuration sees the removals
     {
-      const uint64_t* alive = in_lds ? lds_alive : g_alive;
+      const uint64_t* alive = r_alive;
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS)
         if (!bit_at(alive, sl)) {
           const uint32_t i = p.slot_pos[sl];
@@ -1560,6 +1740,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         }
     }
     __syncthreads();
+    PROF_MARK(12);
     if (rc == STEP_UNCERTAIN || rc == STEP_OVERFLOW) {
       exit_state = rc == STEP_UNCERTAIN ? CARVE_STATE_UNCERTAIN : CARVE_STATE_OVERFLOW;
       stop_ci = ci;
@@ -1579,6 +1760,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     }
   }
   __syncthreads();
+  PROF_MARK(14);
   if (tid == 0) {
     st->state = exit_state;
     st->n_groups = c.n_groups;

@@ -28,10 +28,12 @@ for it in range(3):
 out = (C.c_ulonglong * 16)()
 E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 E.lib().pm_debug_carve_prof(eng._h, out)
-tot = sum(out[:12])
+tot = out[15] + out[9] + out[10] + out[13] + out[12] + out[14]
 print(f"carve kernels {s['ms_carve_kernel']:.3f} ms, {s['carve_steps']} steps ({s['carve_fast_steps']} fast), "
       f"{1e3 * s['ms_carve_kernel'] / s['carve_steps']:.2f} us/step")
 for i, nm in enumerate(names):
     print(f"  {nm:12s} {out[i]:12d} ticks  {100.0 * out[i] / max(tot, 1):5.1f}%  {out[i] / max(s['carve_steps'], 1):8.1f} ticks/step")
-print(f"  fast path split: seed-search={out[9]} same-site-chain={out[10]} proposal-load+filter={out[13]} certificate={out[14]} commit={out[15]}")
+print(f"  fast path (register-accumulated ticks): seed={out[0]} chain/same-site={out[1]} row+filter={out[2]} certificate={out[3]} commit={out[4]} loop-top={out[5]}")
+print(f"  counts: prepares={out[8]} (sum n_list={out[7]}) refills={out[6]} launches={s['carve_launches']}")
+print(f"  launch anatomy (ticks): init/status={out[15]} prepare(compaction)={out[9]} load-list={out[10]} run(all steps)={out[13]} flush={out[12]} group_of+exit={out[14]}")
 print(f"  total ticks {tot}; ticks per ms = {tot / s['ms_carve_kernel']:.0f}")
