@@ -124,13 +124,22 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (the engine has no CPU fallback)", file=sys.stderr)
         return 2
+    # PM_BENCH_BACKEND=gloo + PM_BENCH_SHARE_DEVICE=1: plumbing check of the N>1 path on a 1-GPU box (all ranks
+    # on device 0, collectives on host tensors).  The real path is nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("PM_BENCH_BACKEND", "nccl")
+    if os.environ.get("PM_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from protocol_amd import engine as E, host
     from protocol_amd.swarm import baseline_config, make_swarm
@@ -148,12 +157,12 @@ def main() -> int:
                    group_id_seed=args.seed + rank)
     host.load_swarm(eng, sw)
     if world > 1:
-        w_counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(w_counts, torch.tensor([sw.W], dtype=torch.int64, device=dev))
+        w_counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(w_counts, torch.tensor([sw.W], dtype=torch.int64, device=coll_dev))
         w_counts = [int(x.item()) for x in w_counts]
         w_max = max(w_counts)
-        gather_out = torch.empty(world * w_max, dtype=torch.int32, device=dev)
-        local_tbl = torch.full((w_max,), -1, dtype=torch.int32, device=dev)
+        gather_out = torch.empty(world * w_max, dtype=torch.int32, device=coll_dev)
+        local_tbl = torch.full((w_max,), -1, dtype=torch.int32, device=coll_dev)
     else:
         w_counts = [sw.W]
 
@@ -166,7 +175,7 @@ def main() -> int:
         s = eng.tick()
         if world > 1:  # the one exchange step: all-gather the published table shards over RCCL/xGMI
             ptr, n = eng.device_task_column()
-            local_tbl[:n].copy_(torch.as_tensor(_DevCol(ptr, n), device=dev))
+            local_tbl[:n].copy_(torch.as_tensor(_DevCol(ptr, n), device=dev))   # stays on the GPU for nccl
             dist.all_gather_into_tensor(gather_out, local_tbl)
         return s
 
@@ -184,9 +193,14 @@ def main() -> int:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the gathered table must hold every shard's published column
+        got = gather_out.view(world, w_max).cpu().numpy()
+        ptr, n = eng.device_task_column()
+        mine = torch.as_tensor(_DevCol(ptr, n), device=dev).cpu().numpy()
+        assert (got[rank, :n] == mine).all(), "all-gathered table does not contain this rank's column"
 
     T = sw.T
     total_pairs = float(T) * float(sum(w_counts)) * args.steps

@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
         L.orc_state_set_enabled.argtypes = [vp, vp]
         L.orc_state_set_tasks.argtypes = [vp, vp, sz]
         L.orc_state_set_node_status.argtypes = [vp, vp, sz, C.c_uint32]
+        L.orc_state_remap_tasks.argtypes = [vp, vp, sz]
         L.orc_try_form_new_groups.argtypes = [vp]
         L.orc_try_form_new_groups.restype = sz
         L.orc_try_merge_solo_groups.argtypes = [vp]
@@ -275,6 +276,10 @@ class State:
     def set_tasks(self, tasks: np.ndarray):
         self.tasks = np.ascontiguousarray(tasks)
         lib().orc_state_set_tasks(self._h, _p(self.tasks), len(self.tasks))
+
+    def remap_tasks(self, old_to_new):
+        m = np.ascontiguousarray(old_to_new, dtype=np.int64)
+        lib().orc_state_remap_tasks(self._h, _p(m), len(m))
 
     def set_node_status(self, idx: int, status: int):
         lib().orc_state_set_node_status(self._h, _p(self.nodes), idx, status)

@@ -550,6 +550,18 @@ void orc_state_set_node_status(orc_state* st, orc_node* nodes_mut, size_t idx, u
     orc_dissolve_group(st, (uint32_t)st->node_group[idx]);
 }
 
+void orc_state_remap_tasks(orc_state* st, const int64_t* map, size_t n_old) {
+  for (size_t g = 0; g < st->n_slots; ++g) {
+    grp* gr = &st->groups[g];
+    if (!gr->alive || gr->task < 0) continue;
+    int64_t nt = (size_t)gr->task < n_old ? map[gr->task] : -1;
+    if (nt < 0)
+      orc_dissolve_group(st, (uint32_t)g); /* mod.rs:1259-1288 */
+    else
+      gr->task = nt;
+  }
+}
+
 /* ---- stable merge sort over uint32 index arrays with a context comparator (Rust sort_by is stable;
  * any stable sort produces the same permutation for a consistent comparator). */
 typedef int (*cmp_fn)(void* ctx, uint32_t a, uint32_t b);

@@ -206,6 +206,10 @@ void orc_state_set_tasks(orc_state*, const orc_task* tasks, size_t n_tasks);
  * status_update_impl.rs:8-39: Dead|LowBalance => dissolve the node's group). */
 void orc_state_set_node_status(orc_state*, orc_node* nodes_mut, size_t idx, uint32_t status);
 
+/* Task table replaced (get_all_tasks changed): map[i] = new index of old task i, or -1 if it was deleted.
+ * Groups holding a deleted task are dissolved (on_task_deleted, mod.rs:1259-1288). */
+void orc_state_remap_tasks(orc_state*, const int64_t* map, size_t n_old);
+
 /* mod.rs:478-628 try_form_new_groups. Returns number of groups formed this call. */
 size_t orc_try_form_new_groups(orc_state*);
 /* mod.rs:631-971 try_merge_solo_groups (+ find_best_task_for_group :1122-1189 via chooser).

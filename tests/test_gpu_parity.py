@@ -368,3 +368,64 @@ def test_engine_argument_errors():
     with pytest.raises(E.EngineError):
         eng.set_configs(bad, np.zeros(0, dtype=E.alt_row_dt))
     eng.close()
+
+
+def test_streaming_churn_parity():
+    """BASELINE configs[4] in miniature: every tick new tasks arrive (newest first), ~1 % of the workers die
+    (whole group dissolved) or join, one old task is deleted (its groups dissolve); the engine's incremental
+    state must track the oracle's tick by tick — existing groups are sticky (Appendix A)."""
+    rng = np.random.default_rng(42)
+    sw = make_swarm(9, 1500, 3000)
+    status0 = sw.status.copy()
+    late = rng.random(sw.W) < 0.25
+    sw.status = np.where(late, 0, sw.status).astype(np.uint8)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    flags = host.worker_flags(sw).astype(np.int64)
+    masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+    joiners = list(np.nonzero(late & (status0 == 2))[0])
+    next_uid = 1 << 40
+    for tick in range(6):
+        # ---- task churn: 40 new tasks (newest => front of get_all_tasks), one claimed task deleted from tick 2 on
+        n_new = 40
+        pick = rng.integers(0, len(tasks), n_new)
+        new_rows = tasks[pick].copy()
+        new_rows["created_at"] = int(created.max()) + 1 + np.arange(n_new)[::-1]
+        keep = np.ones(len(tasks), dtype=bool)
+        if tick >= 2:
+            claimed = [g[4] for g in st.groups() if g[4] >= 0]
+            if claimed:
+                keep[claimed[tick % len(claimed)]] = False
+        old_to_new = np.where(keep, n_new + np.cumsum(keep) - 1, -1)
+        tasks = np.concatenate([new_rows, tasks[keep]])
+        masks = np.concatenate([masks[pick], masks[keep]])
+        created = np.concatenate([new_rows["created_at"], created[keep]])
+        uid = np.concatenate([np.arange(next_uid, next_uid + n_new, dtype=np.uint64), uid[keep]])
+        next_uid += n_new
+        st.set_tasks(tasks)
+        st.remap_tasks(old_to_new)
+        eng.upload_tasks(masks, created, uid)
+        # ---- worker churn: ~0.5 % die, ~0.5 % join
+        alive = np.nonzero(st.nodes["status"] == 2)[0]
+        for w in rng.choice(alive, size=15, replace=False):
+            st.set_node_status(int(w), 4)
+            flags[w] &= ~E.W_HEALTHY
+            eng.on_worker_status(int(w), int(flags[w]), True)
+        for _ in range(15):
+            if joiners:
+                w = int(joiners.pop())
+                st.set_node_status(w, 2)
+                flags[w] |= E.W_HEALTHY
+                eng.on_worker_status(w, int(flags[w]), False)
+        # ---- one management tick + every worker's scheduling
+        s = eng.tick()
+        st.try_form_new_groups()
+        st.try_merge_solo_groups()
+        want = [st.get_task_for_node(w) for w in range(sw.W)]
+        got = [(-1 if eng.lookup(w).task == NONE else eng.lookup(w).task) for w in range(sw.W)]
+        assert got == want, f"tick {tick}"
+        assert sorted(oracle_groups(st)) == sorted(engine_groups(eng)), f"tick {tick}"
+        assert s["host_resolved_steps"] == 0
+    eng.close()
