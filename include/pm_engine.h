@@ -149,8 +149,9 @@ typedef struct {
   uint32_t debug_uncertain_every; /* test hook: treat every n-th carve step as a near-tie so the
                                      exact host resolve path runs (0 = off) */
   uint32_t sweep_variant;        /* pair-sweep kernel: 0 = default (best), 1 = scalar reference kernel */
-  uint32_t carve_variant;        /* group formation: 0 = default (full-chip neighbour-list proposals + ordered
-                                    validation), 1 = single-workgroup sequential sweep only */
+  uint32_t carve_variant;        /* group formation: 0 = default (full-chip neighbour-list proposals + speculative
+                                    in-order validation rounds), 1 = single-workgroup sequential sweep only,
+                                    2 = proposals with single-wave sequential validation */
   uint32_t _reserved;
 } pm_engine_config;
 

@@ -29,7 +29,7 @@ static constexpr uint32_t PM_PROP_ROW = 64;            // proposal row stride (e
 static constexpr uint32_t PM_PROP_RESERVE = 24;        // entries beyond max_group_size - 1
 static constexpr uint32_t PM_PROP_MAX_SEEDS = 16384;   // located slots that get a proposal per configuration
 static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
-                                             size_t(PM_CARVE_SLOTS) * 18 + size_t(PM_CARVE_SEL_CAP) * 4 + 2048;
+                                             size_t(PM_CARVE_SLOTS) * 18 + size_t(PM_CARVE_SEL_CAP) * 4 + 2560;
 
 struct CompatArgs {
   uint32_t W, n_cfgs, model_words;
@@ -90,7 +90,7 @@ struct CarveArgs {
   uint32_t W;
   uint32_t proximity;
   uint32_t debug_uncertain_every;
-  uint32_t _pad1;
+  uint32_t rounds_enabled;  // speculative multi-wave validation rounds (carve_variant 0)
   // worker columns
   const uint32_t* wflags;
   const double *lat, *lon, *coslat;

@@ -331,6 +331,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->W = e->W;
   a->proximity = e->cfg.proximity_enabled;
   a->debug_uncertain_every = e->cfg.debug_uncertain_every;
+  a->rounds_enabled = e->cfg.carve_variant == 0 ? 1u : 0u;
   a->wflags = e->d_flags.p;
   a->lat = e->d_lat.p;
   a->lon = e->d_lon.p;
@@ -457,7 +458,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
   st.state = CARVE_STATE_RUNNING;
   st.n_groups = g0;
   st.n_members = m0;
-  const bool use_props = e->cfg.carve_variant == 0 && e->cfg.proximity_enabled;
+  const bool use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
   uint32_t start_ci = 0;
   for (;;) {

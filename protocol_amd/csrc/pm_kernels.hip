@@ -472,6 +472,9 @@ struct BlockRed {
   // mailbox: wave 0 -> workgroup after a run of fast (proposal) steps
   uint32_t f_action, f_n_cand, f_total_available, f_n_groups, f_mem_off, f_steps, f_fast, f_pad;
   unsigned long long f_cand_sum;
+  // speculative rounds: commit order token, stop code, first staged row of the next round
+  unsigned long long token;
+  uint32_t stop, retry_row;
   // proposal rows staged in LDS (they alias the slow path's key array): slot and prop_n word per row
   uint32_t cache_n, cache_pad;
   uint32_t cache_slot[PM_CARVE_CACHE_ROWS];
@@ -553,7 +556,8 @@ __device__ __forceinline__ void ctx_set_geometry(StepCtx& c) {
   c.band = c.big ? PM_TIE_BAND_BIG : PM_TIE_BAND;
 }
 
-enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3, FAST_REPROPOSE = 4 };
+enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3, FAST_REPROPOSE = 4, FAST_SEQ = 5 };
+enum { ROUND_OK = 0, ROUND_SLOW = 1, ROUND_RETRY = 2, ROUND_OVERFLOW = 3 };
 
 // Fast steps, executed by wave 0 alone while the other waves are parked at a barrier: the expensive
 // part of a step (keys for every live candidate + top-k) was done for every possible seed by
@@ -569,7 +573,7 @@ enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3, FAST_RE
 #ifdef PM_CARVE_PROF
 #define FP_DECL uint64_t fp_t = __builtin_amdgcn_s_memtime(), fp_acc[6] = {0, 0, 0, 0, 0, 0}
 #define FP_MARK(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); fp_acc[i] += t_ - fp_t; fp_t = t_; } while (0)
-#define FP_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 6; ++i_) p.status->prof[i_] += fp_acc[i_]; } while (0)
+#define FP_FLUSH() do { (void)fp_acc; } while (0)
 #else
 #define FP_DECL
 #define FP_MARK(i)
@@ -600,11 +604,28 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
   // (a dependent HBM load per member would stall the single validating wave)
   // (lambdas capture plain values: a by-reference capture of `c` would pin the whole context in scratch)
   const uint32_t n_list_v = c.n_list;
-  auto wid_of = [l_wid](uint32_t sl) -> uint32_t { return BIG ? sl : l_wid[sl]; };
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  typedef __attribute__((address_space(3))) uint16_t lds_u16;
+  lds_u64* const A = (lds_u64*)l_alive;
+  const lds_u64* const LOC = (const lds_u64*)l_loc;
+  const lds_u64* const ROWS = (const lds_u64*)l_rows;
+  const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
+  const lds_u32* const C_META = (const lds_u32*)red.cache_meta;
+  const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
+  const lds_u32* const WID3 = (const lds_u32*)l_wid;
+  const lds_u32* const SITE3 = (const lds_u32*)l_site;
+  const lds_u16* const NEXT3 = (const lds_u16*)l_next16;
+  auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
+  auto kill = [A](uint32_t i) {
+    __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto site_of = [SITE3, l_site](uint32_t sl) -> uint32_t { return BIG ? l_site[sl] : SITE3[sl]; };
+  auto wid_of = [WID3](uint32_t sl) -> uint32_t { return BIG ? sl : WID3[sl]; };
   // next located slot at the same site: LDS u16 for small lists, HBM u32 for big ones
-  auto next_of = [l_next16, l_next32, n_list_v](uint32_t sl) -> uint32_t {
+  auto next_of = [NEXT3, l_next32, n_list_v](uint32_t sl) -> uint32_t {
     if (!BIG) {
-      const uint32_t v = l_next16[sl];
+      const uint32_t v = NEXT3[sl];
       return v == 0xFFFFu ? PM_NONE : v;
     }
     const uint32_t v = l_next32[sl];
@@ -624,8 +645,8 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
       if (c.prop_k) {
         while (row_ptr < cache_n) {
           const uint32_t r = row_ptr + lane;
-          const uint32_t sl = r < cache_n ? red.cache_slot[r] : PM_NONE;
-          const bool al = sl != PM_NONE && bit_at(l_alive, sl);
+          const uint32_t sl = r < cache_n ? C_SLOT[r] : PM_NONE;
+          const bool al = sl != PM_NONE && alive_at(sl);
           const uint64_t m = __ballot(al);
           if (m) {
             const int l = __builtin_ctzll(m);
@@ -641,7 +662,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
           bool more = false;
           for (uint32_t j0 = c.prop_limit >> 6; j0 < lw && !more; j0 += 64u) {
             const uint32_t j = j0 + lane;
-            uint64_t ll = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
+            uint64_t ll = j < lw ? (A[j] & LOC[j]) : 0ull;
             if (j == (c.prop_limit >> 6)) ll &= ~((1ull << (c.prop_limit & 63u)) - 1ull);
             more = __ballot(ll != 0ull) != 0ull;
           }
@@ -650,7 +671,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
       } else {
         for (uint32_t j0 = 0; j0 < lw; j0 += 64u) {
           const uint32_t j = j0 + lane;
-          const uint64_t ll = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
+          const uint64_t ll = j < lw ? (A[j] & LOC[j]) : 0ull;
           const uint64_t nz = __ballot(ll != 0ull);
           if (nz) {
             const int src = __builtin_ctzll(nz);
@@ -672,7 +693,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
       uint32_t cnt = 0;
       const uint32_t need = want + 1u;
       for (uint32_t j = 0; j < lw && cnt < need; ++j) {
-        uint64_t w = l_alive[j];
+        uint64_t w = A[j];
         if (!w) continue;
         // take the lowest (need - cnt) set bits of w
         const uint32_t pc = __popcll(w);
@@ -684,7 +705,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         }
         const bool mine = (take >> lane) & 1ull;
         if (mine) members[c.mem_off + cnt + __popcll(take & ((1ull << lane) - 1ull))] = wid_of(j * 64u + lane);
-        if (lane == 0) l_alive[j] = w & ~take;
+        if (lane == 0) A[j] = w & ~take;
         cnt += __popcll(take);
       }
       if (lane == 0) {
@@ -708,13 +729,13 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 
     // ---- same-site shortcut: candidates with the seed's exact coordinates are at distance 0 — ahead of
     // everybody else, in input (slot) order.  If `want` of them are still alive they ARE the group.
-    const uint32_t first_same = want > 0 ? red.cache_next[row_ptr] : PM_NONE;  // staged with the row
+    const uint32_t first_same = want > 0 ? C_NEXT[row_ptr] : PM_NONE;  // staged with the row
     if (first_same != PM_NONE) {
       uint32_t cnt = 0;
       uint32_t t = first_same;
       uint32_t mine_slot = PM_NONE;
       while (t != PM_NONE && cnt < want) {
-        if (bit_at(l_alive, t)) {
+        if (alive_at(t)) {
           if (lane == cnt) mine_slot = t;
           ++cnt;
         }
@@ -722,11 +743,11 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
       }
       if (cnt == want && want <= 64u) {
         if (lane < want) {
-          atomicAnd((unsigned long long*)&l_alive[mine_slot >> 6], ~(1ull << (mine_slot & 63u)));
+          kill(mine_slot);
           members[c.mem_off + 1u + lane] = wid_of(mine_slot);
         }
         if (lane == 0) {
-          atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
+          kill(seed);
           members[c.mem_off] = wid_of(seed);
           g_cfg[c.n_groups] = c.cfg;
           g_n[c.n_groups] = want + 1u;
@@ -745,15 +766,15 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 
     FP_MARK(1);
     // ---- the seed's neighbour list (staged in LDS, row_ptr points at it): one packed key per lane, ascending
-    const uint32_t nk_word = red.cache_meta[row_ptr];
+    const uint32_t nk_word = C_META[row_ptr];
     const uint32_t n_k = nk_word & 0xFFu;
     const bool complete = (nk_word >> 31) != 0u;
     const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
     const bool row_clean = ((nk_word >> 29) & 1u) != 0u;
     const bool tail_clear = ((nk_word >> 28) & 1u) != 0u;
-    const uint64_t e = lane < n_k ? l_rows[row_ptr * PM_PROP_ROW + lane] : ~0ull;
+    const uint64_t e = lane < n_k ? ROWS[row_ptr * PM_PROP_ROW + lane] : ~0ull;
     const uint32_t slot = (uint32_t)(e & SLOT_MASK);
-    const bool alive = lane < n_k && bit_at(l_alive, slot);
+    const bool alive = lane < n_k && alive_at(slot);
     const uint64_t am = __ballot(alive);
     const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
     if ((uint32_t)__popcll(am) < want) {  FAST_RETURN(FAST_SLOW); }  // list exhausted by earlier groups
@@ -772,10 +793,10 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         const double a_m = __longlong_as_double((long long)kb_m);
         const double band = a_m * band_rel + 1e-300;
         if (a_m > PM_A_MAX_SAFE) FAST_RETURN(FAST_SLOW);
-        const uint32_t site_m = l_site[(uint32_t)(e_m & SLOT_MASK)];
+        const uint32_t site_m = site_of((uint32_t)(e_m & SLOT_MASK));
         const uint64_t kb = (e >> SB) << SB;
         const bool near = alive && !sel && kb != noloc_key && (__longlong_as_double((long long)kb) - a_m) <= band;
-        if (__ballot(near && l_site[slot] != site_m)) {  FAST_RETURN(FAST_SLOW); }
+        if (__ballot(near && site_of(slot) != site_m)) {  FAST_RETURN(FAST_SLOW); }
         if (!complete) {
           // candidates beyond the list are >= its last entry: either that entry clears the band, or it sits
           // at e_m's site and the proposer verified (tail_ok) that everything unlisted within the band of
@@ -785,7 +806,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, last_l);
           const uint64_t kb_l = (e_l >> SB) << SB;
           if (kb_l != noloc_key && (__longlong_as_double((long long)kb_l) - a_m) <= band) {
-            if (!(tail_ok && l_site[(uint32_t)(e_l & SLOT_MASK)] == site_m)) FAST_RETURN(FAST_SLOW);
+            if (!(tail_ok && site_of((uint32_t)(e_l & SLOT_MASK)) == site_m)) FAST_RETURN(FAST_SLOW);
           }
         }
       }
@@ -793,11 +814,11 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     FP_MARK(3);
     // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
     if (sel) {
-      atomicAnd((unsigned long long*)&l_alive[slot >> 6], ~(1ull << (slot & 63u)));
+      kill(slot);
       members[c.mem_off + 1u + rank] = wid_of(slot);
     }
     if (lane == 0) {
-      atomicAnd((unsigned long long*)&l_alive[seed >> 6], ~(1ull << (seed & 63u)));
+      kill(seed);
       members[c.mem_off] = wid_of(seed);
       g_cfg[c.n_groups] = c.cfg;
       g_n[c.n_groups] = want + 1u;
@@ -812,6 +833,304 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     c.fast_steps += 1;
     FP_MARK(4);
   }
+}
+
+// Speculative rounds (all waves).  A fast step is bound by the issue latency of one wave, so the waves
+// pipeline: at the start of a round every wave takes one of the next live staged rows (= upcoming seeds in
+// input order) and pre-computes its selection against the current bitmap; then the waves commit strictly in
+// seed order, passing a token through LDS.  Because slots only ever die, a pre-computed selection is still
+// exactly the step's result iff its seed and all its selected slots are still alive at commit time (dead
+// entries ahead of them stay dead, and fewer live neighbours can only remove certificate obligations) — that
+// re-check is one LDS gather.  A wave whose selection was invalidated stops the round (ROUND_RETRY) and the
+// next round restarts from its row.  Used while the configuration has enough live candidates that the loop
+// guards and `want` cannot change within a round; the tail goes through carve_fast_steps.
+template <bool BIG>
+__device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red, StepCtx& c_ref, const uint32_t* l_wid,
+                                              const uint32_t* l_site, const uint16_t* l_next16,
+                                              const uint32_t* l_next32, const uint64_t* l_rows, uint64_t* l_alive,
+                                              uint32_t steps_before) {
+  StepCtx c = c_ref;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
+  constexpr uint64_t SLOT_MASK = (1ull << SB) - 1ull;
+  constexpr uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
+  constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
+  uint32_t* __restrict__ const members = p.members;
+  uint32_t* __restrict__ const g_cfg = p.g_cfg;
+  uint32_t* __restrict__ const g_n = p.g_n;
+  uint32_t* __restrict__ const g_off = p.g_off;
+  const uint32_t dbg_every = p.debug_uncertain_every;
+  const uint32_t n_list_v = c.n_list;
+  // LDS views with an explicit address space: one conversion here instead of a generic-pointer null check and
+  // aperture add in front of every ds_read / ds_write
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  typedef __attribute__((address_space(3))) uint16_t lds_u16;
+  lds_u64* const A = (lds_u64*)l_alive;
+  const lds_u64* const ROWS = (const lds_u64*)l_rows;
+  const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
+  const lds_u32* const C_META = (const lds_u32*)red.cache_meta;
+  const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
+  const lds_u32* const WID3 = (const lds_u32*)l_wid;    // dereferenced only when !BIG
+  const lds_u32* const SITE3 = (const lds_u32*)l_site;  // idem
+  const lds_u16* const NEXT3 = (const lds_u16*)l_next16;
+  auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
+  auto kill = [A](uint32_t i) {
+    __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wid_of = [WID3](uint32_t sl) -> uint32_t { return BIG ? sl : WID3[sl]; };
+  auto site_of = [SITE3, l_site](uint32_t sl) -> uint32_t { return BIG ? l_site[sl] : SITE3[sl]; };
+  auto next_of = [NEXT3, l_next32, n_list_v](uint32_t sl) -> uint32_t {
+    if (!BIG) {
+      const uint32_t v = NEXT3[sl];
+      return v == 0xFFFFu ? PM_NONE : v;
+    }
+    const uint32_t v = l_next32[sl];
+    return v < n_list_v ? v : PM_NONE;
+  };
+  const uint32_t want = c.max_s - 1u;
+  const uint32_t group_n = c.max_s;
+  const uint32_t margin = (CARVE_WAVES + 2u) * c.max_s + c.min_s;
+  const uint32_t cache_n = red.cache_n;
+  const uint32_t cfg = c.cfg;
+  // Every group committed here has exactly max_s members, so all running counters are functions of the
+  // number of commits, and the commit-order token carries it:
+  //   token = commits << 32 | turn index << 1 | stopped
+  // (turn index = rounds' participating waves counted from the start of this call, never reset)
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+  lds_u64* const token = (lds_u64*)&red.token;
+  const uint32_t base_groups = c.n_groups, base_mem = c.mem_off, base_cand = c.n_cand, base_steps = c.steps;
+  // room left in the output arrays, in commits
+  const uint32_t room_g = p.cap_groups > base_groups ? p.cap_groups - base_groups : 0u;
+  const uint32_t room_m = p.cap_members > base_mem ? (p.cap_members - base_mem) / group_n : 0u;
+  const uint32_t max_commits = room_g < room_m ? room_g : room_m;
+  if (tid == 0) {
+    red.token = 0ull;
+    red.stop = ROUND_OK;
+  }
+  lds_barrier();
+  int action = FAST_SEQ;
+  uint32_t next_row = 0, turn_base = 0;
+#ifdef PM_CARVE_PROF
+  const uint64_t rt0 = __builtin_amdgcn_s_memtime();
+  uint64_t t_spec = 0, t_wait = 0, t_commit = 0, t_sync = 0;
+#endif
+  for (;;) {
+#ifdef PM_CARVE_PROF
+    uint64_t ta = __builtin_amdgcn_s_memtime();
+    if (tid == 0) p.status->prof[1] += 1;
+#endif
+    const uint32_t row_ptr = next_row;
+    const uint32_t commits_before = (uint32_t)(red.token >> 32);
+    if (base_cand - commits_before * group_n < margin) {
+      action = FAST_SEQ;
+      break;
+    }
+    // ---- the live staged rows of this 64-row window, in order; wave w takes the w-th
+    const uint32_t rr = row_ptr + lane;
+    const uint32_t sl_l = rr < cache_n ? C_SLOT[rr] : PM_NONE;
+    const bool al_l = sl_l != PM_NONE && alive_at(sl_l);
+    const uint64_t m = __ballot(al_l);
+    if (m == 0ull) {
+      if (row_ptr + 64u >= cache_n) {
+        action = cache_n == PM_CARVE_CACHE_ROWS ? FAST_REFILL : FAST_SEQ;  // SEQ: no located rows left here
+        break;
+      }
+      next_row = row_ptr + 64u;
+      continue;
+    }
+    const uint32_t n_live = __popcll(m);
+    const uint32_t n_round = n_live < CARVE_WAVES ? n_live : CARVE_WAVES;
+    uint64_t mm = m;
+    for (uint32_t k = 0; k < wave && mm; ++k) mm &= mm - 1ull;
+    const bool have = wave < n_round;
+    const uint32_t my_l = have ? (uint32_t)__builtin_ctzll(mm) : 0u;
+    uint64_t ml = m;
+    for (uint32_t k = 0; k + 1u < n_round; ++k) ml &= ml - 1ull;
+    const uint32_t last_l = (uint32_t)__builtin_ctzll(ml);
+
+    // ---- speculative selection for my row (against the bitmap as of now)
+    uint32_t res = ROUND_OK;     // ROUND_SLOW: needs the exact sweep
+    uint32_t my_slot = PM_NONE;  // the slot this lane contributes to the group (lane < want)
+    uint32_t my_wid = 0, seed = PM_NONE, seed_wid = 0;
+    const uint32_t my_row = row_ptr + my_l;
+    if (have) {
+      seed = (uint32_t)__builtin_amdgcn_readlane((int)sl_l, (int)my_l);
+      seed_wid = wid_of(seed);
+      bool done = false;
+      const uint32_t first_same = want > 0 ? C_NEXT[my_row] : PM_NONE;
+      if (first_same != PM_NONE) {  // same-site shortcut (see carve_fast_steps)
+        uint32_t cnt = 0, t = first_same, ms = PM_NONE;
+        while (t != PM_NONE && cnt < want) {
+          if (alive_at(t)) {
+            if (lane == cnt) ms = t;
+            ++cnt;
+          }
+          t = next_of(t);
+        }
+        if (cnt == want) {
+          my_slot = ms;
+          done = true;
+        }
+      }
+      if (!done) {
+        const uint32_t nk_word = C_META[my_row];
+        const uint32_t n_k = nk_word & 0xFFu;
+        const bool complete = (nk_word >> 31) != 0u;
+        const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
+        const bool row_clean = ((nk_word >> 29) & 1u) != 0u;
+        const bool tail_clear = ((nk_word >> 28) & 1u) != 0u;
+        const uint64_t e = lane < n_k ? ROWS[my_row * PM_PROP_ROW + lane] : ~0ull;
+        const uint32_t slot = (uint32_t)(e & SLOT_MASK);
+        const bool alive = lane < n_k && alive_at(slot);
+        const uint64_t am = __ballot(alive);
+        const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
+        if ((uint32_t)__popcll(am) < want) {
+          res = ROUND_SLOW;
+        } else {
+          const bool sel = alive && rank < want;
+          if (want > 0 && !(row_clean && (complete || tail_clear))) {
+            const uint64_t lm = __ballot(sel && rank == want - 1u);
+            const int lane_m = __builtin_ctzll(lm);
+            const uint64_t e_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), lane_m) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, lane_m);
+            const uint64_t kb_m = (e_m >> SB) << SB;
+            if (kb_m != noloc_key) {
+              const double a_m = __longlong_as_double((long long)kb_m);
+              const double band = a_m * band_rel + 1e-300;
+              if (a_m > PM_A_MAX_SAFE) res = ROUND_SLOW;
+              const uint32_t site_m = site_of((uint32_t)(e_m & SLOT_MASK));
+              const uint64_t kb = (e >> SB) << SB;
+              const bool near = alive && !sel && kb != noloc_key && (__longlong_as_double((long long)kb) - a_m) <= band;
+              if (__ballot(near && site_of(slot) != site_m)) res = ROUND_SLOW;
+              if (!complete) {
+                const int last_e = (int)n_k - 1;
+                const uint64_t e_l = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), last_e) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, last_e);
+                const uint64_t kb_l = (e_l >> SB) << SB;
+                if (kb_l != noloc_key && (__longlong_as_double((long long)kb_l) - a_m) <= band)
+                  if (!(tail_ok && site_of((uint32_t)(e_l & SLOT_MASK)) == site_m)) res = ROUND_SLOW;
+              }
+            }
+          }
+          // compact the selected slots into lanes 0..want-1 (lane = rank) so the commit is uniform
+          const uint64_t selm = __ballot(sel);
+          uint64_t walk = selm;
+          for (uint32_t k = 0; k < lane && k < want && walk; ++k) walk &= walk - 1ull;  // <= want-1 iterations
+          const int src = (lane < want && walk) ? __builtin_ctzll(walk) : 0;
+          const uint32_t got = __shfl(slot, src, 64);
+          my_slot = lane < want ? got : PM_NONE;
+        }
+      }
+      if (lane < want && my_slot != PM_NONE) my_wid = wid_of(my_slot);
+    }
+
+    // ---- commit in seed order: wait for the token, re-validate, commit, pass the token on
+#ifdef PM_CARVE_PROF
+    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_spec += tb - ta; ta = tb; }
+#endif
+    if (have) {
+      const uint32_t my_turn = turn_base + wave;
+      unsigned long long tok;
+      // Relaxed on purpose: token, bitmap and directory all live in LDS, and one wave's LDS operations are
+      // performed in issue order, so the commit's bitmap updates are visible before the token that follows
+      // them.  A release/acquire pair would also drain the fire-and-forget HBM stores of every commit.
+      while (((uint32_t)((tok = __hip_atomic_load(token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 1) &
+              0x7FFFFFFFu) != my_turn)
+        __builtin_amdgcn_s_sleep(1);
+#ifdef PM_CARVE_PROF
+      { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; ta = tb; }
+#endif
+      uint32_t commits = (uint32_t)(tok >> 32);
+      uint32_t stopped = (uint32_t)tok & 1u;
+      if (!stopped && alive_at(seed)) {  // a dead slot is no seed: nothing to do
+        uint32_t verdict = res;
+        if (dbg_every && ((steps_before + base_steps + commits + 1u) % dbg_every) == 0u) verdict = ROUND_SLOW;
+        if (verdict == ROUND_OK) {
+          const bool still = lane >= want || alive_at(my_slot);
+          if (__ballot(!still)) verdict = ROUND_RETRY;
+          if (commits >= max_commits) verdict = ROUND_OVERFLOW;
+        }
+        if (verdict == ROUND_OK) {
+          const uint32_t n_groups = base_groups + commits, mem_off = base_mem + commits * group_n;
+          if (lane < want) {
+            kill(my_slot);
+            members[mem_off + 1u + lane] = my_wid;
+          }
+          if (lane == 0) {
+            kill(seed);
+            members[mem_off] = seed_wid;
+            g_cfg[n_groups] = cfg;
+            g_n[n_groups] = group_n;
+            g_off[n_groups] = mem_off;
+          }
+          commits += 1u;
+        } else {
+          stopped = 1u;
+          if (lane == 0) {
+            red.stop = verdict;
+            red.retry_row = my_row;
+#ifdef PM_CARVE_PROF
+            p.status->prof[verdict == ROUND_RETRY ? 3 : 4] += 1;
+#endif
+          }
+        }
+      }
+      if (lane == 0)
+        __hip_atomic_store(token, ((unsigned long long)commits << 32) | ((unsigned long long)(my_turn + 1u) << 1) | stopped,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef PM_CARVE_PROF
+    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_commit += tb - ta; ta = tb; }
+#endif
+    lds_barrier();  // every turn of this round is done
+    turn_base += n_round;
+    const unsigned long long tok_end = red.token;
+    next_row = row_ptr + last_l + 1u;
+#ifdef PM_CARVE_PROF
+    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_sync += tb - ta; ta = tb; }
+#endif
+    if ((uint32_t)tok_end & 1u) {
+      const uint32_t stop = red.stop, retry_row = red.retry_row;
+      if (stop == ROUND_SLOW) {
+        action = FAST_SLOW;
+        break;
+      }
+      if (stop == ROUND_OVERFLOW) {
+        action = FAST_OVERFLOW;
+        break;
+      }
+      // ROUND_RETRY: an earlier commit of this round took one of that wave's slots; redo from its row
+      next_row = retry_row;
+      lds_barrier();
+      if (tid == 0) red.token = tok_end & ~1ull;
+      lds_barrier();
+    }
+  }
+  lds_barrier();
+  {
+    const uint32_t commits = (uint32_t)(red.token >> 32);
+#ifdef PM_CARVE_PROF
+    if (tid == 0) {
+      p.status->prof[0] += __builtin_amdgcn_s_memtime() - rt0;
+      p.status->prof[2] += commits;
+      p.status->prof[5] += t_spec;
+    }
+    if (tid == 64) { p.status->prof[6] += t_wait; p.status->prof[7] += t_commit; p.status->prof[8] += t_sync; }
+#endif
+    c.n_groups = base_groups + commits;
+    c.mem_off = base_mem + commits * group_n;
+    c.n_cand = base_cand - commits * group_n;
+    c.total_available -= commits * group_n;
+    c.steps += commits;
+    c.fast_steps += commits;
+    // sum over the commits of the live candidates before each: base, base - g, base - 2g, ...
+    c.cand_sum += (unsigned long long)commits * base_cand -
+                  (unsigned long long)group_n * ((unsigned long long)commits * (commits ? commits - 1u : 0u) / 2ull);
+  }
+  lds_barrier();
+  c_ref = c;
+  return action;
 }
 
 // LDS carve of one candidate list of at most PM_CARVE_SLOTS slots: worker ids, site ids, packed keys,
@@ -864,7 +1183,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         }
         lds_barrier();
 #ifdef PM_CARVE_PROF
-        if (tid == 0) p.status->prof[6] += 1;
+        (void)0;
 #endif
         const uint32_t rows = red.cache_n;
         {  // all loads of a wave are issued before the first LDS store (rows: one u64 per lane; directory
@@ -893,6 +1212,15 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         }
         lds_barrier();
         cache_valid = true;
+      }
+      if (c.prop_k && c.proximity && p.rounds_enabled) {
+        const int ract = carve_fast_rounds<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive, steps_before);
+        if (ract == FAST_OVERFLOW) return STEP_OVERFLOW;
+        if (ract == FAST_REFILL) {
+          cache_valid = false;
+          continue;
+        }
+        // FAST_SEQ / FAST_SLOW: the sequential fast path below decides (it re-derives the seed)
       }
       // wave 0 commits as many steps as the proposals allow; everyone else waits at the barrier
       if (wave == 0) {
@@ -1666,7 +1994,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       prepared = true;
       PROF_MARK(9);
 #ifdef PM_CARVE_PROF
-      if (tid == 0) { p.status->prof[8] += 1; p.status->prof[7] += c.n_list; }
+      (void)0;
 #endif
       if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
     } else {

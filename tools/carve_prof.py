@@ -34,6 +34,7 @@ print(f"carve kernels {s['ms_carve_kernel']:.3f} ms, {s['carve_steps']} steps ({
 for i, nm in enumerate(names):
     print(f"  {nm:12s} {out[i]:12d} ticks  {100.0 * out[i] / max(tot, 1):5.1f}%  {out[i] / max(s['carve_steps'], 1):8.1f} ticks/step")
 print(f"  fast path (register-accumulated ticks): seed={out[0]} chain/same-site={out[1]} row+filter={out[2]} certificate={out[3]} commit={out[4]} loop-top={out[5]}")
-print(f"  counts: prepares={out[8]} (sum n_list={out[7]}) refills={out[6]} launches={s['carve_launches']}")
+print(f"  rounds: ticks={out[0]} rounds={out[1]} commits={out[2]} retries={out[3]} slow-stops={out[4]}; wave0 spec ticks={out[5]}; wave1 wait={out[6]} commit={out[7]} sync={out[8]}")
+print(f"  counts(unused): prepares={out[8]} (sum n_list={out[7]}) refills={out[6]} launches={s['carve_launches']}")
 print(f"  launch anatomy (ticks): init/status={out[15]} prepare(compaction)={out[9]} load-list={out[10]} run(all steps)={out[13]} flush={out[12]} group_of+exit={out[14]}")
 print(f"  total ticks {tot}; ticks per ms = {tot / s['ms_carve_kernel']:.0f}")
