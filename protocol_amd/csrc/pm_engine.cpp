@@ -1028,6 +1028,7 @@ static int32_t upload_worker_columns(pm_engine* e) {
     std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> sites;
     sites.reserve(W * 2);
     e->h_site.resize(W);
+    std::vector<uint32_t> pop;
     for (size_t w = 0; w < W; ++w) {
       uint64_t a, b;
       std::memcpy(&a, &e->h_lat[w], 8);
@@ -1036,7 +1037,12 @@ static int32_t upload_worker_columns(pm_engine* e) {
       if (e->h_lon[w] == 0.0) b = 0;
       auto it = sites.emplace(std::make_pair(a, b), uint32_t(sites.size())).first;
       e->h_site[w] = it->second;
+      if (it->second >= pop.size()) pop.push_back(0);
+      pop[it->second] += (e->h_flags[w] & PM_W_HAS_LOC) ? 1u : 0u;
     }
+    // bit 31 marks a site shared by two or more located workers (only those can have same-site neighbours)
+    for (size_t w = 0; w < W; ++w)
+      if (pop[e->h_site[w]] >= 2) e->h_site[w] |= 0x80000000u;
   }
   if ((rc = upload(e->d_site, e->h_site.data(), W, e->stream))) return rc;
   HIPCHK(e->d_coslat.ensure(W ? W : 1));

@@ -1640,10 +1640,21 @@ __device__ __noinline__ uint32_t carve_compact_count(const CarveArgs& p, BlockRe
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
   const uint32_t j0 = wave * wpw, j1 = min(n_words, j0 + wpw);
   uint32_t cnt = 0;
-  for (uint32_t j = j0; j < j1; ++j) {
-    const uint32_t i = j * 64u + lane;
-    const bool c = i < n && bit_at(p.alive_g, i) && (p.mode == CARVE_MODE_MERGE || (p.c_compat[i] & cbit) != 0ull);
-    cnt += __popcll(__ballot(c));
+  for (uint32_t jb = j0; jb < j1; jb += 4u) {  // four words per batch: their loads are in flight together
+    uint64_t aw[4], cm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = jb + (uint32_t)u;
+      const uint32_t i = j * 64u + lane;
+      aw[u] = j < j1 ? p.alive_g[j] : 0ull;
+      cm[u] = (j < j1 && i < n && p.mode != CARVE_MODE_MERGE) ? p.c_compat[i] : ~0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = (jb + (uint32_t)u) * 64u + lane;
+      const bool c = i < n && ((aw[u] >> lane) & 1ull) && (cm[u] & cbit) != 0ull;
+      cnt += __popcll(__ballot(c));
+    }
   }
   __syncthreads();  // previous users of red.a are done
   if (lane == 0) red.a[wave] = cnt;
@@ -1662,20 +1673,39 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
   uint64_t* loc = p.bits_scratch + p.bits_stride;
   uint32_t off = 0;
   for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
-  for (uint32_t j = j0; j < j1; ++j) {
-    const uint32_t i = j * 64u + lane;
-    const bool c = i < n && bit_at(p.alive_g, i) && (p.mode == CARVE_MODE_MERGE || (p.c_compat[i] & cbit) != 0ull);
-    const uint64_t bal = __ballot(c);
-    if (c) {
-      const uint32_t s = off + __popcll(bal & ((1ull << lane) - 1ull));
-      p.slot_pos[s] = i;
-      p.slot_wid[s] = p.order[i];
-      p.cc_lat[s] = p.c_lat[i];
-      p.cc_lon[s] = p.c_lon[i];
-      p.cc_cos[s] = p.c_cos[i];
-      p.cc_site[s] = p.c_site[i];
+  for (uint32_t jb = j0; jb < j1; jb += 4u) {
+    uint64_t aw[4], cm[4];
+    uint32_t ow[4], os[4];
+    double la[4], lo[4], co[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // every load of the batch first
+      const uint32_t j = jb + (uint32_t)u;
+      const uint32_t i = j * 64u + lane;
+      const bool in = j < j1 && i < n;
+      aw[u] = j < j1 ? p.alive_g[j] : 0ull;
+      cm[u] = (in && p.mode != CARVE_MODE_MERGE) ? p.c_compat[i] : ~0ull;
+      ow[u] = in ? p.order[i] : 0u;
+      os[u] = in ? p.c_site[i] : 0u;
+      la[u] = in ? p.c_lat[i] : 0.0;
+      lo[u] = in ? p.c_lon[i] : 0.0;
+      co[u] = in ? p.c_cos[i] : 0.0;
     }
-    off += __popcll(bal);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = (jb + (uint32_t)u) * 64u + lane;
+      const bool c = i < n && ((aw[u] >> lane) & 1ull) && (cm[u] & cbit) != 0ull;
+      const uint64_t bal = __ballot(c);
+      if (c) {
+        const uint32_t s = off + __popcll(bal & ((1ull << lane) - 1ull));
+        p.slot_pos[s] = i;
+        p.slot_wid[s] = ow[u];
+        p.cc_lat[s] = la[u];
+        p.cc_lon[s] = lo[u];
+        p.cc_cos[s] = co[u];
+        p.cc_site[s] = os[u];
+      }
+      off += __popcll(bal);
+    }
   }
   __syncthreads();
   const uint32_t lw = (n_list + 63u) >> 6;
@@ -1718,23 +1748,54 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   const uint64_t* alive = p.bits_scratch;
   const uint64_t* loc = p.bits_scratch + p.bits_stride;
   const uint32_t lw = (n_list + 63u) >> 6;
-  for (uint32_t s = wave_g; s < limit; s += n_waves) {
+  for (uint32_t s = wave_g; s < n_list; s += n_waves) {
     if (!(bit_at(alive, s) && bit_at(loc, s))) continue;  // wave-uniform
-    const double slat = p.cc_lat[s], slon = p.cc_lon[s], scos = p.cc_cos[s];
     const uint32_t ssite = p.cc_site[s];
+    // next located slot at the same site (the validator's same-site shortcut walks these links); only sites
+    // shared by several workers (bit 31 of the interned id) can have one
+    uint32_t same = PM_NONE;
+    if (ssite & 0x80000000u) {
+      for (uint32_t j = s >> 6; j < lw; ++j) {
+        const uint32_t t = j * 64u + lane;
+        const bool hit = t > s && t < n_list && ((alive[j] >> lane) & (loc[j] >> lane) & 1ull) && p.cc_site[t] == ssite;
+        const uint64_t hm = __ballot(hit);
+        if (hm) {
+          same = j * 64u + (uint32_t)__builtin_ctzll(hm);
+          break;
+        }
+      }
+    }
+    if (lane == 0) p.same_next[s] = same;
+    if (s >= limit) continue;  // beyond this round's proposal batch
+    const double slat = p.cc_lat[s], slon = p.cc_lon[s], scos = p.cc_cos[s];
     uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull, r3 = ~0ull;
-    uint32_t n_mine = 0, same = PM_NONE;
-    for (uint32_t j = 0; j < lw; ++j) {
-      const uint32_t t = j * 64u + lane;
-      const uint64_t aw = alive[j], lwd = loc[j];
-      if (!((aw >> lane) & 1ull) || t == s) continue;
-      if (t > s && ((lwd >> lane) & 1ull) && same == PM_NONE && p.cc_site[t] == ssite) same = t;
-      const uint64_t k = ((lwd >> lane) & 1ull)
-                             ? pack_key((uint64_t)__double_as_longlong(
-                                            hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB)
-                             : pack_key(PM_KEY_NOLOC, t, SB);
-      top4_insert(k, r0, r1, r2, r3);
-      ++n_mine;
+    uint32_t n_mine = 0;
+    // The sweep is a chain of L2-latency loads: issue the loads of four 64-slot strides together.
+    for (uint32_t j0 = 0; j0 < lw; j0 += 4u) {
+      uint64_t aw[4], lwd[4];
+      double tla[4], tlo[4], tco[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = j0 + (uint32_t)u;
+        const bool in = j < lw;
+        aw[u] = in ? alive[j] : 0ull;
+        lwd[u] = in ? loc[j] : 0ull;
+        const uint32_t t = j * 64u + lane;
+        const bool need = (aw[u] >> lane) & (lwd[u] >> lane) & 1ull;
+        tla[u] = need ? p.cc_lat[t] : 0.0;
+        tlo[u] = need ? p.cc_lon[t] : 0.0;
+        tco[u] = need ? p.cc_cos[t] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t t = (j0 + (uint32_t)u) * 64u + lane;
+        if (!((aw[u] >> lane) & 1ull) || t == s) continue;
+        const bool located = (lwd[u] >> lane) & 1ull;
+        const uint64_t k = located ? pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, tla[u], tlo[u], tco[u])), t, SB)
+                                   : pack_key(PM_KEY_NOLOC, t, SB);
+        top4_insert(k, r0, r1, r2, r3);
+        ++n_mine;
+      }
     }
     uint32_t popped = 0, n_k = 0;
     uint64_t mine = ~0ull, beyond = ~0ull;  // beyond = the (K+1)-th key, if any
@@ -1763,7 +1824,6 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         }
       }
     }
-    same = wave_min(same);
     const uint64_t noloc_kb = (PM_KEY_NOLOC >> SB) << SB;
     // row certificates the validator can rely on instead of re-deriving them at every step:
     //  clean      — no two neighbouring entries within the band of each other sit at different sites (entries in
@@ -1818,7 +1878,6 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     p.prop[(size_t)s * PM_PROP_ROW + lane] = mine;
     if (lane == 0) {
       p.prop_n[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
-      p.same_next[s] = same;
     }
   }
 }
@@ -1826,7 +1885,13 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
 // One proposal per located slot, at most PM_PROP_MAX_SEEDS per round: returns the slot after the word in
 // which the PM_PROP_MAX_SEEDS-th located slot falls (a later round covers the rest), or n_list.
 __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& red, uint32_t n_list) {
-  if (n_list <= PM_PROP_MAX_SEEDS) return n_list;
+  // The configuration is re-prepared (and re-proposed) once half of its list is dead; by then the seed
+  // pointer has advanced through roughly the first eighth of the slots (each group removes max_s slots
+  // spread over the whole list), so later slots never consume this round's proposals: cap the batch.
+  uint32_t cap = n_list / 5u;
+  if (cap < 512u) cap = 512u;
+  if (cap > PM_PROP_MAX_SEEDS) cap = PM_PROP_MAX_SEEDS;
+  if (n_list <= cap) return n_list;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (wave == 0) {
     const uint64_t* g_al = p.bits_scratch;
@@ -1842,7 +1907,7 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
         const uint32_t up = __shfl_up(incl, o, 64);
         if ((int)lane >= o) incl += up;
       }
-      const uint64_t over = __ballot(acc + incl >= PM_PROP_MAX_SEEDS);
+      const uint64_t over = __ballot(acc + incl >= cap);
       if (over) {
         limit = (j0 + (uint32_t)__builtin_ctzll(over) + 1u) * 64u;
         break;
