@@ -81,7 +81,7 @@ struct CarveStatus {
   uint32_t total_available;
   uint32_t fast_steps;   // steps committed from proposals
   uint32_t slow_steps;   // steps that needed the full key sweep
-  unsigned long long prof[16];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
+  unsigned long long prof[24];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
 struct CarveArgs {

@@ -438,6 +438,16 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 
 #define CARVE_THREADS 512
 #define CARVE_WAVES 8
+// a value that is the same in every lane, moved to an SGPR
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// The carve kernels take their argument block through a pointer (see carve_kernel), so the compiler cannot
+// see that the pointers inside it are global memory and would emit FLAT accesses — which count against the
+// LDS counter as well and serialise every LDS wait behind the outstanding HBM traffic.  G() restores the
+// address space at the point of use.
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* G(T* q) {
+  return (__attribute__((address_space(1))) T*)q;
+}
 
 // ---- wave-wide unsigned min via DPP (no LDS traffic): row_shr 1,2,4,8 -> row_bcast15 -> row_bcast31,
 // result broadcast from lane 63 with readlane.
@@ -472,9 +482,8 @@ struct BlockRed {
   // mailbox: wave 0 -> workgroup after a run of fast (proposal) steps
   uint32_t f_action, f_n_cand, f_total_available, f_n_groups, f_mem_off, f_steps, f_fast, f_pad;
   unsigned long long f_cand_sum;
-  // speculative rounds: commit order token, stop code, first staged row of the next round
-  unsigned long long token;
-  uint32_t stop, retry_row;
+  unsigned long long _spare0;
+  uint32_t _spare1, _spare2;
   // proposal rows staged in LDS (they alias the slow path's key array): slot and prop_n word per row
   uint32_t cache_n, cache_pad;
   uint32_t cache_slot[PM_CARVE_CACHE_ROWS];
@@ -509,7 +518,8 @@ __device__ __forceinline__ double hav_a(double lat1, double lon1, double cos1, d
   return s1 * s1 + cos1 * cos2 * (s2 * s2);
 }
 
-__device__ __forceinline__ bool bit_at(const uint64_t* b, uint32_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }
+template <typename P>
+__device__ __forceinline__ bool bit_at(P b, uint32_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }
 
 // Ordering key of a candidate: the f64 bits of its Haversine term `a` with the low SLOT_BITS replaced by
 // the slot number (slot order == input order), so one u64 compare is the whole (distance, input order)
@@ -525,7 +535,7 @@ enum { STEP_CONTINUE = 0, STEP_BREAK = 1, STEP_UNCERTAIN = 2, STEP_OVERFLOW = 3 
 #define PROF_MARK(slot)                                                     \
   do {                                                                      \
     const uint64_t t_ = __builtin_amdgcn_s_memtime();                       \
-    if (threadIdx.x == 0 && (slot) >= 9) p.status->prof[slot] += t_ - prof_t0;  \
+    if (threadIdx.x == 0 && (slot) >= 9) G(p.status)->prof[slot] += t_ - prof_t0;  \
     prof_t0 = t_;                                                           \
   } while (0)
 #else
@@ -566,7 +576,7 @@ enum { ROUND_OK = 0, ROUND_SLOW = 1, ROUND_RETRY = 2, ROUND_OVERFLOW = 3 };
 // as long as the proposal still holds enough live entries and the boundary can be certified; otherwise
 // the step is handed to the exact full sweep (FAST_SLOW).
 #ifdef PM_CARVE_PROF
-#define PROF_COUNT(slot) do { if (lane == 0) p.status->prof[slot] += 1; } while (0)
+#define PROF_COUNT(slot) do { if (lane == 0) G(p.status)->prof[slot] += 1; } while (0)
 #else
 #define PROF_COUNT(slot)
 #endif
@@ -590,10 +600,10 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
   const uint32_t lane = threadIdx.x & 63u;
   // argument-block fields used per step, loaded once: the stores below go through flat pointers the compiler
   // must assume may alias the block itself
-  uint32_t* __restrict__ const members = p.members;
-  uint32_t* __restrict__ const g_cfg = p.g_cfg;
-  uint32_t* __restrict__ const g_n = p.g_n;
-  uint32_t* __restrict__ const g_off = p.g_off;
+  const auto members = G(p.members);
+  const auto g_cfg = G(p.g_cfg);
+  const auto g_n = G(p.g_n);
+  const auto g_off = G(p.g_off);
   const uint32_t cap_groups = p.cap_groups, cap_members = p.cap_members;
   const uint32_t dbg_every = p.debug_uncertain_every;
   constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
@@ -836,31 +846,38 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 }
 
 // Speculative rounds (all waves).  A fast step is bound by the issue latency of one wave, so the waves
-// pipeline: at the start of a round every wave takes one of the next live staged rows (= upcoming seeds in
-// input order) and pre-computes its selection against the current bitmap; then the waves commit strictly in
-// seed order, passing a token through LDS.  Because slots only ever die, a pre-computed selection is still
-// exactly the step's result iff its seed and all its selected slots are still alive at commit time (dead
-// entries ahead of them stay dead, and fewer live neighbours can only remove certificate obligations) — that
-// re-check is one LDS gather.  A wave whose selection was invalidated stops the round (ROUND_RETRY) and the
-// next round restarts from its row.  Used while the configuration has enough live candidates that the loop
-// guards and `want` cannot change within a round; the tail goes through carve_fast_steps.
+// work side by side: at the start of a round every wave takes one of the next live staged rows (= upcoming
+// seeds in input order) and pre-computes its selection against the current bitmap.  Because slots only ever
+// die, a pre-computed selection is still exactly the step's result iff its seed and all its selected slots
+// are still alive when its turn comes (dead entries ahead of them stay dead, and fewer live neighbours can
+// only remove certificate obligations).  The turns are not taken one after the other: every wave posts the
+// slots it would take, compares them against the claims of the waves ahead of it (one LDS read + a readlane
+// loop), posts an 8-bit conflict word, and then all waves replay the round in seed order from those words
+// alone — a handful of scalar operations — and the winners commit concurrently.  The first wave that cannot
+// commit (a slot taken: redo from its row; exact sweep needed) ends the round.  Used while the configuration
+// has enough live candidates that the loop guards and `want` cannot change within a round; the tail goes
+// through carve_fast_steps.
 template <bool BIG>
 __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red, StepCtx& c_ref, const uint32_t* l_wid,
                                               const uint32_t* l_site, const uint16_t* l_next16,
                                               const uint32_t* l_next32, const uint64_t* l_rows, uint64_t* l_alive,
-                                              uint32_t steps_before) {
+                                              uint32_t* l_claim, uint32_t steps_before) {
   StepCtx c = c_ref;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // Everything below that is the same in all lanes is pinned into SGPRs (UNI): values that arrive through
+  // memory or as arguments of a non-inlined function are VGPRs to the compiler, and every branch on them
+  // becomes an exec-mask sequence, every add a VALU instruction — this loop is bound by instruction issue.
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = UNI(tid >> 6);
+  steps_before = UNI(steps_before);
   constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   constexpr uint64_t SLOT_MASK = (1ull << SB) - 1ull;
   constexpr uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
   constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
-  uint32_t* __restrict__ const members = p.members;
-  uint32_t* __restrict__ const g_cfg = p.g_cfg;
-  uint32_t* __restrict__ const g_n = p.g_n;
-  uint32_t* __restrict__ const g_off = p.g_off;
-  const uint32_t dbg_every = p.debug_uncertain_every;
-  const uint32_t n_list_v = c.n_list;
+  const auto members = G(p.members);
+  const auto g_cfg = G(p.g_cfg);
+  const auto g_n = G(p.g_n);
+  const auto g_off = G(p.g_off);
+  const uint32_t dbg_every = UNI(p.debug_uncertain_every);
+  const uint32_t n_list_v = UNI(c.n_list);
   // LDS views with an explicit address space: one conversion here instead of a generic-pointer null check and
   // aperture add in front of every ds_read / ds_write
   typedef __attribute__((address_space(3))) unsigned long long lds_u64;
@@ -874,6 +891,8 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   const lds_u32* const WID3 = (const lds_u32*)l_wid;    // dereferenced only when !BIG
   const lds_u32* const SITE3 = (const lds_u32*)l_site;  // idem
   const lds_u16* const NEXT3 = (const lds_u16*)l_next16;
+  lds_u32* const CLAIM = (lds_u32*)l_claim;             // [CARVE_WAVES * 64] claimed slots of the round
+  lds_u32* const CONF = CLAIM + CARVE_WAVES * 64u;      // [CARVE_WAVES] conflict words
   auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
   auto kill = [A](uint32_t i) {
     __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -888,41 +907,33 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     const uint32_t v = l_next32[sl];
     return v < n_list_v ? v : PM_NONE;
   };
-  const uint32_t want = c.max_s - 1u;
-  const uint32_t group_n = c.max_s;
-  const uint32_t margin = (CARVE_WAVES + 2u) * c.max_s + c.min_s;
-  const uint32_t cache_n = red.cache_n;
-  const uint32_t cfg = c.cfg;
+  const uint32_t group_n = UNI(c.max_s);
+  const uint32_t want = group_n - 1u;
+  const uint32_t margin = (CARVE_WAVES + 2u) * group_n + UNI(c.min_s);
+  const uint32_t cache_n = UNI(red.cache_n);
+  const uint32_t cfg = UNI(c.cfg);
   // Every group committed here has exactly max_s members, so all running counters are functions of the
-  // number of commits, and the commit-order token carries it:
-  //   token = commits << 32 | turn index << 1 | stopped
-  // (turn index = rounds' participating waves counted from the start of this call, never reset)
-  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-  lds_u64* const token = (lds_u64*)&red.token;
-  const uint32_t base_groups = c.n_groups, base_mem = c.mem_off, base_cand = c.n_cand, base_steps = c.steps;
+  // number of commits, which every wave tracks identically (commits_done).
+  const uint32_t base_groups = UNI(c.n_groups), base_mem = UNI(c.mem_off), base_cand = UNI(c.n_cand),
+                 base_steps = UNI(c.steps);
   // room left in the output arrays, in commits
-  const uint32_t room_g = p.cap_groups > base_groups ? p.cap_groups - base_groups : 0u;
-  const uint32_t room_m = p.cap_members > base_mem ? (p.cap_members - base_mem) / group_n : 0u;
-  const uint32_t max_commits = room_g < room_m ? room_g : room_m;
-  if (tid == 0) {
-    red.token = 0ull;
-    red.stop = ROUND_OK;
-  }
-  lds_barrier();
+  const uint32_t cap_g = UNI(p.cap_groups), cap_m = UNI(p.cap_members);
+  const uint32_t room_g = cap_g > base_groups ? cap_g - base_groups : 0u;
+  const uint32_t room_m = cap_m > base_mem ? (cap_m - base_mem) / group_n : 0u;
+  const uint32_t max_commits = UNI(room_g < room_m ? room_g : room_m);
   int action = FAST_SEQ;
-  uint32_t next_row = 0, turn_base = 0;
+  uint32_t next_row = 0, commits_done = 0;
 #ifdef PM_CARVE_PROF
   const uint64_t rt0 = __builtin_amdgcn_s_memtime();
-  uint64_t t_spec = 0, t_wait = 0, t_commit = 0, t_sync = 0;
+  uint64_t t_spec = 0, t_wait = 0, t_commit = 0, t_sync = 0, t_chk = 0, t_b2 = 0;
 #endif
   for (;;) {
 #ifdef PM_CARVE_PROF
     uint64_t ta = __builtin_amdgcn_s_memtime();
-    if (tid == 0) p.status->prof[1] += 1;
+    if (tid == 0) G(p.status)->prof[1] += 1;
 #endif
     const uint32_t row_ptr = next_row;
-    const uint32_t commits_before = (uint32_t)(red.token >> 32);
-    if (base_cand - commits_before * group_n < margin) {
+    if (base_cand - commits_done * group_n < margin) {
       action = FAST_SEQ;
       break;
     }
@@ -941,50 +952,55 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     }
     const uint32_t n_live = __popcll(m);
     const uint32_t n_round = n_live < CARVE_WAVES ? n_live : CARVE_WAVES;
-    uint64_t mm = m;
-    for (uint32_t k = 0; k < wave && mm; ++k) mm &= mm - 1ull;
+    // the lane holding the k-th live row, without a loop: rank of each live lane, one ballot per question
+    const uint32_t rank_l = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     const bool have = wave < n_round;
-    const uint32_t my_l = have ? (uint32_t)__builtin_ctzll(mm) : 0u;
-    uint64_t ml = m;
-    for (uint32_t k = 0; k + 1u < n_round; ++k) ml &= ml - 1ull;
-    const uint32_t last_l = (uint32_t)__builtin_ctzll(ml);
+    const uint64_t mine_b = __ballot(al_l && rank_l == wave);
+    const uint32_t my_l = have ? (uint32_t)__builtin_ctzll(mine_b) : 0u;
+    const uint32_t last_l = (uint32_t)__builtin_ctzll(__ballot(al_l && rank_l == n_round - 1u));
 
-    // ---- speculative selection for my row (against the bitmap as of now)
-    uint32_t res = ROUND_OK;     // ROUND_SLOW: needs the exact sweep
-    uint32_t my_slot = PM_NONE;  // the slot this lane contributes to the group (lane < want)
+    // ---- speculative selection for my row (against the bitmap as of now).  The slots the step would take
+    // go straight into this wave's claim list in LDS: members in selection order, then the seed.
+    uint32_t res = ROUND_OK;  // ROUND_SLOW: needs the exact sweep
     uint32_t my_wid = 0, seed = PM_NONE, seed_wid = 0;
     const uint32_t my_row = row_ptr + my_l;
+    const uint32_t stride = want + 1u;
+    const uint32_t cbase = wave * stride;
     if (have) {
       seed = (uint32_t)__builtin_amdgcn_readlane((int)sl_l, (int)my_l);
+      // every LDS read of the row is issued up front (they return in order, one latency for all)
+      const uint64_t e = ROWS[my_row * PM_PROP_ROW + lane];
+      const uint32_t nk_raw = C_META[my_row];
+      const uint32_t fs_raw = C_NEXT[my_row];
       seed_wid = wid_of(seed);
+      const uint32_t slot = (uint32_t)(e & SLOT_MASK);
+      const uint32_t nk_word = UNI(nk_raw);
+      const uint32_t n_k = nk_word & 0xFFu;
+      const bool alive = lane < n_k && alive_at(slot);
+      const uint32_t first_same = want > 0 ? UNI(fs_raw) : PM_NONE;
       bool done = false;
-      const uint32_t first_same = want > 0 ? C_NEXT[my_row] : PM_NONE;
       if (first_same != PM_NONE) {  // same-site shortcut (see carve_fast_steps)
         uint32_t cnt = 0, t = first_same, ms = PM_NONE;
         while (t != PM_NONE && cnt < want) {
-          if (alive_at(t)) {
+          const uint32_t tn = UNI(next_of(t));  // issued together with the bitmap word
+          if (UNI((uint32_t)alive_at(t))) {
             if (lane == cnt) ms = t;
             ++cnt;
           }
-          t = next_of(t);
+          t = tn;
         }
         if (cnt == want) {
-          my_slot = ms;
+          if (lane < want) CLAIM[cbase + lane] = ms;
           done = true;
         }
       }
       if (!done) {
-        const uint32_t nk_word = C_META[my_row];
-        const uint32_t n_k = nk_word & 0xFFu;
         const bool complete = (nk_word >> 31) != 0u;
         const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
         const bool row_clean = ((nk_word >> 29) & 1u) != 0u;
         const bool tail_clear = ((nk_word >> 28) & 1u) != 0u;
-        const uint64_t e = lane < n_k ? ROWS[my_row * PM_PROP_ROW + lane] : ~0ull;
-        const uint32_t slot = (uint32_t)(e & SLOT_MASK);
-        const bool alive = lane < n_k && alive_at(slot);
         const uint64_t am = __ballot(alive);
-        const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
         if ((uint32_t)__popcll(am) < want) {
           res = ROUND_SLOW;
         } else {
@@ -1013,110 +1029,137 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
               }
             }
           }
-          // compact the selected slots into lanes 0..want-1 (lane = rank) so the commit is uniform
-          const uint64_t selm = __ballot(sel);
-          uint64_t walk = selm;
-          for (uint32_t k = 0; k < lane && k < want && walk; ++k) walk &= walk - 1ull;  // <= want-1 iterations
-          const int src = (lane < want && walk) ? __builtin_ctzll(walk) : 0;
-          const uint32_t got = __shfl(slot, src, 64);
-          my_slot = lane < want ? got : PM_NONE;
+          if (sel) CLAIM[cbase + rank] = slot;  // the scatter is the compaction: rank = position in the group
         }
       }
-      if (lane < want && my_slot != PM_NONE) my_wid = wid_of(my_slot);
+      if (res != ROUND_OK && lane < want) CLAIM[cbase + lane] = 0xFFFFFFFEu;  // no claim
+      if (lane == want) CLAIM[cbase + want] = seed;
     }
-
-    // ---- commit in seed order: wait for the token, re-validate, commit, pass the token on
+    // my claims as the other waves will see them (lane k = member k, lane want = the seed)
+    const uint32_t mine_l = (have && lane <= want) ? CLAIM[cbase + lane] : PM_NONE;
+    if (have && res == ROUND_OK && lane < want) my_wid = wid_of(mine_l);
 #ifdef PM_CARVE_PROF
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_spec += tb - ta; ta = tb; }
 #endif
-    if (have) {
-      const uint32_t my_turn = turn_base + wave;
-      unsigned long long tok;
-      // Relaxed on purpose: token, bitmap and directory all live in LDS, and one wave's LDS operations are
-      // performed in issue order, so the commit's bitmap updates are visible before the token that follows
-      // them.  A release/acquire pair would also drain the fire-and-forget HBM stores of every commit.
-      while (((uint32_t)((tok = __hip_atomic_load(token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 1) &
-              0x7FFFFFFFu) != my_turn)
-        __builtin_amdgcn_s_sleep(1);
+    lds_barrier();
 #ifdef PM_CARVE_PROF
-      { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; ta = tb; }
+    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; ta = tb; }
 #endif
-      uint32_t commits = (uint32_t)(tok >> 32);
-      uint32_t stopped = (uint32_t)tok & 1u;
-      if (!stopped && alive_at(seed)) {  // a dead slot is no seed: nothing to do
-        uint32_t verdict = res;
-        if (dbg_every && ((steps_before + base_steps + commits + 1u) % dbg_every) == 0u) verdict = ROUND_SLOW;
-        if (verdict == ROUND_OK) {
-          const bool still = lane >= want || alive_at(my_slot);
-          if (__ballot(!still)) verdict = ROUND_RETRY;
-          if (commits >= max_commits) verdict = ROUND_OVERFLOW;
+    // ---- which earlier waves of this round claim one of my slots (conf) / my seed (seed_hit)?  Slots only
+    // ever die, so my pre-computed selection is exactly the step's result iff none of its slots is taken by
+    // a group committed before it.
+    uint32_t conf = 0, seed_hit = 0;
+    if (have && wave > 0) {
+      const uint32_t n_foreign = cbase;  // the claim lists of waves 0 .. wave-1 are contiguous
+      for (uint32_t base = 0; base < n_foreign; base += 64u) {
+        const uint32_t idx = base + lane;
+        const uint32_t f = idx < n_foreign ? CLAIM[idx] : 0xFFFFFFFEu;
+        const bool hit_seed = f == seed;
+        bool hit = hit_seed;
+        // lanes beyond `want` of mine_l hold PM_NONE, which no claim equals: no bound check in the loop
+        for (uint32_t e0 = 0; e0 < want; e0 += 8u) {
+#pragma unroll
+          for (uint32_t u = 0; u < 8u; ++u)
+            hit |= f == (uint32_t)__builtin_amdgcn_readlane((int)mine_l, (int)((e0 + u) & 63u));
         }
-        if (verdict == ROUND_OK) {
-          const uint32_t n_groups = base_groups + commits, mem_off = base_mem + commits * group_n;
-          if (lane < want) {
-            kill(my_slot);
-            members[mem_off + 1u + lane] = my_wid;
-          }
-          if (lane == 0) {
-            kill(seed);
-            members[mem_off] = seed_wid;
-            g_cfg[n_groups] = cfg;
-            g_n[n_groups] = group_n;
-            g_off[n_groups] = mem_off;
-          }
-          commits += 1u;
-        } else {
-          stopped = 1u;
-          if (lane == 0) {
-            red.stop = verdict;
-            red.retry_row = my_row;
-#ifdef PM_CARVE_PROF
-            p.status->prof[verdict == ROUND_RETRY ? 3 : 4] += 1;
-#endif
+        if (__ballot(hit)) {
+          for (uint32_t v = 0; v < wave; ++v) {
+            const bool in_v = idx >= v * stride && idx < (v + 1u) * stride;
+            if (__ballot(hit && in_v)) conf |= 1u << v;
+            if (__ballot(hit_seed && in_v)) seed_hit |= 1u << v;
           }
         }
       }
-      if (lane == 0)
-        __hip_atomic_store(token, ((unsigned long long)commits << 32) | ((unsigned long long)(my_turn + 1u) << 1) | stopped,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    if (have && lane == 0) CONF[wave] = conf | (seed_hit << 8) | (res << 16);
+#ifdef PM_CARVE_PROF
+    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_chk += tb - ta; ta = tb; }
+#endif
+    lds_barrier();
+#ifdef PM_CARVE_PROF
+    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_b2 += tb - ta; ta = tb; }
+#endif
+    // ---- every wave replays the round identically, in seed order, from the conflict words: a wave whose
+    // seed was taken is no step at all; the first wave that cannot commit (exact sweep needed, a slot taken,
+    // arrays full) ends the round.  Straight-line scalar code: taken branches are what this loop would pay for.
+    const uint32_t cw = lane < n_round ? CONF[lane] : 0u;
+    uint32_t dbg_at = 0xFFFFFFFFu;  // commit count at which the debug hook forces the exact sweep
+    if (dbg_every) {
+      const uint32_t r = (steps_before + base_steps + commits_done + 1u) % dbg_every;
+      dbg_at = commits_done + (r ? dbg_every - r : 0u);
+    }
+    uint32_t cmask = 0, stop_code = ROUND_OK, stop_wave = 0, commits = commits_done, open = 1u;
+#pragma unroll
+    for (uint32_t v = 0; v < CARVE_WAVES; ++v) {
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)v);
+      const uint32_t seed_taken = ((word >> 8) & cmask & 0xFFu) ? 1u : 0u;
+      uint32_t verdict = word >> 16;
+      verdict = commits == dbg_at ? (uint32_t)ROUND_SLOW : verdict;
+      const uint32_t v_ok = (word & cmask & 0xFFu) ? (uint32_t)ROUND_RETRY : (uint32_t)ROUND_OK;
+      const uint32_t v_ok2 = commits >= max_commits ? (uint32_t)ROUND_OVERFLOW : v_ok;
+      verdict = verdict == ROUND_OK ? v_ok2 : verdict;
+      const uint32_t consider = (v < n_round ? 1u : 0u) & open & (seed_taken ^ 1u);
+      const uint32_t ok = consider & (verdict == ROUND_OK ? 1u : 0u);
+      const uint32_t stop_now = consider & (ok ^ 1u);
+      cmask |= ok << v;
+      commits += ok;
+      stop_code = stop_now ? verdict : stop_code;
+      stop_wave = stop_now ? v : stop_wave;
+      open &= stop_now ^ 1u;
+    }
+    if (have && ((cmask >> wave) & 1u)) {
+      const uint32_t ci = commits_done + (uint32_t)__popc(cmask & ((1u << wave) - 1u));
+      const uint32_t n_groups = base_groups + ci, mem_off = base_mem + ci * group_n;
+      if (lane < want) {
+        kill(mine_l);
+        members[mem_off + 1u + lane] = my_wid;
+      }
+      if (lane == 0) {
+        kill(seed);
+        members[mem_off] = seed_wid;
+        g_cfg[n_groups] = cfg;
+        g_n[n_groups] = group_n;
+        g_off[n_groups] = mem_off;
+      }
+    }
+    commits_done = commits;
 #ifdef PM_CARVE_PROF
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_commit += tb - ta; ta = tb; }
 #endif
-    lds_barrier();  // every turn of this round is done
-    turn_base += n_round;
-    const unsigned long long tok_end = red.token;
-    next_row = row_ptr + last_l + 1u;
+    lds_barrier();  // the round's bitmap updates are in place
 #ifdef PM_CARVE_PROF
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_sync += tb - ta; ta = tb; }
 #endif
-    if ((uint32_t)tok_end & 1u) {
-      const uint32_t stop = red.stop, retry_row = red.retry_row;
-      if (stop == ROUND_SLOW) {
+    next_row = row_ptr + last_l + 1u;
+    if (stop_code != ROUND_OK) {
+#ifdef PM_CARVE_PROF
+      if (tid == 0) G(p.status)->prof[stop_code == ROUND_RETRY ? 3 : 4] += 1;
+#endif
+      if (stop_code == ROUND_SLOW) {
         action = FAST_SLOW;
         break;
       }
-      if (stop == ROUND_OVERFLOW) {
+      if (stop_code == ROUND_OVERFLOW) {
         action = FAST_OVERFLOW;
         break;
       }
       // ROUND_RETRY: an earlier commit of this round took one of that wave's slots; redo from its row
-      next_row = retry_row;
-      lds_barrier();
-      if (tid == 0) red.token = tok_end & ~1ull;
-      lds_barrier();
+      uint64_t t = m;
+      for (uint32_t k = 0; k < stop_wave; ++k) t &= t - 1ull;
+      next_row = row_ptr + (uint32_t)__builtin_ctzll(t);
     }
   }
   lds_barrier();
   {
-    const uint32_t commits = (uint32_t)(red.token >> 32);
+    const uint32_t commits = commits_done;
 #ifdef PM_CARVE_PROF
     if (tid == 0) {
-      p.status->prof[0] += __builtin_amdgcn_s_memtime() - rt0;
-      p.status->prof[2] += commits;
-      p.status->prof[5] += t_spec;
+      G(p.status)->prof[0] += __builtin_amdgcn_s_memtime() - rt0;
+      G(p.status)->prof[2] += commits;
+      G(p.status)->prof[5] += t_spec;
     }
-    if (tid == 64) { p.status->prof[6] += t_wait; p.status->prof[7] += t_commit; p.status->prof[8] += t_sync; }
+    if (tid == 64) { G(p.status)->prof[6] += t_wait; G(p.status)->prof[7] += t_commit; G(p.status)->prof[8] += t_sync; G(p.status)->prof[16] += t_chk; G(p.status)->prof[17] += t_b2; }
+    if (tid == 448) { G(p.status)->prof[18] += t_chk; G(p.status)->prof[19] += t_spec; }
 #endif
     c.n_groups = base_groups + commits;
     c.mem_off = base_mem + commits * group_n;
@@ -1192,13 +1235,13 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
 #pragma unroll
           for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
             const uint32_t r = wave + k * CARVE_WAVES;
-            rowv[k] = r < rows ? p.prop[(size_t)red.cache_slot[r] * PM_PROP_ROW + lane] : ~0ull;
+            rowv[k] = r < rows ? G(p.prop)[(size_t)red.cache_slot[r] * PM_PROP_ROW + lane] : ~0ull;
           }
           uint32_t meta = 0, nx = PM_NONE;
           if (tid < rows) {
             const uint32_t sl = red.cache_slot[tid];
-            meta = p.prop_n[sl];
-            nx = p.same_next[sl];
+            meta = G(p.prop_n)[sl];
+            nx = G(p.same_next)[sl];
           }
 #pragma unroll
           for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
@@ -1214,7 +1257,8 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         cache_valid = true;
       }
       if (c.prop_k && c.proximity && p.rounds_enabled) {
-        const int ract = carve_fast_rounds<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive, steps_before);
+        const int ract = carve_fast_rounds<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive,
+                                                reinterpret_cast<uint32_t*>(part), steps_before);
         if (ract == FAST_OVERFLOW) return STEP_OVERFLOW;
         if (ract == FAST_REFILL) {
           cache_valid = false;
@@ -1320,7 +1364,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
       }
 
       // ---- keys (registers only; the seed's coordinates are one uniform load each)
-      const double slat = p.cc_lat[seed], slon = p.cc_lon[seed], scos = p.cc_cos[seed];
+      const double slat = G(p.cc_lat)[seed], slon = G(p.cc_lon)[seed], scos = G(p.cc_cos)[seed];
       uint64_t lmin = ~0ull;
       for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
         uint64_t k = ~0ull;
@@ -1329,7 +1373,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
             k = s;
           } else if (bit_at(l_loc, s)) {
             k = pack_key((uint64_t)__double_as_longlong(
-                             hav_a(slat, slon, scos, p.cc_lat[s], p.cc_lon[s], p.cc_cos[s])), s, SB);
+                             hav_a(slat, slon, scos, G(p.cc_lat)[s], G(p.cc_lon)[s], G(p.cc_cos)[s])), s, SB);
           } else if (!located_only) {
             k = pack_key(PM_KEY_NOLOC, s, SB);
           }
@@ -1396,7 +1440,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
               if (n_sel < PM_CARVE_SEL_CAP)
                 sel_out[n_sel] = bs;
               else if (c.mem_off + 1u + n_sel < p.cap_members)
-                p.members[c.mem_off + 1u + n_sel] = wid_of(bs);
+                G(p.members)[c.mem_off + 1u + n_sel] = wid_of(bs);
             }
             last = b;
             ++n_sel;
@@ -1428,14 +1472,14 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
       const uint32_t ls = (uint32_t)(last & ((1ull << SB) - 1ull));
       const double a_m = __longlong_as_double((long long)last_key);
       const double band = a_m * band_rel + 1e-300;
-      const double mlat = p.cc_lat[ls], mlon = p.cc_lon[ls];  // uniform loads
+      const double mlat = G(p.cc_lat)[ls], mlon = G(p.cc_lon)[ls];  // uniform loads
       if (a_m > PM_A_MAX_SAFE) uncertain = 1;
       for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
         const uint64_t k = l_key[s];
         const uint64_t kb = (k >> SB) << SB;
         const double a = __longlong_as_double((long long)kb);
         const bool near = k != ~0ull && kb != noloc_key && fabs(a - a_m) <= band;
-        if (near && (p.cc_lat[s] != mlat || p.cc_lon[s] != mlon)) uncertain = 1;
+        if (near && (G(p.cc_lat)[s] != mlat || G(p.cc_lon)[s] != mlon)) uncertain = 1;
       }
     }
     const uint64_t ub = __ballot(uncertain != 0);
@@ -1447,7 +1491,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
 #pragma unroll
     for (uint32_t k = 0; k < CARVE_WAVES; ++k) any |= red.flag[k];
     if (any) {
-      if (tid == 0) p.status->stop_seed = l_wid[seed];
+      if (tid == 0) G(p.status)->stop_seed = l_wid[seed];
       return STEP_UNCERTAIN;
     }
     if (c.n_groups >= p.cap_groups || c.mem_off + total > p.cap_members) return STEP_OVERFLOW;
@@ -1463,13 +1507,13 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
     }
     if (wave == 0) {  // group record + members: LDS -> fire-and-forget global stores
       if (lane == 0) {
-        p.members[c.mem_off] = wid_of(seed);
-        p.g_cfg[c.n_groups] = c.cfg;
-        p.g_n[c.n_groups] = total;
-        p.g_off[c.n_groups] = c.mem_off;
+        G(p.members)[c.mem_off] = wid_of(seed);
+        G(p.g_cfg)[c.n_groups] = c.cfg;
+        G(p.g_n)[c.n_groups] = total;
+        G(p.g_off)[c.n_groups] = c.mem_off;
       }
       const uint32_t lim = n_sel < PM_CARVE_SEL_CAP ? n_sel : PM_CARVE_SEL_CAP;
-      for (uint32_t r = lane; r < lim; r += 64u) p.members[c.mem_off + 1u + r] = wid_of(sel_out[r]);
+      for (uint32_t r = lane; r < lim; r += 64u) G(p.members)[c.mem_off + 1u + r] = wid_of(sel_out[r]);
     }
     PROF_MARK(7);
     lds_barrier();
@@ -1542,7 +1586,7 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
       use_dist = false;
       located_only = false;
     }
-    const double slat = p.cc_lat[seed], slon = p.cc_lon[seed], scos = p.cc_cos[seed];
+    const double slat = G(p.cc_lat)[seed], slon = G(p.cc_lon)[seed], scos = G(p.cc_cos)[seed];
     uint64_t lmin = ~0ull;
     for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
       uint64_t k = ~0ull;
@@ -1550,7 +1594,7 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
         if (!use_dist) {
           k = s;
         } else if (bit_at(loc, s)) {
-          k = pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, p.cc_lat[s], p.cc_lon[s], p.cc_cos[s])), s, SB);
+          k = pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, G(p.cc_lat)[s], G(p.cc_lon)[s], G(p.cc_cos)[s])), s, SB);
         } else if (!located_only) {
           k = pack_key(PM_KEY_NOLOC, s, SB);
         }
@@ -1569,7 +1613,7 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
       __syncthreads();
       if (b == ~0ull) break;
       if (tid == 0 && c.mem_off + 1u + n_sel < p.cap_members)
-        p.members[c.mem_off + 1u + n_sel] = wid[(uint32_t)(b & ((1ull << SB) - 1ull))];
+        G(p.members)[c.mem_off + 1u + n_sel] = wid[(uint32_t)(b & ((1ull << SB) - 1ull))];
       last = b;
       ++n_sel;
       if (lmin == b) {
@@ -1595,7 +1639,7 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
     const uint32_t ls = (uint32_t)(last & ((1ull << SB) - 1ull));
     const double a_m = __longlong_as_double((long long)last_key);
     const double band = a_m * PM_TIE_BAND_MEM + 1e-300;
-    const double mlat = p.cc_lat[ls], mlon = p.cc_lon[ls];
+    const double mlat = G(p.cc_lat)[ls], mlon = G(p.cc_lon)[ls];
     if (a_m > PM_A_MAX_SAFE) uncertain = 1;
     for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
       const uint64_t k = key[s];
@@ -1603,11 +1647,11 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
       const uint64_t kb = (k >> SB) << SB;
       if (kb == ((PM_KEY_NOLOC >> SB) << SB)) continue;
       const double a = __longlong_as_double((long long)kb);
-      if (fabs(a - a_m) <= band && (p.cc_lat[s] != mlat || p.cc_lon[s] != mlon)) uncertain = 1;
+      if (fabs(a - a_m) <= band && (G(p.cc_lat)[s] != mlat || G(p.cc_lon)[s] != mlon)) uncertain = 1;
     }
   }
   if (__syncthreads_or(uncertain)) {
-    if (tid == 0) p.status->stop_seed = wid[seed];
+    if (tid == 0) G(p.status)->stop_seed = wid[seed];
     return STEP_UNCERTAIN;
   }
   if (c.n_groups >= p.cap_groups || c.mem_off + total > p.cap_members) return STEP_OVERFLOW;
@@ -1617,10 +1661,10 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
       atomicAnd((unsigned long long*)&alive[s >> 6], ~(1ull << (s & 63u)));
   }
   if (tid == 0) {
-    p.members[c.mem_off] = wid[seed];
-    p.g_cfg[c.n_groups] = c.cfg;
-    p.g_n[c.n_groups] = total;
-    p.g_off[c.n_groups] = c.mem_off;
+    G(p.members)[c.mem_off] = wid[seed];
+    G(p.g_cfg)[c.n_groups] = c.cfg;
+    G(p.g_n)[c.n_groups] = total;
+    G(p.g_off)[c.n_groups] = c.mem_off;
   }
   __syncthreads();
   c.n_groups += 1;
@@ -1646,8 +1690,8 @@ __device__ __noinline__ uint32_t carve_compact_count(const CarveArgs& p, BlockRe
     for (int u = 0; u < 4; ++u) {
       const uint32_t j = jb + (uint32_t)u;
       const uint32_t i = j * 64u + lane;
-      aw[u] = j < j1 ? p.alive_g[j] : 0ull;
-      cm[u] = (j < j1 && i < n && p.mode != CARVE_MODE_MERGE) ? p.c_compat[i] : ~0ull;
+      aw[u] = j < j1 ? G(p.alive_g)[j] : 0ull;
+      cm[u] = (j < j1 && i < n && p.mode != CARVE_MODE_MERGE) ? G(p.c_compat)[i] : ~0ull;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1669,8 +1713,8 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
   const uint32_t n_words = (n + 63u) >> 6;
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
   const uint32_t j0 = wave * wpw, j1 = min(n_words, j0 + wpw);
-  uint64_t* alive = p.bits_scratch;
-  uint64_t* loc = p.bits_scratch + p.bits_stride;
+  const auto alive = G(p.bits_scratch);
+  const auto loc = G(p.bits_scratch) + p.bits_stride;
   uint32_t off = 0;
   for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
   for (uint32_t jb = j0; jb < j1; jb += 4u) {
@@ -1682,13 +1726,13 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
       const uint32_t j = jb + (uint32_t)u;
       const uint32_t i = j * 64u + lane;
       const bool in = j < j1 && i < n;
-      aw[u] = j < j1 ? p.alive_g[j] : 0ull;
-      cm[u] = (in && p.mode != CARVE_MODE_MERGE) ? p.c_compat[i] : ~0ull;
-      ow[u] = in ? p.order[i] : 0u;
-      os[u] = in ? p.c_site[i] : 0u;
-      la[u] = in ? p.c_lat[i] : 0.0;
-      lo[u] = in ? p.c_lon[i] : 0.0;
-      co[u] = in ? p.c_cos[i] : 0.0;
+      aw[u] = j < j1 ? G(p.alive_g)[j] : 0ull;
+      cm[u] = (in && p.mode != CARVE_MODE_MERGE) ? G(p.c_compat)[i] : ~0ull;
+      ow[u] = in ? G(p.order)[i] : 0u;
+      os[u] = in ? G(p.c_site)[i] : 0u;
+      la[u] = in ? G(p.c_lat)[i] : 0.0;
+      lo[u] = in ? G(p.c_lon)[i] : 0.0;
+      co[u] = in ? G(p.c_cos)[i] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1697,12 +1741,12 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
       const uint64_t bal = __ballot(c);
       if (c) {
         const uint32_t s = off + __popcll(bal & ((1ull << lane) - 1ull));
-        p.slot_pos[s] = i;
-        p.slot_wid[s] = ow[u];
-        p.cc_lat[s] = la[u];
-        p.cc_lon[s] = lo[u];
-        p.cc_cos[s] = co[u];
-        p.cc_site[s] = os[u];
+        G(p.slot_pos)[s] = i;
+        G(p.slot_wid)[s] = ow[u];
+        G(p.cc_lat)[s] = la[u];
+        G(p.cc_lon)[s] = lo[u];
+        G(p.cc_cos)[s] = co[u];
+        G(p.cc_site)[s] = os[u];
       }
       off += __popcll(bal);
     }
@@ -1712,7 +1756,7 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
   for (uint32_t base = 0; base < lw * 64u; base += CARVE_THREADS) {
     const uint32_t s = base + tid;
     const bool in = s < n_list;
-    const bool hl = in && bit_at(p.loc_g, p.slot_pos[s]);
+    const bool hl = in && bit_at(p.loc_g, G(p.slot_pos)[s]);
     const uint64_t ba = __ballot(in), bl = __ballot(hl);
     if (lane == 0 && (s >> 6) < lw) {
       alive[s >> 6] = ba;
@@ -1737,7 +1781,7 @@ __device__ __forceinline__ void top4_insert(uint64_t k, uint64_t& r0, uint64_t& 
 
 __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa) {
   const CarveArgs& p = *pa;  // argument block in device memory: read through the scalar cache, never copied
-  const CarveStatus* st = p.status;
+  const auto st = G((const CarveStatus*)p.status);
   if (st->state != CARVE_STATE_RUNNING || st->cur_ci >= p.n_avail) return;
   const uint32_t K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
   if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
@@ -1745,19 +1789,19 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   const double TIE_BAND = n_list > PM_CARVE_SLOTS ? PM_TIE_BAND_BIG : PM_TIE_BAND;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_g = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-  const uint64_t* alive = p.bits_scratch;
-  const uint64_t* loc = p.bits_scratch + p.bits_stride;
+  const auto alive = G((const uint64_t*)p.bits_scratch);
+  const auto loc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
   const uint32_t lw = (n_list + 63u) >> 6;
   for (uint32_t s = wave_g; s < n_list; s += n_waves) {
     if (!(bit_at(alive, s) && bit_at(loc, s))) continue;  // wave-uniform
-    const uint32_t ssite = p.cc_site[s];
+    const uint32_t ssite = G(p.cc_site)[s];
     // next located slot at the same site (the validator's same-site shortcut walks these links); only sites
     // shared by several workers (bit 31 of the interned id) can have one
     uint32_t same = PM_NONE;
     if (ssite & 0x80000000u) {
       for (uint32_t j = s >> 6; j < lw; ++j) {
         const uint32_t t = j * 64u + lane;
-        const bool hit = t > s && t < n_list && ((alive[j] >> lane) & (loc[j] >> lane) & 1ull) && p.cc_site[t] == ssite;
+        const bool hit = t > s && t < n_list && ((alive[j] >> lane) & (loc[j] >> lane) & 1ull) && G(p.cc_site)[t] == ssite;
         const uint64_t hm = __ballot(hit);
         if (hm) {
           same = j * 64u + (uint32_t)__builtin_ctzll(hm);
@@ -1765,9 +1809,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         }
       }
     }
-    if (lane == 0) p.same_next[s] = same;
+    if (lane == 0) G(p.same_next)[s] = same;
     if (s >= limit) continue;  // beyond this round's proposal batch
-    const double slat = p.cc_lat[s], slon = p.cc_lon[s], scos = p.cc_cos[s];
+    const double slat = G(p.cc_lat)[s], slon = G(p.cc_lon)[s], scos = G(p.cc_cos)[s];
     uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull, r3 = ~0ull;
     uint32_t n_mine = 0;
     // The sweep is a chain of L2-latency loads: issue the loads of four 64-slot strides together.
@@ -1782,9 +1826,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         lwd[u] = in ? loc[j] : 0ull;
         const uint32_t t = j * 64u + lane;
         const bool need = (aw[u] >> lane) & (lwd[u] >> lane) & 1ull;
-        tla[u] = need ? p.cc_lat[t] : 0.0;
-        tlo[u] = need ? p.cc_lon[t] : 0.0;
-        tco[u] = need ? p.cc_cos[t] : 0.0;
+        tla[u] = need ? G(p.cc_lat)[t] : 0.0;
+        tlo[u] = need ? G(p.cc_lon)[t] : 0.0;
+        tco[u] = need ? G(p.cc_cos)[t] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1817,7 +1861,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
             if (!((alive[j] >> lane) & 1ull) || t == s) continue;
             const uint64_t k = ((loc[j] >> lane) & 1ull)
                                    ? pack_key((uint64_t)__double_as_longlong(
-                                                  hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB)
+                                                  hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB)
                                    : pack_key(PM_KEY_NOLOC, t, SB);
             if (k > v) top4_insert(k, r0, r1, r2, r3);
           }
@@ -1833,7 +1877,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     uint32_t clean = 1, tail_clear = 0, tail_ok = 0;
     {
       const uint64_t kb = (mine >> SB) << SB;
-      const uint32_t my_site = (lane < n_k && kb != noloc_kb) ? p.cc_site[(uint32_t)(mine & ((1ull << SB) - 1ull))] : 0u;
+      const uint32_t my_site = (lane < n_k && kb != noloc_kb) ? G(p.cc_site)[(uint32_t)(mine & ((1ull << SB) - 1ull))] : 0u;
       const uint64_t nkb_lo = __shfl_down((uint32_t)kb, 1, 64), nkb_hi = __shfl_down((uint32_t)(kb >> 32), 1, 64);
       const uint64_t nkb = (nkb_hi << 32) | nkb_lo;
       const uint32_t nsite = __shfl_down(my_site, 1, 64);
@@ -1859,25 +1903,25 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         if (a_b - a_last > a_b * (4.0 * TIE_BAND) + 1e-300) {
           tail_clear = 1;
         } else {
-          const uint32_t site_last = p.cc_site[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
+          const uint32_t site_last = G(p.cc_site)[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
           const double band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
           int bad = 0;
           for (uint32_t j = 0; j < lw; ++j) {
             const uint32_t t = j * 64u + lane;
             if (!((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
             const uint64_t k = pack_key((uint64_t)__double_as_longlong(
-                                            hav_a(slat, slon, scos, p.cc_lat[t], p.cc_lon[t], p.cc_cos[t])), t, SB);
+                                            hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB);
             if (k <= e_last) continue;  // listed
             const double a = __longlong_as_double((long long)((k >> SB) << SB));
-            if (a - a_last <= band2 && p.cc_site[t] != site_last) bad = 1;
+            if (a - a_last <= band2 && G(p.cc_site)[t] != site_last) bad = 1;
           }
           tail_ok = __ballot(bad) == 0ull;
         }
       }
     }
-    p.prop[(size_t)s * PM_PROP_ROW + lane] = mine;
+    G(p.prop)[(size_t)s * PM_PROP_ROW + lane] = mine;
     if (lane == 0) {
-      p.prop_n[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
+      G(p.prop_n)[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
     }
   }
 }
@@ -1894,8 +1938,8 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
   if (n_list <= cap) return n_list;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (wave == 0) {
-    const uint64_t* g_al = p.bits_scratch;
-    const uint64_t* g_lc = p.bits_scratch + p.bits_stride;
+    const auto g_al = G((const uint64_t*)p.bits_scratch);
+    const auto g_lc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
     const uint32_t lwp = (n_list + 63u) >> 6;
     uint32_t acc = 0, limit = n_list;
     for (uint32_t j0 = 0; j0 < lwp; j0 += 64u) {
@@ -1941,7 +1985,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   uint32_t& s_n = *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&red) + sizeof(BlockRed));
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  CarveStatus* st = p.status;
+  const auto st = G(p.status);
   uint32_t flags = flags_in;
   if (!(flags & CARVE_F_INIT) && st->state != CARVE_STATE_RUNNING) return;  // queued behind a finished carve
   PROF_DECL;
@@ -1966,15 +2010,15 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         const uint32_t w = base + tid;
         bool e = false;
         if (w < p.W) {
-          const uint32_t f = p.wflags[w];
-          e = (f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && p.group_of[w] < 0;
+          const uint32_t f = G(p.wflags)[w];
+          e = (f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && G(p.group_of)[w] < 0;
         }
         const uint64_t bal = __ballot(e);
         if (lane == 0) red.a[wave] = __popcll(bal);
         __syncthreads();
         uint32_t off = s_n;
         for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
-        if (e) p.order[off + __popcll(bal & ((1ull << lane) - 1ull))] = w;
+        if (e) G(p.order)[off + __popcll(bal & ((1ull << lane) - 1ull))] = w;
         __syncthreads();
         if (tid == 0) {
           uint32_t tot = 0;
@@ -1993,19 +2037,19 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       const uint32_t i = base + tid;
       bool has_loc = false;
       if (i < n) {
-        const uint32_t w = p.order[i];
-        has_loc = (p.wflags[w] & PM_W_HAS_LOC) != 0;
-        p.c_lat[i] = p.lat[w];
-        p.c_lon[i] = p.lon[w];
-        p.c_cos[i] = p.coslat[w];
-        p.c_site[i] = p.site[w];
-        p.c_compat[i] = p.compat[w];
+        const uint32_t w = G(p.order)[i];
+        has_loc = (G(p.wflags)[w] & PM_W_HAS_LOC) != 0;
+        G(p.c_lat)[i] = G(p.lat)[w];
+        G(p.c_lon)[i] = G(p.lon)[w];
+        G(p.c_cos)[i] = G(p.coslat)[w];
+        G(p.c_site)[i] = G(p.site)[w];
+        G(p.c_compat)[i] = G(p.compat)[w];
       }
       const uint64_t bl = __ballot(has_loc);
       const uint64_t ba = __ballot(i < n);
       if (lane == 0 && (i >> 6) < n_words) {
-        p.loc_g[i >> 6] = bl;
-        p.alive_g[i >> 6] = ba;
+        G(p.loc_g)[i >> 6] = bl;
+        G(p.alive_g)[i >> 6] = ba;
       }
     }
     __syncthreads();
@@ -2093,9 +2137,9 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     }
     if (in_lds) {
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) {
-        lds_wid[sl] = p.slot_wid[sl];
-        lds_site[sl] = p.cc_site[sl];
-        const uint32_t nx = (c.use_props && c.prop_k) ? p.same_next[sl] : PM_NONE;
+        lds_wid[sl] = G(p.slot_wid)[sl];
+        lds_site[sl] = G(p.cc_site)[sl];
+        const uint32_t nx = (c.use_props && c.prop_k) ? G(p.same_next)[sl] : PM_NONE;
         lds_next[sl] = nx < c.n_list ? (uint16_t)nx : (uint16_t)0xFFFFu;
       }
     }
@@ -2119,7 +2163,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     (void)slow_before_cfg;
     __syncthreads();
     if (big) {  // slots -> worker ids for everything this run appended
-      for (uint32_t k = mem_before_run + tid; k < c.mem_off; k += CARVE_THREADS) p.members[k] = p.slot_wid[p.members[k]];
+      for (uint32_t k = mem_before_run + tid; k < c.mem_off; k += CARVE_THREADS) G(p.members)[k] = G(p.slot_wid)[G(p.members)[k]];
       __syncthreads();
     }
     PROF_MARK(13);
@@ -2128,8 +2172,8 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       const uint64_t* alive = r_alive;
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS)
         if (!bit_at(alive, sl)) {
-          const uint32_t i = p.slot_pos[sl];
-          atomicAnd((unsigned long long*)&p.alive_g[i >> 6], ~(1ull << (i & 63u)));
+          const uint32_t i = G(p.slot_pos)[sl];
+          atomicAnd((unsigned long long*)&G(p.alive_g)[i >> 6], ~(1ull << (i & 63u)));
         }
     }
     __syncthreads();
@@ -2148,8 +2192,8 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   if (p.mode == CARVE_MODE_FORM) {
     __syncthreads();
     for (uint32_t g = groups_at_entry + wave; g < c.n_groups; g += CARVE_WAVES) {
-      const uint32_t off = p.g_off[g], gn = p.g_n[g];
-      for (uint32_t k = lane; k < gn; k += 64u) p.group_of[p.members[off + k]] = (int32_t)g;
+      const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
+      for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
     }
   }
   __syncthreads();
