@@ -81,6 +81,8 @@ struct CarveStatus {
   uint32_t total_available;
   uint32_t fast_steps;   // steps committed from proposals
   uint32_t slow_steps;   // steps that needed the full key sweep
+  uint32_t n_solo;       // single-node groups carved (the merge pass only runs when there are two or more)
+  uint32_t _pad_solo;
   unsigned long long prof[24];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
@@ -153,6 +155,7 @@ void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const 
                         uint32_t* out, hipStream_t s);
 void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block, long long* val_by_block,
                    uint32_t n_blocks, hipStream_t s);
+void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 

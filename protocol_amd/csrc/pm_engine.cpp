@@ -16,6 +16,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -154,6 +157,14 @@ struct pm_engine {
   DevBuf<pm_assignment> d_table;
   DevBuf<uint32_t> d_task_col;
   pm_assignment* h_table_pinned = nullptr;
+  // pinned staging for the group records a carve appended (absorbed into the host list by absorb_groups)
+  uint32_t* h_gstage = nullptr;
+  size_t h_gstage_cap = 0;
+  hipEvent_t ev_groups = nullptr;
+  bool absorb_pending = false;
+  uint32_t ab_g0 = 0, ab_g1 = 0, ab_m0 = 0, ab_m1 = 0, ab_solo = 0;
+  uint32_t* h_gtask_pinned = nullptr;
+  size_t h_gtask_cap = 0;
   size_t h_table_cap = 0;
   DevBuf<uint32_t> d_nb_idx;
   DevBuf<long long> d_nb_val;
@@ -420,12 +431,44 @@ static int32_t host_resolve_form_step(pm_engine* e, uint32_t cfg, CarveStatus* s
   HIPCHK(hipStreamSynchronize(e->stream));
   st->n_groups += 1;
   st->n_members += n;
+  st->n_solo += n == 1 ? 1u : 0u;
   st->steps_total += 1;
   return PM_OK;
 }
 
 // Run the persistent carve kernel until it reports DONE, settling UNCERTAIN steps on the host.
-static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
+// Append the group records of the last carve to the host list (ids from the generate_group_id stream).
+static int32_t absorb_groups(pm_engine* e) {
+  if (!e->absorb_pending) return PM_OK;
+  HIPCHK(hipEventSynchronize(e->ev_groups));
+  const uint32_t g0 = e->ab_g0, ng = e->ab_g1 - e->ab_g0, m0 = e->ab_m0;
+  const uint32_t *g_cfg = e->h_gstage, *g_n = g_cfg + ng, *g_off = g_cfg + 2 * size_t(ng),
+                 *members = g_cfg + 3 * size_t(ng);
+  e->groups.reserve(e->groups.size() + ng);
+  for (uint32_t k = 0; k < ng; ++k) {
+    Group gr;
+    gr.id = splitmix64_next(&e->id_rng);
+    gr.cfg = g_cfg[k];
+    gr.task = PM_NONE;
+    gr.task_uid = 0;
+    gr.members.assign(members + (g_off[k] - m0), members + (g_off[k] - m0) + g_n[k]);
+    for (uint32_t w : gr.members) e->h_group_of[w] = int32_t(g0 + k);
+    e->groups.push_back(std::move(gr));
+  }
+  e->absorb_pending = false;
+  return PM_OK;
+}
+
+// PM_TRACE_HOST=1: host-side timestamps (us since the first mark) on stderr, to find where a match waits
+static void host_mark(const char* what) {
+  static const bool on = [] { const char* v = getenv("PM_TRACE_HOST"); return v && *v == '1'; }();
+  if (!on) return;
+  static const auto t0 = std::chrono::steady_clock::now();
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(stderr, "[pm host] %10.1f us  %s\n", us, what);
+}
+
+static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = false) {
   int32_t rc = ensure_compat(e);
   if (rc) return rc;
   rc = push_groups(e);
@@ -468,7 +511,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
       // prepare the first candidate list, then (propose, validate) pairs: one per configuration plus one
       // per re-proposal round; launches queued behind a finished carve return immediately
       HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, start_ci, lds, e->stream));
-      for (uint32_t k = 0; k < a.n_avail - start_ci + 8u; ++k) {
+      for (uint32_t k = 0; k < a.n_avail - start_ci + 3u; ++k) {
         launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
         HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
         e->tick_carve_launches += 2;
@@ -478,8 +521,10 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
     }
     HIPCHK(hipEventRecord(e->kev[3], e->stream));
     e->tick_carve_launches++;
+    host_mark("form: carve queued");
     HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    host_mark("form: status back");
     {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
@@ -515,34 +560,41 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed) {
   e->tick_cand_sum += st.cand_sum;
   std::memcpy(e->carve_prof, st.prof, sizeof(st.prof));
 
-  // pull the new group records into the host list and give them ids (generate_group_id stream)
+  // The new group records stay in HBM for the match; their ids (generate_group_id stream) and empty task
+  // words are filled in on the device, and a copy travels to pinned host memory for absorb_groups().
   const uint32_t g1 = st.n_groups, m1 = st.n_members;
   if (g1 > g0) {
-    const uint32_t ng = g1 - g0;
-    std::vector<uint32_t> g_cfg(ng), g_n(ng), g_off(ng), members(m1 - m0);
-    HIPCHK(hipMemcpyAsync(g_cfg.data(), e->d_g_cfg.p + g0, ng * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(g_n.data(), e->d_g_n.p + g0, ng * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(g_off.data(), e->d_g_off.p + g0, ng * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(members.data(), e->d_members.p + m0, size_t(m1 - m0) * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    std::vector<uint64_t> ids(ng);
-    std::vector<uint32_t> none(ng, PM_NONE);
-    for (uint32_t k = 0; k < ng; ++k) {
-      Group gr;
-      gr.id = splitmix64_next(&e->id_rng);
-      gr.cfg = g_cfg[k];
-      gr.task = PM_NONE;
-      gr.task_uid = 0;
-      gr.members.assign(members.begin() + (g_off[k] - m0), members.begin() + (g_off[k] - m0) + g_n[k]);
-      for (uint32_t w : gr.members) e->h_group_of[w] = int32_t(g0 + k);
-      ids[k] = gr.id;
-      e->groups.push_back(std::move(gr));
+    const uint32_t ng = g1 - g0, nm = m1 - m0;
+    const size_t need = size_t(3) * ng + nm;
+    if (e->h_gstage_cap < need) {
+      if (e->h_gstage) (void)hipHostFree(e->h_gstage);
+      e->h_gstage = nullptr;
+      e->h_gstage_cap = 0;
+      const size_t cap = std::max<size_t>(need, size_t(4) * std::max<uint32_t>(e->W, 1));
+      HIPCHK(hipHostMalloc((void**)&e->h_gstage, cap * sizeof(uint32_t)));
+      e->h_gstage_cap = cap;
     }
-    HIPCHK(hipMemcpyAsync(e->d_g_id.p + g0, ids.data(), size_t(ng) * 8, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_g_task.p + g0, none.data(), size_t(ng) * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    uint32_t* st_cfg = e->h_gstage;
+    HIPCHK(hipMemcpyAsync(st_cfg, e->d_g_cfg.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(st_cfg + ng, e->d_g_n.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(st_cfg + 2 * size_t(ng), e->d_g_off.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(st_cfg + 3 * size_t(ng), e->d_members.p + m0, size_t(nm) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(e->ev_groups, e->stream));
+    host_mark("form: group copies queued");
+    launch_group_ids(e->d_g_id.p + g0, e->d_g_task.p + g0, ng, e->id_rng, e->stream);
+    HIPCHK(hipGetLastError());
+    e->absorb_pending = true;
+    e->ab_g0 = g0;
+    e->ab_g1 = g1;
+    e->ab_m0 = m0;
+    e->ab_m1 = m1;
+    e->ab_solo = st.n_solo;
     e->d_n_groups = g1;
     e->d_n_members = m1;
+    if (!defer_absorb) {
+      rc = absorb_groups(e);
+      if (rc) return rc;
+    }
   }
   if (n_formed) *n_formed = g1 - g0;
   return PM_OK;
@@ -618,6 +670,7 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   if (e->W == 0) return PM_OK;
   const uint32_t n_planes = uint32_t(e->cfgs.size());
 
+  host_mark("match: selector launch");
   launch_worker_selector(e->d_group_of.p, e->d_g_cfg.p, e->W, e->d_sel.p, e->stream);
   HIPCHK(hipEventRecord(e->kev[4], e->stream));
   launch_pair_sweep(variant, e->d_sel.p, e->W, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_scratch.p,
@@ -634,7 +687,7 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   }
   launch_group_rank(e->d_group_of.p, e->d_g_n.p, e->d_g_off.p, e->d_members.p, e->d_addr_rank.p, e->W,
                     e->d_rank_in_group.p, e->d_by_rank.p, e->stream);
-  const size_t G = e->groups.size();
+  const size_t G = e->d_n_groups;  // == groups.size() once the last carve is absorbed
   if (G) HIPCHK(hipMemcpyAsync(e->d_g_task_next.p, e->d_g_task.p, G * 4, hipMemcpyDeviceToDevice, e->stream));
   ClaimArgs c{};
   c.W = e->W;
@@ -668,11 +721,19 @@ static int32_t publish(pm_engine* e) {
     HIPCHK(hipHostMalloc((void**)&e->h_table_pinned, sizeof(pm_assignment) * std::max<uint32_t>(e->W, 1)));
     e->h_table_cap = e->W;
   }
-  std::vector<uint32_t> g_task(G);
+  if (e->h_gtask_cap < G) {
+    if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
+    e->h_gtask_pinned = nullptr;
+    e->h_gtask_cap = 0;
+    const size_t cap = std::max<size_t>(G, std::max<uint32_t>(e->W, 1));
+    HIPCHK(hipHostMalloc((void**)&e->h_gtask_pinned, cap * sizeof(uint32_t)));
+    e->h_gtask_cap = cap;
+  }
+  const uint32_t* g_task = e->h_gtask_pinned;
   if (e->W)
     HIPCHK(hipMemcpyAsync(e->h_table_pinned, e->d_table.p, sizeof(pm_assignment) * e->W, hipMemcpyDeviceToHost,
                           e->stream));
-  if (G) HIPCHK(hipMemcpyAsync(g_task.data(), e->d_g_task_next.p, G * 4, hipMemcpyDeviceToHost, e->stream));
+  if (G) HIPCHK(hipMemcpyAsync(e->h_gtask_pinned, e->d_g_task_next.p, G * 4, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (size_t g = 0; g < G; ++g) {
     e->groups[g].task = g_task[g];
@@ -742,9 +803,13 @@ static void host_merge_select(pm_engine* e, const std::vector<uint32_t>& rem, co
 static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
   if (n_merged) *n_merged = 0;
   if (!e->have_cfgs || !e->have_workers) return set_error(PM_ESTATE, "configs and workers must be uploaded first");
-  size_t solo = 0;
+  size_t solo = e->absorb_pending ? e->ab_solo : 0;  // single-node groups of the carve not yet absorbed
   for (const Group& g : e->groups) solo += g.members.size() == 1;
   if (solo < 2) return PM_OK;  // mod.rs:641-644
+  {
+    int32_t rc0 = absorb_groups(e);
+    if (rc0) return rc0;
+  }
   int32_t rc = ensure_compat(e);
   if (rc) return rc;
   rc = pull_compat(e);
@@ -923,6 +988,10 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
       delete e;
       return set_error(PM_ENODEV, "hipEventCreate failed");
     }
+  if (hipEventCreateWithFlags(&e->ev_groups, hipEventDisableTiming) != hipSuccess) {
+    delete e;
+    return set_error(PM_ENODEV, "hipEventCreate failed");
+  }
   *out = e;
   return PM_OK;
 }
@@ -947,6 +1016,9 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release(); e->d_scratch.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
   e->d_table.release(); e->d_task_col.release(); e->d_nb_idx.release(); e->d_nb_val.release();
+  if (e->h_gstage) (void)hipHostFree(e->h_gstage);
+  if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
+  if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
   if (e->h_table_pinned) (void)hipHostFree(e->h_table_pinned);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1379,16 +1451,25 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   int32_t rc = ensure_compat(e);
   if (rc) return rc;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
-  rc = run_form(e, &n_formed);
+  // The host copy of the new groups is built while the pair sweep runs, unless the merge pass needs it.
+  host_mark("tick: compat queued");
+  rc = run_form(e, &n_formed, /*defer_absorb=*/true);
   if (rc) return rc;
+  host_mark("tick: form done");
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
   rc = run_merge(e, &n_merged);
   if (rc) return rc;
+  host_mark("tick: merge done");
   HIPCHK(hipEventRecord(e->ev[3], e->stream));
   rc = run_match(e, false, nullptr);
   if (rc) return rc;
+  host_mark("tick: match queued");
   HIPCHK(hipEventRecord(e->ev[4], e->stream));
+  rc = absorb_groups(e);
+  if (rc) return rc;
+  host_mark("tick: groups absorbed");
   rc = publish(e);
+  host_mark("tick: published");
   if (rc) return rc;
   HIPCHK(hipEventRecord(e->ev[5], e->stream));
   HIPCHK(hipEventSynchronize(e->ev[5]));

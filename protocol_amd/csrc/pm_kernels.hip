@@ -2194,6 +2194,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     for (uint32_t g = groups_at_entry + wave; g < c.n_groups; g += CARVE_WAVES) {
       const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
       for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
+      if (gn == 1u && lane == 0) atomicAdd(&p.status->n_solo, 1u);  // rare
     }
   }
   __syncthreads();
@@ -2353,6 +2354,23 @@ void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
   if (blocks > 2048u) blocks = 2048u;
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(carve_propose_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+}
+
+// ids of freshly carved groups: outputs k+1 .. of the splitmix64 stream whose state is `state`
+// (generate_group_id, injected — SURVEY section 8c), and an empty task word for each
+__global__ __launch_bounds__(256) void group_ids_kernel(uint64_t* __restrict__ g_id, uint32_t* __restrict__ g_task,
+                                                        uint32_t n, uint64_t state) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= n) return;
+  uint64_t z = state + (uint64_t)(k + 1u) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  g_id[k] = z ^ (z >> 31);
+  g_task[k] = PM_NONE;
+}
+void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(group_ids_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, g_id, g_task, n, rng_state);
 }
 
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s) {
