@@ -535,7 +535,7 @@ enum { STEP_CONTINUE = 0, STEP_BREAK = 1, STEP_UNCERTAIN = 2, STEP_OVERFLOW = 3 
 #define PROF_MARK(slot)                                                     \
   do {                                                                      \
     const uint64_t t_ = __builtin_amdgcn_s_memtime();                       \
-    if (threadIdx.x == 0 && (slot) >= 9) G(p.status)->prof[slot] += t_ - prof_t0;  \
+    if (threadIdx.x == 0) G(p.status)->prof[slot] += t_ - prof_t0;  \
     prof_t0 = t_;                                                           \
   } while (0)
 #else
@@ -575,21 +575,26 @@ enum { ROUND_OK = 0, ROUND_SLOW = 1, ROUND_RETRY = 2, ROUND_OVERFLOW = 3 };
 // only ever REMOVED, the reference's sorted remaining list is the proposal list minus the dead entries,
 // as long as the proposal still holds enough live entries and the boundary can be certified; otherwise
 // the step is handed to the exact full sweep (FAST_SLOW).
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
 #define PROF_COUNT(slot) do { if (lane == 0) G(p.status)->prof[slot] += 1; } while (0)
 #else
 #define PROF_COUNT(slot)
 #endif
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
 #define FP_DECL uint64_t fp_t = __builtin_amdgcn_s_memtime(), fp_acc[6] = {0, 0, 0, 0, 0, 0}
 #define FP_MARK(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); fp_acc[i] += t_ - fp_t; fp_t = t_; } while (0)
-#define FP_FLUSH() do { (void)fp_acc; } while (0)
+#define FP_FLUSH() do { if (lane == 0) { G(p.status)->prof[23] += fp_acc[0] + fp_acc[5]; } } while (0)
 #else
 #define FP_DECL
 #define FP_MARK(i)
 #define FP_FLUSH()
 #endif
 #define FAST_RETURN(code) do { FP_FLUSH(); c_ref = c; return (code); } while (0)
+#ifdef PM_CARVE_PROF  // why a step went to the exact sweep: 16 no proposal, 17 debug hook, 18 row exhausted, 19 certificate
+#define SLOW_RETURN(why) do { if (lane == 0) G(p.status)->prof[why] += 1; FAST_RETURN(FAST_SLOW); } while (0)
+#else
+#define SLOW_RETURN(why) FAST_RETURN(FAST_SLOW)
+#endif
 
 template <bool BIG>
 __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed& red, StepCtx& c_ref,
@@ -643,8 +648,10 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
   };
   const uint32_t lw = (c.n_list + 63u) >> 6;
   uint32_t row_ptr = 0;  // staged rows are in ascending slot order, and so are the seeds
+  uint32_t fc_j = 0;     // first bitmap word that may still hold a live slot (first-come steps)
   const uint32_t cache_n = red.cache_n;
   FP_DECL;
+  PROF_COUNT(20);  // calls
   for (;;) {
     FP_MARK(5);
     if (!(c.total_available >= c.min_s && c.n_cand >= c.min_s && c.n_cand > 0)) FAST_RETURN(FAST_DONE);
@@ -699,51 +706,72 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 
     if (f_loc == PM_NONE) {
       // no located candidate (or proximity off): the group is the first `want + 1` live slots in input
-      // order (mod.rs:553-561; a seed without location makes the sort a no-op, :238)
-      uint32_t cnt = 0;
-      const uint32_t need = want + 1u;
-      for (uint32_t j = 0; j < lw && cnt < need; ++j) {
-        uint64_t w = A[j];
-        if (!w) continue;
-        // take the lowest (need - cnt) set bits of w
-        const uint32_t pc = __popcll(w);
-        uint64_t take = w;
-        if (pc > need - cnt) {
-          uint64_t keep = w;
-          for (uint32_t k = 0; k < need - cnt; ++k) keep &= keep - 1ull;
-          take = w & ~keep;
+      // order (mod.rs:553-561; a seed without location makes the sort a no-op, :238).
+      // Once there is no located candidate there never will be one again, so the rest of the configuration
+      // is drained right here; these steps always take the lowest live slots, every word below fc_j is
+      // empty for good, and the scan resumes where it stopped.
+      uint32_t n_cand = UNI(c.n_cand), total_av = UNI(c.total_available), n_groups = UNI(c.n_groups),
+               mem_off = UNI(c.mem_off), steps = 0;
+      const uint32_t min_s = UNI(c.min_s), max_s = UNI(c.max_s), cfg = UNI(c.cfg);
+      unsigned long long cand_sum = 0;
+      int ret = FAST_DONE;
+      for (;;) {
+        if (!(total_av >= min_s && n_cand >= min_s && n_cand > 0u)) break;
+        const uint32_t need = max_s < n_cand ? max_s : n_cand;  // want + 1 (mod.rs:545-551)
+        if (n_groups >= cap_groups || mem_off + need > cap_members) {
+          ret = FAST_OVERFLOW;
+          break;
         }
-        const bool mine = (take >> lane) & 1ull;
-        if (mine) members[c.mem_off + cnt + __popcll(take & ((1ull << lane) - 1ull))] = wid_of(j * 64u + lane);
-        if (lane == 0) A[j] = w & ~take;
-        cnt += __popcll(take);
+        uint32_t cnt = 0;
+        for (uint32_t j = fc_j; j < lw && cnt < need; ++j) {
+          const uint64_t w = A[j];
+          const uint32_t w_lo = UNI((uint32_t)w), w_hi = UNI((uint32_t)(w >> 32));
+          if (!(w_lo | w_hi)) continue;
+          fc_j = j;
+          // the lowest (need - cnt) set bits of w: rank of each set bit within the word, one ballot
+          const uint32_t rk = __builtin_amdgcn_mbcnt_hi(w_hi, __builtin_amdgcn_mbcnt_lo(w_lo, 0u));
+          const bool mine = ((w >> lane) & 1ull) && rk < need - cnt;
+          const uint64_t take = __ballot(mine);
+          if (mine) members[mem_off + cnt + rk] = wid_of(j * 64u + lane);
+          if (lane == 0) A[j] = w & ~take;
+          cnt += __popcll(take);
+        }
+        if (lane == 0) {
+          g_cfg[n_groups] = cfg;
+          g_n[n_groups] = cnt;
+          g_off[n_groups] = mem_off;
+        }
+        n_groups += 1;
+        mem_off += cnt;
+        cand_sum += n_cand;
+        n_cand -= cnt;
+        total_av -= cnt;
+        steps += 1;
+        PROF_COUNT(21);  // first-come steps
       }
-      if (lane == 0) {
-        g_cfg[c.n_groups] = c.cfg;
-        g_n[c.n_groups] = cnt;
-        g_off[c.n_groups] = c.mem_off;
-      }
-      c.n_groups += 1;
-      c.mem_off += cnt;
-      c.cand_sum += c.n_cand;
-      c.n_cand -= cnt;
-      c.total_available -= cnt;
-      c.steps += 1;
-      c.fast_steps += 1;
-      continue;
+      c.n_groups = n_groups;
+      c.mem_off = mem_off;
+      c.cand_sum += cand_sum;
+      c.n_cand = n_cand;
+      c.total_available = total_av;
+      c.steps += steps;
+      c.fast_steps += steps;
+      FAST_RETURN(ret);
     }
 
+    PROF_COUNT(22);  // located sequential steps (attempts)
     const uint32_t seed = f_loc;
-    if (c.prop_k == 0 || seed >= c.prop_limit) {  FAST_RETURN(FAST_SLOW); }
-    if (dbg_every && ((steps_before + c.steps + 1u) % dbg_every) == 0u) FAST_RETURN(FAST_SLOW);
+    if (c.prop_k == 0 || seed >= c.prop_limit) {  SLOW_RETURN(16); }
+    if (dbg_every && ((steps_before + c.steps + 1u) % dbg_every) == 0u) SLOW_RETURN(17);
 
-    // ---- same-site shortcut: candidates with the seed's exact coordinates are at distance 0 — ahead of
-    // everybody else, in input (slot) order.  If `want` of them are still alive they ARE the group.
+    // ---- candidates with the seed's exact coordinates are at distance 0 — ahead of everybody else, in input
+    // (slot) order — and the proposal rows of shared sites leave them out: the same_next chain lists them
+    // (all of them lie behind the seed: a live one in front of it would have been the seed).  The group is
+    // the first live ones of the chain, topped up from the row.
     const uint32_t first_same = want > 0 ? C_NEXT[row_ptr] : PM_NONE;  // staged with the row
+    uint32_t cnt = 0, mine_slot = PM_NONE;
     if (first_same != PM_NONE) {
-      uint32_t cnt = 0;
       uint32_t t = first_same;
-      uint32_t mine_slot = PM_NONE;
       while (t != PM_NONE && cnt < want) {
         if (alive_at(t)) {
           if (lane == cnt) mine_slot = t;
@@ -751,28 +779,8 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         }
         t = next_of(t);
       }
-      if (cnt == want && want <= 64u) {
-        if (lane < want) {
-          kill(mine_slot);
-          members[c.mem_off + 1u + lane] = wid_of(mine_slot);
-        }
-        if (lane == 0) {
-          kill(seed);
-          members[c.mem_off] = wid_of(seed);
-          g_cfg[c.n_groups] = c.cfg;
-          g_n[c.n_groups] = want + 1u;
-          g_off[c.n_groups] = c.mem_off;
-        }
-        c.n_groups += 1;
-        c.mem_off += want + 1u;
-        c.cand_sum += c.n_cand;
-        c.n_cand -= want + 1u;
-        c.total_available -= want + 1u;
-        c.steps += 1;
-        c.fast_steps += 1;
-        continue;
-      }
     }
+    const uint32_t need = want - cnt;  // still to come from the row
 
     FP_MARK(1);
     // ---- the seed's neighbour list (staged in LDS, row_ptr points at it): one packed key per lane, ascending
@@ -787,12 +795,12 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     const bool alive = lane < n_k && alive_at(slot);
     const uint64_t am = __ballot(alive);
     const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
-    if ((uint32_t)__popcll(am) < want) {  FAST_RETURN(FAST_SLOW); }  // list exhausted by earlier groups
-    const bool sel = alive && rank < want;
+    if ((uint32_t)__popcll(am) < need) {  SLOW_RETURN(18); }  // list exhausted by earlier groups
+    const bool sel = alive && rank < need;
     FP_MARK(2);
     // the proposer certified the whole row (clean) and its tail (complete / tail_clear): nothing left to prove
-    if (want > 0 && !(row_clean && (complete || tail_clear))) {
-      const uint64_t lm = __ballot(sel && rank == want - 1u);
+    if (need > 0 && !(row_clean && (complete || tail_clear))) {
+      const uint64_t lm = __ballot(sel && rank == need - 1u);
       const int lane_m = __builtin_ctzll(lm);
       const uint64_t e_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), lane_m) << 32) |
                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, lane_m);
@@ -802,11 +810,11 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         // must sit at the same site (then the reference's distances tie exactly and slot order decides)
         const double a_m = __longlong_as_double((long long)kb_m);
         const double band = a_m * band_rel + 1e-300;
-        if (a_m > PM_A_MAX_SAFE) FAST_RETURN(FAST_SLOW);
+        if (a_m > PM_A_MAX_SAFE) SLOW_RETURN(19);
         const uint32_t site_m = site_of((uint32_t)(e_m & SLOT_MASK));
         const uint64_t kb = (e >> SB) << SB;
         const bool near = alive && !sel && kb != noloc_key && (__longlong_as_double((long long)kb) - a_m) <= band;
-        if (__ballot(near && site_of(slot) != site_m)) {  FAST_RETURN(FAST_SLOW); }
+        if (__ballot(near && site_of(slot) != site_m)) {  SLOW_RETURN(19); }
         if (!complete) {
           // candidates beyond the list are >= its last entry: either that entry clears the band, or it sits
           // at e_m's site and the proposer verified (tail_ok) that everything unlisted within the band of
@@ -816,16 +824,21 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, last_l);
           const uint64_t kb_l = (e_l >> SB) << SB;
           if (kb_l != noloc_key && (__longlong_as_double((long long)kb_l) - a_m) <= band) {
-            if (!(tail_ok && site_of((uint32_t)(e_l & SLOT_MASK)) == site_m)) FAST_RETURN(FAST_SLOW);
+            if (!(tail_ok && site_of((uint32_t)(e_l & SLOT_MASK)) == site_m)) SLOW_RETURN(19);
           }
         }
       }
     }
     FP_MARK(3);
-    // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
+    // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): same-site members
+    // first (distance 0, slot order), then the row's in key order
+    if (lane < cnt) {
+      kill(mine_slot);
+      members[c.mem_off + 1u + lane] = wid_of(mine_slot);
+    }
     if (sel) {
       kill(slot);
-      members[c.mem_off + 1u + rank] = wid_of(slot);
+      members[c.mem_off + 1u + cnt + rank] = wid_of(slot);
     }
     if (lane == 0) {
       kill(seed);
@@ -909,7 +922,6 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   };
   const uint32_t group_n = UNI(c.max_s);
   const uint32_t want = group_n - 1u;
-  const uint32_t margin = (CARVE_WAVES + 2u) * group_n + UNI(c.min_s);
   const uint32_t cache_n = UNI(red.cache_n);
   const uint32_t cfg = UNI(c.cfg);
   // Every group committed here has exactly max_s members, so all running counters are functions of the
@@ -925,16 +937,34 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   uint32_t next_row = 0, commits_done = 0;
 #ifdef PM_CARVE_PROF
   const uint64_t rt0 = __builtin_amdgcn_s_memtime();
+  uint32_t n_rounds_prof = 0;
+#endif
+#ifdef PM_CARVE_PROF_FINE
   uint64_t t_spec = 0, t_wait = 0, t_commit = 0, t_sync = 0, t_chk = 0, t_b2 = 0;
 #endif
   for (;;) {
 #ifdef PM_CARVE_PROF
+    ++n_rounds_prof;
+#endif
+#ifdef PM_CARVE_PROF_FINE
     uint64_t ta = __builtin_amdgcn_s_memtime();
-    if (tid == 0) G(p.status)->prof[1] += 1;
 #endif
     const uint32_t row_ptr = next_row;
-    if (base_cand - commits_done * group_n < margin) {
+    // Every commit of a round takes a full group (want = max_s - 1), which needs max_s live candidates in
+    // front of it (mod.rs:545-551) — that also keeps the loop guards true (max_s >= min_s): the round is as
+    // wide as the candidates allow, and the last partial group of a configuration goes to carve_fast_steps.
+    const uint32_t n_cand_now = base_cand - commits_done * group_n;
+    uint32_t n_fit = 0;
+#pragma unroll
+    for (uint32_t k = 1; k <= CARVE_WAVES; ++k) n_fit += (k * group_n <= n_cand_now) ? 1u : 0u;
+    if (n_fit == 0u) {
       action = FAST_SEQ;
+      break;
+    }
+    // More than half of the list is dead: the neighbour lists are thinning out.  Re-prepare (compact) and
+    // re-propose now, before rows start running out of live entries and every step needs the exact sweep.
+    if (n_cand_now * 2u < n_list_v && n_list_v > 256u && commits_done > 0u) {
+      action = FAST_REPROPOSE;
       break;
     }
     // ---- the live staged rows of this 64-row window, in order; wave w takes the w-th
@@ -951,7 +981,7 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
       continue;
     }
     const uint32_t n_live = __popcll(m);
-    const uint32_t n_round = n_live < CARVE_WAVES ? n_live : CARVE_WAVES;
+    const uint32_t n_round = n_live < n_fit ? n_live : n_fit;
     // the lane holding the k-th live row, without a loop: rank of each live lane, one ballot per question
     const uint32_t rank_l = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     const bool have = wave < n_round;
@@ -978,9 +1008,13 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
       const uint32_t n_k = nk_word & 0xFFu;
       const bool alive = lane < n_k && alive_at(slot);
       const uint32_t first_same = want > 0 ? UNI(fs_raw) : PM_NONE;
-      bool done = false;
-      if (first_same != PM_NONE) {  // same-site shortcut (see carve_fast_steps)
-        uint32_t cnt = 0, t = first_same, ms = PM_NONE;
+      // Candidates at the seed's own site are at distance 0 — ahead of everybody else, in slot order — and
+      // the proposal rows of shared sites leave them out: the same_next chain lists them (all of them lie
+      // behind the seed: a live one in front of it would have been the seed).  The group is the first live
+      // ones of the chain, topped up from the row.
+      uint32_t cnt = 0, ms = PM_NONE;
+      if (first_same != PM_NONE) {
+        uint32_t t = first_same;
         while (t != PM_NONE && cnt < want) {
           const uint32_t tn = UNI(next_of(t));  // issued together with the bitmap word
           if (UNI((uint32_t)alive_at(t))) {
@@ -989,24 +1023,22 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
           }
           t = tn;
         }
-        if (cnt == want) {
-          if (lane < want) CLAIM[cbase + lane] = ms;
-          done = true;
-        }
       }
-      if (!done) {
+      if (lane < cnt) CLAIM[cbase + lane] = ms;
+      if (cnt < want) {
+        const uint32_t need = want - cnt;  // still to come from the row
         const bool complete = (nk_word >> 31) != 0u;
         const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
         const bool row_clean = ((nk_word >> 29) & 1u) != 0u;
         const bool tail_clear = ((nk_word >> 28) & 1u) != 0u;
         const uint64_t am = __ballot(alive);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-        if ((uint32_t)__popcll(am) < want) {
+        if ((uint32_t)__popcll(am) < need) {
           res = ROUND_SLOW;
         } else {
-          const bool sel = alive && rank < want;
-          if (want > 0 && !(row_clean && (complete || tail_clear))) {
-            const uint64_t lm = __ballot(sel && rank == want - 1u);
+          const bool sel = alive && rank < need;
+          if (!(row_clean && (complete || tail_clear))) {
+            const uint64_t lm = __ballot(sel && rank == need - 1u);
             const int lane_m = __builtin_ctzll(lm);
             const uint64_t e_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), lane_m) << 32) |
                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, lane_m);
@@ -1029,7 +1061,7 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
               }
             }
           }
-          if (sel) CLAIM[cbase + rank] = slot;  // the scatter is the compaction: rank = position in the group
+          if (sel) CLAIM[cbase + cnt + rank] = slot;  // the scatter is the compaction: rank = position in the group
         }
       }
       if (res != ROUND_OK && lane < want) CLAIM[cbase + lane] = 0xFFFFFFFEu;  // no claim
@@ -1038,11 +1070,11 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     // my claims as the other waves will see them (lane k = member k, lane want = the seed)
     const uint32_t mine_l = (have && lane <= want) ? CLAIM[cbase + lane] : PM_NONE;
     if (have && res == ROUND_OK && lane < want) my_wid = wid_of(mine_l);
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_spec += tb - ta; ta = tb; }
 #endif
     lds_barrier();
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; ta = tb; }
 #endif
     // ---- which earlier waves of this round claim one of my slots (conf) / my seed (seed_hit)?  Slots only
@@ -1072,11 +1104,11 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
       }
     }
     if (have && lane == 0) CONF[wave] = conf | (seed_hit << 8) | (res << 16);
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_chk += tb - ta; ta = tb; }
 #endif
     lds_barrier();
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_b2 += tb - ta; ta = tb; }
 #endif
     // ---- every wave replays the round identically, in seed order, from the conflict words: a wave whose
@@ -1123,11 +1155,11 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
       }
     }
     commits_done = commits;
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_commit += tb - ta; ta = tb; }
 #endif
     lds_barrier();  // the round's bitmap updates are in place
-#ifdef PM_CARVE_PROF
+#ifdef PM_CARVE_PROF_FINE
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_sync += tb - ta; ta = tb; }
 #endif
     next_row = row_ptr + last_l + 1u;
@@ -1155,9 +1187,12 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
 #ifdef PM_CARVE_PROF
     if (tid == 0) {
       G(p.status)->prof[0] += __builtin_amdgcn_s_memtime() - rt0;
+      G(p.status)->prof[1] += n_rounds_prof;
       G(p.status)->prof[2] += commits;
-      G(p.status)->prof[5] += t_spec;
     }
+#endif
+#ifdef PM_CARVE_PROF_FINE
+    if (tid == 0) G(p.status)->prof[5] += t_spec;
     if (tid == 64) { G(p.status)->prof[6] += t_wait; G(p.status)->prof[7] += t_commit; G(p.status)->prof[8] += t_sync; G(p.status)->prof[16] += t_chk; G(p.status)->prof[17] += t_b2; }
     if (tid == 448) { G(p.status)->prof[18] += t_chk; G(p.status)->prof[19] += t_spec; }
 #endif
@@ -1198,9 +1233,12 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
   for (;;) {
     if (have_props) {
       if (!cache_valid && c.prop_k) {
+        PROF_DECL;
         // ---- stage the proposal rows of the next PM_CARVE_CACHE_ROWS live located slots in LDS (they
         // alias l_key, which only the slow sweep uses): wave 0 lists the slots, all waves copy the rows
         if (wave == 0) {
+          // 64 bitmap words per pass, one word per lane; the non-empty ones are then visited in order with
+          // the whole wave looking at one word (lane = bit): rank within the word + running base = row
           uint32_t base = 0;
           for (uint32_t j0 = 0; j0 < lw && base < PM_CARVE_CACHE_ROWS; j0 += 64u) {
             const uint32_t j = j0 + lane;
@@ -1208,26 +1246,21 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
             // proposals exist for slots below prop_limit only
             if (j * 64u + 64u > c.prop_limit)
               w = (j * 64u >= c.prop_limit) ? 0ull : (w & ((1ull << (c.prop_limit & 63u)) - 1ull));
-            const uint32_t cnt = __popcll(w);
-            uint32_t incl = cnt;  // inclusive prefix sum over the 64 lanes
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-              const uint32_t up = __shfl_up(incl, o, 64);
-              if ((int)lane >= o) incl += up;
+            uint64_t nz = __ballot(w != 0ull);
+            while (nz && base < PM_CARVE_CACHE_ROWS) {
+              const int src = __builtin_ctzll(nz);
+              nz &= nz - 1ull;
+              const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, src);
+              const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), src);
+              const uint32_t bit = ((lane < 32u ? w_lo >> lane : w_hi >> (lane - 32u)) & 1u);
+              const uint32_t r = base + __builtin_amdgcn_mbcnt_hi(w_hi, __builtin_amdgcn_mbcnt_lo(w_lo, 0u));
+              if (bit && r < PM_CARVE_CACHE_ROWS) red.cache_slot[r] = (j0 + (uint32_t)src) * 64u + lane;
+              base += (uint32_t)__popc(w_lo) + (uint32_t)__popc(w_hi);
             }
-            uint32_t r = base + incl - cnt;
-            while (w && r < PM_CARVE_CACHE_ROWS) {
-              red.cache_slot[r++] = j * 64u + __builtin_ctzll(w);
-              w &= w - 1ull;
-            }
-            base += __shfl(incl, 63, 64);
           }
           if (lane == 0) red.cache_n = base < PM_CARVE_CACHE_ROWS ? base : PM_CARVE_CACHE_ROWS;
         }
         lds_barrier();
-#ifdef PM_CARVE_PROF
-        (void)0;
-#endif
         const uint32_t rows = red.cache_n;
         {  // all loads of a wave are issued before the first LDS store (rows: one u64 per lane; directory
            // words: one staged row per thread)
@@ -1255,11 +1288,16 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         }
         lds_barrier();
         cache_valid = true;
+        PROF_MARK(20);  // staging
+#ifdef PM_CARVE_PROF
+        if (tid == 0) G(p.status)->prof[21] += 1;
+#endif
       }
       if (c.prop_k && c.proximity && p.rounds_enabled) {
         const int ract = carve_fast_rounds<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive,
                                                 reinterpret_cast<uint32_t*>(part), steps_before);
         if (ract == FAST_OVERFLOW) return STEP_OVERFLOW;
+        if (ract == FAST_REPROPOSE) return STEP_CONTINUE;  // re-prepare + next proposal round
         if (ract == FAST_REFILL) {
           cache_valid = false;
           continue;
@@ -1332,7 +1370,6 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         }
       }
     }
-    PROF_MARK(0);
 
     const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // fill to max (mod.rs:545-551)
     uint32_t seed = f_any;
@@ -1381,8 +1418,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         l_key[s] = k;
         lmin = k < lmin ? k : lmin;
       }
-      PROF_MARK(1);
-      n_sel = 0;
+        n_sel = 0;
       last = 0;
       if (want > 0) {
         if (want <= PM_CARVE_PART) {
@@ -1403,10 +1439,8 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
             }
           }
           if (lane == 0) red.part_n[wave] = cnt;
-          PROF_MARK(2);
-          lds_barrier();
-          PROF_MARK(3);
-          // ---- level 2: 16-way merge of the sorted partial lists, redundantly in every wave
+                lds_barrier();
+                // ---- level 2: 16-way merge of the sorted partial lists, redundantly in every wave
           uint32_t ptr = 0;
           const uint32_t my_n = lane < CARVE_WAVES ? red.part_n[lane] : 0u;
           uint64_t head = my_n ? part[lane * PM_CARVE_PART] : ~0ull;
@@ -1423,8 +1457,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
             }
           }
           if (wave == 0 && lane < n_sel) sel_out[lane] = (uint32_t)(mine & ((1ull << SB) - 1ull));
-          PROF_MARK(4);
-        } else {
+              } else {
           // ---- wide groups: one workgroup-wide round per member (wave argmin -> LDS -> fold)
           while (n_sel < want) {
             const uint64_t v = wave_min_u64(lmin);
@@ -1484,9 +1517,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
     }
     const uint64_t ub = __ballot(uncertain != 0);
     if (lane == 0) red.flag[wave] = ub != 0ull;
-    PROF_MARK(5);
     lds_barrier();
-    PROF_MARK(6);
     uint32_t any = 0;
 #pragma unroll
     for (uint32_t k = 0; k < CARVE_WAVES; ++k) any |= red.flag[k];
@@ -1515,9 +1546,8 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
       const uint32_t lim = n_sel < PM_CARVE_SEL_CAP ? n_sel : PM_CARVE_SEL_CAP;
       for (uint32_t r = lane; r < lim; r += 64u) G(p.members)[c.mem_off + 1u + r] = wid_of(sel_out[r]);
     }
-    PROF_MARK(7);
     lds_barrier();
-    PROF_MARK(8);
+    PROF_MARK(22);  // one exact step
     c.n_groups += 1;
     c.mem_off += total;
     c.cand_sum += c.n_cand;
@@ -1812,6 +1842,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     if (lane == 0) G(p.same_next)[s] = same;
     if (s >= limit) continue;  // beyond this round's proposal batch
     const double slat = G(p.cc_lat)[s], slon = G(p.cc_lon)[s], scos = G(p.cc_cos)[s];
+    const bool shared = (ssite & 0x80000000u) != 0u;
     uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull, r3 = ~0ull;
     uint32_t n_mine = 0;
     // The sweep is a chain of L2-latency loads: issue the loads of four 64-slot strides together.
@@ -1829,6 +1860,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         tla[u] = need ? G(p.cc_lat)[t] : 0.0;
         tlo[u] = need ? G(p.cc_lon)[t] : 0.0;
         tco[u] = need ? G(p.cc_cos)[t] : 0.0;
+        // candidates at the seed's own (shared) site are not listed: the validator takes them from the
+        // same_next chain, ahead of everything in the row
+        if (shared && need && G(p.cc_site)[t] == ssite) aw[u] &= ~(1ull << lane);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1859,6 +1893,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
           for (uint32_t j = 0; j < lw; ++j) {
             const uint32_t t = j * 64u + lane;
             if (!((alive[j] >> lane) & 1ull) || t == s) continue;
+            if (shared && ((loc[j] >> lane) & 1ull) && G(p.cc_site)[t] == ssite) continue;  // not listed
             const uint64_t k = ((loc[j] >> lane) & 1ull)
                                    ? pack_key((uint64_t)__double_as_longlong(
                                                   hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB)
@@ -1909,6 +1944,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
           for (uint32_t j = 0; j < lw; ++j) {
             const uint32_t t = j * 64u + lane;
             if (!((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
+            if (shared && G(p.cc_site)[t] == ssite) continue;  // same-site candidates never enter the row
             const uint64_t k = pack_key((uint64_t)__double_as_longlong(
                                             hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB);
             if (k <= e_last) continue;  // listed
@@ -2102,9 +2138,6 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       }
       prepared = true;
       PROF_MARK(9);
-#ifdef PM_CARVE_PROF
-      (void)0;
-#endif
       if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
     } else {
       c.n_list = st->n_list;
@@ -2302,8 +2335,8 @@ void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const u
     }
     uint32_t* part_count = scratch + (size_t)n_chunks * R;
     if (n_words == 0) {
-      hipMemsetAsync(part_first, 0xFF, sizeof(uint32_t) * R, s);
-      hipMemsetAsync(part_count, 0, sizeof(uint32_t) * R, s);
+      (void)hipMemsetAsync(part_first, 0xFF, sizeof(uint32_t) * R, s);
+      (void)hipMemsetAsync(part_count, 0, sizeof(uint32_t) * R, s);
     } else {
       const size_t lds = (size_t)n_planes * wpc * sizeof(uint64_t);
       hipLaunchKernelGGL(pair_sweep_planes_kernel<64>, dim3(rb, n_chunks), dim3(256), lds, s, row_sel, R, planes,
