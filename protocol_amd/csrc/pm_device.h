@@ -83,7 +83,7 @@ struct CarveStatus {
   uint32_t slow_steps;   // steps that needed the full key sweep
   uint32_t n_solo;       // single-node groups carved (the merge pass only runs when there are two or more)
   uint32_t _pad_solo;
-  unsigned long long prof[24];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
+  unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
 struct CarveArgs {

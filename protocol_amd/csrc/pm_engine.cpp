@@ -89,7 +89,7 @@ struct pm_engine {
   float k_ms_compat = 0, k_ms_carve = 0, k_ms_sweep = 0;
   bool k_sweep_recorded = false, k_compat_recorded = false;
   uint64_t tick_cand_sum = 0;
-  unsigned long long carve_prof[24]{};
+  unsigned long long carve_prof[32]{};
   std::mutex mu;
 
   // ---- configuration tables

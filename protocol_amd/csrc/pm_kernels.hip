@@ -1797,15 +1797,72 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
 }
 
 // Proposal generator: one wave per located live slot of the prepared configuration.  The wave sweeps the
-// whole candidate list (coalesced 64-slot strides), every lane keeps its four smallest keys in registers,
+// whole candidate list (coalesced 64-slot strides), every lane keeps its PM_TOPN smallest keys in registers,
 // and K rounds of DPP argmin pop the K nearest in (key, slot) order.  A lane whose four entries are all
 // consumed re-sweeps its own slots for keys beyond the last one popped.
-__device__ __forceinline__ void top4_insert(uint64_t k, uint64_t& r0, uint64_t& r1, uint64_t& r2, uint64_t& r3) {
-  if (k < r3) {
-    r3 = k;
-    if (r3 < r2) { const uint64_t t = r2; r2 = r3; r3 = t; }
-    if (r2 < r1) { const uint64_t t = r1; r1 = r2; r2 = t; }
-    if (r1 < r0) { const uint64_t t = r0; r0 = r1; r1 = t; }
+#define PM_TOPN 8  // smallest keys each lane keeps (a lane holding more than that of the K nearest re-sweeps)
+struct TopN {
+  uint64_t r[PM_TOPN];  // ascending; ~0 = empty
+};
+__device__ __forceinline__ void topn_insert(uint64_t k, TopN& q) {
+  if (k < q.r[PM_TOPN - 1]) {
+    q.r[PM_TOPN - 1] = k;
+#pragma unroll
+    for (int i = PM_TOPN - 1; i > 0; --i) {
+      const uint64_t lo = q.r[i] < q.r[i - 1] ? q.r[i] : q.r[i - 1];
+      const uint64_t hi = q.r[i] < q.r[i - 1] ? q.r[i - 1] : q.r[i];
+      q.r[i - 1] = lo;
+      q.r[i] = hi;
+    }
+  }
+}
+__device__ __forceinline__ void topn_pop(TopN& q) {
+#pragma unroll
+  for (int i = 0; i + 1 < PM_TOPN; ++i) q.r[i] = q.r[i + 1];
+  q.r[PM_TOPN - 1] = ~0ull;
+}
+
+struct SweepBatch {
+  uint64_t aw[4], lwd[4];  // alive / located words of the four strides (lane = bit)
+  double tla[4], tlo[4], tco[4];
+  uint32_t tsi[4];
+};
+// Loads of four 64-slot strides starting at word j0.  Every load is unconditional (indices clamped into the
+// list) and independent of the others — a load guarded by the bitmap word would wait for that word first —
+// so a whole batch is in flight at once; the bitmaps are applied when the keys are formed.
+template <typename BP>
+__device__ __forceinline__ void sweep_load(const CarveArgs& p, BP alive, BP loc, uint32_t lw, uint32_t n_list,
+                                           uint32_t j0, uint32_t lane, bool shared, SweepBatch& b) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t j = j0 + (uint32_t)u;
+    const uint32_t jc = j < lw ? j : lw - 1u;
+    const uint32_t t = j * 64u + lane;
+    const uint32_t tc = t < n_list ? t : n_list - 1u;
+    b.aw[u] = alive[jc];
+    b.lwd[u] = loc[jc];
+    b.tla[u] = G(p.cc_lat)[tc];
+    b.tlo[u] = G(p.cc_lon)[tc];
+    b.tco[u] = G(p.cc_cos)[tc];
+    b.tsi[u] = shared ? G(p.cc_site)[tc] : 0u;
+  }
+}
+__device__ __forceinline__ void sweep_keys(const SweepBatch& b, uint32_t lw, uint32_t j0, uint32_t lane, uint32_t s,
+                                           bool shared, uint32_t ssite, double slat, double slon, double scos,
+                                           uint32_t SB, TopN& q, uint32_t& n_mine) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t j = j0 + (uint32_t)u;
+    const uint32_t t = j * 64u + lane;
+    if (j >= lw || !((b.aw[u] >> lane) & 1ull) || t == s) continue;
+    const bool located = (b.lwd[u] >> lane) & 1ull;
+    // candidates at the seed's own (shared) site are not listed: the validator takes them from the
+    // same_next chain, ahead of everything in the row
+    if (shared && located && b.tsi[u] == ssite) continue;
+    const uint64_t k = located ? pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, b.tla[u], b.tlo[u], b.tco[u])), t, SB)
+                               : pack_key(PM_KEY_NOLOC, t, SB);
+    topn_insert(k, q);
+    ++n_mine;
   }
 }
 
@@ -1827,58 +1884,68 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     const uint32_t ssite = G(p.cc_site)[s];
     // next located slot at the same site (the validator's same-site shortcut walks these links); only sites
     // shared by several workers (bit 31 of the interned id) can have one
+#ifdef PM_CARVE_PROF
+    uint64_t pt = __builtin_amdgcn_s_memtime(), pt_same = 0, pt_sweep = 0, pt_pop = 0, pt_flags = 0, n_resweep = 0;
+#define PP_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - pt; pt = t_; } while (0)
+#else
+#define PP_MARK(var)
+#endif
     uint32_t same = PM_NONE;
     if (ssite & 0x80000000u) {
-      for (uint32_t j = s >> 6; j < lw; ++j) {
-        const uint32_t t = j * 64u + lane;
-        const bool hit = t > s && t < n_list && ((alive[j] >> lane) & (loc[j] >> lane) & 1ull) && G(p.cc_site)[t] == ssite;
-        const uint64_t hm = __ballot(hit);
-        if (hm) {
-          same = j * 64u + (uint32_t)__builtin_ctzll(hm);
-          break;
+      // eight strides per step, every load unconditional and independent (see sweep_load): the last member
+      // of a site scans to the end of the list, and a load per step would make that wave the launch's tail
+      for (uint32_t j0 = s >> 6; j0 < lw && same == PM_NONE; j0 += 8u) {
+        uint32_t si[8];
+        uint64_t m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t j = j0 + (uint32_t)u;
+          const uint32_t jc = j < lw ? j : lw - 1u;
+          const uint32_t t = j * 64u + lane;
+          si[u] = G(p.cc_site)[t < n_list ? t : n_list - 1u];
+          m[u] = alive[jc] & loc[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t j = j0 + (uint32_t)u;
+          const uint32_t t = j * 64u + lane;
+          const bool hit = j < lw && t > s && t < n_list && ((m[u] >> lane) & 1ull) && si[u] == ssite;
+          const uint64_t hm = __ballot(hit);
+          if (hm && same == PM_NONE) same = j * 64u + (uint32_t)__builtin_ctzll(hm);
         }
       }
     }
     if (lane == 0) G(p.same_next)[s] = same;
+    PP_MARK(pt_same);
+#ifdef PM_CARVE_PROF
+    if (s >= limit && lane == 0) {
+      atomicAdd((unsigned long long*)&p.status->prof[5], (unsigned long long)pt_same);
+      atomicMax((unsigned long long*)&p.status->prof[23], (unsigned long long)pt_same);
+    }
+#endif
     if (s >= limit) continue;  // beyond this round's proposal batch
     const double slat = G(p.cc_lat)[s], slon = G(p.cc_lon)[s], scos = G(p.cc_cos)[s];
     const bool shared = (ssite & 0x80000000u) != 0u;
-    uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull, r3 = ~0ull;
+    TopN q;
+#pragma unroll
+    for (int i = 0; i < PM_TOPN; ++i) q.r[i] = ~0ull;
     uint32_t n_mine = 0;
-    // The sweep is a chain of L2-latency loads: issue the loads of four 64-slot strides together.
-    for (uint32_t j0 = 0; j0 < lw; j0 += 4u) {
-      uint64_t aw[4], lwd[4];
-      double tla[4], tlo[4], tco[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t j = j0 + (uint32_t)u;
-        const bool in = j < lw;
-        aw[u] = in ? alive[j] : 0ull;
-        lwd[u] = in ? loc[j] : 0ull;
-        const uint32_t t = j * 64u + lane;
-        const bool need = (aw[u] >> lane) & (lwd[u] >> lane) & 1ull;
-        tla[u] = need ? G(p.cc_lat)[t] : 0.0;
-        tlo[u] = need ? G(p.cc_lon)[t] : 0.0;
-        tco[u] = need ? G(p.cc_cos)[t] : 0.0;
-        // candidates at the seed's own (shared) site are not listed: the validator takes them from the
-        // same_next chain, ahead of everything in the row
-        if (shared && need && G(p.cc_site)[t] == ssite) aw[u] &= ~(1ull << lane);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t t = (j0 + (uint32_t)u) * 64u + lane;
-        if (!((aw[u] >> lane) & 1ull) || t == s) continue;
-        const bool located = (lwd[u] >> lane) & 1ull;
-        const uint64_t k = located ? pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, tla[u], tlo[u], tco[u])), t, SB)
-                                   : pack_key(PM_KEY_NOLOC, t, SB);
-        top4_insert(k, r0, r1, r2, r3);
-        ++n_mine;
-      }
+    // The sweep is a chain of L2-latency loads with ~70 f64 operations per key in between.  One wave per SIMD
+    // has nobody to hide that latency behind, so the loop is software-pipelined: the loads of the next four
+    // 64-slot strides are in flight while the keys of the current four are computed (two register sets).
+    SweepBatch ba, bb;
+    sweep_load(p, alive, loc, lw, n_list, 0u, lane, shared, ba);
+    for (uint32_t j0 = 0; j0 < lw; j0 += 8u) {
+      sweep_load(p, alive, loc, lw, n_list, j0 + 4u, lane, shared, bb);
+      sweep_keys(ba, lw, j0, lane, s, shared, ssite, slat, slon, scos, SB, q, n_mine);
+      sweep_load(p, alive, loc, lw, n_list, j0 + 8u, lane, shared, ba);
+      sweep_keys(bb, lw, j0 + 4u, lane, s, shared, ssite, slat, slon, scos, SB, q, n_mine);
     }
+    PP_MARK(pt_sweep);
     uint32_t popped = 0, n_k = 0;
     uint64_t mine = ~0ull, beyond = ~0ull;  // beyond = the (K+1)-th key, if any
     while (n_k <= K) {
-      const uint64_t v = wave_min_u64(r0);
+      const uint64_t v = wave_min_u64(q.r[0]);
       if (v == ~0ull) break;
       if (n_k == K) {
         beyond = v;
@@ -1886,10 +1953,13 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       }
       if (lane == n_k) mine = v;
       ++n_k;
-      if (r0 == v) {
-        r0 = r1; r1 = r2; r2 = r3; r3 = ~0ull;
+      if (q.r[0] == v) {
+        topn_pop(q);
         ++popped;
-        if (r0 == ~0ull && popped < n_mine) {  // entries were dropped: re-sweep this lane's slots beyond v
+#ifdef PM_CARVE_PROF
+        if (q.r[0] == ~0ull && popped < n_mine) n_resweep = 1;
+#endif
+        if (q.r[0] == ~0ull && popped < n_mine) {  // entries were dropped: re-sweep this lane's slots beyond v
           for (uint32_t j = 0; j < lw; ++j) {
             const uint32_t t = j * 64u + lane;
             if (!((alive[j] >> lane) & 1ull) || t == s) continue;
@@ -1898,11 +1968,12 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
                                    ? pack_key((uint64_t)__double_as_longlong(
                                                   hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB)
                                    : pack_key(PM_KEY_NOLOC, t, SB);
-            if (k > v) top4_insert(k, r0, r1, r2, r3);
+            if (k > v) topn_insert(k, q);
           }
         }
       }
     }
+    PP_MARK(pt_pop);
     const uint64_t noloc_kb = (PM_KEY_NOLOC >> SB) << SB;
     // row certificates the validator can rely on instead of re-deriving them at every step:
     //  clean      — no two neighbouring entries within the band of each other sit at different sites (entries in
@@ -1940,21 +2011,58 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         } else {
           const uint32_t site_last = G(p.cc_site)[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
           const double band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
+          // The unlisted candidates closest to the last entry are still in the lanes' registers (ascending):
+          // check those within the band; only a lane whose registers are all within the band AND that dropped
+          // candidates during the sweep cannot tell, and falls back to a re-sweep of its own slots.
           int bad = 0;
-          for (uint32_t j = 0; j < lw; ++j) {
-            const uint32_t t = j * 64u + lane;
-            if (!((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
-            if (shared && G(p.cc_site)[t] == ssite) continue;  // same-site candidates never enter the row
-            const uint64_t k = pack_key((uint64_t)__double_as_longlong(
-                                            hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB);
-            if (k <= e_last) continue;  // listed
-            const double a = __longlong_as_double((long long)((k >> SB) << SB));
-            if (a - a_last <= band2 && G(p.cc_site)[t] != site_last) bad = 1;
+          bool unknown = false;
+          uint32_t in_regs = 0;
+#pragma unroll
+          for (int i = 0; i < PM_TOPN; ++i) {
+            const uint64_t k = q.r[i];
+            if (k == ~0ull) continue;
+            ++in_regs;
+            const uint64_t kb2 = (k >> SB) << SB;
+            if (kb2 == noloc_kb) continue;
+            const double a = __longlong_as_double((long long)kb2);
+            if (a - a_last <= band2) {
+              if (G(p.cc_site)[(uint32_t)(k & ((1ull << SB) - 1ull))] != site_last) bad = 1;
+              if (i == PM_TOPN - 1) unknown = true;
+            }
+          }
+          unknown = unknown && (n_mine - popped > in_regs);
+          if (__ballot(unknown)) {
+            for (uint32_t j = 0; j < lw; ++j) {
+              const uint32_t t = j * 64u + lane;
+              if (!unknown || !((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
+              if (shared && G(p.cc_site)[t] == ssite) continue;  // same-site candidates never enter the row
+              const uint64_t k = pack_key((uint64_t)__double_as_longlong(
+                                              hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB);
+              if (k <= e_last) continue;  // listed
+              const double a = __longlong_as_double((long long)((k >> SB) << SB));
+              if (a - a_last <= band2 && G(p.cc_site)[t] != site_last) bad = 1;
+            }
           }
           tail_ok = __ballot(bad) == 0ull;
         }
       }
     }
+    PP_MARK(pt_flags);
+#ifdef PM_CARVE_PROF
+    {
+      const uint64_t any_re = __ballot(n_resweep != 0);
+      if (lane == 0) {
+        unsigned long long* pr = (unsigned long long*)p.status->prof;
+        atomicAdd(&pr[5], (unsigned long long)pt_same);
+        atomicAdd(&pr[6], (unsigned long long)pt_sweep);
+        atomicAdd(&pr[7], (unsigned long long)pt_pop);
+        atomicAdd(&pr[8], (unsigned long long)pt_flags);
+        atomicAdd(&pr[24], 1ull);
+        atomicAdd(&pr[25], any_re ? 1ull : 0ull);
+        atomicMax(&pr[23], (unsigned long long)(pt_same + pt_sweep + pt_pop + pt_flags));
+      }
+    }
+#endif
     G(p.prop)[(size_t)s * PM_PROP_ROW + lane] = mine;
     if (lane == 0) {
       G(p.prop_n)[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);

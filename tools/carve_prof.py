@@ -23,7 +23,7 @@ host.load_swarm(eng, sw)
 for it in range(3):
     eng.reset_groups()
     s = eng.tick()
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 32)()
 E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 E.lib().pm_debug_carve_prof(eng._h, out)
 tot = out[15] + out[9] + out[10] + out[13] + out[12] + out[14]
@@ -36,6 +36,7 @@ print(f"  launch anatomy (ticks): init/status={out[15]} ({pct(out[15])}) prepare
 print(f"  inside run: rounds={out[0]} ({pct(out[0])}; {out[1]} rounds, {out[2]} commits, {out[3]} retries, {out[4]} exact-sweep stops) "
       f"sequential path={out[11]} ({pct(out[11])}) staging={out[20]} ({pct(out[20])}; {out[21]} refills) exact steps={out[22]} ({pct(out[22])})")
 print(f"  exact-sweep reasons: no proposal={out[16]} debug hook={out[17]} row exhausted={out[18]} certificate={out[19]}")
+print(f"  proposer waves: {out[24]} proposals ({out[25]} with a lane re-sweep); ticks summed over waves: same-site links={out[5]} sweep={out[6]} pop={out[7]} flags={out[8]}; slowest wave={out[23]}")
 if out[5]:
     print(f"  fine: wave0 spec={out[5]}; wave1 wait={out[6]} commit={out[7]} sync={out[8]} chk={out[16]} b2wait={out[17]}; wave7 chk={out[18]} spec={out[19]}")
 print(f"  total ticks {tot}; ticks per ms = {tot / s['ms_carve_kernel']:.0f}")
