@@ -1714,19 +1714,23 @@ __device__ __noinline__ uint32_t carve_compact_count(const CarveArgs& p, BlockRe
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
   const uint32_t j0 = wave * wpw, j1 = min(n_words, j0 + wpw);
   uint32_t cnt = 0;
-  for (uint32_t jb = j0; jb < j1; jb += 4u) {  // four words per batch: their loads are in flight together
-    uint64_t aw[4], cm[4];
+  const bool merge = p.mode == CARVE_MODE_MERGE;
+  const auto alive_g = G((const uint64_t*)p.alive_g);
+  const auto c_compat = G((const uint64_t*)p.c_compat);
+  for (uint32_t jb = j0; jb < j1; jb += 8u) {  // eight words per batch; every load unconditional (clamped
+    uint64_t aw[8], cm[8];                     // index) and independent, so the whole batch is in flight at once
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const uint32_t j = jb + (uint32_t)u;
       const uint32_t i = j * 64u + lane;
-      aw[u] = j < j1 ? G(p.alive_g)[j] : 0ull;
-      cm[u] = (j < j1 && i < n && p.mode != CARVE_MODE_MERGE) ? G(p.c_compat)[i] : ~0ull;
+      aw[u] = alive_g[j < n_words ? j : n_words - 1u];
+      cm[u] = merge ? ~0ull : c_compat[i < n ? i : n - 1u];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t i = (jb + (uint32_t)u) * 64u + lane;
-      const bool c = i < n && ((aw[u] >> lane) & 1ull) && (cm[u] & cbit) != 0ull;
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t j = jb + (uint32_t)u;
+      const uint32_t i = j * 64u + lane;
+      const bool c = j < j1 && i < n && ((aw[u] >> lane) & 1ull) && (cm[u] & cbit) != 0ull;
       cnt += __popcll(__ballot(c));
     }
   }
@@ -1747,31 +1751,36 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
   const auto loc = G(p.bits_scratch) + p.bits_stride;
   uint32_t off = 0;
   for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
+  const bool merge = p.mode == CARVE_MODE_MERGE;
+  const auto alive_g = G((const uint64_t*)p.alive_g);
+  const auto c_compat = G((const uint64_t*)p.c_compat);
   for (uint32_t jb = j0; jb < j1; jb += 4u) {
-    uint64_t aw[4], cm[4];
+    uint64_t aw[4], cm[4], lg[4];
     uint32_t ow[4], os[4];
     double la[4], lo[4], co[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {  // every load of the batch first
+    for (int u = 0; u < 4; ++u) {  // every load of the batch first, unconditional (clamped index)
       const uint32_t j = jb + (uint32_t)u;
       const uint32_t i = j * 64u + lane;
-      const bool in = j < j1 && i < n;
-      aw[u] = j < j1 ? G(p.alive_g)[j] : 0ull;
-      cm[u] = (in && p.mode != CARVE_MODE_MERGE) ? G(p.c_compat)[i] : ~0ull;
-      ow[u] = in ? G(p.order)[i] : 0u;
-      os[u] = in ? G(p.c_site)[i] : 0u;
-      la[u] = in ? G(p.c_lat)[i] : 0.0;
-      lo[u] = in ? G(p.c_lon)[i] : 0.0;
-      co[u] = in ? G(p.c_cos)[i] : 0.0;
+      const uint32_t ic = i < n ? i : n - 1u;
+      aw[u] = alive_g[j < n_words ? j : n_words - 1u];
+      lg[u] = G(p.loc_g)[j < n_words ? j : n_words - 1u];
+      cm[u] = merge ? ~0ull : c_compat[ic];
+      ow[u] = G(p.order)[ic];
+      os[u] = G(p.c_site)[ic];
+      la[u] = G(p.c_lat)[ic];
+      lo[u] = G(p.c_lon)[ic];
+      co[u] = G(p.c_cos)[ic];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t i = (jb + (uint32_t)u) * 64u + lane;
-      const bool c = i < n && ((aw[u] >> lane) & 1ull) && (cm[u] & cbit) != 0ull;
+      const uint32_t j = jb + (uint32_t)u;
+      const uint32_t i = j * 64u + lane;
+      const bool c = j < j1 && i < n && ((aw[u] >> lane) & 1ull) && (cm[u] & cbit) != 0ull;
       const uint64_t bal = __ballot(c);
       if (c) {
         const uint32_t s = off + __popcll(bal & ((1ull << lane) - 1ull));
-        G(p.slot_pos)[s] = i;
+        G(p.slot_pos)[s] = i | (((uint32_t)(lg[u] >> lane) & 1u) << 31);  // bit 31: has a location
         G(p.slot_wid)[s] = ow[u];
         G(p.cc_lat)[s] = la[u];
         G(p.cc_lon)[s] = lo[u];
@@ -1783,14 +1792,23 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
   }
   __syncthreads();
   const uint32_t lw = (n_list + 63u) >> 6;
-  for (uint32_t base = 0; base < lw * 64u; base += CARVE_THREADS) {
-    const uint32_t s = base + tid;
-    const bool in = s < n_list;
-    const bool hl = in && bit_at(p.loc_g, G(p.slot_pos)[s]);
-    const uint64_t ba = __ballot(in), bl = __ballot(hl);
-    if (lane == 0 && (s >> 6) < lw) {
-      alive[s >> 6] = ba;
-      loc[s >> 6] = bl;
+  // slot bitmaps: alive = all ones, loc from bit 31 of slot_pos (four independent coalesced loads per step)
+  for (uint32_t base = 0; base < lw * 64u; base += 4u * CARVE_THREADS) {
+    uint32_t sp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t s = base + (uint32_t)u * CARVE_THREADS + tid;
+      sp[u] = G(p.slot_pos)[s < n_list ? s : n_list - 1u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t s = base + (uint32_t)u * CARVE_THREADS + tid;
+      const bool in = s < n_list;
+      const uint64_t ba = __ballot(in), bl = __ballot(in && (sp[u] >> 31));
+      if (lane == 0 && (s >> 6) < lw) {
+        alive[s >> 6] = ba;
+        loc[s >> 6] = bl;
+      }
     }
   }
   __syncthreads();
@@ -2227,9 +2245,15 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         c.max_s = p.max_size[ci];
         if (p.mode == CARVE_MODE_FORM && c.total_available < c.min_s) continue;  // `while` never entered (:507)
         const uint64_t cbit = 1ull << p.avail_cfg[ci];
+        PROF_MARK(29);  // loop overhead
         c.n_list = carve_compact_count(p, red, n, cbit);
+        PROF_MARK(26);
+#ifdef PM_CARVE_PROF
+        if (tid == 0) G(p.status)->prof[30] += 1;
+#endif
         if (c.n_list < c.min_s || c.n_list == 0) continue;  // mod.rs:517-519
         carve_compact_place(p, red, n, cbit, c.n_list);
+        PROF_MARK(27);
         break;
       }
       if (ci >= p.n_avail) {
@@ -2245,7 +2269,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         c.prop_limit = carve_prop_limit(p, red, c.n_list);
       }
       prepared = true;
-      PROF_MARK(9);
+      PROF_MARK(28);
       if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
     } else {
       c.n_list = st->n_list;
@@ -2313,7 +2337,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       const uint64_t* alive = r_alive;
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS)
         if (!bit_at(alive, sl)) {
-          const uint32_t i = G(p.slot_pos)[sl];
+          const uint32_t i = G(p.slot_pos)[sl] & 0x7FFFFFFFu;  // bit 31: the slot has a location
           atomicAnd((unsigned long long*)&G(p.alive_g)[i >> 6], ~(1ull << (i & 63u)));
         }
     }

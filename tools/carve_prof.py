@@ -26,6 +26,7 @@ for it in range(3):
 out = (C.c_ulonglong * 32)()
 E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 E.lib().pm_debug_carve_prof(eng._h, out)
+out[9] = out[26] + out[27] + out[28] + out[29]
 tot = out[15] + out[9] + out[10] + out[13] + out[12] + out[14]
 print(f"carve kernels {s['ms_carve_kernel']:.3f} ms, {s['carve_steps']} steps ({s['carve_fast_steps']} fast), "
       f"{1e3 * s['ms_carve_kernel'] / s['carve_steps']:.2f} us/step")
@@ -35,6 +36,7 @@ print(f"  launch anatomy (ticks): init/status={out[15]} ({pct(out[15])}) prepare
       f"group_of+exit={out[14]} ({pct(out[14])})")
 print(f"  inside run: rounds={out[0]} ({pct(out[0])}; {out[1]} rounds, {out[2]} commits, {out[3]} retries, {out[4]} exact-sweep stops) "
       f"sequential path={out[11]} ({pct(out[11])}) staging={out[20]} ({pct(out[20])}; {out[21]} refills) exact steps={out[22]} ({pct(out[22])})")
+print(f"  prepare: count passes={out[26]} ({out[30]} calls) placement={out[27]} proposal limit={out[28]} other={out[29]}")
 print(f"  exact-sweep reasons: no proposal={out[16]} debug hook={out[17]} row exhausted={out[18]} certificate={out[19]}")
 print(f"  proposer waves: {out[24]} proposals ({out[25]} with a lane re-sweep); ticks summed over waves: same-site links={out[5]} sweep={out[6]} pop={out[7]} flags={out[8]}; slowest wave={out[23]}")
 if out[5]:
