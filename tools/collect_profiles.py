@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Collect the per-round profile artefacts on the GPU box (run through gpurun), into gpurun_out/<tag>/:
+
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2`
+  <tag>_timeline.txt       per-launch timeline of the last match of that run
+  <tag>_bench.json         the bench line of the default `bench.py` command (with the CPU baseline)
+  <tag>_pmc_traffic.json   HBM bytes per match from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes
+
+usage: python tools/collect_profiles.py <tag> [--skip-bench]
+Copy the files you want judged into profiles/ afterwards.
+"""
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, **kw):
+    print("+", cmd, flush=True)
+    return subprocess.run(cmd, shell=True, **kw)
+
+
+def pmc_sum(db, counter):
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else cols[0])
+    q = (f"select {name_col}, sum(value), count(*) from counters_collection where counter_name = ? "
+         f"group by {name_col}")
+    return {k: (t, n) for k, t, n in c.execute(q, (counter,))}
+
+
+def main():
+    tag = sys.argv[1]
+    out = os.path.join(ROOT, "gpurun_out", tag)
+    os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    py = sys.executable
+    bench = os.path.join(ROOT, "bench.py")
+
+    # 1. kernel trace
+    d = os.path.join(out, "trace")
+    run(f"cd /tmp && rocprofv3 --kernel-trace --stats -d {d} -o t -- {py} {bench} --steps 10 --warmup 2 "
+        f"--no-cpu-baseline > {out}/trace_bench.log 2>&1", env=env)
+    db = os.path.join(d, "t_results.db")
+    run(f"{py} {ROOT}/tools/rocpd_summary.py {db} {out}/{tag}_kernel_stats.csv")
+    run(f"{py} {ROOT}/tools/tick_timeline.py {db} --all > {out}/{tag}_timeline.txt")
+
+    # 2. PMC passes (counters on their own, no trace domains besides the kernel trace)
+    matches = 4  # --steps 3 --warmup 1
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        dd = os.path.join(out, "pmc_" + counter)
+        run(f"cd /tmp && rocprofv3 --pmc {counter} -d {dd} -o p -- {py} {bench} --steps 3 --warmup 1 "
+            f"--no-cpu-baseline > {out}/pmc_{counter}.log 2>&1", env=env)
+        try:
+            sums[counter] = pmc_sum(os.path.join(dd, "p_results.db"), counter)
+        except Exception as ex:  # noqa: BLE001
+            print("pmc pass failed:", counter, ex)
+            sums[counter] = {}
+    groups = {"carve": ("carve_kernel", "carve_propose_kernel"),
+              "pair_sweep": ("pair_sweep", "pair_combine", "build_planes"),
+              "compat_kernel": ("compat_kernel",)}
+    traffic = {}
+    for g, pats in groups.items():
+        f = sum(t for k, (t, _n) in sums.get("FETCH_SIZE", {}).items() if any(p in k for p in pats))
+        w = sum(t for k, (t, _n) in sums.get("WRITE_SIZE", {}).items() if any(p in k for p in pats))
+        traffic[g] = {"FETCH_SIZE_KB_per_match": f / matches, "WRITE_SIZE_KB_per_match": w / matches,
+                      "hbm_bytes_per_match": (f + w) * 1024.0 / matches,
+                      "hbm_bytes_per_match_fetch_x2": (2 * f + w) * 1024.0 / matches}
+    traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python bench.py --steps 3 "
+                        "--warmup 1` (4 full-swarm matches each); values are per match = sum over the kernels' "
+                        "dispatches / 4.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a wide "
+                        "coalesced stream (x2 variant given); other access widths and WRITE_SIZE are uncalibrated.  "
+                        "The candidate tables are L2/MALL resident, so memory-side traffic is far below the "
+                        "algorithmic bytes.")
+    with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+
+    # 3. the default bench line
+    if "--skip-bench" not in sys.argv:
+        r = run(f"{py} {bench}", env=env, capture_output=True, text=True)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        with open(os.path.join(out, f"{tag}_bench.json"), "w") as fh:
+            fh.write((line[-1] if line else r.stdout + r.stderr) + "\n")
+        print(line[-1] if line else r.stdout[-2000:] + r.stderr[-2000:])
+    # drop the bulky raw databases, keep the summaries
+    run(f"rm -rf {out}/trace {out}/pmc_FETCH_SIZE {out}/pmc_WRITE_SIZE")
+
+
+if __name__ == "__main__":
+    main()
