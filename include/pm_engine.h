@@ -150,8 +150,11 @@ typedef struct {
                                      exact host resolve path runs (0 = off) */
   uint32_t sweep_variant;        /* pair-sweep kernel: 0 = default (best), 1 = scalar reference kernel */
   uint32_t carve_variant;        /* group formation: 0 = default (full-chip neighbour-list proposals + speculative
-                                    in-order validation rounds), 1 = single-workgroup sequential sweep only,
-                                    2 = proposals with single-wave sequential validation */
+                                    in-order validation rounds; the next configuration is prepared and proposed
+                                    on a second stream while the current one is validated),
+                                    1 = single-workgroup sequential sweep only,
+                                    2 = proposals with single-wave sequential validation (one stream),
+                                    3 = proposals + rounds on one stream, strictly one launch after the other */
   uint32_t _reserved;
 } pm_engine_config;
 

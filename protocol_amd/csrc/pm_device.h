@@ -60,7 +60,20 @@ enum {
   CARVE_F_INIT = 1u << 0,   // build the eligible list + position columns (first launch of a carve)
   CARVE_F_RUN = 1u << 1,    // process the prepared configuration
   CARVE_F_ALL = 1u << 2,    // keep going through every configuration in this launch (no proposals)
-  CARVE_F_PROPS = 1u << 3   // neighbour-list proposals of carve_propose_kernel are available
+  CARVE_F_PROPS = 1u << 3,  // neighbour-list proposals of carve_propose_kernel are available
+  // pipelined carve (two list buffers; preparation + proposals of the next configuration run on a second
+  // stream while the current one is validated):
+  CARVE_F_PIPE = 1u << 4,   // this launch belongs to a pipelined carve
+  CARVE_F_PREP = 1u << 5,   // (pipelined) prepare-only launch for this argument block's list buffer
+  CARVE_F_BUF1 = 1u << 6    // (pipelined) the launch works on list buffer 1 (else 0)
+};
+enum { CARVE_LIST_EMPTY = 0, CARVE_LIST_READY = 1, CARVE_LIST_REPREP = 2 };
+// One prepared candidate list of a pipelined carve.
+struct CarveList {
+  uint32_t ci;          // configuration (position in the carve order) the buffer holds / held last; n_avail = none left
+  uint32_t n_list, prop_k, prop_limit;
+  uint32_t state;       // CARVE_LIST_*
+  uint32_t _pad[3];
 };
 
 // Device-resident state of one carve (try_form_new_groups / one merge configuration); it persists across
@@ -83,6 +96,7 @@ struct CarveStatus {
   uint32_t slow_steps;   // steps that needed the full key sweep
   uint32_t n_solo;       // single-node groups carved (the merge pass only runs when there are two or more)
   uint32_t _pad_solo;
+  CarveList list[2];     // pipelined carve: the two list buffers
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
@@ -109,6 +123,9 @@ struct CarveArgs {
   uint32_t* c_site;
   uint64_t* c_compat;
   uint64_t *alive_g, *loc_g;  // bitmaps over positions (bits_stride words each)
+  uint64_t* alive_snap;       // pipelined carve: this list buffer's private copy of alive_g, taken by the PREP
+                              // launch (the validator of the other buffer clears bits in alive_g meanwhile, and
+                              // the two compaction passes must see the same bitmap)
   // ... and by candidate slot of the prepared configuration
   double *cc_lat, *cc_lon, *cc_cos;
   uint32_t* cc_site;
@@ -157,7 +174,7 @@ void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block
                    uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
-void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
+void launch_carve_propose(const CarveArgs* d_args, uint32_t W, uint32_t buf, hipStream_t s);  // buf: 0/1 pipelined, PM_NONE otherwise
 
 }  // namespace pm
 #endif

@@ -148,7 +148,11 @@ struct pm_engine {
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
   DevBuf<uint32_t> d_slot_pos, d_slot_wid;
   DevBuf<CarveStatus> d_status;
-  DevBuf<CarveArgs> d_carve_args;
+  DevBuf<CarveArgs> d_carve_args;       // [2]: the second block points at the second list buffer (pipelined carve)
+  DevBuf<unsigned char> d_list2;        // second set of per-slot arrays, one allocation
+  hipStream_t stream2 = nullptr;        // preparation + proposals of the next configuration
+  std::vector<hipEvent_t> ev_prep, ev_run;  // cross-stream edges of the pipelined carve, one per launch pair
+  hipEvent_t ev_init = nullptr;
   DevBuf<uint32_t> d_m_cfg, d_m_n, d_m_off, d_m_members;  // MERGE batches
 
   // ---- sweep scratch
@@ -334,15 +338,15 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_same_next.ensure(cap));
   HIPCHK(e->d_prop.ensure(cap * PM_PROP_ROW));
   HIPCHK(e->d_status.ensure(1));
-  HIPCHK(e->d_carve_args.ensure(1));
+  HIPCHK(e->d_carve_args.ensure(2));
   const uint32_t stride = uint32_t((cap + 63) / 64);
-  HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
+  HIPCHK(e->d_bits.ensure(size_t(stride) * 5));
   std::memset(a, 0, sizeof(*a));
   a->mode = mode;
   a->W = e->W;
   a->proximity = e->cfg.proximity_enabled;
   a->debug_uncertain_every = e->cfg.debug_uncertain_every;
-  a->rounds_enabled = e->cfg.carve_variant == 0 ? 1u : 0u;
+  a->rounds_enabled = (e->cfg.carve_variant == 0 || e->cfg.carve_variant == 3) ? 1u : 0u;
   a->wflags = e->d_flags.p;
   a->lat = e->d_lat.p;
   a->lon = e->d_lon.p;
@@ -370,8 +374,40 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->prop_n = e->d_prop_n.p;
   a->same_next = e->d_same_next.p;
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
+  a->alive_snap = e->d_bits.p + size_t(stride) * 4;
   a->bits_stride = stride;
   a->status = e->d_status.p;
+  return PM_OK;
+}
+
+// The second list buffer of a pipelined carve: `b` = `a` with its per-slot arrays in e->d_list2.
+static int32_t second_list_args(pm_engine* e, const CarveArgs& a, CarveArgs* b) {
+  const size_t cap = std::max<size_t>(e->W, 1);
+  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += al(bytes);
+    return o;
+  };
+  const size_t o_lat = take(cap * 8), o_lon = take(cap * 8), o_cos = take(cap * 8), o_site = take(cap * 4),
+               o_pos = take(cap * 4), o_wid = take(cap * 4), o_pn = take(cap * 4), o_sn = take(cap * 4),
+               o_prop = take(cap * PM_PROP_ROW * 8), o_bits = take(size_t(a.bits_stride) * 2 * 8),
+               o_snap = take(size_t(a.bits_stride) * 8);
+  HIPCHK(e->d_list2.ensure(off));
+  unsigned char* base = e->d_list2.p;
+  *b = a;
+  b->cc_lat = reinterpret_cast<double*>(base + o_lat);
+  b->cc_lon = reinterpret_cast<double*>(base + o_lon);
+  b->cc_cos = reinterpret_cast<double*>(base + o_cos);
+  b->cc_site = reinterpret_cast<uint32_t*>(base + o_site);
+  b->slot_pos = reinterpret_cast<uint32_t*>(base + o_pos);
+  b->slot_wid = reinterpret_cast<uint32_t*>(base + o_wid);
+  b->prop_n = reinterpret_cast<uint32_t*>(base + o_pn);
+  b->same_next = reinterpret_cast<uint32_t*>(base + o_sn);
+  b->prop = reinterpret_cast<uint64_t*>(base + o_prop);
+  b->bits_scratch = reinterpret_cast<uint64_t*>(base + o_bits);
+  b->alive_snap = reinterpret_cast<uint64_t*>(base + o_snap);
   return PM_OK;
 }
 
@@ -502,20 +538,67 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   st.n_groups = g0;
   st.n_members = m0;
   const bool use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
+  // default: pipelined — the next configuration is prepared and proposed on a second stream while the
+  // current one is validated (3 = the same launches on one stream, strictly one after the other)
+  const bool pipelined = use_props && e->cfg.carve_variant == 0;
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
+  if (pipelined) {
+    CarveArgs a2;
+    rc = second_list_args(e, a, &a2);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_carve_args.p + 1, &a2, sizeof(a2), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // a2 is a stack object
+  }
   uint32_t start_ci = 0;
   for (;;) {
     HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->kev[2], e->stream));
+    uint32_t pj = 0;  // launch pair counter of the pipelined carve (parity = list buffer)
+    auto queue_pairs = [&](uint32_t count) -> int32_t {
+      if (!pipelined) {
+        for (uint32_t k = 0; k < count; ++k) {
+          launch_carve_propose(e->d_carve_args.p, e->W, PM_NONE, e->stream);
+          HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
+          e->tick_carve_launches += 2;
+        }
+        return PM_OK;
+      }
+      for (uint32_t k = 0; k < count; ++k, ++pj) {
+        while (e->ev_prep.size() <= pj) {
+          hipEvent_t x = nullptr, y = nullptr;
+          HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+          HIPCHK(hipEventCreateWithFlags(&y, hipEventDisableTiming));
+          e->ev_prep.push_back(x);
+          e->ev_run.push_back(y);
+        }
+        const uint32_t b = pj & 1u;
+        const uint32_t fl = CARVE_F_PIPE | CARVE_F_PROPS | (b ? CARVE_F_BUF1 : 0u);
+        const CarveArgs* ab = e->d_carve_args.p + b;
+        // the buffer is free once the validation two pairs back is done
+        if (pj >= 2) HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_run[pj - 2], 0));
+        HIPCHK(launch_carve(ab, fl | CARVE_F_PREP, 0, lds, e->stream2));
+        launch_carve_propose(ab, e->W, b, e->stream2);
+        HIPCHK(hipEventRecord(e->ev_prep[pj], e->stream2));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_prep[pj], 0));
+        HIPCHK(launch_carve(ab, fl | CARVE_F_RUN, 0, lds, e->stream));
+        HIPCHK(hipEventRecord(e->ev_run[pj], e->stream));
+        e->tick_carve_launches += 3;
+      }
+      return PM_OK;
+    };
     if (use_props) {
       // prepare the first candidate list, then (propose, validate) pairs: one per configuration plus one
       // per re-proposal round; launches queued behind a finished carve return immediately
-      HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, start_ci, lds, e->stream));
-      for (uint32_t k = 0; k < a.n_avail - start_ci + 3u; ++k) {
-        launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
-        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
-        e->tick_carve_launches += 2;
+      if (pipelined) {
+        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PIPE | CARVE_F_PROPS, start_ci, lds, e->stream));
+        HIPCHK(hipEventRecord(e->ev_init, e->stream));
+        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_init, 0));
+        rc = queue_pairs(a.n_avail - start_ci + 8u);
+      } else {
+        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, start_ci, lds, e->stream));
+        rc = queue_pairs(a.n_avail - start_ci + 3u);
       }
+      if (rc) return rc;
     } else {
       HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, start_ci, lds, e->stream));
     }
@@ -534,11 +617,8 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
     if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
     while (st.state == CARVE_STATE_RUNNING && use_props) {  // more re-proposal rounds than were queued
       HIPCHK(hipEventRecord(e->kev[2], e->stream));
-      for (uint32_t k = 0; k < 16u; ++k) {
-        launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
-        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
-        e->tick_carve_launches += 2;
-      }
+      rc = queue_pairs(16u);
+      if (rc) return rc;
       HIPCHK(hipEventRecord(e->kev[3], e->stream));
       HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
@@ -549,6 +629,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
     if (st.state == CARVE_STATE_DONE) break;
     if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
     if (st.state != CARVE_STATE_UNCERTAIN) return set_error(PM_ENODEV, "carve kernel did not complete");
+    if (pipelined) HIPCHK(hipStreamSynchronize(e->stream2));  // nothing of this carve may still be queued
     rc = host_resolve_form_step(e, avail[st.stop_ci], &st);
     if (rc) return rc;
     e->tick_host_resolved++;
@@ -988,6 +1069,11 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
       delete e;
       return set_error(PM_ENODEV, "hipEventCreate failed");
     }
+  if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_init, hipEventDisableTiming) != hipSuccess) {
+    delete e;
+    return set_error(PM_ENODEV, "hipStreamCreate failed");
+  }
   if (hipEventCreateWithFlags(&e->ev_groups, hipEventDisableTiming) != hipSuccess) {
     delete e;
     return set_error(PM_ENODEV, "hipEventCreate failed");
@@ -1019,6 +1105,11 @@ void pm_engine_destroy(pm_engine* e) {
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
   if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
   if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
+  if (e->ev_init) (void)hipEventDestroy(e->ev_init);
+  for (hipEvent_t x : e->ev_prep) (void)hipEventDestroy(x);
+  for (hipEvent_t x : e->ev_run) (void)hipEventDestroy(x);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
+  e->d_list2.release();
   if (e->h_table_pinned) (void)hipHostFree(e->h_table_pinned);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);

@@ -1708,14 +1708,15 @@ __device__ __noinline__ int carve_step_mem(const CarveArgs& p, BlockRed& red, St
 
 // Stable compaction of the live positions of this configuration into list slots: two passes over
 // contiguous per-wave ranges.  Returns the list length; red.a keeps the per-wave counts for the placement.
-__device__ __noinline__ uint32_t carve_compact_count(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit) {
+__device__ __noinline__ uint32_t carve_compact_count(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit,
+                                                      const uint64_t* alive_bits) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t n_words = (n + 63u) >> 6;
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
   const uint32_t j0 = wave * wpw, j1 = min(n_words, j0 + wpw);
   uint32_t cnt = 0;
   const bool merge = p.mode == CARVE_MODE_MERGE;
-  const auto alive_g = G((const uint64_t*)p.alive_g);
+  const auto alive_g = G(alive_bits);
   const auto c_compat = G((const uint64_t*)p.c_compat);
   for (uint32_t jb = j0; jb < j1; jb += 8u) {  // eight words per batch; every load unconditional (clamped
     uint64_t aw[8], cm[8];                     // index) and independent, so the whole batch is in flight at once
@@ -1742,7 +1743,8 @@ __device__ __noinline__ uint32_t carve_compact_count(const CarveArgs& p, BlockRe
   return total;
 }
 
-__device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit, uint32_t n_list) {
+__device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& red, uint32_t n, uint64_t cbit, uint32_t n_list,
+                                                  const uint64_t* alive_bits) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n_words = (n + 63u) >> 6;
   const uint32_t wpw = (n_words + CARVE_WAVES - 1u) / CARVE_WAVES;
@@ -1752,7 +1754,7 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
   uint32_t off = 0;
   for (uint32_t k = 0; k < wave; ++k) off += red.a[k];
   const bool merge = p.mode == CARVE_MODE_MERGE;
-  const auto alive_g = G((const uint64_t*)p.alive_g);
+  const auto alive_g = G(alive_bits);
   const auto c_compat = G((const uint64_t*)p.c_compat);
   for (uint32_t jb = j0; jb < j1; jb += 4u) {
     uint64_t aw[4], cm[4], lg[4];
@@ -1884,11 +1886,18 @@ __device__ __forceinline__ void sweep_keys(const SweepBatch& b, uint32_t lw, uin
   }
 }
 
-__global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa) {
+__global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa, uint32_t buf) {
   const CarveArgs& p = *pa;  // argument block in device memory: read through the scalar cache, never copied
   const auto st = G((const CarveStatus*)p.status);
-  if (st->state != CARVE_STATE_RUNNING || st->cur_ci >= p.n_avail) return;
-  const uint32_t K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
+  if (st->state != CARVE_STATE_RUNNING) return;
+  uint32_t K, n_list, limit;
+  if (buf == PM_NONE) {
+    if (st->cur_ci >= p.n_avail) return;
+    K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
+  } else {  // pipelined carve: the list this argument block's buffers hold
+    if (st->list[buf].state != CARVE_LIST_READY || st->list[buf].ci >= p.n_avail) return;
+    K = st->list[buf].prop_k, n_list = st->list[buf].n_list, limit = st->list[buf].prop_limit;
+  }
   if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
   const uint32_t SB = n_list > PM_CARVE_SLOTS ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   const double TIE_BAND = n_list > PM_CARVE_SLOTS ? PM_TIE_BAND_BIG : PM_TIE_BAND;
@@ -2150,6 +2159,15 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   const auto st = G(p.status);
   uint32_t flags = flags_in;
   if (!(flags & CARVE_F_INIT) && st->state != CARVE_STATE_RUNNING) return;  // queued behind a finished carve
+  // Pipelined carve (CARVE_F_PIPE): two list buffers (two argument blocks that differ in the per-slot arrays).
+  // A PREP launch builds the list of this block's buffer `pb` — on a second stream, while the other buffer is
+  // being validated — and a RUN launch validates it.  A list prepared early is a superset of the candidates
+  // still alive when its turn comes (nodes only ever leave), so the RUN launch refreshes the live bits from
+  // the position bitmap and everything downstream is unchanged.  list[b].ci stays behind after a buffer is
+  // done: the next search starts after the other buffer's ci.
+  const bool pipe = (flags & CARVE_F_PIPE) != 0u;
+  const uint32_t pb = (flags & CARVE_F_BUF1) ? 1u : 0u;
+  bool pipe_single = false;  // PREP: rebuild exactly list[pb].ci (re-prepare / refresh), no search
   PROF_DECL;
 
   uint32_t n;
@@ -2218,12 +2236,52 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     c.total_available = n;  // mod.rs:503
     ci = start_ci;
     prepared = false;
+    if (pipe) {  // pipelined: the lists are built by the PREP launches
+      if (tid == 0) {
+        st->n_eligible = n;
+        st->total_available = n;
+        for (int b = 0; b < 2; ++b) {
+          st->list[b].ci = start_ci - 1u;  // "the configuration before the first one" (wraps for 0)
+          st->list[b].n_list = st->list[b].prop_k = st->list[b].prop_limit = 0;
+          st->list[b].state = CARVE_LIST_EMPTY;
+        }
+      }
+      return;
+    }
   } else {
     n = st->n_eligible;
     c.total_available = st->total_available;
-    ci = st->cur_ci;
-    prepared = true;
-    if (ci >= p.n_avail) return;
+    if (pipe) {
+      const uint32_t l_state = st->list[pb].state, l_ci = st->list[pb].ci;
+      const uint32_t o_state = st->list[pb ^ 1u].state, o_ci = st->list[pb ^ 1u].ci;
+      if (flags & CARVE_F_PREP) {
+        prepared = false;
+        if (l_state == CARVE_LIST_REPREP || (l_state == CARVE_LIST_READY && l_ci < p.n_avail)) {
+          ci = l_ci;  // re-prepare after half of it died, or refresh a list that is still waiting for its turn
+          pipe_single = true;
+        } else {
+          ci = o_ci + 1u;  // the configuration after the one the other buffer holds (or held last)
+        }
+      } else {
+        // configurations are validated strictly in order: not while the other buffer waits for its
+        // re-preparation or holds an earlier configuration
+        if (l_state != CARVE_LIST_READY) return;
+        if (o_state == CARVE_LIST_REPREP || (o_state == CARVE_LIST_READY && o_ci < l_ci)) return;
+        if (l_ci >= p.n_avail) {  // nothing left to prepare, nothing left to validate
+          if (tid == 0) {
+            st->state = CARVE_STATE_DONE;
+            st->cur_ci = p.n_avail;
+          }
+          return;
+        }
+        ci = l_ci;
+        prepared = true;
+      }
+    } else {
+      ci = st->cur_ci;
+      prepared = true;
+      if (ci >= p.n_avail) return;
+    }
   }
   c.n_groups = st->n_groups;
   c.mem_off = st->n_members;
@@ -2240,23 +2298,48 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       c.n_list = 0;
       c.prop_k = 0;
       c.prop_limit = 0;
-      for (; ci < p.n_avail; ++ci) {
+      const uint32_t ci_end = pipe_single ? ci + 1u : p.n_avail;
+      // pipelined: the validator of the other buffer clears bits of alive_g while this runs; the count and
+      // the placement pass must see one and the same bitmap, so they work on a private copy (any mixture of
+      // old and new words is a valid superset of the nodes alive when this list's turn comes)
+      const uint64_t* prep_bits = p.alive_g;
+      if (pipe) {
+        const uint32_t nw = (n + 63u) >> 6;
+        for (uint32_t j = tid; j < nw; j += CARVE_THREADS)
+          G(p.alive_snap)[j] = __hip_atomic_load(&G(p.alive_g)[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        prep_bits = p.alive_snap;
+      }
+      for (; ci < ci_end; ++ci) {
         c.min_s = p.min_size[ci];
         c.max_s = p.max_size[ci];
         if (p.mode == CARVE_MODE_FORM && c.total_available < c.min_s) continue;  // `while` never entered (:507)
         const uint64_t cbit = 1ull << p.avail_cfg[ci];
         PROF_MARK(29);  // loop overhead
-        c.n_list = carve_compact_count(p, red, n, cbit);
+        c.n_list = carve_compact_count(p, red, n, cbit, prep_bits);
         PROF_MARK(26);
 #ifdef PM_CARVE_PROF
         if (tid == 0) G(p.status)->prof[30] += 1;
 #endif
         if (c.n_list < c.min_s || c.n_list == 0) continue;  // mod.rs:517-519
-        carve_compact_place(p, red, n, cbit, c.n_list);
+        carve_compact_place(p, red, n, cbit, c.n_list, prep_bits);
         PROF_MARK(27);
         break;
       }
-      if (ci >= p.n_avail) {
+      if (pipe) {
+        if (ci >= ci_end) {  // PREP found nothing
+          if (tid == 0) {
+            if (pipe_single) {
+              st->list[pb].state = CARVE_LIST_EMPTY;  // this configuration cannot form another group
+            } else {
+              st->list[pb].ci = p.n_avail;  // no configuration left
+              st->list[pb].n_list = st->list[pb].prop_k = st->list[pb].prop_limit = 0;
+              st->list[pb].state = CARVE_LIST_READY;
+            }
+          }
+          return;
+        }
+      } else if (ci >= p.n_avail) {
         exit_state = CARVE_STATE_DONE;
         break;
       }
@@ -2270,16 +2353,58 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       }
       prepared = true;
       PROF_MARK(28);
+      if (pipe) {  // PREP launch: publish the list, the proposer follows on this stream
+        if (tid == 0) {
+          st->list[pb].ci = ci;
+          st->list[pb].n_list = c.n_list;
+          st->list[pb].prop_k = c.prop_k;
+          st->list[pb].prop_limit = c.prop_limit;
+          st->list[pb].state = CARVE_LIST_READY;
+        }
+        return;
+      }
       if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
     } else {
-      c.n_list = st->n_list;
-      c.prop_k = st->prop_k;
-      c.prop_limit = st->prop_limit;
+      c.n_list = pipe ? st->list[pb].n_list : st->n_list;
+      c.prop_k = pipe ? st->list[pb].prop_k : st->prop_k;
+      c.prop_limit = pipe ? st->list[pb].prop_limit : st->prop_limit;
       c.min_s = p.min_size[ci];
       c.max_s = p.max_size[ci];
     }
     c.cfg = p.avail_cfg[ci];
     c.n_cand = c.n_list;
+    if (pipe) {
+      // the list was built while earlier configurations were still being carved: take the live bits from
+      // the position bitmap (four independent slot_pos loads, then four bitmap words, per step)
+      const auto sa = G(p.bits_scratch);
+      const uint32_t lwp = (c.n_list + 63u) >> 6;
+      uint32_t cnt = 0;
+      for (uint32_t base = 0; base < lwp * 64u; base += 4u * CARVE_THREADS) {
+        uint32_t sp[4];
+        uint64_t aw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t sl = base + (uint32_t)u * CARVE_THREADS + tid;
+          sp[u] = G(p.slot_pos)[sl < c.n_list ? sl : c.n_list - 1u] & 0x7FFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) aw[u] = G(p.alive_g)[sp[u] >> 6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t sl = base + (uint32_t)u * CARVE_THREADS + tid;
+          const uint64_t ba = __ballot(sl < c.n_list && ((aw[u] >> (sp[u] & 63u)) & 1ull));
+          if (lane == 0 && (sl >> 6) < lwp) sa[sl >> 6] = ba;
+          cnt += (uint32_t)__popcll(ba);  // wave-uniform
+        }
+      }
+      __syncthreads();  // previous users of red.a are done
+      if (lane == 0) red.a[wave] = cnt;
+      __syncthreads();
+      uint32_t total = 0;
+      for (uint32_t k = 0; k < CARVE_WAVES; ++k) total += red.a[k];
+      c.n_cand = total;
+      __syncthreads();
+    }
 
     // ---- run the prepared configuration.  Three storage modes:
     //   small (<= PM_CARVE_SLOTS slots):  every per-slot array in LDS
@@ -2348,6 +2473,10 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       stop_ci = ci;
       break;
     }
+    if (pipe) {  // RUN launch of a pipelined carve: hand the buffer back, the PREP launches do the rest
+      if (tid == 0) st->list[pb].state = rc == STEP_BREAK ? CARVE_LIST_EMPTY : CARVE_LIST_REPREP;
+      break;
+    }
     prepared = false;
     if (rc == STEP_BREAK) ++ci;  // configuration exhausted; STEP_CONTINUE => re-prepare the same configuration
     if (!(flags & CARVE_F_ALL)) flags &= ~CARVE_F_RUN;  // per-configuration launch: prepare the next list, leave
@@ -2372,10 +2501,12 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     st->stop_ci = stop_ci;
     st->n_eligible = n;
     st->cand_sum += c.cand_sum;
-    st->cur_ci = exit_state == CARVE_STATE_DONE ? p.n_avail : ci;
-    st->n_list = c.n_list;
-    st->prop_k = c.prop_k;
-    st->prop_limit = c.prop_limit;
+    if (!pipe) {
+      st->cur_ci = exit_state == CARVE_STATE_DONE ? p.n_avail : ci;
+      st->n_list = c.n_list;
+      st->prop_k = c.prop_k;
+      st->prop_limit = c.prop_limit;
+    }
     st->total_available = c.total_available;
     st->fast_steps += c.fast_steps;
     st->slow_steps += c.steps - c.fast_steps;
@@ -2513,12 +2644,12 @@ void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block
                      idx_by_block, val_by_block);
 }
 
-void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
+void launch_carve_propose(const CarveArgs* d_args, uint32_t W, uint32_t buf, hipStream_t s) {
   // one wave per located slot, grid-stride; 2048 workgroups x 4 waves keep all 256 CUs busy
   uint32_t blocks = (W + 3u) / 4u;
   if (blocks > 2048u) blocks = 2048u;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(carve_propose_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+  hipLaunchKernelGGL(carve_propose_kernel, dim3(blocks), dim3(256), 0, s, d_args, buf);
 }
 
 // ids of freshly carved groups: outputs k+1 .. of the splitmix64 stream whose state is `state`
