@@ -538,9 +538,11 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   st.n_groups = g0;
   st.n_members = m0;
   const bool use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
-  // default: pipelined — the next configuration is prepared and proposed on a second stream while the
-  // current one is validated (3 = the same launches on one stream, strictly one after the other)
-  const bool pipelined = use_props && e->cfg.carve_variant == 0;
+  // 3 = pipelined: the next configuration is prepared and proposed on a second stream while the current one
+  // is validated.  Bit-exact like the others, but measured slower at BASELINE configs[1] (3.8 vs 3.2 ms):
+  // most validation launches end because half of their list is dead, the re-preparation that follows cannot
+  // overlap anything, and lists prepared early start with dead entries, so they hit that threshold sooner.
+  const bool pipelined = use_props && e->cfg.carve_variant == 3;
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
   if (pipelined) {
     CarveArgs a2;
@@ -576,7 +578,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
         const CarveArgs* ab = e->d_carve_args.p + b;
         // the buffer is free once the validation two pairs back is done
         if (pj >= 2) HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_run[pj - 2], 0));
-        HIPCHK(launch_carve(ab, fl | CARVE_F_PREP, 0, lds, e->stream2));
+        HIPCHK(launch_carve(ab, fl | CARVE_F_PREP, 0, lds, e->stream2));  // (CARVE_F_WAIT: late start, slower still)
         launch_carve_propose(ab, e->W, b, e->stream2);
         HIPCHK(hipEventRecord(e->ev_prep[pj], e->stream2));
         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_prep[pj], 0));
