@@ -243,6 +243,24 @@ def main() -> int:
                      "note": "dependent chain of ~2k carve steps: latency-bound by construction, see DESIGN.md §6"},
         "kernels": kernels,
     }
+    if rank == 0 and world == 1:
+        # PCIe-inclusive rate, reported beside (never as) `value`: the same match when the worker and task
+        # columns arrive as host buffers through the C ABI (pm_upload_workers + pm_upload_tasks) every time
+        packed = host.pack_workers(sw)
+        tmasks = sw.task_masks()
+        t_up = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            u0 = time.perf_counter()
+            eng.upload_workers(packed)
+            eng.upload_tasks(tmasks, sw.created_at, sw.task_uid)
+            eng.reset_groups()
+            eng.tick()
+            t_up.append(time.perf_counter() - u0)
+        up = sorted(t_up)[len(t_up) // 2]
+        out["pcie_inclusive"] = {"ms_per_match": up * 1e3, "value": float(sw.T) * float(sw.W) / up,
+                                 "unit": "pair-evals/s",
+                                 "note": "host SoA columns -> HBM (workers + tasks) + match, p50 of 5"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sw)
     else:

@@ -89,6 +89,23 @@ def test_config2_full_size_properties():
     eng2.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 7])
+@pytest.mark.parametrize("carve_variant", [0, 3])
+def test_config1_full_size_groups_bit_exact(seed, carve_variant):
+    """BASELINE configs[1] (10k workers, 24 mixed configurations): the groups — ids, configurations, members in
+    carve order — equal the oracle's; the oracle's carve needs ~2 s at this size (its pair sweep is not run)."""
+    sw = baseline_config(1, seed=seed)
+    st = oracle_state_for(sw, reference_shaped=False)
+    eng = E.Engine(carve_variant=carve_variant)
+    host.load_swarm(eng, sw)
+    assert st.try_form_new_groups() == eng.form_groups()
+    assert st.try_merge_solo_groups() == eng.merge_solo_groups()
+    assert oracle_groups(st) == engine_groups(eng)
+    s = eng.last_stats()
+    assert s["host_resolved_steps"] == 0
+    eng.close()
+
+
 def test_config1_full_size_properties():
     sw = baseline_config(1, seed=3)
     eng = E.Engine()
