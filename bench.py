@@ -243,7 +243,7 @@ def main() -> int:
                      "note": "dependent chain of ~2k carve steps: latency-bound by construction, see DESIGN.md §6"},
         "kernels": kernels,
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # PCIe-inclusive rate, reported beside (never as) `value`: the same match when the worker and task
         # columns arrive as host buffers through the C ABI (pm_upload_workers + pm_upload_tasks) every time
         packed = host.pack_workers(sw)
