@@ -288,6 +288,34 @@ int32_t pm_host_build_model_table(const char* const* req_models, uint32_t n_rows
 int32_t pm_host_config_order(const pm_config_row* cfgs, uint32_t n_cfgs, uint64_t enabled,
                              uint32_t* order_out, uint32_t* n_out);
 
+/* ---- the step right after the match: group variables in the task that is handed to the worker
+ * (SURVEY section 8f row 3).  The engine returns numbers (pm_assignment); these helpers do the string work
+ * the reference does with chained `str::replace` calls, in the same order — every pass scans the result of
+ * the previous one.  Output convention: *needed = strlen(result) + 1; PM_ERANGE if cap is too small (nothing
+ * is written then); out may be NULL with cap 0 to size the buffer.
+ *
+ * pm_host_group_vars — scheduler_impl.rs:160-183, applied by the reference to every env-var value and every
+ *   cmd argument: ${GROUP_INDEX}, ${GROUP_SIZE}, ${NEXT_P2P_ADDRESS}, ${GROUP_ID}, ${TOTAL_UPLOAD_COUNT},
+ *   ${LAST_FILE_IDX} (= pm_host_last_file_idx(total_upload_count)).
+ * pm_host_volume_vars — scheduler_impl.rs:185-200: ${GROUP_ID} in host_path / container_path.
+ * pm_host_upload_name_vars — orchestrator/src/api/routes/storage.rs:150-215: ${NODE_GROUP_ID},
+ *   ${NODE_GROUP_SIZE}, ${NODE_GROUP_INDEX} (only when the node is in a group: group_id != NULL), then
+ *   ${TOTAL_UPLOAD_COUNT_AFTER} and ${CURRENT_FILE_INDEX} (= upload_count saturating-minus 1).
+ * pm_host_last_file_idx — `total_upload_count.parse::<u32>().unwrap_or(0).saturating_sub(1)`
+ *   (scheduler_impl.rs:155-158): Rust u32 syntax (optional '+', ASCII digits, no blanks, no overflow). */
+typedef struct pm_group_vars {
+  uint32_t group_index;            /* pm_assignment.group_index */
+  uint32_t group_size;             /* pm_assignment.group_size */
+  const char* next_p2p_address;    /* p2p id of pm_assignment.next_worker ("" if unknown) */
+  const char* group_id;            /* the group's id string */
+  const char* total_upload_count;  /* decimal count of `upload:<node>:<group>:*` keys, as the reference keeps it */
+} pm_group_vars;
+int32_t pm_host_group_vars(const char* in, const pm_group_vars* v, char* out, size_t cap, size_t* needed);
+int32_t pm_host_volume_vars(const char* in, const char* group_id, char* out, size_t cap, size_t* needed);
+int32_t pm_host_upload_name_vars(const char* in, const char* group_id, uint32_t group_size, uint32_t group_index,
+                                 uint64_t upload_count, char* out, size_t cap, size_t* needed);
+uint32_t pm_host_last_file_idx(const char* total_upload_count);
+
 uint32_t pm_abi_version(void);
 
 #ifdef __cplusplus

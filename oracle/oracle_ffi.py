@@ -108,6 +108,16 @@ def lib() -> C.CDLL:
                                      C.POINTER(C.c_int64)]
         L.orc_group_info.restype = C.c_int
         L.orc_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_group_vars.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.orc_group_vars.restype = C.c_void_p
+        L.orc_volume_vars.argtypes = [C.c_char_p, C.c_char_p]
+        L.orc_volume_vars.restype = C.c_void_p
+        L.orc_upload_name_vars.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.orc_upload_name_vars.restype = C.c_void_p
+        L.orc_last_file_idx.argtypes = [C.c_char_p]
+        L.orc_last_file_idx.restype = C.c_uint32
+        L.orc_free_string.argtypes = [C.c_void_p]
+        L.orc_free_string.restype = None
         L.orc_splitmix64.argtypes = [C.POINTER(C.c_uint64)]
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_compat_masks.argtypes = [vp, sz, vp, sz, vp]
@@ -379,3 +389,30 @@ def from_swarm(sw):
     tasks["topologies"] = tp
     enabled = np.array([(sw.enabled_mask() >> i) & 1 for i in range(len(sw.configs))], dtype=np.uint8)
     return nodes, cfgs, tasks, enabled
+
+
+# ---- group variables (scheduler_impl.rs:155-200, storage.rs:150-215)
+
+def _take(ptr) -> str:
+    try:
+        return C.string_at(ptr).decode()
+    finally:
+        lib().orc_free_string(ptr)
+
+
+def group_vars(text, group_index, group_size, next_p2p_address, group_id, total_upload_count) -> str:
+    return _take(lib().orc_group_vars(text.encode(), group_index, group_size, next_p2p_address.encode(),
+                                      group_id.encode(), total_upload_count.encode()))
+
+
+def volume_vars(text, group_id) -> str:
+    return _take(lib().orc_volume_vars(text.encode(), group_id.encode()))
+
+
+def upload_name_vars(text, group_id, group_size, group_index, upload_count) -> str:
+    gid = None if group_id is None else group_id.encode()
+    return _take(lib().orc_upload_name_vars(text.encode(), gid, group_size, group_index, upload_count))
+
+
+def last_file_idx(total_upload_count) -> int:
+    return int(lib().orc_last_file_idx(total_upload_count.encode()))

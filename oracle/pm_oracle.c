@@ -978,3 +978,89 @@ void orc_pair_sweep_per_worker(const orc_task* tasks, size_t n_tasks, const orc_
     count_out[w] = count;
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Group variables (scheduler_impl.rs:155-200, storage.rs:150-215): chains of Rust `str::replace`, i.e.
+ * every non-overlapping match from the left is replaced and the NEXT replace runs over that result. */
+
+/* one `s.replace(pat, with)`: consumes s (free), returns a new malloc'd string */
+static char* orc_replace(char* s, const char* pat, const char* with) {
+  const size_t ls = strlen(s), lp = strlen(pat), lw = strlen(with);
+  size_t hits = 0;
+  for (const char* q = s; (q = strstr(q, pat)) != NULL; q += lp) ++hits;
+  char* out = (char*)malloc(ls + hits * (lw > lp ? lw - lp : 0) + 1);
+  char* o = out;
+  const char* q = s;
+  for (;;) {
+    const char* h = strstr(q, pat);
+    if (!h) break;
+    memcpy(o, q, (size_t)(h - q));
+    o += h - q;
+    memcpy(o, with, lw);
+    o += lw;
+    q = h + lp;
+  }
+  strcpy(o, q);
+  free(s);
+  return out;
+}
+
+static char* orc_dup(const char* s) {
+  char* r = (char*)malloc(strlen(s) + 1);
+  strcpy(r, s);
+  return r;
+}
+
+/* `total_upload_count.parse::<u32>().unwrap_or(0).saturating_sub(1)` (scheduler_impl.rs:155-158) */
+uint32_t orc_last_file_idx(const char* t) {
+  size_t i = 0;
+  unsigned long long v = 0;
+  if (t[0] == '+') i = 1;          /* u32::from_str accepts one leading '+' */
+  if (t[i] == '\0') return 0;      /* empty / sign only: Err */
+  for (; t[i]; ++i) {
+    if (t[i] < '0' || t[i] > '9') return 0; /* Err: InvalidDigit */
+    v = v * 10ull + (unsigned long long)(t[i] - '0');
+    if (v > 4294967295ull) return 0;        /* Err: PosOverflow */
+  }
+  return v == 0 ? 0u : (uint32_t)(v - 1ull);
+}
+
+char* orc_group_vars(const char* in, uint32_t group_index, uint32_t group_size, const char* next_p2p_address,
+                     const char* group_id, const char* total_upload_count) {
+  char num[32];
+  char* s = orc_dup(in);
+  snprintf(num, sizeof num, "%u", group_index);
+  s = orc_replace(s, "${GROUP_INDEX}", num);           /* :162, :173 */
+  snprintf(num, sizeof num, "%u", group_size);
+  s = orc_replace(s, "${GROUP_SIZE}", num);            /* :163, :174 */
+  s = orc_replace(s, "${NEXT_P2P_ADDRESS}", next_p2p_address);
+  s = orc_replace(s, "${GROUP_ID}", group_id);
+  s = orc_replace(s, "${TOTAL_UPLOAD_COUNT}", total_upload_count);
+  snprintf(num, sizeof num, "%u", orc_last_file_idx(total_upload_count));
+  s = orc_replace(s, "${LAST_FILE_IDX}", num);
+  return s;
+}
+
+char* orc_volume_vars(const char* in, const char* group_id) { /* :185-200 */
+  return orc_replace(orc_dup(in), "${GROUP_ID}", group_id);
+}
+
+char* orc_upload_name_vars(const char* in, const char* group_id, uint32_t group_size, uint32_t group_index,
+                           uint64_t upload_count) {
+  char num[32];
+  char* s = orc_dup(in);
+  if (group_id) { /* storage.rs:150-158 */
+    s = orc_replace(s, "${NODE_GROUP_ID}", group_id);
+    snprintf(num, sizeof num, "%u", group_size);
+    s = orc_replace(s, "${NODE_GROUP_SIZE}", num);
+    snprintf(num, sizeof num, "%u", group_index);
+    s = orc_replace(s, "${NODE_GROUP_INDEX}", num);
+  }
+  snprintf(num, sizeof num, "%llu", (unsigned long long)upload_count);
+  s = orc_replace(s, "${TOTAL_UPLOAD_COUNT_AFTER}", num); /* :210-212 (the `contains` guard changes nothing) */
+  snprintf(num, sizeof num, "%llu", (unsigned long long)(upload_count ? upload_count - 1 : 0)); /* :208 */
+  s = orc_replace(s, "${CURRENT_FILE_INDEX}", num);
+  return s;
+}
+
+void orc_free_string(char* s) { free(s); }

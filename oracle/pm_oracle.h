@@ -255,6 +255,18 @@ void orc_pair_sweep_per_worker(const orc_task* tasks, size_t n_tasks, const orc_
                                const int32_t* cfg_of_node, size_t n_nodes, uint32_t* first_out,
                                uint32_t* count_out);
 
+/* ---- group variables of the task handed to a grouped node (scheduler_impl.rs:155-200) and of the upload
+ * file name (orchestrator/src/api/routes/storage.rs:150-215).  Each returns a malloc'd string (free with
+ * orc_free_string). */
+char* orc_group_vars(const char* in, uint32_t group_index, uint32_t group_size, const char* next_p2p_address,
+                     const char* group_id, const char* total_upload_count);
+char* orc_volume_vars(const char* in, const char* group_id);
+/* group_id == NULL: the node is in no group (storage.rs:159-163) */
+char* orc_upload_name_vars(const char* in, const char* group_id, uint32_t group_size, uint32_t group_index,
+                           uint64_t upload_count);
+uint32_t orc_last_file_idx(const char* total_upload_count);
+void orc_free_string(char* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,6 +265,85 @@ int32_t pm_host_config_order(const pm_config_row* cfgs, uint32_t n_cfgs, uint64_
   return PM_OK;
 }
 
+// ---- group variables (scheduler_impl.rs:155-200, storage.rs:150-215)
+
+namespace {
+// str::replace: every non-overlapping occurrence, scanning left to right; an empty pattern never occurs here
+void replace_all(std::string& s, std::string_view pat, std::string_view with) {
+  if (pat.empty()) return;
+  std::string out;
+  size_t pos = 0;
+  for (;;) {
+    const size_t hit = s.find(pat, pos);
+    if (hit == std::string::npos) break;
+    out.append(s, pos, hit - pos);
+    out.append(with);
+    pos = hit + pat.size();
+  }
+  if (pos == 0) return;  // no occurrence
+  out.append(s, pos, std::string::npos);
+  s.swap(out);
+}
+int32_t give(const std::string& r, char* out, size_t cap, size_t* needed) {
+  if (needed) *needed = r.size() + 1;
+  if (cap < r.size() + 1 || !out) {
+    if (!out && cap == 0 && needed) return PM_OK;  // sizing call
+    return pm::set_error(PM_ERANGE, "output buffer too small");
+  }
+  std::memcpy(out, r.c_str(), r.size() + 1);
+  return PM_OK;
+}
+}  // namespace
+
+uint32_t pm_host_last_file_idx(const char* total_upload_count) {
+  // u32::from_str: optional '+', at least one ASCII digit, nothing else, no overflow; Err => 0
+  if (!total_upload_count) return 0;
+  const char* p = total_upload_count;
+  if (*p == '+') ++p;
+  if (!*p) return 0;
+  uint64_t v = 0;
+  for (; *p; ++p) {
+    if (*p < '0' || *p > '9') return 0;
+    v = v * 10 + uint64_t(*p - '0');
+    if (v > 0xFFFFFFFFull) return 0;
+  }
+  return v ? uint32_t(v - 1) : 0u;  // saturating_sub(1)
+}
+
+int32_t pm_host_group_vars(const char* in, const pm_group_vars* v, char* out, size_t cap, size_t* needed) {
+  if (!in || !v || !v->next_p2p_address || !v->group_id || !v->total_upload_count)
+    return pm::set_error(PM_EINVAL, "null argument");
+  std::string s(in);
+  replace_all(s, "${GROUP_INDEX}", std::to_string(v->group_index));
+  replace_all(s, "${GROUP_SIZE}", std::to_string(v->group_size));
+  replace_all(s, "${NEXT_P2P_ADDRESS}", v->next_p2p_address);
+  replace_all(s, "${GROUP_ID}", v->group_id);
+  replace_all(s, "${TOTAL_UPLOAD_COUNT}", v->total_upload_count);
+  replace_all(s, "${LAST_FILE_IDX}", std::to_string(pm_host_last_file_idx(v->total_upload_count)));
+  return give(s, out, cap, needed);
+}
+
+int32_t pm_host_volume_vars(const char* in, const char* group_id, char* out, size_t cap, size_t* needed) {
+  if (!in || !group_id) return pm::set_error(PM_EINVAL, "null argument");
+  std::string s(in);
+  replace_all(s, "${GROUP_ID}", group_id);
+  return give(s, out, cap, needed);
+}
+
+int32_t pm_host_upload_name_vars(const char* in, const char* group_id, uint32_t group_size, uint32_t group_index,
+                                 uint64_t upload_count, char* out, size_t cap, size_t* needed) {
+  if (!in) return pm::set_error(PM_EINVAL, "null argument");
+  std::string s(in);
+  if (group_id) {  // storage.rs:150-158: only for a node that is in a group
+    replace_all(s, "${NODE_GROUP_ID}", group_id);
+    replace_all(s, "${NODE_GROUP_SIZE}", std::to_string(group_size));
+    replace_all(s, "${NODE_GROUP_INDEX}", std::to_string(group_index));
+  }
+  replace_all(s, "${TOTAL_UPLOAD_COUNT_AFTER}", std::to_string(upload_count));
+  replace_all(s, "${CURRENT_FILE_INDEX}", std::to_string(upload_count ? upload_count - 1 : 0));
+  return give(s, out, cap, needed);
+}
+
 uint32_t pm_abi_version(void) { return PM_ABI_VERSION; }
 
 }  // extern "C"

@@ -67,6 +67,11 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class GroupVars(C.Structure):
+    _fields_ = [("group_index", C.c_uint32), ("group_size", C.c_uint32), ("next_p2p_address", C.c_char_p),
+                ("group_id", C.c_char_p), ("total_upload_count", C.c_char_p)]
+
+
 class Assignment(C.Structure):
     _fields_ = [("task", C.c_uint32), ("group_slot", C.c_uint32), ("group_index", C.c_uint32),
                 ("group_size", C.c_uint32), ("next_worker", C.c_uint32), ("group_id", C.c_uint64)]
@@ -79,7 +84,8 @@ EXPORTS = [
     "pm_on_worker_status", "pm_dissolve_group", "pm_reset_groups", "pm_compat_masks", "pm_form_groups",
     "pm_merge_solo_groups", "pm_get_groups", "pm_match", "pm_match_per_task", "pm_newest_task", "pm_tick",
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
-    "pm_host_build_model_table", "pm_host_config_order", "pm_abi_version",
+    "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
+    "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
 ]
 
 _lib = None
@@ -132,9 +138,16 @@ def lib() -> C.CDLL:
         L.pm_host_model_matches.argtypes = [C.c_char_p, C.c_char_p]
         L.pm_host_build_model_table.argtypes = [C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, vp]
         L.pm_host_config_order.argtypes = [vp, u32, u64, vp, C.POINTER(u32)]
+        sz = C.c_size_t
+        L.pm_host_group_vars.argtypes = [C.c_char_p, C.POINTER(GroupVars), C.c_char_p, sz, C.POINTER(sz)]
+        L.pm_host_volume_vars.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
+        L.pm_host_upload_name_vars.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, C.c_char_p, sz, C.POINTER(sz)]
+        L.pm_host_last_file_idx.argtypes = [C.c_char_p]
+        L.pm_host_last_file_idx.restype = u32
         for name in EXPORTS:
             fn = getattr(L, name)
-            if name not in ("pm_last_error", "pm_abi_version", "pm_engine_destroy", "pm_engine_config_default"):
+            if name not in ("pm_last_error", "pm_abi_version", "pm_engine_destroy", "pm_engine_config_default",
+                            "pm_host_last_file_idx"):
                 fn.restype = i32
         _lib = L
     return _lib

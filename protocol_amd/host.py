@@ -120,3 +120,36 @@ def load_swarm(eng: E.Engine, sw: Swarm, *, enabled: int | None = None):
     eng.upload_tasks(sw.task_masks(), sw.created_at, sw.task_uid)
     eng.set_enabled_mask(sw.enabled_mask() if enabled is None else enabled)
     return cfg_rows, alt_rows, req_models
+
+
+# ---- group variables of the assigned task
+
+def _render(call) -> str:
+    need = C.c_size_t(0)
+    E.check(call(None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    E.check(call(buf, need.value, C.byref(need)))
+    return buf.value.decode()
+
+
+def group_vars(text: str, group_index: int, group_size: int, next_p2p_address: str, group_id: str,
+               total_upload_count: str) -> str:
+    """scheduler_impl.rs:160-183 for one env-var value / cmd argument."""
+    v = E.GroupVars(group_index, group_size, next_p2p_address.encode(), group_id.encode(), total_upload_count.encode())
+    return _render(lambda o, c, n: E.lib().pm_host_group_vars(text.encode(), C.byref(v), o, c, n))
+
+
+def volume_vars(text: str, group_id: str) -> str:
+    """scheduler_impl.rs:185-200 for host_path / container_path."""
+    return _render(lambda o, c, n: E.lib().pm_host_volume_vars(text.encode(), group_id.encode(), o, c, n))
+
+
+def upload_name_vars(text: str, group_id, group_size: int, group_index: int, upload_count: int) -> str:
+    """storage.rs:150-215 for the upload file-name template (group_id None: the node is in no group)."""
+    gid = None if group_id is None else group_id.encode()
+    return _render(lambda o, c, n: E.lib().pm_host_upload_name_vars(text.encode(), gid, group_size, group_index,
+                                                                    upload_count, o, c, n))
+
+
+def last_file_idx(total_upload_count: str) -> int:
+    return int(E.lib().pm_host_last_file_idx(total_upload_count.encode()))

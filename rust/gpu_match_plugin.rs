@@ -108,6 +108,15 @@ pub struct pm_stats {
     pub host_resolved_steps: u32, pub carve_launches: u32, pub pair_evals: u64, pub carve_cand_sum: u64,
 }
 
+#[repr(C)]
+pub struct pm_group_vars {
+    pub group_index: u32,
+    pub group_size: u32,
+    pub next_p2p_address: *const c_char,
+    pub group_id: *const c_char,
+    pub total_upload_count: *const c_char,
+}
+
 #[link(name = "pm_engine")]
 extern "C" {
     fn pm_engine_config_default(cfg: *mut pm_engine_config);
@@ -122,6 +131,8 @@ extern "C" {
     fn pm_on_worker_status(e: *mut c_void, worker: u32, flags_new: u32, dead: u32) -> i32;
     fn pm_tick(e: *mut c_void, stats: *mut pm_stats) -> i32;
     fn pm_lookup_task_for_worker(e: *mut c_void, worker: u32, out: *mut pm_assignment) -> i32;
+    fn pm_host_group_vars(input: *const c_char, v: *const pm_group_vars, out: *mut c_char, cap: usize, needed: *mut usize) -> i32;
+    fn pm_host_volume_vars(input: *const c_char, group_id: *const c_char, out: *mut c_char, cap: usize, needed: *mut usize) -> i32;
     fn pm_host_parse_requirements(s: *const c_char, cfg: *mut pm_config_row, alts: *mut pm_gpu_alt_row,
                                   alt_cap: u32, models_out: *mut c_char, models_cap: usize) -> i32;
     fn pm_host_build_model_table(req_models: *const *const c_char, n_rows: u32,
@@ -265,13 +276,27 @@ impl GpuMatchPlugin {
             return Ok(vec![]);
         }
         let mut task = self.tasks.read()[a.task as usize].clone();
+        // group variables (scheduler_impl.rs:155-200) through the library's helpers — the same chained
+        // replace order as the reference; the upload count still comes from the `upload:<node>:<group>:*` scan
+        let gid = CString::new(format!("{:x}", a.group_id))?;
+        let next = CString::new(self.p2p_ids.read().get(a.next_worker as usize).cloned().unwrap_or_default())?;
+        let count = CString::new(self.upload_count(node_address, a.group_id).to_string())?;
+        let vars = pm_group_vars { group_index: a.group_index, group_size: a.group_size,
+            next_p2p_address: next.as_ptr(), group_id: gid.as_ptr(), total_upload_count: count.as_ptr() };
+        let render = |s: &str| -> Result<String> {
+            let cin = CString::new(s)?;
+            let mut need = 0usize;
+            check(unsafe { pm_host_group_vars(cin.as_ptr(), &vars, std::ptr::null_mut(), 0, &mut need) })?;
+            let mut buf = vec![0u8; need];
+            check(unsafe { pm_host_group_vars(cin.as_ptr(), &vars, buf.as_mut_ptr() as *mut c_char, need, &mut need) })?;
+            buf.pop();
+            Ok(String::from_utf8(buf)?)
+        };
         let env = task.env_vars.get_or_insert_with(Default::default);
         env.insert("GROUP_INDEX".to_string(), a.group_index.to_string());
-        for (_, v) in env.iter_mut() {
-            *v = v.replace("${GROUP_INDEX}", &a.group_index.to_string())
-                .replace("${GROUP_SIZE}", &a.group_size.to_string())
-                .replace("${GROUP_ID}", &format!("{:x}", a.group_id));
-        }
+        for (_, v) in env.iter_mut() { *v = render(v)?; }
+        if let Some(cmd) = task.cmd.as_mut() { for arg in cmd.iter_mut() { *arg = render(arg)?; } }
+        // volume mounts: pm_host_volume_vars on host_path / container_path (same calling convention)
         Ok(vec![task])
     }
 

@@ -29,6 +29,16 @@ def main() -> int:
                 print(f"[{sec}] {k['name']}: model string not found verbatim: {m!r}")
                 bad += 1
     n = sum(len(kats[s]) for s in ("parser", "parser_errors", "meets"))
+    # group-variable templates: every template string must appear verbatim in the reference tests it cites
+    gv = json.load(open(os.path.join(HERE, "group_vars_kats.json")))
+    srcs = {"group_vars": open("/root/reference/crates/orchestrator/src/plugins/node_groups/tests.rs").read(),
+            "upload_name": open("/root/reference/crates/orchestrator/src/api/routes/storage.rs").read()}
+    for sec, src2 in srcs.items():
+        for k in gv[sec]:
+            n += 1
+            if "$" in k["in"] and f'"{k["in"]}"' not in src2 and k["in"] not in src2:
+                print(f"[{sec}] {k['name']}: template not found verbatim: {k['in']!r}")
+                bad += 1
     print(f"checked {n} vectors, {bad} mismatches")
     return 1 if bad else 0
 
