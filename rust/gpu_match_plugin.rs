@@ -9,7 +9,7 @@
 //! wait-free lookup of the table published by the last tick (scheduler_impl.rs:11-110).
 #![allow(non_camel_case_types, dead_code)]
 
-use std::ffi::{c_char, CStr};
+use std::ffi::{c_char, CStr, CString};
 use std::os::raw::c_void;
 
 use alloy::primitives::Address;
@@ -180,6 +180,8 @@ pub struct GpuMatchPlugin {
     config_names: Vec<String>,
     /// worker index = position in the last `NodeStore::get_nodes()` snapshot given to `sync_nodes`
     addresses: parking_lot::RwLock<Vec<Address>>,
+    /// p2p id per worker index (node.p2p_id.unwrap_or_default(), scheduler_impl.rs:118-128)
+    p2p_ids: parking_lot::RwLock<Vec<String>>,
     tasks: parking_lot::RwLock<Vec<Task>>,
 }
 
@@ -203,12 +205,15 @@ impl GpuMatchPlugin {
         // pm_config_row / pm_gpu_alt_row here (omitted: field-by-field copy), intern requirement model
         // strings, and call pm_set_configs — PM_EINVAL maps to the reference's "Plugin configuration is invalid".
         let this = Self { engine, config_names: templates.iter().map(|t| t.name.clone()).collect(),
-                          addresses: Default::default(), tasks: Default::default() };
+                          addresses: Default::default(), p2p_ids: Default::default(), tasks: Default::default() };
         this.set_configs(&templates);
         this
     }
 
     fn set_configs(&self, _templates: &[NodeGroupConfiguration]) { /* pack rows + pm_set_configs + pm_set_model_table */ }
+
+    /// Number of `upload:<node>:<group>:*` keys (scheduler_impl.rs:130-153): stays with the Redis store.
+    fn upload_count(&self, _node: &Address, _group_id: u64) -> usize { 0 /* store.scan_match(pattern).count() */ }
 
     /// Called with the snapshot of `store_context.node_store.get_nodes()` (node_store.rs:163-209); the
     /// ORDER of that Vec is the tie-break of the reference and is passed through unchanged.
@@ -237,6 +242,7 @@ impl GpuMatchPlugin {
             addr_rank: addr_rank.as_ptr(), lat: lat.as_ptr(), lon: lon.as_ptr() };
         check(unsafe { pm_upload_workers(self.engine, &soa, 1) })?;
         *self.addresses.write() = nodes.iter().map(|x| x.address).collect();
+        *self.p2p_ids.write() = nodes.iter().map(|x| x.p2p_id.clone().unwrap_or_default()).collect();
         Ok(())
     }
 
