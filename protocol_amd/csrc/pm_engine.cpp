@@ -73,6 +73,7 @@ struct Group {
   uint32_t task;      // index into the current task table or PM_NONE
   uint64_t task_uid;  // identity of the claimed task across uploads
   std::vector<uint32_t> members;  // carve order; BTreeSet order is derived from addr_rank
+  bool dead = false;              // dissolved, not yet removed from the list (compact_groups)
 };
 
 using Table = std::vector<pm_assignment>;
@@ -134,6 +135,8 @@ struct pm_engine {
 
   // ---- groups: the host vector is the source of truth between calls; device arrays mirror it
   std::vector<Group> groups;
+  size_t n_dead_groups = 0;  // dissolved entries still in `groups` (slots shift only when they are removed)
+  bool flags_dirty = false;  // h_flags changed since the last upload of the column
   std::vector<int32_t> h_group_of;
   uint64_t id_rng = 0;
   bool groups_dirty = true;
@@ -192,22 +195,38 @@ static int32_t upload(DevBuf<T>& d, const T* src, size_t n, hipStream_t s) {
 
 static void reset_groups_locked(pm_engine* e) {
   e->groups.clear();
+  e->n_dead_groups = 0;
   e->h_group_of.assign(e->W, -1);
   e->id_rng = e->cfg.group_id_seed;
   e->groups_dirty = true;
 }
 
-static void dissolve_locked(pm_engine* e, uint32_t slot) {  // dissolve_group, mod.rs:1423-1487
-  if (slot >= e->groups.size()) return;
-  e->groups.erase(e->groups.begin() + slot);
+// dissolve_group (mod.rs:1423-1487).  A status storm dissolves hundreds of groups per tick; removing each from
+// the list right away would renumber every later slot (O(groups + workers) per call).  The entry is only
+// marked here — the members are free at once — and compact_groups() removes all marked entries in one pass,
+// in list order, before anything looks at slot numbers again.
+static void dissolve_locked(pm_engine* e, uint32_t slot) {
+  if (slot >= e->groups.size() || e->groups[slot].dead) return;
+  for (uint32_t w : e->groups[slot].members) e->h_group_of[w] = -1;
+  e->groups[slot].dead = true;
+  e->n_dead_groups++;
+  e->groups_dirty = true;
+}
+
+static void compact_groups(pm_engine* e) {
+  if (!e->n_dead_groups) return;
+  e->groups.erase(std::remove_if(e->groups.begin(), e->groups.end(), [](const Group& g) { return g.dead; }),
+                  e->groups.end());
   std::fill(e->h_group_of.begin(), e->h_group_of.end(), -1);
   for (size_t g = 0; g < e->groups.size(); ++g)
     for (uint32_t w : e->groups[g].members) e->h_group_of[w] = int32_t(g);
+  e->n_dead_groups = 0;
   e->groups_dirty = true;
 }
 
 // Mirror the host group list into HBM (packed member pool, slot = index).
 static int32_t push_groups(pm_engine* e) {
+  compact_groups(e);
   if (!e->groups_dirty) return PM_OK;
   const size_t G = e->groups.size();
   std::vector<uint32_t> g_cfg(G), g_n(G), g_off(G), g_task(G), members;
@@ -251,8 +270,21 @@ static int32_t push_groups(pm_engine* e) {
   return PM_OK;
 }
 
+// status changes only touch the host copy of the flags column; the column goes up once before its next use
+static int32_t sync_flags(pm_engine* e) {
+  if (!e->flags_dirty || !e->have_workers) return PM_OK;
+  HIPCHK(hipMemcpyAsync(e->d_flags.p, e->h_flags.data(), size_t(e->W) * 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));  // pageable source
+  e->flags_dirty = false;
+  return PM_OK;
+}
+
 static int32_t ensure_compat(pm_engine* e) {
   if (!e->have_cfgs || !e->have_workers) return set_error(PM_ESTATE, "configs and workers must be uploaded first");
+  {
+    int32_t rcf = sync_flags(e);
+    if (rcf) return rcf;
+  }
   if (!e->compat_dirty) return PM_OK;
   for (const pm_gpu_alt_row& a : e->alts)
     if ((a.flags & PM_G_MODEL) && a.model_row >= e->model_rows)
@@ -885,6 +917,7 @@ static void host_merge_select(pm_engine* e, const std::vector<uint32_t>& rem, co
 
 static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
   if (n_merged) *n_merged = 0;
+  compact_groups(e);
   if (!e->have_cfgs || !e->have_workers) return set_error(PM_ESTATE, "configs and workers must be uploaded first");
   size_t solo = e->absorb_pending ? e->ab_solo : 0;  // single-node groups of the carve not yet absorbed
   for (const Group& g : e->groups) solo += g.members.size() == 1;
@@ -1307,21 +1340,37 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
   e->tplanes_dirty = true;
   // re-bind claimed tasks by identity; groups whose task vanished are dissolved (on_task_deleted,
   // mod.rs:1259-1288)
-  bool any_claim = false;
-  for (const Group& g : e->groups) any_claim |= g.task != PM_NONE;
-  if (any_claim) {
-    std::unordered_map<uint64_t, uint32_t> by_uid;
+  // Only the claimed tasks have to be found again: an open-addressing table of their ids (a few thousand
+  // entries, cache-resident), one pass over the new id column.
+  size_t n_claim = 0;
+  for (const Group& g : e->groups) n_claim += (!g.dead && g.task != PM_NONE);
+  if (n_claim) {
+    size_t cap = 64;
+    while (cap < n_claim * 4) cap <<= 1;
+    const uint64_t EMPTY = ~0ull;  // a task id of all ones simply stays unresolved in the table path below
+    std::vector<uint64_t> keys(cap, EMPTY);
+    std::vector<uint32_t> vals(cap, PM_NONE);
+    auto slot_of = [&](uint64_t k) {
+      size_t h = size_t(splitmix64_mix(k)) & (cap - 1);
+      while (keys[h] != EMPTY && keys[h] != k) h = (h + 1) & (cap - 1);
+      return h;
+    };
     if (e->tasks_have_uid) {
-      by_uid.reserve(e->T * 2);
-      for (uint32_t i = 0; i < e->T; ++i) by_uid.emplace(e->h_tuid[i], i);
+      for (const Group& g : e->groups)
+        if (!g.dead && g.task != PM_NONE && g.task_uid != EMPTY) keys[slot_of(g.task_uid)] = g.task_uid;
+      for (uint32_t i = 0; i < e->T; ++i) {
+        const uint64_t k = e->h_tuid[i];
+        size_t h = size_t(splitmix64_mix(k)) & (cap - 1);
+        while (keys[h] != EMPTY && keys[h] != k) h = (h + 1) & (cap - 1);
+        if (keys[h] == k && vals[h] == PM_NONE) vals[h] = i;  // first occurrence, like a map's emplace
+      }
     }
     for (size_t g = e->groups.size(); g-- > 0;) {
       Group& gr = e->groups[g];
-      if (gr.task == PM_NONE) continue;
+      if (gr.dead || gr.task == PM_NONE) continue;
       uint32_t ni = PM_NONE;
       if (e->tasks_have_uid) {
-        auto it = by_uid.find(gr.task_uid);
-        if (it != by_uid.end()) ni = it->second;
+        if (gr.task_uid != EMPTY) ni = vals[slot_of(gr.task_uid)];
       } else if (gr.task_uid < e->T) {
         ni = uint32_t(gr.task_uid);
       }
@@ -1342,8 +1391,7 @@ int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, u
   if (!e->have_workers || worker >= e->W) return set_error(PM_ERANGE, "worker index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   e->h_flags[worker] = flags_new;
-  HIPCHK(hipMemcpyAsync(e->d_flags.p + worker, &e->h_flags[worker], 4, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  e->flags_dirty = true;   // uploaded once before the next kernel that reads the column (sync_flags)
   e->compat_dirty = true;  // HAS_SPECS etc. may have changed with the row
   if (dead && e->h_group_of[worker] >= 0) dissolve_locked(e, uint32_t(e->h_group_of[worker]));  // status_update_impl.rs:17-29
   return PM_OK;
@@ -1352,8 +1400,10 @@ int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, u
 int32_t pm_dissolve_group(pm_engine* e, uint32_t slot) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  compact_groups(e);  // `slot` is a number of the compacted list (what pm_get_groups reports)
   if (slot >= e->groups.size()) return set_error(PM_ERANGE, "group slot out of range");
   dissolve_locked(e, slot);
+  compact_groups(e);
   return PM_OK;
 }
 
@@ -1407,6 +1457,7 @@ int32_t pm_get_groups(pm_engine* e, int32_t* group_of_worker, pm_group* groups, 
                       uint32_t* n_groups, uint32_t* members, uint32_t cap_members, uint32_t* n_members) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  compact_groups(e);
   const uint32_t G = uint32_t(e->groups.size());
   uint32_t M = 0;
   for (const Group& g : e->groups) M += uint32_t(g.members.size());
