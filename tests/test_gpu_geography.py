@@ -1,0 +1,135 @@
+"""Degenerate geographies through the carve: they drive the certificate / same-site / host-resolve branches of
+the proposal rows and the speculative rounds.  Every case: groups (ids, configurations, members in carve order)
+bit-exact against the oracle, for the default launch order, the sequential kernel and the pipelined variant."""
+import numpy as np
+import pytest
+
+from protocol_amd import engine as E
+from protocol_amd import host
+from protocol_amd.swarm import make_swarm
+from helpers import engine_groups, oracle_groups, oracle_state_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(sw, expect_host_resolved=None, **engine_kw):
+    for variant in (0, 1, 3):
+        st = oracle_state_for(sw, reference_shaped=True)
+        eng = E.Engine(carve_variant=variant, **engine_kw)
+        host.load_swarm(eng, sw)
+        assert st.try_form_new_groups() == eng.form_groups(), variant
+        assert oracle_groups(st) == engine_groups(eng), variant
+        resolved = eng.last_stats()["host_resolved_steps"]
+        if expect_host_resolved is not None:
+            assert (resolved > 0) == expect_host_resolved, (variant, resolved)
+        eng.close()
+
+
+def _set_configs(sw, configs):
+    """replace the configurations and fold the tasks' topology indices onto them"""
+    sw.configs = configs
+    n = len(configs)
+    sw.topo = (sw.topo.astype(np.int64) % n).astype(np.int16)
+    sw.topo[sw.n_topo[:, None] <= np.arange(sw.topo.shape[1])[None, :]] = -2
+    sw.topo[~sw.restricted] = -2
+    return sw
+
+
+def _swarm(seed=31, W=700):
+    return _set_configs(make_swarm(seed, 50, W), [("quad", 4, 4, None), ("pairs", 2, 2, None)])
+
+
+def test_every_worker_at_one_site():
+    sw = _swarm()
+    sw.has_loc[:] = True
+    sw.lat[:] = 48.8566
+    sw.lon[:] = 2.3522
+    _check(sw, expect_host_resolved=False)      # exact ties everywhere: input order decides, no near-ties
+
+
+def test_no_worker_has_a_location():
+    sw = _swarm()
+    sw.has_loc[:] = False
+    _check(sw, expect_host_resolved=False)
+
+
+def test_two_sites_and_some_unlocated():
+    sw = _swarm()
+    rng = np.random.default_rng(3)
+    sw.has_loc[:] = rng.random(sw.W) < 0.8
+    west = rng.random(sw.W) < 0.5
+    sw.lat[:] = np.where(west, 37.7749, 52.52)
+    sw.lon[:] = np.where(west, -122.4194, 13.405)
+    _check(sw, expect_host_resolved=False)
+
+
+def test_wide_groups_drain_a_city():
+    """groups of 16 out of clusters of ~40 co-located nodes: the same-site chain runs dry and is topped up from
+    the proposal row"""
+    sw = _set_configs(make_swarm(32, 50, 1200), [("wide", 9, 16, None), ("rest", 2, 3, None)])
+    rng = np.random.default_rng(5)
+    city = rng.integers(0, 30, sw.W)
+    sw.has_loc[:] = True
+    sw.lat[:] = -60.0 + 4.0 * city
+    sw.lon[:] = -170.0 + 11.0 * city
+    jitter = rng.random(sw.W) < 0.3          # a third of the nodes sit near, not at, their city
+    sw.lat[:] += np.where(jitter, rng.normal(0, 0.05, sw.W), 0.0)
+    sw.lon[:] += np.where(jitter, rng.normal(0, 0.05, sw.W), 0.0)
+    _check(sw, expect_host_resolved=False)
+
+
+def test_last_ulp_neighbours():
+    """coordinates that differ in the last bits of the mantissa: distinct sites a few ulps apart — wherever two
+    of them fall inside the certificate band the engine must not guess (the host settles such a step with
+    glibc); either way the result is the oracle's"""
+    sw = _swarm(33, 400)
+    sw.has_loc[:] = True
+    base_lat = np.float64(40.7128)
+    base_lon = np.float64(-74.0060)
+    k = np.arange(sw.W) % 7
+    sw.lat[:] = base_lat + k * np.spacing(base_lat)
+    sw.lon[:] = base_lon - k * np.spacing(base_lon)
+    _check(sw)
+
+
+def test_antipodal_points_are_outside_the_reference_domain():
+    """Two clusters at exact antipodes.  For such pairs the reference's Haversine term rounds to a > 1 about half
+    of the time, its distance is NaN, and `partial_cmp(..).unwrap_or(Equal)` (mod.rs:239-253) stops being an
+    order: what `sort_by` returns then depends on the sort implementation (recent Rust may even panic), and the
+    oracle's merge sort is just one such outcome.  The engine orders by the Haversine term itself, which stays
+    well defined; all it can promise here is a valid, deterministic carve — the same for every kernel variant."""
+    sw = _swarm(34, 300)
+    sw.has_loc[:] = True
+    east = (np.arange(sw.W) % 2) == 0
+    rng = np.random.default_rng(9)
+    sw.lat[:] = np.where(east, 10.0, -10.0) + rng.normal(0, 1e-7, sw.W)
+    sw.lon[:] = np.where(east, 20.0, -160.0) + rng.normal(0, 1e-7, sw.W)
+    st = oracle_state_for(sw, reference_shaped=True)
+    n_oracle = st.try_form_new_groups()
+    results = []
+    for variant in (0, 1, 3):
+        eng = E.Engine(carve_variant=variant)
+        host.load_swarm(eng, sw)
+        assert eng.form_groups() == n_oracle          # the greedy count does not depend on the order
+        gow, groups, members = eng.get_groups()
+        seen = np.zeros(sw.W, dtype=np.int32)
+        np.add.at(seen, members, 1)
+        assert seen.max() <= 1
+        for g in groups:
+            mem = members[int(g["member_begin"]):int(g["member_begin"]) + int(g["n_members"])]
+            # a group never straddles the antipodes: the three nearest of a seed are in its own cluster
+            assert len(set(east[mem].tolist())) == 1
+        results.append(engine_groups(eng))
+        eng.close()
+    assert results[0] == results[1] == results[2]
+
+
+def test_proximity_disabled_is_first_come():
+    sw = _swarm(35, 500)
+    for variant in (0, 1, 3):
+        st = oracle_state_for(sw, reference_shaped=True, proximity=False)
+        eng = E.Engine(carve_variant=variant, proximity=False)
+        host.load_swarm(eng, sw)
+        assert st.try_form_new_groups() == eng.form_groups()
+        assert oracle_groups(st) == engine_groups(eng)
+        eng.close()
