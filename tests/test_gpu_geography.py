@@ -92,6 +92,18 @@ def test_last_ulp_neighbours():
     _check(sw)
 
 
+def test_mirror_sites_tie_exactly_and_go_to_the_host():
+    """Two sites mirrored about the seed's meridian are exactly equidistant — in the reference too, where the
+    stable sort then falls back to input order.  They are different sites, so the certificate cannot vouch for
+    the slot order: those steps are settled on the host, and the result is the oracle's."""
+    sw = _swarm(36, 360)
+    sw.has_loc[:] = True
+    which = np.arange(sw.W) % 12           # one node in twelve at the centre, the rest alternate east / west
+    sw.lat[:] = 12.5
+    sw.lon[:] = np.where(which == 0, 30.0, np.where(which % 2 == 1, 30.25, 29.75))
+    _check(sw, expect_host_resolved=True)
+
+
 def test_antipodal_points_are_outside_the_reference_domain():
     """Two clusters at exact antipodes.  For such pairs the reference's Haversine term rounds to a > 1 about half
     of the time, its distance is NaN, and `partial_cmp(..).unwrap_or(Equal)` (mod.rs:239-253) stops being an
