@@ -196,6 +196,7 @@ static int32_t upload(DevBuf<T>& d, const T* src, size_t n, hipStream_t s) {
 static void reset_groups_locked(pm_engine* e) {
   e->groups.clear();
   e->n_dead_groups = 0;
+  e->absorb_pending = false;  // records of a carve that was never absorbed belong to the old list
   e->h_group_of.assign(e->W, -1);
   e->id_rng = e->cfg.group_id_seed;
   e->groups_dirty = true;
@@ -537,7 +538,9 @@ static void host_mark(const char* what) {
 }
 
 static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = false) {
-  int32_t rc = ensure_compat(e);
+  int32_t rc = absorb_groups(e);  // a match that failed half-way may have left the last carve unabsorbed
+  if (rc) return rc;
+  rc = ensure_compat(e);
   if (rc) return rc;
   rc = push_groups(e);
   if (rc) return rc;
