@@ -452,23 +452,26 @@ __device__ __forceinline__ __attribute__((address_space(1))) T* G(T* q) {
 // ---- wave-wide unsigned min via DPP (no LDS traffic): row_shr 1,2,4,8 -> row_bcast15 -> row_bcast31,
 // result broadcast from lane 63 with readlane.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp_min_step(uint64_t v) {
-  const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
-  const uint32_t ohi =
-      (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
-  const uint64_t o = ((uint64_t)ohi << 32) | olo;
-  return o < v ? o : v;
+__device__ __forceinline__ uint32_t dpp_min32_step(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, CTRL, ROW_MASK, 0xF, false);
+  return o < v ? o : v;  // folds into one v_min_u32 with a DPP operand
 }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = dpp_min32_step<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_min32_step<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_min32_step<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_min32_step<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_min32_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_min32_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit minimum as two 32-bit reductions (high words, then the low words of the lanes that hold the minimal
+// high word): a 64-bit compare-and-select per DPP step costs about three times as many instructions
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-  v = dpp_min_step<0x111, 0xF>(v);  // row_shr:1
-  v = dpp_min_step<0x112, 0xF>(v);  // row_shr:2
-  v = dpp_min_step<0x114, 0xF>(v);  // row_shr:4
-  v = dpp_min_step<0x118, 0xF>(v);  // row_shr:8
-  v = dpp_min_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
-  v = dpp_min_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
-  const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, 63);
-  const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
-  return ((uint64_t)hi << 32) | lo;
+  const uint32_t hi = (uint32_t)(v >> 32);
+  const uint32_t mh = wave_min_u32(hi);
+  const uint32_t ml = wave_min_u32(hi == mh ? (uint32_t)v : 0xFFFFFFFFu);
+  return ((uint64_t)mh << 32) | ml;
 }
 
 // barrier for exchanges that go through LDS only (no global-memory drain)
