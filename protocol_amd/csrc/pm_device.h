@@ -65,9 +65,7 @@ enum {
   // stream while the current one is validated):
   CARVE_F_PIPE = 1u << 4,   // this launch belongs to a pipelined carve
   CARVE_F_PREP = 1u << 5,   // (pipelined) prepare-only launch for this argument block's list buffer
-  CARVE_F_BUF1 = 1u << 6,   // (pipelined) the launch works on list buffer 1 (else 0)
-  CARVE_F_WAIT = 1u << 7    // (pipelined) PREP: start when the validator of the other buffer says go (late start
-                            // keeps the early list fresh; a timeout makes the wait advisory)
+  CARVE_F_BUF1 = 1u << 6    // (pipelined) the launch works on list buffer 1 (else 0)
 };
 enum { CARVE_LIST_EMPTY = 0, CARVE_LIST_READY = 1, CARVE_LIST_REPREP = 2 };
 // One prepared candidate list of a pipelined carve.
@@ -99,8 +97,6 @@ struct CarveStatus {
   uint32_t n_solo;       // single-node groups carved (the merge pass only runs when there are two or more)
   uint32_t _pad_solo;
   CarveList list[2];     // pipelined carve: the two list buffers
-  uint32_t go[2];        // go[b] = 1: the validator of buffer b is nearly done (or done) — prepare the next list
-  uint32_t _pad_go[2];
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 

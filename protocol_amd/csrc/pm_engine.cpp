@@ -576,7 +576,8 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   // 3 = pipelined: the next configuration is prepared and proposed on a second stream while the current one
   // is validated.  Bit-exact like the others, but measured slower at BASELINE configs[1] (3.8 vs 3.2 ms):
   // most validation launches end because half of their list is dead, the re-preparation that follows cannot
-  // overlap anything, and lists prepared early start with dead entries, so they hit that threshold sooner.
+  // overlap anything, and lists prepared early start with dead entries, so they hit that threshold sooner
+  // (starting the preparation late, on a device-side signal from the validator, was slower still: 4.3 ms).
   const bool pipelined = use_props && e->cfg.carve_variant == 3;
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
   if (pipelined) {
@@ -613,7 +614,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
         const CarveArgs* ab = e->d_carve_args.p + b;
         // the buffer is free once the validation two pairs back is done
         if (pj >= 2) HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_run[pj - 2], 0));
-        HIPCHK(launch_carve(ab, fl | CARVE_F_PREP, 0, lds, e->stream2));  // (CARVE_F_WAIT: late start, slower still)
+        HIPCHK(launch_carve(ab, fl | CARVE_F_PREP, 0, lds, e->stream2));
         launch_carve_propose(ab, e->W, b, e->stream2);
         HIPCHK(hipEventRecord(e->ev_prep[pj], e->stream2));
         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_prep[pj], 0));

@@ -561,7 +561,6 @@ struct StepCtx {
   uint32_t slot_bits;
   double band;
   bool big;  // per-slot arrays live in HBM/L2 (list above PM_CARVE_SLOTS), bitmaps + staged rows in LDS
-  uint32_t go_slot;  // pipelined carve: status->go[] entry to raise when this list is nearly used up (PM_NONE = none)
 };
 
 __device__ __forceinline__ void ctx_set_geometry(StepCtx& c) {
@@ -939,7 +938,6 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   const uint32_t max_commits = UNI(room_g < room_m ? room_g : room_m);
   int action = FAST_SEQ;
   uint32_t next_row = 0, commits_done = 0;
-  uint32_t go_slot = UNI(c.go_slot);
 #ifdef PM_CARVE_PROF
   const uint64_t rt0 = __builtin_amdgcn_s_memtime();
   uint32_t n_rounds_prof = 0;
@@ -965,12 +963,6 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     if (n_fit == 0u) {
       action = FAST_SEQ;
       break;
-    }
-    // pipelined carve: with a quarter of the list left, the remaining validation takes about as long as the
-    // preparation + proposals of the next configuration — tell the PREP launch on the other stream to start
-    if (go_slot != PM_NONE && n_cand_now * 4u < n_list_v) {
-      if (tid == 0) __hip_atomic_store(&G(p.status)->go[go_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      go_slot = PM_NONE;
     }
     // More than half of the list is dead: the neighbour lists are thinning out.  Re-prepare (compact) and
     // re-propose now, before rows start running out of live entries and every step needs the exact sweep.
@@ -1207,7 +1199,6 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     if (tid == 64) { G(p.status)->prof[6] += t_wait; G(p.status)->prof[7] += t_commit; G(p.status)->prof[8] += t_sync; G(p.status)->prof[16] += t_chk; G(p.status)->prof[17] += t_b2; }
     if (tid == 448) { G(p.status)->prof[18] += t_chk; G(p.status)->prof[19] += t_spec; }
 #endif
-    c.go_slot = go_slot;
     c.n_groups = base_groups + commits;
     c.mem_off = base_mem + commits * group_n;
     c.n_cand = base_cand - commits * group_n;
@@ -2180,21 +2171,6 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   const bool pipe = (flags & CARVE_F_PIPE) != 0u;
   const uint32_t pb = (flags & CARVE_F_BUF1) ? 1u : 0u;
   bool pipe_single = false;  // PREP: rebuild exactly list[pb].ci (re-prepare / refresh), no search
-  const bool pipe_run = pipe && !(flags & (CARVE_F_PREP | CARVE_F_INIT));
-  // every way out of a pipelined RUN launch says go
-#define PIPE_GO() do { if (pipe_run && tid == 0) __hip_atomic_store(&st->go[pb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
-  if (pipe && (flags & CARVE_F_PREP) && (flags & CARVE_F_WAIT)) {
-    if (tid == 0) {
-      const uint64_t t0 = __builtin_amdgcn_s_memtime();
-      while (__hip_atomic_load(&st->go[pb ^ 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        __builtin_amdgcn_s_sleep(64);
-        if (__builtin_amdgcn_s_memtime() - t0 > 10000000ull) break;  // ~5 ms: the wait is advisory
-      }
-      __hip_atomic_store(&st->go[pb ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (st->state != CARVE_STATE_RUNNING) return;
-  }
   PROF_DECL;
 
   uint32_t n;
@@ -2205,7 +2181,6 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   c.steps = 0;
   c.fast_steps = 0;
   c.cand_sum = 0;
-  c.go_slot = pipe_run ? pb : PM_NONE;
   uint32_t ci;          // configuration being prepared / run
   bool prepared;
   if (flags & CARVE_F_INIT) {
@@ -2294,16 +2269,13 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         // configurations are validated strictly in order: not while the other buffer waits for its
         // re-preparation or holds an earlier configuration
         if (l_state != CARVE_LIST_READY ||
-            (o_state == CARVE_LIST_REPREP || (o_state == CARVE_LIST_READY && o_ci < l_ci))) {
-          PIPE_GO();
+            (o_state == CARVE_LIST_REPREP || (o_state == CARVE_LIST_READY && o_ci < l_ci)))
           return;
-        }
         if (l_ci >= p.n_avail) {  // nothing left to prepare, nothing left to validate
           if (tid == 0) {
             st->state = CARVE_STATE_DONE;
             st->cur_ci = p.n_avail;
           }
-          PIPE_GO();
           return;
         }
         ci = l_ci;
@@ -2525,7 +2497,6 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   }
   __syncthreads();
   PROF_MARK(14);
-  PIPE_GO();
   if (tid == 0) {
     st->state = exit_state;
     st->n_groups = c.n_groups;
