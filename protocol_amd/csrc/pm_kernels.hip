@@ -2106,7 +2106,8 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
   // The configuration is re-prepared (and re-proposed) once half of its list is dead; by then the seed
   // pointer has advanced through roughly the first eighth of the slots (each group removes max_s slots
   // spread over the whole list), so later slots never consume this round's proposals: cap the batch.
-  uint32_t cap = n_list / 5u;
+  // (big lists: a seventh — their proposal sweeps are what a match of 100 k workers spends its time on)
+  uint32_t cap = n_list > PM_CARVE_SLOTS ? n_list / 7u : n_list / 5u;
   if (cap < 512u) cap = 512u;
   if (cap > PM_PROP_MAX_SEEDS) cap = PM_PROP_MAX_SEEDS;
   if (n_list <= cap) return n_list;
