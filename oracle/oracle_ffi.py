@@ -122,6 +122,8 @@ def lib() -> C.CDLL:
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_compat_masks.argtypes = [vp, sz, vp, sz, vp]
         L.orc_pair_sweep_per_worker.argtypes = [vp, sz, vp, vp, sz, vp, vp]
+        L.orc_pair_sweep_per_worker_mt.argtypes = [vp, sz, vp, vp, sz, vp, vp, C.c_uint32]
+        L.orc_pair_sweep_per_worker_mt.restype = C.c_int
         _lib = L
     return _lib
 
@@ -234,12 +236,17 @@ def compat_masks(nodes: np.ndarray, cfgs: np.ndarray) -> np.ndarray:
     return out
 
 
-def pair_sweep_per_worker(tasks: np.ndarray, cfgs: np.ndarray, cfg_of_node: np.ndarray):
+def pair_sweep_per_worker(tasks: np.ndarray, cfgs: np.ndarray, cfg_of_node: np.ndarray, threads: int = 1):
+    """threads > 1: the nodes are split over POSIX threads (independent heartbeats)"""
     cfg_of_node = np.ascontiguousarray(cfg_of_node, dtype=np.int32)
     first = np.zeros(len(cfg_of_node), dtype=np.uint32)
     count = np.zeros(len(cfg_of_node), dtype=np.uint32)
-    lib().orc_pair_sweep_per_worker(_p(tasks), len(tasks), _p(cfgs), _p(cfg_of_node), len(cfg_of_node),
-                                    _p(first), _p(count))
+    if threads > 1:
+        lib().orc_pair_sweep_per_worker_mt(_p(tasks), len(tasks), _p(cfgs), _p(cfg_of_node), len(cfg_of_node),
+                                           _p(first), _p(count), threads)
+    else:
+        lib().orc_pair_sweep_per_worker(_p(tasks), len(tasks), _p(cfgs), _p(cfg_of_node), len(cfg_of_node),
+                                        _p(first), _p(count))
     return first, count
 
 

@@ -12,6 +12,7 @@
 #include "pm_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -977,6 +978,49 @@ void orc_pair_sweep_per_worker(const orc_task* tasks, size_t n_tasks, const orc_
     first_out[w] = first;
     count_out[w] = count;
   }
+}
+
+/* The same sweep with the nodes split over threads: in the reference the heartbeats of different nodes are
+ * independent requests on the tokio worker threads, so this is what all host cores can do for that phase
+ * (bench.py: cpu_baseline.all_cores).  Group formation stays sequential, as it is in the reference. */
+typedef struct {
+  const orc_task* tasks; size_t n_tasks; const orc_config* cfgs; const int32_t* cfg_of_node;
+  size_t start, stride, n_nodes; uint32_t* first_out; uint32_t* count_out;
+} orc_sweep_job;
+
+static void* orc_sweep_thread(void* arg) { /* nodes start, start + stride, ...: grouped nodes come in runs */
+  const orc_sweep_job* j = (const orc_sweep_job*)arg;
+  for (size_t w = j->start; w < j->n_nodes; w += j->stride)
+    orc_pair_sweep_per_worker(j->tasks, j->n_tasks, j->cfgs, j->cfg_of_node + w, 1, j->first_out + w,
+                              j->count_out + w);
+  return NULL;
+}
+
+int orc_pair_sweep_per_worker_mt(const orc_task* tasks, size_t n_tasks, const orc_config* cfgs,
+                                 const int32_t* cfg_of_node, size_t n_nodes, uint32_t* first_out,
+                                 uint32_t* count_out, uint32_t n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 1024) n_threads = 1024;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
+  orc_sweep_job* jobs = (orc_sweep_job*)malloc(sizeof(orc_sweep_job) * n_threads);
+  int rc = 0;
+  uint32_t started = 0;
+  for (uint32_t i = 0; i < n_threads; ++i) {
+    jobs[i] = (orc_sweep_job){tasks, n_tasks, cfgs, cfg_of_node, i, n_threads, n_nodes, first_out, count_out};
+    if (pthread_create(&th[i], NULL, orc_sweep_thread, &jobs[i]) != 0) {
+      orc_sweep_thread(&jobs[i]); /* run it here */
+      th[i] = 0;
+      rc = 1;
+      continue;
+    }
+    started |= 1u; /* at least one */
+  }
+  (void)started;
+  for (uint32_t i = 0; i < n_threads; ++i)
+    if (th[i]) pthread_join(th[i], NULL);
+  free(th);
+  free(jobs);
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------

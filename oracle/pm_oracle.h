@@ -255,6 +255,12 @@ void orc_pair_sweep_per_worker(const orc_task* tasks, size_t n_tasks, const orc_
                                const int32_t* cfg_of_node, size_t n_nodes, uint32_t* first_out,
                                uint32_t* count_out);
 
+/* the same, nodes split over n_threads POSIX threads (returns 1 if a thread could not be started and its share ran
+ * on the caller) */
+int orc_pair_sweep_per_worker_mt(const orc_task* tasks, size_t n_tasks, const orc_config* cfgs,
+                                 const int32_t* cfg_of_node, size_t n_nodes, uint32_t* first_out,
+                                 uint32_t* count_out, uint32_t n_threads);
+
 /* ---- group variables of the task handed to a grouped node (scheduler_impl.rs:155-200) and of the upload
  * file name (orchestrator/src/api/routes/storage.rs:150-215).  Each returns a malloc'd string (free with
  * orc_free_string). */

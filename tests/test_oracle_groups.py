@@ -264,3 +264,21 @@ def test_disabled_config_forms_nothing_and_variants_agree():
     fast.try_form_new_groups()
     assert ref.groups() == fast.groups()
     assert ref.counters()[0] > fast.counters()[0]      # the reference shape recomputes Haversines
+
+
+def test_threaded_pair_sweep_equals_the_sequential_one():
+    """bench.py's all-cores CPU baseline splits the nodes of the reference-orientation sweep over threads"""
+    import numpy as np
+    from oracle import oracle_ffi as orc
+    from protocol_amd.swarm import make_swarm
+    sw = make_swarm(11, 700, 900)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False)
+    st.try_form_new_groups()
+    cfg_of_node = np.full(sw.W, -1, dtype=np.int32)
+    for _, _, c, mem, _ in st.groups():
+        cfg_of_node[mem] = c
+    a = orc.pair_sweep_per_worker(tasks, cfgs, cfg_of_node)
+    for threads in (2, 5, 64):
+        b = orc.pair_sweep_per_worker(tasks, cfgs, cfg_of_node, threads=threads)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
