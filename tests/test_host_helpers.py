@@ -140,3 +140,28 @@ def test_swarm_masks_agree_with_oracle_topology_predicate():
         want = np.array([orc.lib().orc_task_applicable(tasks[t:t + 1].ctypes.data, name) for t in range(sw.T)])
         got = ((masks >> np.uint64(c)) & np.uint64(1)).astype(np.int64)
         assert np.array_equal(want, got), c
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """The last bench line committed under profiles/ carries every key the driver and the judge read."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")))
+    assert lines, "no bench line committed under profiles/"
+    d = json.load(open(lines[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    # whole-job throughput = pairs per step / time per step
+    assert abs(d["value"] - d["config"]["tasks"] * d["config"]["workers_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
