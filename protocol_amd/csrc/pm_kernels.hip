@@ -421,15 +421,17 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// Carve kernel: the whole greedy group formation of one tick inside ONE persistent workgroup
-// (16 waves).  The greedy is a chain of dependent steps (group g+1's seed depends on what group g
-// removed), so there is no cross-workgroup traffic to pay for: candidates are position-compacted,
-// the alive/candidate bitmaps live in LDS, and every step is
+// Carve kernel: the sequential part of the greedy group formation inside ONE workgroup (8 waves).  The
+// greedy is a chain of dependent steps (group g+1's seed depends on what group g removed), so there is no
+// cross-workgroup traffic to pay for: candidates are position-compacted, the alive/candidate bitmaps live
+// in LDS.  The exact form of a step is
 //   seed search (bitmap scan) -> Haversine term for every remaining candidate -> top-(max-1)
-//   selection by (key, position) with a wavefront argmin staged through LDS -> commit.
+//   selection by (key, position) with a wavefront argmin staged through LDS -> commit;
+// almost every step is instead served from the neighbour lists carve_propose_kernel computed on the whole
+// chip (carve_fast_rounds / carve_fast_steps below), which only have to be filtered against the bitmap.
 //
 // Ordering key.  The reference sorts by d = 6371 * 2 * atan2(sqrt(a), sqrt(1-a)) computed with glibc
-// libm (mod.rs:218-231).  d is a monotone function of a, so the kernel orders by a (f64, OCML sin)
+// libm (mod.rs:218-231).  d is a monotone function of a, so the kernel orders by a (f64, polynomial sin: sin_band)
 // and proves the selection equal to the reference's: if every candidate whose a lies within a
 // relative 2^-36 band around the last selected one has bit-identical coordinates (then the
 // reference's distances tie exactly and the stable sort falls back to input order, like the
@@ -1216,8 +1218,8 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
 
 // LDS carve of one candidate list of at most PM_CARVE_SLOTS slots: worker ids, site ids, packed keys,
 // the alive / loc bitmaps and the per-wave partial selections all live in LDS (slot s is owned by thread
-// s % 1024).  Fast steps come from the proposals; a slow step is the exact full sweep: keys for every
-// live candidate, two-level selection (DPP argmin rounds per wave, 16-way merge), certificate, commit —
+// s % CARVE_THREADS).  Fast steps come from the proposals; a slow step is the exact full sweep: keys for every
+// live candidate, two-level selection (DPP argmin rounds per wave, 8-way merge), certificate, commit —
 // three LDS-only barriers.  Runs until the configuration is exhausted, a recompaction is due, or a step
 // cannot be certified.
 template <bool BIG>
@@ -1307,7 +1309,8 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         }
         // FAST_SEQ / FAST_SLOW: the sequential fast path below decides (it re-derives the seed)
       }
-      // wave 0 commits as many steps as the proposals allow; everyone else waits at the barrier
+      // whatever the rounds left over (tails, first-come groups, the step that needs the exact sweep): wave 0
+      // commits as many steps as the proposals allow; everyone else waits at the barrier
       if (wave == 0) {
         PROF_DECL;
         const int act = carve_fast_steps<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive, l_loc, steps_before);
@@ -1443,7 +1446,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
           }
           if (lane == 0) red.part_n[wave] = cnt;
                 lds_barrier();
-                // ---- level 2: 16-way merge of the sorted partial lists, redundantly in every wave
+                // ---- level 2: merge of the waves' sorted partial lists, redundantly in every wave
           uint32_t ptr = 0;
           const uint32_t my_n = lane < CARVE_WAVES ? red.part_n[lane] : 0u;
           uint64_t head = my_n ? part[lane * PM_CARVE_PART] : ~0ull;
@@ -1821,7 +1824,7 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
 
 // Proposal generator: one wave per located live slot of the prepared configuration.  The wave sweeps the
 // whole candidate list (coalesced 64-slot strides), every lane keeps its PM_TOPN smallest keys in registers,
-// and K rounds of DPP argmin pop the K nearest in (key, slot) order.  A lane whose four entries are all
+// and K rounds of DPP argmin pop the K nearest in (key, slot) order.  A lane whose PM_TOPN entries are all
 // consumed re-sweeps its own slots for keys beyond the last one popped.
 #define PM_TOPN 8  // smallest keys each lane keeps (a lane holding more than that of the K nearest re-sweeps)
 struct TopN {
