@@ -17,6 +17,9 @@
  *              orc_parse_requirements   shared/src/models/node.rs:659-736,1044-1063,1082-1116,1229-1241
  *              orc_meets                shared/src/models/node.rs:740-1042,1065-1080,1118-1227
  *              orc_newest_task          orchestrator/src/plugins/newest_task/mod.rs:29-55
+ *            in tests/golden/group_vars_kats.json:
+ *              orc_group_vars, orc_last_file_idx   orchestrator/src/plugins/node_groups/tests.rs:565-676
+ *              orc_upload_name_vars                orchestrator/src/api/routes/storage.rs:575-760
  *            and structurally (group counts / sizes / membership) by ports of
  *            orchestrator/src/plugins/node_groups/tests.rs.
  *   PARITY UNPINNED (the reference itself is non-deterministic or depends on
