@@ -165,3 +165,42 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
     # whole-job throughput = pairs per step / time per step
     assert abs(d["value"] - d["config"]["tasks"] * d["config"]["workers_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_parser_differential_fuzz_product_vs_oracle():
+    """Two independent implementations of ComputeRequirements::from_str (C++ product, C oracle) on a few thousand
+    strings assembled from the grammar's tokens and from junk: same outcome class, same parsed requirements."""
+    import random
+    from test_oracle_kats import req_to_dict
+    rng = random.Random(20250801)
+    keys = ["gpu:count", "gpu:model", "gpu:memory_mb", "gpu:memory_mb_min", "gpu:memory_mb_max",
+            "gpu:total_memory_min", "gpu:total_memory_max", "cpu:cores", "ram_mb", "storage_gb", "gpu", "cpu", "gpu:", ":",
+            "GPU:count", "gpu:Count", "ram", "storage"]
+    vals = ["0", "1", "8", "80000", "4294967295", "4294967296", "-1", "+2", "1.5", "", " 4 ", "x", "H100", "a100,h100",
+            "RTX_4090", "rtx 3090", "a=b", "1e3", "0x10", "００"]
+    seps = [";", ";", ";", ";;", " ; ", ",", "\n", ""]
+    eqs = ["=", "=", "=", " = ", "==", ":", ""]
+    code_map = {0: E.PM_OK, 1: E.PM_EPARSE, 2: E.PM_EPANIC}
+    n_ok = n_err = n_panic = 0
+    for _ in range(4000):
+        parts = [rng.choice(keys) + rng.choice(eqs) + rng.choice(vals) for _ in range(rng.randint(0, 6))]
+        s = "".join(p + rng.choice(seps) for p in parts)
+        if rng.random() < 0.1:
+            s = s.replace("gpu", "gpu ", 1)
+        ocode, orow, _ = orc.parse_requirements(s)
+        if ocode == 3:          # more alternatives than the oracle's fixed row holds
+            continue
+        try:
+            got = parsed_to_dict(*host.parse_requirements(s))
+            pcode = E.PM_OK
+        except E.EngineError as ex:
+            pcode, got = ex.code, None
+        assert pcode == code_map[ocode], repr(s)
+        if ocode == 0:
+            assert got == req_to_dict(orow), repr(s)
+            n_ok += 1
+        elif ocode == 1:
+            n_err += 1
+        else:
+            n_panic += 1
+    assert n_ok > 200 and n_err > 200      # the generator reaches both sides of the grammar
