@@ -150,12 +150,9 @@ typedef struct {
                                      exact host resolve path runs (0 = off) */
   uint32_t sweep_variant;        /* pair-sweep kernel: 0 = default (best), 1 = scalar reference kernel */
   uint32_t carve_variant;        /* group formation: 0 = default (full-chip neighbour-list proposals + speculative
-                                    in-order validation rounds, one launch after the other),
-                                    1 = single-workgroup sequential sweep only,
-                                    2 = proposals with single-wave sequential validation,
-                                    3 = like 0, but the next configuration is prepared and proposed on a second
-                                        stream while the current one is validated (experimental: bit-exact,
-                                        measured slower — DESIGN.md section 4.2) */
+                                    in-order validation rounds),
+                                    1 = single-workgroup sequential exact sweep only (the straightforward kernel),
+                                    2 = proposals with single-wave sequential validation (no speculative rounds) */
   uint32_t _reserved;
 } pm_engine_config;
 

@@ -61,21 +61,7 @@ enum {
   CARVE_F_RUN = 1u << 1,    // process the prepared configuration
   CARVE_F_ALL = 1u << 2,    // keep going through every configuration in this launch (no proposals)
   CARVE_F_PROPS = 1u << 3,  // neighbour-list proposals of carve_propose_kernel are available
-  // pipelined carve (two list buffers; preparation + proposals of the next configuration run on a second
-  // stream while the current one is validated):
-  CARVE_F_PIPE = 1u << 4,   // this launch belongs to a pipelined carve
-  CARVE_F_PREP = 1u << 5,   // (pipelined) prepare-only launch for this argument block's list buffer
-  CARVE_F_BUF1 = 1u << 6    // (pipelined) the launch works on list buffer 1 (else 0)
 };
-enum { CARVE_LIST_EMPTY = 0, CARVE_LIST_READY = 1, CARVE_LIST_REPREP = 2 };
-// One prepared candidate list of a pipelined carve.
-struct CarveList {
-  uint32_t ci;          // configuration (position in the carve order) the buffer holds / held last; n_avail = none left
-  uint32_t n_list, prop_k, prop_limit;
-  uint32_t state;       // CARVE_LIST_*
-  uint32_t _pad[3];
-};
-
 // Device-resident state of one carve (try_form_new_groups / one merge configuration); it persists across
 // the launches of the propose / validate sequence.
 struct CarveStatus {
@@ -96,7 +82,6 @@ struct CarveStatus {
   uint32_t slow_steps;   // steps that needed the full key sweep
   uint32_t n_solo;       // single-node groups carved (the merge pass only runs when there are two or more)
   uint32_t _pad_solo;
-  CarveList list[2];     // pipelined carve: the two list buffers
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
@@ -123,9 +108,6 @@ struct CarveArgs {
   uint32_t* c_site;
   uint64_t* c_compat;
   uint64_t *alive_g, *loc_g;  // bitmaps over positions (bits_stride words each)
-  uint64_t* alive_snap;       // pipelined carve: this list buffer's private copy of alive_g, taken by the PREP
-                              // launch (the validator of the other buffer clears bits in alive_g meanwhile, and
-                              // the two compaction passes must see the same bitmap)
   // ... and by candidate slot of the prepared configuration
   double *cc_lat, *cc_lon, *cc_cos;
   uint32_t* cc_site;
@@ -163,10 +145,9 @@ void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint3
 void launch_claim_publish(const ClaimArgs& a, hipStream_t s);
 void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t n_planes, uint64_t* planes,
                          hipStream_t s);
-uint32_t pair_sweep_scratch_chunks(int variant, uint32_t R, uint32_t n_cols, uint32_t n_planes);
 void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
-                       const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, uint32_t* scratch,
-                       uint32_t max_chunks, uint32_t* first, uint32_t* count, hipStream_t s);
+                       const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, uint32_t* first, uint32_t* count,
+                       hipStream_t s);
 void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
                         const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, const uint32_t* rank,
                         uint32_t* out, hipStream_t s);
@@ -174,7 +155,7 @@ void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block
                    uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
-void launch_carve_propose(const CarveArgs* d_args, uint32_t W, uint32_t buf, hipStream_t s);  // buf: 0/1 pipelined, PM_NONE otherwise
+void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 
 }  // namespace pm
 #endif

@@ -76,7 +76,19 @@ struct Group {
   bool dead = false;              // dissolved, not yet removed from the list (compact_groups)
 };
 
-using Table = std::vector<pm_assignment>;
+// Published assignment table: two buffers, each guarded by a sequence counter (seqlock).  pm_tick writes the
+// buffer that is NOT current, then flips `pub_cur`; a reader copies its 32-byte row with relaxed atomic loads
+// between two reads of the buffer's counter and retries if the counter moved or was odd.  A buffer is rewritten
+// only by the publish AFTER the next one, so a retry needs two publishes within one row copy.  No lock, no
+// reference count, no allocation on the read path.  Buffers only grow; replaced allocations are retired, not
+// freed, until the engine is destroyed (a reader may still hold the old pointer — its sequence check fails).
+struct PubTable {
+  std::atomic<uint64_t> seq{0};
+  std::atomic<uint64_t*> words{nullptr};  // 4 x u64 per row (pm_assignment is 32 bytes, 8-byte aligned)
+  std::atomic<uint32_t> n{0};
+  size_t cap_rows = 0;
+};
+static_assert(sizeof(pm_assignment) == 32, "published rows are copied as four 64-bit words");
 
 }  // namespace pm
 
@@ -151,16 +163,12 @@ struct pm_engine {
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
   DevBuf<uint32_t> d_slot_pos, d_slot_wid;
   DevBuf<CarveStatus> d_status;
-  DevBuf<CarveArgs> d_carve_args;       // [2]: the second block points at the second list buffer (pipelined carve)
-  DevBuf<unsigned char> d_list2;        // second set of per-slot arrays, one allocation
-  hipStream_t stream2 = nullptr;        // preparation + proposals of the next configuration
-  std::vector<hipEvent_t> ev_prep, ev_run;  // cross-stream edges of the pipelined carve, one per launch pair
-  hipEvent_t ev_init = nullptr;
+  DevBuf<CarveArgs> d_carve_args;
   DevBuf<uint32_t> d_m_cfg, d_m_n, d_m_off, d_m_members;  // MERGE batches
 
   // ---- sweep scratch
   DevBuf<uint64_t> d_sel, d_wplanes, d_sel_perm;
-  DevBuf<uint32_t> d_scratch, d_first, d_count, d_rank, d_chosen, d_perm;
+  DevBuf<uint32_t> d_first, d_count, d_rank, d_chosen, d_perm;
   DevBuf<pm_assignment> d_table;
   DevBuf<uint32_t> d_task_col;
   pm_assignment* h_table_pinned = nullptr;
@@ -176,7 +184,9 @@ struct pm_engine {
   DevBuf<uint32_t> d_nb_idx;
   DevBuf<long long> d_nb_val;
 
-  std::shared_ptr<const Table> published;
+  PubTable pub[2];
+  std::atomic<int> pub_cur{-1};
+  std::vector<uint64_t*> pub_retired;
   pm_stats last_stats{};
   uint32_t tick_host_resolved = 0, tick_carve_launches = 0, tick_carve_steps = 0;
 };
@@ -371,15 +381,15 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_same_next.ensure(cap));
   HIPCHK(e->d_prop.ensure(cap * PM_PROP_ROW));
   HIPCHK(e->d_status.ensure(1));
-  HIPCHK(e->d_carve_args.ensure(2));
+  HIPCHK(e->d_carve_args.ensure(1));
   const uint32_t stride = uint32_t((cap + 63) / 64);
-  HIPCHK(e->d_bits.ensure(size_t(stride) * 5));
+  HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
   std::memset(a, 0, sizeof(*a));
   a->mode = mode;
   a->W = e->W;
   a->proximity = e->cfg.proximity_enabled;
   a->debug_uncertain_every = e->cfg.debug_uncertain_every;
-  a->rounds_enabled = (e->cfg.carve_variant == 0 || e->cfg.carve_variant == 3) ? 1u : 0u;
+  a->rounds_enabled = e->cfg.carve_variant == 0 ? 1u : 0u;
   a->wflags = e->d_flags.p;
   a->lat = e->d_lat.p;
   a->lon = e->d_lon.p;
@@ -407,40 +417,8 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->prop_n = e->d_prop_n.p;
   a->same_next = e->d_same_next.p;
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
-  a->alive_snap = e->d_bits.p + size_t(stride) * 4;
   a->bits_stride = stride;
   a->status = e->d_status.p;
-  return PM_OK;
-}
-
-// The second list buffer of a pipelined carve: `b` = `a` with its per-slot arrays in e->d_list2.
-static int32_t second_list_args(pm_engine* e, const CarveArgs& a, CarveArgs* b) {
-  const size_t cap = std::max<size_t>(e->W, 1);
-  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    const size_t o = off;
-    off += al(bytes);
-    return o;
-  };
-  const size_t o_lat = take(cap * 8), o_lon = take(cap * 8), o_cos = take(cap * 8), o_site = take(cap * 4),
-               o_pos = take(cap * 4), o_wid = take(cap * 4), o_pn = take(cap * 4), o_sn = take(cap * 4),
-               o_prop = take(cap * PM_PROP_ROW * 8), o_bits = take(size_t(a.bits_stride) * 2 * 8),
-               o_snap = take(size_t(a.bits_stride) * 8);
-  HIPCHK(e->d_list2.ensure(off));
-  unsigned char* base = e->d_list2.p;
-  *b = a;
-  b->cc_lat = reinterpret_cast<double*>(base + o_lat);
-  b->cc_lon = reinterpret_cast<double*>(base + o_lon);
-  b->cc_cos = reinterpret_cast<double*>(base + o_cos);
-  b->cc_site = reinterpret_cast<uint32_t*>(base + o_site);
-  b->slot_pos = reinterpret_cast<uint32_t*>(base + o_pos);
-  b->slot_wid = reinterpret_cast<uint32_t*>(base + o_wid);
-  b->prop_n = reinterpret_cast<uint32_t*>(base + o_pn);
-  b->same_next = reinterpret_cast<uint32_t*>(base + o_sn);
-  b->prop = reinterpret_cast<uint64_t*>(base + o_prop);
-  b->bits_scratch = reinterpret_cast<uint64_t*>(base + o_bits);
-  b->alive_snap = reinterpret_cast<uint64_t*>(base + o_snap);
   return PM_OK;
 }
 
@@ -528,6 +506,14 @@ static int32_t absorb_groups(pm_engine* e) {
   return PM_OK;
 }
 
+// Every entry point that reads the host group list or h_group_of first takes in the records of a carve whose
+// absorption was deferred (pm_tick defers it behind the pair sweep; a tick that failed half-way leaves it pending).
+#define ABSORB_PENDING(e)                 \
+  do {                                    \
+    int32_t rc_abs_ = absorb_groups(e);   \
+    if (rc_abs_) return rc_abs_;          \
+  } while (0)
+
 // PM_TRACE_HOST=1: host-side timestamps (us since the first mark) on stderr, to find where a match waits
 static void host_mark(const char* what) {
   static const bool on = [] { const char* v = getenv("PM_TRACE_HOST"); return v && *v == '1'; }();
@@ -573,69 +559,24 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   st.n_groups = g0;
   st.n_members = m0;
   const bool use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
-  // 3 = pipelined: the next configuration is prepared and proposed on a second stream while the current one
-  // is validated.  Bit-exact like the others, but measured slower at BASELINE configs[1] (3.8 vs 3.2 ms):
-  // most validation launches end because half of their list is dead, the re-preparation that follows cannot
-  // overlap anything, and lists prepared early start with dead entries, so they hit that threshold sooner
-  // (starting the preparation late, on a device-side signal from the validator, was slower still: 4.3 ms).
-  const bool pipelined = use_props && e->cfg.carve_variant == 3;
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
-  if (pipelined) {
-    CarveArgs a2;
-    rc = second_list_args(e, a, &a2);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(e->d_carve_args.p + 1, &a2, sizeof(a2), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // a2 is a stack object
-  }
   uint32_t start_ci = 0;
   for (;;) {
     HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->kev[2], e->stream));
-    uint32_t pj = 0;  // launch pair counter of the pipelined carve (parity = list buffer)
     auto queue_pairs = [&](uint32_t count) -> int32_t {
-      if (!pipelined) {
-        for (uint32_t k = 0; k < count; ++k) {
-          launch_carve_propose(e->d_carve_args.p, e->W, PM_NONE, e->stream);
-          HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
-          e->tick_carve_launches += 2;
-        }
-        return PM_OK;
-      }
-      for (uint32_t k = 0; k < count; ++k, ++pj) {
-        while (e->ev_prep.size() <= pj) {
-          hipEvent_t x = nullptr, y = nullptr;
-          HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-          HIPCHK(hipEventCreateWithFlags(&y, hipEventDisableTiming));
-          e->ev_prep.push_back(x);
-          e->ev_run.push_back(y);
-        }
-        const uint32_t b = pj & 1u;
-        const uint32_t fl = CARVE_F_PIPE | CARVE_F_PROPS | (b ? CARVE_F_BUF1 : 0u);
-        const CarveArgs* ab = e->d_carve_args.p + b;
-        // the buffer is free once the validation two pairs back is done
-        if (pj >= 2) HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_run[pj - 2], 0));
-        HIPCHK(launch_carve(ab, fl | CARVE_F_PREP, 0, lds, e->stream2));
-        launch_carve_propose(ab, e->W, b, e->stream2);
-        HIPCHK(hipEventRecord(e->ev_prep[pj], e->stream2));
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_prep[pj], 0));
-        HIPCHK(launch_carve(ab, fl | CARVE_F_RUN, 0, lds, e->stream));
-        HIPCHK(hipEventRecord(e->ev_run[pj], e->stream));
-        e->tick_carve_launches += 3;
+      for (uint32_t k = 0; k < count; ++k) {
+        launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
+        e->tick_carve_launches += 2;
       }
       return PM_OK;
     };
     if (use_props) {
       // prepare the first candidate list, then (propose, validate) pairs: one per configuration plus one
       // per re-proposal round; launches queued behind a finished carve return immediately
-      if (pipelined) {
-        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PIPE | CARVE_F_PROPS, start_ci, lds, e->stream));
-        HIPCHK(hipEventRecord(e->ev_init, e->stream));
-        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_init, 0));
-        rc = queue_pairs(a.n_avail - start_ci + 8u);
-      } else {
-        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, start_ci, lds, e->stream));
-        rc = queue_pairs(a.n_avail - start_ci + 3u);
-      }
+      HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, start_ci, lds, e->stream));
+      rc = queue_pairs(a.n_avail - start_ci + 3u);
       if (rc) return rc;
     } else {
       HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, start_ci, lds, e->stream));
@@ -667,7 +608,6 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
     if (st.state == CARVE_STATE_DONE) break;
     if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
     if (st.state != CARVE_STATE_UNCERTAIN) return set_error(PM_ENODEV, "carve kernel did not complete");
-    if (pipelined) HIPCHK(hipStreamSynchronize(e->stream2));  // nothing of this carve may still be queued
     rc = host_resolve_form_step(e, avail[st.stop_ci], &st);
     if (rc) return rc;
     e->tick_host_resolved++;
@@ -734,15 +674,11 @@ static int32_t ensure_task_planes(pm_engine* e) {
   return PM_OK;
 }
 
-static int32_t ensure_sweep_scratch(pm_engine* e, uint32_t R, uint32_t n_cols, uint32_t* max_chunks) {
-  const int variant = int(e->cfg.sweep_variant);
-  const uint32_t chunks = pair_sweep_scratch_chunks(variant, R, n_cols, uint32_t(e->cfgs.size()));
-  HIPCHK(e->d_scratch.ensure(size_t(2) * chunks * std::max<uint32_t>(R, 1)));
+static int32_t ensure_sweep_outputs(pm_engine* e, uint32_t R) {
   HIPCHK(e->d_first.ensure(std::max<uint32_t>(R, 1)));
   HIPCHK(e->d_count.ensure(std::max<uint32_t>(R, 1)));
   HIPCHK(e->d_rank.ensure(std::max<uint32_t>(R, 1)));
   HIPCHK(e->d_chosen.ensure(std::max<uint32_t>(R, 1)));
-  *max_chunks = chunks;
   return PM_OK;
 }
 
@@ -780,8 +716,7 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
     rc = ensure_task_planes(e);
     if (rc) return rc;
   }
-  uint32_t max_chunks = 0;
-  rc = ensure_sweep_scratch(e, e->W, e->T, &max_chunks);
+  rc = ensure_sweep_outputs(e, e->W);
   if (rc) return rc;
   HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
   HIPCHK(e->d_table.ensure(std::max<uint32_t>(e->W, 1)));
@@ -792,8 +727,8 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   host_mark("match: selector launch");
   launch_worker_selector(e->d_group_of.p, e->d_g_cfg.p, e->W, e->d_sel.p, e->stream);
   HIPCHK(hipEventRecord(e->kev[4], e->stream));
-  launch_pair_sweep(variant, e->d_sel.p, e->W, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_scratch.p,
-                    max_chunks, e->d_first.p, e->d_count.p, e->stream);
+  launch_pair_sweep(variant, e->d_sel.p, e->W, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_first.p,
+                    e->d_count.p, e->stream);
   HIPCHK(hipEventRecord(e->kev[5], e->stream));
   e->k_sweep_recorded = true;
   const uint32_t* chosen = e->d_first.p;  // PM_CHOOSE_FIRST: the first applicable task
@@ -859,8 +794,31 @@ static int32_t publish(pm_engine* e) {
     e->groups[g].task_uid = (g_task[g] != PM_NONE && e->tasks_have_uid) ? e->h_tuid[g_task[g]] : g_task[g];
   }
   std::swap(e->d_g_task, e->d_g_task_next);
-  auto t = std::make_shared<Table>(e->h_table_pinned, e->h_table_pinned + e->W);
-  std::atomic_store_explicit(&e->published, std::shared_ptr<const Table>(std::move(t)), std::memory_order_release);
+  // swap in the new snapshot (see PubTable)
+  const int cur = e->pub_cur.load(std::memory_order_relaxed);
+  const int nx = cur < 0 ? 0 : (cur ^ 1);
+  PubTable& t = e->pub[nx];
+  const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+  t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
+  std::atomic_thread_fence(std::memory_order_release);
+  uint64_t* words = t.words.load(std::memory_order_relaxed);
+  if (t.cap_rows < e->W || !words) {
+    const size_t cap = std::max<size_t>(size_t(e->W) + e->W / 8 + 64, 64);
+    uint64_t* nw = static_cast<uint64_t*>(std::malloc(cap * 32));
+    if (!nw) {
+      t.seq.store(s0 + 2, std::memory_order_release);
+      return set_error(PM_ENOMEM, "out of host memory for the published table");
+    }
+    if (words) e->pub_retired.push_back(words);
+    words = nw;
+    t.cap_rows = cap;
+    t.words.store(nw, std::memory_order_relaxed);
+  }
+  const uint64_t* src = reinterpret_cast<const uint64_t*>(e->h_table_pinned);
+  for (size_t i = 0; i < size_t(e->W) * 4; ++i) __atomic_store_n(&words[i], src[i], __ATOMIC_RELAXED);
+  t.n.store(e->W, std::memory_order_relaxed);
+  t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
+  e->pub_cur.store(nx, std::memory_order_release);
   return PM_OK;
 }
 
@@ -1108,11 +1066,6 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
       delete e;
       return set_error(PM_ENODEV, "hipEventCreate failed");
     }
-  if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_init, hipEventDisableTiming) != hipSuccess) {
-    delete e;
-    return set_error(PM_ENODEV, "hipStreamCreate failed");
-  }
   if (hipEventCreateWithFlags(&e->ev_groups, hipEventDisableTiming) != hipSuccess) {
     delete e;
     return set_error(PM_ENODEV, "hipEventCreate failed");
@@ -1138,18 +1091,15 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop_n.release(); e->d_prop.release(); e->d_same_next.release();
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
-  e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release(); e->d_scratch.release();
+  e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
   e->d_table.release(); e->d_task_col.release(); e->d_nb_idx.release(); e->d_nb_val.release();
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
   if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
   if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
-  if (e->ev_init) (void)hipEventDestroy(e->ev_init);
-  for (hipEvent_t x : e->ev_prep) (void)hipEventDestroy(x);
-  for (hipEvent_t x : e->ev_run) (void)hipEventDestroy(x);
-  if (e->stream2) (void)hipStreamDestroy(e->stream2);
-  e->d_list2.release();
   if (e->h_table_pinned) (void)hipHostFree(e->h_table_pinned);
+  for (PubTable& t : e->pub) std::free(t.words.load());
+  for (uint64_t* q : e->pub_retired) std::free(q);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->kev)
@@ -1330,6 +1280,7 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
   if (t->n && (!t->topo_mask || !t->created_at)) return set_error(PM_EINVAL, "null task column");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
+  ABSORB_PENDING(e);
   e->T = t->n;
   e->h_tmask.assign(t->topo_mask, t->topo_mask + t->n);
   e->h_created.assign(t->created_at, t->created_at + t->n);
@@ -1394,6 +1345,7 @@ int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, u
   std::lock_guard<std::mutex> lk(e->mu);
   if (!e->have_workers || worker >= e->W) return set_error(PM_ERANGE, "worker index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
+  ABSORB_PENDING(e);
   e->h_flags[worker] = flags_new;
   e->flags_dirty = true;   // uploaded once before the next kernel that reads the column (sync_flags)
   e->compat_dirty = true;  // HAS_SPECS etc. may have changed with the row
@@ -1404,6 +1356,7 @@ int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, u
 int32_t pm_dissolve_group(pm_engine* e, uint32_t slot) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  ABSORB_PENDING(e);
   compact_groups(e);  // `slot` is a number of the compacted list (what pm_get_groups reports)
   if (slot >= e->groups.size()) return set_error(PM_ERANGE, "group slot out of range");
   dissolve_locked(e, slot);
@@ -1461,6 +1414,7 @@ int32_t pm_get_groups(pm_engine* e, int32_t* group_of_worker, pm_group* groups, 
                       uint32_t* n_groups, uint32_t* members, uint32_t cap_members, uint32_t* n_members) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  ABSORB_PENDING(e);
   compact_groups(e);
   const uint32_t G = uint32_t(e->groups.size());
   uint32_t M = 0;
@@ -1494,6 +1448,7 @@ int32_t pm_match(pm_engine* e, uint32_t* task_of_worker, uint32_t* applicable_co
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
+  ABSORB_PENDING(e);
   std::vector<uint32_t> cnt;
   int32_t rc = run_match(e, applicable_count != nullptr, &cnt);
   if (rc) return rc;
@@ -1510,14 +1465,14 @@ int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candida
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
   if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
+  ABSORB_PENDING(e);
   int32_t rc = ensure_compat(e);
   if (rc) return rc;
   rc = push_groups(e);
   if (rc) return rc;
   const int variant = int(e->cfg.sweep_variant);
   const uint32_t n_planes = uint32_t(e->cfgs.size());
-  uint32_t max_chunks = 0;
-  rc = ensure_sweep_scratch(e, e->T, e->W, &max_chunks);
+  rc = ensure_sweep_outputs(e, e->T);
   if (rc) return rc;
   HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
   launch_eligible_selector(e->d_flags.p, e->d_group_of.p, e->d_compat.p, e->enabled, e->W, e->d_sel.p, e->stream);
@@ -1538,8 +1493,8 @@ int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candida
     HIPCHK(e->d_wplanes.ensure(std::max<size_t>(n_words * n_planes, 1)));
     launch_build_planes(cols, e->W, n_planes, e->d_wplanes.p, e->stream);
   }
-  launch_pair_sweep(variant, e->d_tmask.p, e->T, cols, e->d_wplanes.p, e->W, n_planes, e->d_scratch.p, max_chunks,
-                    e->d_first.p, e->d_count.p, e->stream);
+  launch_pair_sweep(variant, e->d_tmask.p, e->T, cols, e->d_wplanes.p, e->W, n_planes, e->d_first.p, e->d_count.p,
+                    e->stream);
   HIPCHK(hipGetLastError());
   if (best_worker && e->T)
     HIPCHK(hipMemcpyAsync(best_worker, e->d_first.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1647,11 +1602,24 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
 
 int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t worker, pm_assignment* out) {
   if (!e || !out) return set_error(PM_EINVAL, "null argument");
-  std::shared_ptr<const Table> t = std::atomic_load_explicit(&e->published, std::memory_order_acquire);
-  if (!t) return set_error(PM_ESTATE, "no assignment table published yet");
-  if (worker >= t->size()) return set_error(PM_ERANGE, "worker index out of range");
-  *out = (*t)[worker];
-  return PM_OK;
+  for (;;) {
+    const int cur = e->pub_cur.load(std::memory_order_acquire);
+    if (cur < 0) return set_error(PM_ESTATE, "no assignment table published yet");
+    const PubTable& t = e->pub[cur];
+    const uint64_t s1 = t.seq.load(std::memory_order_acquire);
+    if (s1 & 1u) continue;  // two publishes since `cur` was read: take the newer buffer
+    const uint64_t* words = t.words.load(std::memory_order_relaxed);
+    const uint32_t n = t.n.load(std::memory_order_relaxed);
+    uint64_t row[4] = {0, 0, 0, 0};
+    const bool in_range = worker < n;
+    if (in_range)
+      for (int k = 0; k < 4; ++k) row[k] = __atomic_load_n(&words[size_t(worker) * 4 + k], __ATOMIC_RELAXED);
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (t.seq.load(std::memory_order_relaxed) != s1) continue;
+    if (!in_range) return set_error(PM_ERANGE, "worker index out of range");
+    std::memcpy(out, row, sizeof(*out));
+    return PM_OK;
+  }
 }
 
 int32_t pm_device_task_column(pm_engine* e, uint64_t* device_ptr, uint32_t* n) {
@@ -1663,11 +1631,13 @@ int32_t pm_device_task_column(pm_engine* e, uint64_t* device_ptr, uint32_t* n) {
   return PM_OK;
 }
 
-// debug (not part of the public header): phase tick counters of the last carve (PM_CARVE_PROF builds)
-int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out16) {
-  if (!e || !out16) return set_error(PM_EINVAL, "null argument");
+// debug (not part of the public header, declared in pm_internal.h): phase tick counters of the last carve
+// (PM_CARVE_PROF builds); copies min(cap, 32) entries
+int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap) {
+  if (!e || !out) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
-  std::memcpy(out16, e->carve_prof, sizeof(e->carve_prof));
+  const uint32_t n = std::min<uint32_t>(cap, uint32_t(sizeof(e->carve_prof) / sizeof(e->carve_prof[0])));
+  std::memcpy(out, e->carve_prof, size_t(n) * sizeof(unsigned long long));
   return PM_OK;
 }
 

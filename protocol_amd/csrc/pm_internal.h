@@ -39,4 +39,7 @@ inline uint64_t splitmix64_mix(uint64_t x) {
 }
 
 }  // namespace pm
+
+// debug export (PM_CARVE_PROF builds): copies min(cap, 32) phase counters of the last carve
+extern "C" int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap);
 #endif

@@ -129,15 +129,39 @@ __global__ __launch_bounds__(256) void coslat_kernel(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Phase B, scalar kernel (sweep_variant 1): rows live in lanes, the swept axis is wave-uniform.
-// Every (row, col) pair is evaluated: hit = (row_sel & col_mask) != 0; folds count and first hit.
-// grid = (ceil(R/256), n_chunks); partials are combined by pair_finalize_kernel.
+// Phase B.  hit(row, col) = (row_sel[row] & col_mask[col]) != 0; per row: first hit and hit count.
+// Both kernels split the swept axis over blockIdx.y so that a few thousand workgroups fill the chip, keep a
+// row's partial result in registers and fold it into first[] / count[] with one atomicMin + atomicAdd per
+// (row, split) that saw a hit (pair_init_kernel sets first = PM_NONE, count = 0 beforehand; min and sum are
+// order-independent, so the result is deterministic).  With a single split the results are stored directly.
 
+__global__ __launch_bounds__(256) void pair_init_kernel(uint32_t* __restrict__ first, uint32_t* __restrict__ count,
+                                                        uint32_t R) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r < R) {
+    first[r] = PM_NONE;
+    count[r] = 0u;
+  }
+}
+
+__device__ __forceinline__ void pair_fold(uint32_t* __restrict__ first, uint32_t* __restrict__ count, uint32_t r,
+                                          uint32_t f, uint32_t cnt, bool atomic) {
+  if (!atomic) {
+    first[r] = f;
+    count[r] = cnt;
+  } else if (cnt) {
+    atomicMin(&first[r], f);
+    atomicAdd(&count[r], cnt);
+  }
+}
+
+// Scalar kernel (sweep_variant 1): rows live in lanes, the swept axis is wave-uniform (s_load), one pair per
+// compare.  Kept as the straightforward kernel the bit-sliced one is checked against.
 __global__ __launch_bounds__(256) void pair_sweep_scalar_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                 const uint64_t* __restrict__ col_mask,
                                                                 uint32_t n_cols, uint32_t chunk,
-                                                                uint32_t* __restrict__ part_first,
-                                                                uint32_t* __restrict__ part_count) {
+                                                                uint32_t* __restrict__ first_out,
+                                                                uint32_t* __restrict__ count_out, uint32_t atomic) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   const uint32_t c0 = blockIdx.y * chunk;
   const uint32_t c1 = min(n_cols, c0 + chunk);
@@ -149,10 +173,7 @@ __global__ __launch_bounds__(256) void pair_sweep_scalar_kernel(const uint64_t* 
     cnt += hit;
     first = hit ? min(first, c) : first;
   }
-  if (r < R) {
-    part_first[(size_t)blockIdx.y * R + r] = first;
-    part_count[(size_t)blockIdx.y * R + r] = cnt;
-  }
+  if (r < R) pair_fold(first_out, count_out, r, first, cnt, atomic != 0u);
 }
 
 // rank-th hit of a row (seeded chooser): second pass over the same pairs.
@@ -192,42 +213,41 @@ __global__ __launch_bounds__(256) void build_planes_kernel(const uint64_t* __res
   }
 }
 
-template <int MAXP>
+// grid = (ceil(R / 256), n_split): workgroup (x, y) sweeps its 256 rows over the plane words
+// [y * words_per_split, (y + 1) * words_per_split), staged through LDS in pieces of words_per_piece.
 __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                 const uint64_t* __restrict__ planes,
                                                                 uint32_t n_words, uint32_t n_planes,
-                                                                uint32_t words_per_chunk,
-                                                                uint32_t* __restrict__ part_first,
-                                                                uint32_t* __restrict__ part_count) {
-  extern __shared__ uint64_t s_pl[];  // [n_planes][words_per_chunk]
+                                                                uint32_t words_per_split, uint32_t words_per_piece,
+                                                                uint32_t* __restrict__ first_out,
+                                                                uint32_t* __restrict__ count_out, uint32_t atomic) {
+  extern __shared__ uint64_t s_pl[];  // [n_planes][words_per_piece]
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t j0 = blockIdx.y * words_per_chunk;
-  const uint32_t nj = min(words_per_chunk, n_words - j0);
-  for (uint32_t i = threadIdx.x; i < n_planes * nj; i += 256u) {
-    const uint32_t b = i / nj, j = i - b * nj;
-    s_pl[b * words_per_chunk + j] = planes[(size_t)b * n_words + j0 + j];
-  }
-  __syncthreads();
+  const uint32_t w0 = blockIdx.y * words_per_split;
+  const uint32_t w1 = min(n_words, w0 + words_per_split);
   const uint64_t sel = r < R ? row_sel[r] : 0ull;
   uint32_t first = PM_NONE, cnt = 0;
-  for (uint32_t j = 0; j < nj; ++j) {
-    uint64_t hits = 0;
-    uint64_t s = sel;
-    while (s) {  // OR the planes this row selects; rows of one group share the selector
-      const uint32_t b = __builtin_ctzll(s);
-      s &= s - 1;
-      if (b < n_planes) hits |= s_pl[b * words_per_chunk + j];
+  for (uint32_t j0 = w0; j0 < w1; j0 += words_per_piece) {
+    const uint32_t nj = min(words_per_piece, w1 - j0);
+    __syncthreads();  // the previous piece has been consumed
+    for (uint32_t b = 0; b < n_planes; ++b)
+      for (uint32_t j = threadIdx.x; j < nj; j += 256u) s_pl[b * words_per_piece + j] = planes[(size_t)b * n_words + j0 + j];
+    __syncthreads();
+    for (uint32_t j = 0; j < nj; ++j) {
+      uint64_t hits = 0;
+      uint64_t s = sel;
+      while (s) {  // OR the planes this row selects; rows of one group share the selector
+        const uint32_t b = __builtin_ctzll(s);
+        s &= s - 1;
+        if (b < n_planes) hits |= s_pl[b * words_per_piece + j];
+      }
+      cnt += __popcll(hits);
+      if (hits && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(hits);
     }
-    cnt += __popcll(hits);
-    if (hits && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(hits);
   }
-  if (r < R) {
-    part_first[(size_t)blockIdx.y * R + r] = first;
-    part_count[(size_t)blockIdx.y * R + r] = cnt;
-  }
+  if (r < R) pair_fold(first_out, count_out, r, first, cnt, atomic != 0u);
 }
 
-template <int MAXP>
 __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                  const uint64_t* __restrict__ planes,
                                                                  uint32_t n_words, uint32_t n_planes,
@@ -256,22 +276,6 @@ __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t*
     }
   }
   out[r] = res;
-}
-
-// Combine chunk partials: first = min over chunks, count = sum.
-__global__ __launch_bounds__(256) void pair_combine_kernel(const uint32_t* __restrict__ part_first,
-                                                           const uint32_t* __restrict__ part_count, uint32_t R,
-                                                           uint32_t n_chunks, uint32_t* __restrict__ first,
-                                                           uint32_t* __restrict__ count) {
-  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  if (r >= R) return;
-  uint32_t f = PM_NONE, c = 0;
-  for (uint32_t k = 0; k < n_chunks; ++k) {
-    f = min(f, part_first[(size_t)k * R + r]);
-    c += part_count[(size_t)k * R + r];
-  }
-  first[r] = f;
-  count[r] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -811,14 +815,16 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, lane_m);
       const uint64_t kb_m = (e_m >> SB) << SB;
       if (kb_m != noloc_key) {
-        // exactness certificate: every live unselected candidate within the band of the last selected one
-        // must sit at the same site (then the reference's distances tie exactly and slot order decides)
+        // exactness certificate: every live candidate of the row within the band AROUND the last selected one
+        // — selected or not — must sit at its site (then the reference's distances tie exactly there and slot
+        // order decides).  The test is symmetric: a selected entry of another site just below the boundary and
+        // an unselected one of the boundary's site just above it may be ordered either way by the reference.
         const double a_m = __longlong_as_double((long long)kb_m);
         const double band = a_m * band_rel + 1e-300;
         if (a_m > PM_A_MAX_SAFE) SLOW_RETURN(19);
         const uint32_t site_m = site_of((uint32_t)(e_m & SLOT_MASK));
         const uint64_t kb = (e >> SB) << SB;
-        const bool near = alive && !sel && kb != noloc_key && (__longlong_as_double((long long)kb) - a_m) <= band;
+        const bool near = alive && kb != noloc_key && fabs(__longlong_as_double((long long)kb) - a_m) <= band;
         if (__ballot(near && site_of(slot) != site_m)) {  SLOW_RETURN(19); }
         if (!complete) {
           // candidates beyond the list are >= its last entry: either that entry clears the band, or it sits
@@ -1054,7 +1060,8 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
               if (a_m > PM_A_MAX_SAFE) res = ROUND_SLOW;
               const uint32_t site_m = site_of((uint32_t)(e_m & SLOT_MASK));
               const uint64_t kb = (e >> SB) << SB;
-              const bool near = alive && !sel && kb != noloc_key && (__longlong_as_double((long long)kb) - a_m) <= band;
+              // symmetric band around the last selected entry, selected entries included (see carve_fast_steps)
+              const bool near = alive && kb != noloc_key && fabs(__longlong_as_double((long long)kb) - a_m) <= band;
               if (__ballot(near && site_of(slot) != site_m)) res = ROUND_SLOW;
               if (!complete) {
                 const int last_e = (int)n_k - 1;
@@ -1892,18 +1899,12 @@ __device__ __forceinline__ void sweep_keys(const SweepBatch& b, uint32_t lw, uin
   }
 }
 
-__global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa, uint32_t buf) {
+__global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa) {
   const CarveArgs& p = *pa;  // argument block in device memory: read through the scalar cache, never copied
   const auto st = G((const CarveStatus*)p.status);
   if (st->state != CARVE_STATE_RUNNING) return;
-  uint32_t K, n_list, limit;
-  if (buf == PM_NONE) {
-    if (st->cur_ci >= p.n_avail) return;
-    K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
-  } else {  // pipelined carve: the list this argument block's buffers hold
-    if (st->list[buf].state != CARVE_LIST_READY || st->list[buf].ci >= p.n_avail) return;
-    K = st->list[buf].prop_k, n_list = st->list[buf].n_list, limit = st->list[buf].prop_limit;
-  }
+  if (st->cur_ci >= p.n_avail) return;
+  const uint32_t K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
   if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
   const uint32_t SB = n_list > PM_CARVE_SLOTS ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   const double TIE_BAND = n_list > PM_CARVE_SLOTS ? PM_TIE_BAND_BIG : PM_TIE_BAND;
@@ -2167,15 +2168,6 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   const auto st = G(p.status);
   uint32_t flags = flags_in;
   if (!(flags & CARVE_F_INIT) && st->state != CARVE_STATE_RUNNING) return;  // queued behind a finished carve
-  // Pipelined carve (CARVE_F_PIPE): two list buffers (two argument blocks that differ in the per-slot arrays).
-  // A PREP launch builds the list of this block's buffer `pb` — on a second stream, while the other buffer is
-  // being validated — and a RUN launch validates it.  A list prepared early is a superset of the candidates
-  // still alive when its turn comes (nodes only ever leave), so the RUN launch refreshes the live bits from
-  // the position bitmap and everything downstream is unchanged.  list[b].ci stays behind after a buffer is
-  // done: the next search starts after the other buffer's ci.
-  const bool pipe = (flags & CARVE_F_PIPE) != 0u;
-  const uint32_t pb = (flags & CARVE_F_BUF1) ? 1u : 0u;
-  bool pipe_single = false;  // PREP: rebuild exactly list[pb].ci (re-prepare / refresh), no search
   PROF_DECL;
 
   uint32_t n;
@@ -2244,53 +2236,12 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     c.total_available = n;  // mod.rs:503
     ci = start_ci;
     prepared = false;
-    if (pipe) {  // pipelined: the lists are built by the PREP launches
-      if (tid == 0) {
-        st->n_eligible = n;
-        st->total_available = n;
-        for (int b = 0; b < 2; ++b) {
-          st->list[b].ci = start_ci - 1u;  // "the configuration before the first one" (wraps for 0)
-          st->list[b].n_list = st->list[b].prop_k = st->list[b].prop_limit = 0;
-          st->list[b].state = CARVE_LIST_EMPTY;
-        }
-      }
-      return;
-    }
   } else {
     n = st->n_eligible;
     c.total_available = st->total_available;
-    if (pipe) {
-      const uint32_t l_state = st->list[pb].state, l_ci = st->list[pb].ci;
-      const uint32_t o_state = st->list[pb ^ 1u].state, o_ci = st->list[pb ^ 1u].ci;
-      if (flags & CARVE_F_PREP) {
-        prepared = false;
-        if (l_state == CARVE_LIST_REPREP || (l_state == CARVE_LIST_READY && l_ci < p.n_avail)) {
-          ci = l_ci;  // re-prepare after half of it died, or refresh a list that is still waiting for its turn
-          pipe_single = true;
-        } else {
-          ci = o_ci + 1u;  // the configuration after the one the other buffer holds (or held last)
-        }
-      } else {
-        // configurations are validated strictly in order: not while the other buffer waits for its
-        // re-preparation or holds an earlier configuration
-        if (l_state != CARVE_LIST_READY ||
-            (o_state == CARVE_LIST_REPREP || (o_state == CARVE_LIST_READY && o_ci < l_ci)))
-          return;
-        if (l_ci >= p.n_avail) {  // nothing left to prepare, nothing left to validate
-          if (tid == 0) {
-            st->state = CARVE_STATE_DONE;
-            st->cur_ci = p.n_avail;
-          }
-          return;
-        }
-        ci = l_ci;
-        prepared = true;
-      }
-    } else {
-      ci = st->cur_ci;
-      prepared = true;
-      if (ci >= p.n_avail) return;
-    }
+    ci = st->cur_ci;
+    prepared = true;
+    if (ci >= p.n_avail) return;
   }
   c.n_groups = st->n_groups;
   c.mem_off = st->n_members;
@@ -2307,48 +2258,23 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       c.n_list = 0;
       c.prop_k = 0;
       c.prop_limit = 0;
-      const uint32_t ci_end = pipe_single ? ci + 1u : p.n_avail;
-      // pipelined: the validator of the other buffer clears bits of alive_g while this runs; the count and
-      // the placement pass must see one and the same bitmap, so they work on a private copy (any mixture of
-      // old and new words is a valid superset of the nodes alive when this list's turn comes)
-      const uint64_t* prep_bits = p.alive_g;
-      if (pipe) {
-        const uint32_t nw = (n + 63u) >> 6;
-        for (uint32_t j = tid; j < nw; j += CARVE_THREADS)
-          G(p.alive_snap)[j] = __hip_atomic_load(&G(p.alive_g)[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        prep_bits = p.alive_snap;
-      }
-      for (; ci < ci_end; ++ci) {
+      for (; ci < p.n_avail; ++ci) {
         c.min_s = p.min_size[ci];
         c.max_s = p.max_size[ci];
         if (p.mode == CARVE_MODE_FORM && c.total_available < c.min_s) continue;  // `while` never entered (:507)
         const uint64_t cbit = 1ull << p.avail_cfg[ci];
         PROF_MARK(29);  // loop overhead
-        c.n_list = carve_compact_count(p, red, n, cbit, prep_bits);
+        c.n_list = carve_compact_count(p, red, n, cbit, p.alive_g);
         PROF_MARK(26);
 #ifdef PM_CARVE_PROF
         if (tid == 0) G(p.status)->prof[30] += 1;
 #endif
         if (c.n_list < c.min_s || c.n_list == 0) continue;  // mod.rs:517-519
-        carve_compact_place(p, red, n, cbit, c.n_list, prep_bits);
+        carve_compact_place(p, red, n, cbit, c.n_list, p.alive_g);
         PROF_MARK(27);
         break;
       }
-      if (pipe) {
-        if (ci >= ci_end) {  // PREP found nothing
-          if (tid == 0) {
-            if (pipe_single) {
-              st->list[pb].state = CARVE_LIST_EMPTY;  // this configuration cannot form another group
-            } else {
-              st->list[pb].ci = p.n_avail;  // no configuration left
-              st->list[pb].n_list = st->list[pb].prop_k = st->list[pb].prop_limit = 0;
-              st->list[pb].state = CARVE_LIST_READY;
-            }
-          }
-          return;
-        }
-      } else if (ci >= p.n_avail) {
+      if (ci >= p.n_avail) {
         exit_state = CARVE_STATE_DONE;
         break;
       }
@@ -2362,58 +2288,16 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       }
       prepared = true;
       PROF_MARK(28);
-      if (pipe) {  // PREP launch: publish the list, the proposer follows on this stream
-        if (tid == 0) {
-          st->list[pb].ci = ci;
-          st->list[pb].n_list = c.n_list;
-          st->list[pb].prop_k = c.prop_k;
-          st->list[pb].prop_limit = c.prop_limit;
-          st->list[pb].state = CARVE_LIST_READY;
-        }
-        return;
-      }
       if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
     } else {
-      c.n_list = pipe ? st->list[pb].n_list : st->n_list;
-      c.prop_k = pipe ? st->list[pb].prop_k : st->prop_k;
-      c.prop_limit = pipe ? st->list[pb].prop_limit : st->prop_limit;
+      c.n_list = st->n_list;
+      c.prop_k = st->prop_k;
+      c.prop_limit = st->prop_limit;
       c.min_s = p.min_size[ci];
       c.max_s = p.max_size[ci];
     }
     c.cfg = p.avail_cfg[ci];
     c.n_cand = c.n_list;
-    if (pipe) {
-      // the list was built while earlier configurations were still being carved: take the live bits from
-      // the position bitmap (four independent slot_pos loads, then four bitmap words, per step)
-      const auto sa = G(p.bits_scratch);
-      const uint32_t lwp = (c.n_list + 63u) >> 6;
-      uint32_t cnt = 0;
-      for (uint32_t base = 0; base < lwp * 64u; base += 4u * CARVE_THREADS) {
-        uint32_t sp[4];
-        uint64_t aw[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t sl = base + (uint32_t)u * CARVE_THREADS + tid;
-          sp[u] = G(p.slot_pos)[sl < c.n_list ? sl : c.n_list - 1u] & 0x7FFFFFFFu;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) aw[u] = G(p.alive_g)[sp[u] >> 6];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t sl = base + (uint32_t)u * CARVE_THREADS + tid;
-          const uint64_t ba = __ballot(sl < c.n_list && ((aw[u] >> (sp[u] & 63u)) & 1ull));
-          if (lane == 0 && (sl >> 6) < lwp) sa[sl >> 6] = ba;
-          cnt += (uint32_t)__popcll(ba);  // wave-uniform
-        }
-      }
-      __syncthreads();  // previous users of red.a are done
-      if (lane == 0) red.a[wave] = cnt;
-      __syncthreads();
-      uint32_t total = 0;
-      for (uint32_t k = 0; k < CARVE_WAVES; ++k) total += red.a[k];
-      c.n_cand = total;
-      __syncthreads();
-    }
 
     // ---- run the prepared configuration.  Three storage modes:
     //   small (<= PM_CARVE_SLOTS slots):  every per-slot array in LDS
@@ -2482,10 +2366,6 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       stop_ci = ci;
       break;
     }
-    if (pipe) {  // RUN launch of a pipelined carve: hand the buffer back, the PREP launches do the rest
-      if (tid == 0) st->list[pb].state = rc == STEP_BREAK ? CARVE_LIST_EMPTY : CARVE_LIST_REPREP;
-      break;
-    }
     prepared = false;
     if (rc == STEP_BREAK) ++ci;  // configuration exhausted; STEP_CONTINUE => re-prepare the same configuration
     if (!(flags & CARVE_F_ALL)) flags &= ~CARVE_F_RUN;  // per-configuration launch: prepare the next list, leave
@@ -2510,12 +2390,10 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     st->stop_ci = stop_ci;
     st->n_eligible = n;
     st->cand_sum += c.cand_sum;
-    if (!pipe) {
-      st->cur_ci = exit_state == CARVE_STATE_DONE ? p.n_avail : ci;
-      st->n_list = c.n_list;
-      st->prop_k = c.prop_k;
-      st->prop_limit = c.prop_limit;
-    }
+    st->cur_ci = exit_state == CARVE_STATE_DONE ? p.n_avail : ci;
+    st->n_list = c.n_list;
+    st->prop_k = c.prop_k;
+    st->prop_limit = c.prop_limit;
     st->total_available = c.total_available;
     st->fast_steps += c.fast_steps;
     st->slow_steps += c.steps - c.fast_steps;
@@ -2570,67 +2448,38 @@ void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t n_p
                      n_words, n_planes, planes);
 }
 
-// Pair sweep: rows x cols -> first hit + hit count per row.  scratch holds 2 * n_chunks * R u32.
+// Pair sweep: rows x cols -> first hit + hit count per row.
 void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
-                       const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, uint32_t* scratch,
-                       uint32_t max_chunks, uint32_t* first, uint32_t* count, hipStream_t s) {
+                       const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, uint32_t* first, uint32_t* count,
+                       hipStream_t s) {
   if (R == 0) return;
   const uint32_t rb = (R + 255u) / 256u;
-  uint32_t n_chunks;
-  uint32_t* part_first = scratch;
+  // enough workgroups to cover 256 CUs several times over
+  const uint32_t want_split = (2048u + rb - 1u) / rb;
   if (variant == 1) {
-    // enough workgroups to cover 256 CUs several times over
-    n_chunks = (4096u + rb - 1u) / rb;
-    if (n_chunks > max_chunks) n_chunks = max_chunks;
-    uint32_t chunk = (n_cols + n_chunks - 1u) / (n_chunks ? n_chunks : 1u);
+    uint32_t n_split = want_split < (n_cols ? n_cols : 1u) ? want_split : (n_cols ? n_cols : 1u);
+    uint32_t chunk = (n_cols + n_split - 1u) / n_split;
     if (chunk == 0) chunk = 1;
-    n_chunks = n_cols ? (n_cols + chunk - 1u) / chunk : 1u;
-    uint32_t* part_count = scratch + (size_t)n_chunks * R;
-    hipLaunchKernelGGL(pair_sweep_scalar_kernel, dim3(rb, n_chunks), dim3(256), 0, s, row_sel, R, col_mask, n_cols,
-                       chunk, part_first, part_count);
-    hipLaunchKernelGGL(pair_combine_kernel, dim3(rb), dim3(256), 0, s, part_first, part_count, R, n_chunks, first,
-                       count);
-  } else {
-    const uint32_t n_words = (n_cols + 63u) / 64u;
-    uint32_t wpc = 0;
-    if (n_words) {
-      n_chunks = (2048u + rb - 1u) / rb;
-      if (n_chunks > max_chunks) n_chunks = max_chunks;
-      if (n_chunks > n_words) n_chunks = n_words;
-      wpc = (n_words + n_chunks - 1u) / n_chunks;
-      const uint32_t lds_cap_words = (48u * 1024u / 8u) / (n_planes ? n_planes : 1u);
-      if (wpc > lds_cap_words) wpc = lds_cap_words;
-      n_chunks = (n_words + wpc - 1u) / wpc;
-    } else {
-      n_chunks = 1;
-      wpc = 1;
-    }
-    uint32_t* part_count = scratch + (size_t)n_chunks * R;
-    if (n_words == 0) {
-      (void)hipMemsetAsync(part_first, 0xFF, sizeof(uint32_t) * R, s);
-      (void)hipMemsetAsync(part_count, 0, sizeof(uint32_t) * R, s);
-    } else {
-      const size_t lds = (size_t)n_planes * wpc * sizeof(uint64_t);
-      hipLaunchKernelGGL(pair_sweep_planes_kernel<64>, dim3(rb, n_chunks), dim3(256), lds, s, row_sel, R, planes,
-                         n_words, n_planes, wpc, part_first, part_count);
-    }
-    hipLaunchKernelGGL(pair_combine_kernel, dim3(rb), dim3(256), 0, s, part_first, part_count, R, n_chunks, first,
-                       count);
-  }
-}
-
-uint32_t pair_sweep_scratch_chunks(int variant, uint32_t R, uint32_t n_cols, uint32_t n_planes) {
-  const uint32_t rb = (R + 255u) / 256u;
-  if (rb == 0) return 1;
-  if (variant == 1) {
-    uint32_t n_chunks = (4096u + rb - 1u) / rb;
-    return n_chunks + 1u;
+    n_split = n_cols ? (n_cols + chunk - 1u) / chunk : 1u;
+    if (n_split > 1u) hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
+    hipLaunchKernelGGL(pair_sweep_scalar_kernel, dim3(rb, n_split), dim3(256), 0, s, row_sel, R, col_mask, n_cols,
+                       chunk, first, count, n_split > 1u ? 1u : 0u);
+    return;
   }
   const uint32_t n_words = (n_cols + 63u) / 64u;
+  if (n_words == 0) {
+    hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
+    return;
+  }
+  uint32_t n_split = want_split < n_words ? want_split : n_words;
+  const uint32_t wps = (n_words + n_split - 1u) / n_split;
+  n_split = (n_words + wps - 1u) / wps;
   const uint32_t lds_cap_words = (48u * 1024u / 8u) / (n_planes ? n_planes : 1u);
-  uint32_t by_lds = n_words / (lds_cap_words ? lds_cap_words : 1u) + 2u;
-  uint32_t by_fill = (2048u + rb - 1u) / rb + 1u;
-  return by_lds > by_fill ? by_lds : by_fill;
+  const uint32_t wpp = wps < lds_cap_words ? wps : lds_cap_words;
+  const size_t lds = (size_t)n_planes * wpp * sizeof(uint64_t);
+  if (n_split > 1u) hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
+  hipLaunchKernelGGL(pair_sweep_planes_kernel, dim3(rb, n_split), dim3(256), lds, s, row_sel, R, planes, n_words,
+                     n_planes, wps, wpp, first, count, n_split > 1u ? 1u : 0u);
 }
 
 void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
@@ -2642,7 +2491,7 @@ void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const 
     hipLaunchKernelGGL(pair_select_scalar_kernel, dim3(rb), dim3(256), 0, s, row_sel, R, col_mask, n_cols, rank, out);
   } else {
     const uint32_t n_words = (n_cols + 63u) / 64u;
-    hipLaunchKernelGGL(pair_select_planes_kernel<64>, dim3(rb), dim3(256), 0, s, row_sel, R, planes, n_words,
+    hipLaunchKernelGGL(pair_select_planes_kernel, dim3(rb), dim3(256), 0, s, row_sel, R, planes, n_words,
                        n_planes, rank, out);
   }
 }
@@ -2653,12 +2502,12 @@ void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block
                      idx_by_block, val_by_block);
 }
 
-void launch_carve_propose(const CarveArgs* d_args, uint32_t W, uint32_t buf, hipStream_t s) {
+void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
   // one wave per located slot, grid-stride; 2048 workgroups x 4 waves keep all 256 CUs busy
   uint32_t blocks = (W + 3u) / 4u;
   if (blocks > 2048u) blocks = 2048u;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(carve_propose_kernel, dim3(blocks), dim3(256), 0, s, d_args, buf);
+  hipLaunchKernelGGL(carve_propose_kernel, dim3(blocks), dim3(256), 0, s, d_args);
 }
 
 // ids of freshly carved groups: outputs k+1 .. of the splitmix64 stream whose state is `state`

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 NONE = 0xFFFFFFFF
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 3])
+@pytest.mark.parametrize("carve_variant", [0, 1, 2])
 def test_form_groups_big_lists_bit_exact(carve_variant):
     """30k workers: several configurations have > 8192 candidates (big-list mode, proposal batches of 16384)."""
     sw = make_swarm(2, 2000, 30000, zipf=True)
@@ -67,6 +67,97 @@ def _check_tasks(sw, eng):
         assert a.group_size == int(groups[gow[w]]["n_members"])
 
 
+def _sha(*arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _engine_digests(sw, eng):
+    """the digests of tools/make_golden_scale.py, computed from what the engine published"""
+    _, groups, members = eng.get_groups()
+    gsha = _sha(groups["id"].astype(np.uint64), groups["config"].astype(np.uint32),
+                groups["n_members"].astype(np.uint32), members.astype(np.uint32))
+    tbl = np.zeros(sw.W, dtype=E.assignment_dt)
+    for w in range(sw.W):
+        a = eng.lookup(w)
+        tbl[w] = (a.task, a.group_slot, a.group_index, a.group_size, a.next_worker, a.group_id)
+    return gsha, tbl
+
+
+def _check_against_golden(name, carve_variant):
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scale_digests.json")))[name]
+    sw = baseline_config(gold["config"], seed=gold["seed"])
+    assert (sw.W, sw.T) == (gold["W"], gold["T"])
+    eng = E.Engine(carve_variant=carve_variant, group_id_seed=gold["seed"])
+    host.load_swarm(eng, sw)
+    stats = eng.tick()
+    task, count = eng.match()                  # the claim is sticky: the same table, plus the applicable counts
+    assert stats["n_formed"] == gold["n_formed"] and stats["n_merged"] == gold["n_merged"]
+    got = engine_groups(eng)
+    assert len(got) == gold["n_groups"]
+    # the explicit head and tail first: they localise a mismatch before the digest just says "different"
+    assert [[g[0], g[1], g[2]] for g in got[:1000]] == gold["first_groups"]
+    assert [[g[0], g[1], g[2]] for g in got[-1000:]] == gold["last_groups"]
+    gsha, tbl = _engine_digests(sw, eng)
+    assert gsha == gold["groups_sha256"], "group list (ids, configurations, sizes, members) differs from the oracle"
+    assert np.array_equal(tbl["task"], task)
+    assert _sha(tbl["task"].astype(np.uint32)) == gold["task_sha256"], "per-worker task column differs"
+    assert _sha(count.astype(np.uint32)) == gold["count_sha256"], "applicable-task counts differ"
+    assert _sha(tbl["group_index"].astype(np.uint32), tbl["group_size"].astype(np.uint32),
+                tbl["next_worker"].astype(np.uint32)) == gold["table_sha256"], "GROUP_INDEX / SIZE / NEXT differ"
+    assert stats["host_resolved_steps"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("carve_variant", [0, 2])
+def test_config1_full_size_against_oracle_digest(carve_variant):
+    """BASELINE configs[1], every group and every worker's row against the oracle's committed digests
+    (tests/golden/scale_digests.json, tools/make_golden_scale.py)."""
+    _check_against_golden("cfg1_seed1", carve_variant)
+
+
+def test_config2_full_size_against_oracle_digest():
+    """BASELINE configs[2] (1M tasks x 100k workers, Zipf): big-list mode, PM_TIE_BAND_BIG and tenth-of-a-list
+    proposal batches are all live here; the oracle needs ~1 min for the carve and 1e11 string compares for the
+    sweep, so its result is committed as digests plus the first / last 1000 groups."""
+    _check_against_golden("cfg2_seed1", 0)
+
+
+def test_config1_full_table_against_live_oracle():
+    """configs[1]: every worker's (task, applicable count, GROUP_INDEX, GROUP_SIZE, NEXT) against the oracle run
+    here, its pair sweep on all host cores (seed 2; seed 1 is pinned by the committed digest)."""
+    import os
+    sw = baseline_config(1, seed=2)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False, group_id_seed=2)
+    st.try_form_new_groups()
+    st.try_merge_solo_groups()
+    eng = E.Engine(group_id_seed=2)
+    host.load_swarm(eng, sw)
+    eng.tick()
+    task, count = eng.match()
+    assert [g[:3] for g in oracle_groups(st)] == [g[:3] for g in engine_groups(eng)]
+    cfg_of_node = np.full(sw.W, -1, dtype=np.int32)
+    for _, _, cfg, mem, _ in st.groups():
+        cfg_of_node[mem] = cfg
+    first_o, count_o = orc.pair_sweep_per_worker(tasks, cfgs, cfg_of_node, threads=os.cpu_count() or 1)
+    assert np.array_equal(task, first_o) and np.array_equal(count, count_o)
+    for w in range(sw.W):
+        a = eng.lookup(w)
+        if cfg_of_node[w] < 0:
+            assert a.task == NONE and a.group_slot == NONE
+            continue
+        if w % 7 == 0:      # O(T) each: every 7th grouped worker through the oracle's own filter_tasks
+            t, gi, gs, nxt = st.filter_tasks(w)
+            assert (a.task, a.group_index, a.group_size, a.next_worker) == (NONE if t < 0 else t, gi, gs, nxt), w
+    eng.close()
+
+
 def test_config2_full_size_properties():
     """BASELINE configs[2]: 1M tasks x 100k workers, Zipf-skewed topologies."""
     sw = baseline_config(2, seed=1)
@@ -90,7 +181,7 @@ def test_config2_full_size_properties():
 
 
 @pytest.mark.parametrize("seed", [1, 2, 7])
-@pytest.mark.parametrize("carve_variant", [0, 3])
+@pytest.mark.parametrize("carve_variant", [0, 2])
 def test_config1_full_size_groups_bit_exact(seed, carve_variant):
     """BASELINE configs[1] (10k workers, 24 mixed configurations): the groups — ids, configurations, members in
     carve order — equal the oracle's; the oracle's carve needs ~2 s at this size (its pair sweep is not run)."""

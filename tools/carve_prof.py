@@ -24,8 +24,8 @@ for it in range(3):
     eng.reset_groups()
     s = eng.tick()
 out = (C.c_ulonglong * 32)()
-E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-E.lib().pm_debug_carve_prof(eng._h, out)
+E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
+E.lib().pm_debug_carve_prof(eng._h, out, 32)
 out[9] = out[26] + out[27] + out[28] + out[29]
 tot = out[15] + out[9] + out[10] + out[13] + out[12] + out[14]
 print(f"carve kernels {s['ms_carve_kernel']:.3f} ms, {s['carve_steps']} steps ({s['carve_fast_steps']} fast), "
