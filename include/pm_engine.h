@@ -243,7 +243,8 @@ typedef struct {
   uint64_t carve_cand_sum;      /* sum over carve steps of the remaining candidates scanned (roofline bytes) */
 } pm_stats;
 
-/* One full-swarm match: compat masks -> form groups -> merge solo groups -> pair sweep + claim ->
+/* One full-swarm match on one GPU (a multi-GPU engine uses the stepwise tick below): compat masks -> form groups
+ * -> merge solo groups -> pair sweep + claim ->
  * publish the assignment table (run_group_management_loop body, mod.rs:180-203, plus one
  * get_task_for_node per worker, scheduler/mod.rs:26-36). */
 int32_t pm_tick(pm_engine*, pm_stats* stats);
@@ -267,6 +268,48 @@ int32_t pm_lookup_task_for_worker(pm_engine*, uint32_t worker, pm_assignment* ou
  * entries) for device-side consumers — e.g. the cross-shard RCCL all-gather of table shards.  The
  * pointer stays valid until the next worker upload; contents are rewritten by pm_tick / pm_match. */
 int32_t pm_device_task_column(pm_engine*, uint64_t* device_ptr, uint32_t* n);
+
+/* ------------------------------------------------------------------ multi-GPU
+ * One engine per GPU (one process per GPU), every engine holds the WHOLE swarm — 100k worker rows are 6 MB — and
+ * worker w is owned by rank shard_of_worker[w] (the caller's hash of the address, e.g. splitmix64(address) %
+ * world).  The reference carves from ONE pool (node_groups/mod.rs:492-503), so the carve domain is not split:
+ * what is split is the parallel work, and every rank ends a tick with bit-identical groups and tables.
+ *   - the sequential validation chain of try_form_new_groups runs replicated (identical inputs, deterministic);
+ *   - the neighbour-list proposals of a batch — the full-chip sweep that dominates at 100k workers — are dealt
+ *     round-robin over the ranks (seed i of the batch -> rank i % world) and all-gathered once per batch;
+ *   - the pair sweep + chooser + claim run for the OWNED workers only; the published rows are all-gathered once
+ *     per tick and scattered into every rank's full table (the "cross-shard conflict-resolution all-gather");
+ *   - pm_match_per_task bids with the owned workers only; the caller folds the per-task bests (min index / sum).
+ * The collectives are the caller's (RCCL ncclAllGather, or torch.distributed): the engine hands out device
+ * pointers.  recv = [world][bytes_per_rank]; send = this rank's contribution (bytes_per_rank bytes); issue
+ * all-gather(send -> recv) on the engine's stream (pm_set_stream) and call the next step.  bytes_per_rank == 0:
+ * nothing to exchange for this step.  Status / task / worker updates are replicated calls: every rank receives
+ * every event.  A stepwise tick with world == 1 is the plain tick in steps (no exchange). */
+typedef struct {
+  uint64_t send_ptr, recv_ptr; /* device pointers */
+  uint64_t bytes_per_rank;
+} pm_dist_xfer;
+
+/* All work of this engine goes to the caller's HIP stream (hipStream_t), e.g. the stream its RCCL calls use, so
+ * kernels and collectives are ordered without host synchronisation.  NULL = back to the engine's own stream. */
+int32_t pm_set_stream(pm_engine*, void* hip_stream);
+/* After pm_upload_workers (and again whenever the row count changes).  world == 1 switches back. */
+int32_t pm_dist_configure(pm_engine*, uint32_t rank, uint32_t world, const uint8_t* shard_of_worker);
+/* The tick in steps:
+ *   pm_dist_tick_begin                      compat sweep, first candidate list
+ *   loop: pm_dist_carve_next(&x, &more)     waits for the carve, settles near-ties on the host (replicated);
+ *                                           more == 1: this rank's proposals are queued -> all-gather x ->
+ *         pm_dist_carve_validate            validation of the batch + preparation of the next one
+ *   pm_dist_match_begin(&x)                 solo merge, pair sweep + claim of the owned workers -> all-gather x ->
+ *   pm_dist_tick_end(&stats)                scatter into the full table, publish (pm_lookup_* serve every worker) */
+int32_t pm_dist_tick_begin(pm_engine*);
+int32_t pm_dist_carve_next(pm_engine*, pm_dist_xfer* x, uint32_t* more);
+int32_t pm_dist_carve_validate(pm_engine*);
+int32_t pm_dist_match_begin(pm_engine*, pm_dist_xfer* x);
+int32_t pm_dist_tick_end(pm_engine*, pm_stats* stats);
+/* pm_match_per_task with the results left on the device (u32[T] each, worker indices are global) for a
+ * device-side fold across ranks; not available with a non-zero price column. */
+int32_t pm_match_per_task_device(pm_engine*, uint64_t* best_ptr, uint64_t* count_ptr, uint32_t* n_tasks);
 
 /* ------------------------------------------------------------------ host helpers (no GPU needed)
  * ComputeRequirements::from_str (shared/src/models/node.rs:180-374).  Fills cfg->flags/cpu/ram/

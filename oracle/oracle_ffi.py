@@ -74,6 +74,8 @@ def lib() -> C.CDLL:
         L.orc_is_node_compatible_with_config.restype = C.c_int
         L.orc_calculate_distance.argtypes = [C.c_double] * 4
         L.orc_calculate_distance.restype = C.c_double
+        L.orc_distance_column.argtypes = [C.c_double, C.c_double, vp, vp, sz, vp]
+        L.orc_distance_column.restype = None
         L.orc_sort_configs.argtypes = [vp, sz, vp]
         L.orc_sort_configs.restype = C.c_int
         L.orc_available_configs.argtypes = [vp, vp, sz, vp, vp]
@@ -191,6 +193,14 @@ def model_matches(spec_model: str, req_model: str) -> bool:
 
 def calculate_distance(lat1, lon1, lat2, lon2) -> float:
     return lib().orc_calculate_distance(lat1, lon1, lat2, lon2)
+
+
+def distance_column(lat0: float, lon0: float, lat: np.ndarray, lon: np.ndarray) -> np.ndarray:
+    lat = np.ascontiguousarray(lat, dtype=np.float64)
+    lon = np.ascontiguousarray(lon, dtype=np.float64)
+    out = np.zeros(len(lat), dtype=np.float64)
+    lib().orc_distance_column(lat0, lon0, _p(lat), _p(lon), len(lat), _p(out))
+    return out
 
 
 def make_config(name: str, min_size: int, max_size: int, requirements: str | None) -> np.ndarray:

@@ -366,6 +366,11 @@ double orc_calculate_distance(double lat1, double lon1, double lat2, double lon2
   return EARTH_RADIUS_KM * c;
 }
 
+/* the same function over a column (test models that need many distances to one reference point) */
+void orc_distance_column(double lat0, double lon0, const double* lat, const double* lon, size_t n, double* out) {
+  for (size_t i = 0; i < n; ++i) out[i] = orc_calculate_distance(lat0, lon0, lat[i], lon[i]);
+}
+
 /* ------------------------------------------------------------------ config ordering */
 
 int orc_sort_configs(const orc_config* cfgs, size_t n, uint32_t* order) { /* mod.rs:138-164 */

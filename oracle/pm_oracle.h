@@ -156,6 +156,7 @@ int orc_is_node_compatible_with_config(const orc_config* cfg, const orc_node* no
 
 /* orchestrator/src/plugins/node_groups/mod.rs:218-231  Haversine, glibc libm. */
 double orc_calculate_distance(double lat1, double lon1, double lat2, double lon2);
+void orc_distance_column(double lat0, double lon0, const double* lat, const double* lon, size_t n, double* out);
 
 /* orchestrator/src/plugins/node_groups/mod.rs:138-164: validity panics + template sort.
  * order_out[i] = index (into cfgs) of the i-th template after the stable sort.

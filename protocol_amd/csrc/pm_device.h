@@ -26,6 +26,7 @@ static constexpr double PM_TIE_BAND_BIG = 1.0 / 2147483648.0;   // 2^-31
 static constexpr double PM_TIE_BAND_MEM = 1.0 / 268435456.0;    // 2^-28
 static constexpr uint32_t PM_CARVE_CACHE_ROWS = 128;   // proposal rows staged in LDS (128 * 64 * 8 B = the key array)
 static constexpr uint32_t PM_PROP_ROW = 64;            // proposal row stride (entries)
+static constexpr uint32_t PM_PROP_META = 63;           // entry of a row that carries its flags word (so K <= 63)
 static constexpr uint32_t PM_PROP_RESERVE = 48;        // entries beyond max_group_size - 1 (24 -> 48: exact steps 1.3 % -> 0.4 %)
 static constexpr uint32_t PM_PROP_MAX_SEEDS = 16384;   // located slots that get a proposal per configuration
 static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
@@ -41,16 +42,17 @@ struct CompatArgs {
 };
 
 struct ClaimArgs {
-  uint32_t W;
+  uint32_t R;            // rows: all workers, or the workers `rows` lists (multi-GPU: the ones this rank owns)
+  const uint32_t* rows;  // nullptr = row r is worker r
   const int32_t* group_of;
   const uint32_t *g_n, *g_off, *g_task;
   const uint64_t* g_id;
   uint32_t* g_task_next;
-  const uint32_t* chosen;
+  const uint32_t* chosen;         // per row
   const uint32_t* rank_in_group;  // per worker
   const uint32_t* by_rank;        // per member slot: worker of that rank
-  pm_assignment* table;
-  uint32_t* task_col;  // compact per-worker task column (device-side consumers)
+  pm_assignment* table;  // per worker; with `rows`: per row (this rank's segment of the exchange buffer)
+  uint32_t* task_col;    // compact per-worker task column (device-side consumers; not written with `rows`)
 };
 
 enum { CARVE_MODE_FORM = 0, CARVE_MODE_MERGE = 1 };
@@ -77,6 +79,8 @@ struct CarveStatus {
   uint32_t n_list;       // slots of the prepared candidate list
   uint32_t prop_k;       // entries per proposal for the prepared configuration (0 = no proposals)
   uint32_t prop_limit;   // proposals exist for located slots below this slot number
+  uint32_t rows_pr;      // rows per rank of this batch in the proposal buffer: ceil(seeds / world)
+  uint32_t _pad_rows;
   uint32_t total_available;
   uint32_t fast_steps;   // steps committed from proposals
   uint32_t slow_steps;   // steps that needed the full key sweep
@@ -117,9 +121,17 @@ struct CarveArgs {
   uint64_t* keys;          // packed keys when the candidate list does not fit in LDS
   uint32_t bits_stride;
   uint32_t _pad0;
-  // proposals: PM_PROP_ROW packed keys per slot, sorted ascending (carve_propose_kernel)
+  // proposals (carve_propose_kernel): one row of PM_PROP_ROW u64 per seed of the batch — packed keys sorted
+  // ascending, the flags word in entry PM_PROP_META (low byte: entries; bit 31: the row holds every live
+  // candidate; bits 30..28: tail_ok, clean, tail_clear).  Seed i of a batch (rank among the live located slots
+  // below prop_limit) belongs to rank i % world and is row i / world of that rank's segment; `prop` holds all
+  // segments back to back ([world][rows_pr] rows — what the all-gather delivers), `prop_send` is this rank's
+  // segment (the same memory as `prop` when world == 1).
   uint64_t* prop;
-  uint32_t* prop_n;        // low byte: entries; bit 31: the list holds every live candidate
+  uint64_t* prop_send;
+  uint64_t* seed_map;      // per bitmap word below prop_limit: the batch's seeds (live & located at preparation)
+  uint32_t* seed_prefix;   // per bitmap word: seeds in front of the word
+  uint32_t dist_rank, dist_world;
   uint32_t* same_next;     // next located slot at the same site (identical coordinates), PM_NONE = none
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
@@ -134,11 +146,15 @@ struct CarveArgs {
 
 void launch_compat(const CompatArgs& a, hipStream_t s);
 void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s);
-void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t W, uint64_t* sel, hipStream_t s);
+void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t R, const uint32_t* rows,
+                            uint64_t* sel, hipStream_t s);
 void launch_eligible_selector(const uint32_t* wflags, const int32_t* group_of, const uint64_t* compat,
-                              uint64_t enabled, uint32_t W, uint64_t* sel, hipStream_t s);
-void launch_chooser_rank(const int32_t* group_of, const uint64_t* g_id, const uint32_t* count, uint32_t W,
-                         uint64_t seed, uint32_t* rank, hipStream_t s);
+                              uint64_t enabled, uint32_t W, const uint8_t* shard, uint32_t my_rank, uint64_t* sel,
+                              hipStream_t s);
+void launch_chooser_rank(const int32_t* group_of, const uint64_t* g_id, const uint32_t* count, uint32_t R,
+                         const uint32_t* rows, uint64_t seed, uint32_t* rank, hipStream_t s);
+void launch_table_scatter(const pm_assignment* x, const uint32_t* xrow, uint32_t W, pm_assignment* table,
+                          uint32_t* task_col, uint32_t* g_task_next, hipStream_t s);
 void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint32_t* g_off, const uint32_t* members,
                        const uint32_t* addr_rank, uint32_t W, uint32_t* rank_in_group, uint32_t* by_rank,
                        hipStream_t s);

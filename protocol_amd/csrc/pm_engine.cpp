@@ -94,9 +94,15 @@ static_assert(sizeof(pm_assignment) == 32, "published rows are copied as four 64
 
 using namespace pm;
 
+namespace pm {
+struct FormRun;
+}
+
 struct pm_engine {
   pm_engine_config cfg{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // the stream every kernel and copy of this engine goes to
+  hipStream_t stream_owned = nullptr;  // created with the engine; `stream` unless pm_set_stream handed one in
+  bool own_stream = true;
   hipEvent_t ev[6]{};
   hipEvent_t kev[6]{};  // kernel-only brackets: compat, carve, sweep
   float k_ms_compat = 0, k_ms_carve = 0, k_ms_sweep = 0;
@@ -123,8 +129,8 @@ struct pm_engine {
       h_addr_rank;
   std::vector<double> h_lat, h_lon;
   std::vector<uint32_t> h_site;  // equal (lat, lon) bit patterns <=> equal site id
-  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_prop_n, d_same_next;
-  DevBuf<uint64_t> d_prop;
+  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_same_next, d_seed_prefix;
+  DevBuf<uint64_t> d_prop, d_prop_send, d_seed_map;
   uint32_t tick_fast_steps = 0;
   DevBuf<uint32_t> d_flags, d_gpu_count, d_gpu_mem, d_gpu_cls, d_cpu_cores, d_ram, d_storage, d_addr_rank;
   DevBuf<double> d_lat, d_lon, d_coslat;
@@ -188,6 +194,19 @@ struct pm_engine {
   std::atomic<int> pub_cur{-1};
   std::vector<uint64_t*> pub_retired;
   pm_stats last_stats{};
+
+  // ---- multi-GPU (pm_dist_*): this engine is rank `dist_rank` of `dist_world`, every rank holds the whole swarm
+  uint32_t dist_rank = 0, dist_world = 1;
+  std::vector<uint8_t> h_shard;        // owner rank of every worker
+  std::vector<uint32_t> h_own_rows;    // workers owned by this rank, ascending
+  uint32_t dist_cap_t = 0;             // table rows per rank in the exchange buffer (largest shard)
+  DevBuf<uint8_t> d_shard;
+  DevBuf<uint32_t> d_own_rows, d_xrow; // d_xrow[w] = shard * cap_t + index within the shard
+  DevBuf<uint64_t> d_sel_own;
+  DevBuf<pm_assignment> d_table_x;     // [world][cap_t] exchange buffer of published rows
+  pm::FormRun* form = nullptr;         // carve in progress (stepwise tick)
+  int dist_phase = 0;                  // 0 idle, 1 carving, 2 carve done, 3 match queued
+  uint32_t dist_n_formed = 0, dist_n_merged = 0;
   uint32_t tick_host_resolved = 0, tick_carve_launches = 0, tick_carve_steps = 0;
 };
 
@@ -377,9 +396,15 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_slot_wid.ensure(cap));
   HIPCHK(e->d_c_site.ensure(cap));
   HIPCHK(e->d_cc_site.ensure(cap));
-  HIPCHK(e->d_prop_n.ensure(cap));
   HIPCHK(e->d_same_next.ensure(cap));
-  HIPCHK(e->d_prop.ensure(cap * PM_PROP_ROW));
+  {  // proposal rows: at most PM_PROP_MAX_SEEDS + 63 seeds per batch, dealt round-robin over the ranks
+    const size_t world = e->dist_world;
+    const size_t rows_pr = (size_t(PM_PROP_MAX_SEEDS) + 64 + world - 1) / world;
+    HIPCHK(e->d_prop.ensure(rows_pr * world * PM_PROP_ROW));
+    if (world > 1) HIPCHK(e->d_prop_send.ensure(rows_pr * PM_PROP_ROW));
+    HIPCHK(e->d_seed_map.ensure((cap + 63) / 64 + 64));
+    HIPCHK(e->d_seed_prefix.ensure((cap + 63) / 64 + 64));
+  }
   HIPCHK(e->d_status.ensure(1));
   HIPCHK(e->d_carve_args.ensure(1));
   const uint32_t stride = uint32_t((cap + 63) / 64);
@@ -414,7 +439,11 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->c_site = e->d_c_site.p;
   a->cc_site = e->d_cc_site.p;
   a->prop = e->d_prop.p;
-  a->prop_n = e->d_prop_n.p;
+  a->prop_send = e->dist_world > 1 ? e->d_prop_send.p : e->d_prop.p;
+  a->seed_map = e->d_seed_map.p;
+  a->seed_prefix = e->d_seed_prefix.p;
+  a->dist_rank = e->dist_rank;
+  a->dist_world = e->dist_world;
   a->same_next = e->d_same_next.p;
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
   a->bits_stride = stride;
@@ -523,27 +552,50 @@ static void host_mark(const char* what) {
   fprintf(stderr, "[pm host] %10.1f us  %s\n", us, what);
 }
 
-static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = false) {
+// One try_form_new_groups run (mod.rs:478-628) as a resumable sequence, so the same code serves the
+// single-GPU tick (launches queued blindly, status read when they are done) and the stepwise multi-GPU tick
+// (one status read per proposal batch, the all-gather of the batch's rows issued by the caller in between).
+struct FormRun {
+  CarveArgs a;
+  CarveStatus st;
+  std::vector<uint32_t> avail;
+  uint32_t g0 = 0, m0 = 0, start_ci = 0;
+  size_t lds = 0;
+  bool use_props = false;
+  bool nothing = false;  // no configuration / no worker: nothing to carve
+};
+
+static int32_t form_queue_init(pm_engine* e, FormRun* r) {
+  HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
+  if (r->use_props)
+    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, r->start_ci, r->lds, e->stream));
+  else
+    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, r->start_ci, r->lds, e->stream));
+  e->tick_carve_launches++;
+  return PM_OK;
+}
+
+static int32_t form_begin(pm_engine* e, FormRun* r) {
   int32_t rc = absorb_groups(e);  // a match that failed half-way may have left the last carve unabsorbed
   if (rc) return rc;
   rc = ensure_compat(e);
   if (rc) return rc;
   rc = push_groups(e);
   if (rc) return rc;
-  std::vector<uint32_t> avail;
-  available_order(e->cfgs.data(), uint32_t(e->cfgs.size()), e->enabled, &avail);
-  const uint32_t g0 = e->d_n_groups, m0 = e->d_n_members;
-  if (n_formed) *n_formed = 0;
-  if (avail.empty() || e->W == 0) return PM_OK;
-
-  CarveArgs a;
+  available_order(e->cfgs.data(), uint32_t(e->cfgs.size()), e->enabled, &r->avail);
+  r->g0 = e->d_n_groups;
+  r->m0 = e->d_n_members;
+  r->start_ci = 0;
+  r->nothing = r->avail.empty() || e->W == 0;
+  if (r->nothing) return PM_OK;
+  CarveArgs& a = r->a;
   rc = fill_carve_args(e, &a, CARVE_MODE_FORM, 0);
   if (rc) return rc;
-  a.n_avail = uint32_t(avail.size());
-  for (size_t i = 0; i < avail.size(); ++i) {
-    a.avail_cfg[i] = avail[i];
-    a.min_size[i] = e->cfgs[avail[i]].min_group_size;
-    a.max_size[i] = e->cfgs[avail[i]].max_group_size;
+  a.n_avail = uint32_t(r->avail.size());
+  for (size_t i = 0; i < r->avail.size(); ++i) {
+    a.avail_cfg[i] = r->avail[i];
+    a.min_size[i] = e->cfgs[r->avail[i]].min_group_size;
+    a.max_size[i] = e->cfgs[r->avail[i]].max_group_size;
   }
   a.g_cfg = e->d_g_cfg.p;
   a.g_n = e->d_g_n.p;
@@ -552,68 +604,59 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   a.cap_groups = uint32_t(std::min<size_t>(e->d_g_cfg.cap, 0xFFFFFFFFu));
   a.cap_members = uint32_t(std::min<size_t>(e->d_members.cap, 0xFFFFFFFFu));
   bool in_lds;
-  const size_t lds = carve_lds_bytes(a.bits_stride, &in_lds);
-
-  CarveStatus st{};
-  st.state = CARVE_STATE_RUNNING;
-  st.n_groups = g0;
-  st.n_members = m0;
-  const bool use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
+  r->lds = carve_lds_bytes(a.bits_stride, &in_lds);
+  r->st = CarveStatus{};
+  r->st.state = CARVE_STATE_RUNNING;
+  r->st.n_groups = r->g0;
+  r->st.n_members = r->m0;
+  r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
-  uint32_t start_ci = 0;
+  HIPCHK(hipEventRecord(e->kev[2], e->stream));
+  return form_queue_init(e, r);  // prepares the first candidate list (all of it when there are no proposals)
+}
+
+// (propose, validate) pairs: one per configuration plus one per re-proposal round; launches queued behind a
+// finished carve return immediately
+static int32_t form_queue_pairs(pm_engine* e, FormRun* r, uint32_t count) {
+  for (uint32_t k = 0; k < count; ++k) {
+    launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, r->lds, e->stream));
+    e->tick_carve_launches += 2;
+  }
+  return PM_OK;
+}
+
+// Wait for everything queued so far and read the carve's status.  An UNCERTAIN step is settled on the host
+// (glibc distances) and the carve re-armed from that configuration; the caller sees RUNNING then.
+static int32_t form_poll(pm_engine* e, FormRun* r) {
   for (;;) {
-    HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipEventRecord(e->kev[2], e->stream));
-    auto queue_pairs = [&](uint32_t count) -> int32_t {
-      for (uint32_t k = 0; k < count; ++k) {
-        launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
-        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, lds, e->stream));
-        e->tick_carve_launches += 2;
-      }
-      return PM_OK;
-    };
-    if (use_props) {
-      // prepare the first candidate list, then (propose, validate) pairs: one per configuration plus one
-      // per re-proposal round; launches queued behind a finished carve return immediately
-      HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, start_ci, lds, e->stream));
-      rc = queue_pairs(a.n_avail - start_ci + 3u);
-      if (rc) return rc;
-    } else {
-      HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, start_ci, lds, e->stream));
-    }
     HIPCHK(hipEventRecord(e->kev[3], e->stream));
-    e->tick_carve_launches++;
-    host_mark("form: carve queued");
-    HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&r->st, e->d_status.p, sizeof(r->st), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    host_mark("form: status back");
     {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
       e->k_ms_carve += ms;
-    }
-    if (st.state == CARVE_STATE_DONE) break;
-    if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
-    while (st.state == CARVE_STATE_RUNNING && use_props) {  // more re-proposal rounds than were queued
       HIPCHK(hipEventRecord(e->kev[2], e->stream));
-      rc = queue_pairs(16u);
-      if (rc) return rc;
-      HIPCHK(hipEventRecord(e->kev[3], e->stream));
-      HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-      float ms = 0;
-      HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
-      e->k_ms_carve += ms;
     }
-    if (st.state == CARVE_STATE_DONE) break;
-    if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
-    if (st.state != CARVE_STATE_UNCERTAIN) return set_error(PM_ENODEV, "carve kernel did not complete");
-    rc = host_resolve_form_step(e, avail[st.stop_ci], &st);
+    if (r->st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
+    if (r->st.state != CARVE_STATE_UNCERTAIN) return PM_OK;
+    int32_t rc = host_resolve_form_step(e, r->avail[r->st.stop_ci], &r->st);
     if (rc) return rc;
     e->tick_host_resolved++;
-    start_ci = st.stop_ci;
-    st.state = CARVE_STATE_RUNNING;
+    r->start_ci = r->st.stop_ci;
+    r->st.state = CARVE_STATE_RUNNING;
+    rc = form_queue_init(e, r);
+    if (rc) return rc;
+    // read the status again: the INIT launch prepares the next list (and, without proposals, runs on to the end
+    // or the next stop) — the caller sizes the batch's exchange from what it reports
   }
+}
+
+static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool defer_absorb) {
+  if (n_formed) *n_formed = 0;
+  if (r->nothing) return PM_OK;
+  const CarveStatus& st = r->st;
   e->tick_fast_steps += st.fast_steps;
   e->tick_carve_steps += st.steps_total;
   e->tick_cand_sum += st.cand_sum;
@@ -621,7 +664,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
 
   // The new group records stay in HBM for the match; their ids (generate_group_id stream) and empty task
   // words are filled in on the device, and a copy travels to pinned host memory for absorb_groups().
-  const uint32_t g1 = st.n_groups, m1 = st.n_members;
+  const uint32_t g0 = r->g0, m0 = r->m0, g1 = st.n_groups, m1 = st.n_members;
   if (g1 > g0) {
     const uint32_t ng = g1 - g0, nm = m1 - m0;
     const size_t need = size_t(3) * ng + nm;
@@ -651,12 +694,35 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
     e->d_n_groups = g1;
     e->d_n_members = m1;
     if (!defer_absorb) {
-      rc = absorb_groups(e);
+      int32_t rc = absorb_groups(e);
       if (rc) return rc;
     }
   }
   if (n_formed) *n_formed = g1 - g0;
   return PM_OK;
+}
+
+static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = false) {
+  FormRun r;
+  int32_t rc = form_begin(e, &r);
+  if (rc) return rc;
+  if (!r.nothing) {
+    uint32_t batch = r.a.n_avail + 3u;
+    for (;;) {
+      if (r.use_props) {
+        rc = form_queue_pairs(e, &r, batch);
+        if (rc) return rc;
+      }
+      host_mark("form: carve queued");
+      rc = form_poll(e, &r);
+      if (rc) return rc;
+      host_mark("form: status back");
+      if (r.st.state == CARVE_STATE_DONE) break;
+      if (r.st.state != CARVE_STATE_RUNNING || !r.use_props) return set_error(PM_ENODEV, "carve kernel did not complete");
+      batch = 16u;  // more re-proposal rounds than were queued, or re-armed after a host-resolved step
+    }
+  }
+  return form_finish(e, &r, n_formed, defer_absorb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -706,7 +772,9 @@ static int32_t pick_task_for_config(pm_engine* e, uint32_t cfg, uint64_t group_i
   return PM_OK;
 }
 
-static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* count_out) {
+// The pair sweep + chooser + claim for every worker — or, in a multi-GPU tick (`dist`), for the workers this
+// rank owns, whose rows go packed into this rank's segment of the exchange buffer (pm_dist_match_begin).
+static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* count_out, bool dist = false) {
   if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
     return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
   int32_t rc = push_groups(e);
@@ -716,7 +784,9 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
     rc = ensure_task_planes(e);
     if (rc) return rc;
   }
-  rc = ensure_sweep_outputs(e, e->W);
+  const uint32_t R = dist ? uint32_t(e->h_own_rows.size()) : e->W;
+  const uint32_t* rows = dist ? e->d_own_rows.p : nullptr;
+  rc = ensure_sweep_outputs(e, R);
   if (rc) return rc;
   HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
   HIPCHK(e->d_table.ensure(std::max<uint32_t>(e->W, 1)));
@@ -725,17 +795,17 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   const uint32_t n_planes = uint32_t(e->cfgs.size());
 
   host_mark("match: selector launch");
-  launch_worker_selector(e->d_group_of.p, e->d_g_cfg.p, e->W, e->d_sel.p, e->stream);
+  launch_worker_selector(e->d_group_of.p, e->d_g_cfg.p, R, rows, e->d_sel.p, e->stream);
   HIPCHK(hipEventRecord(e->kev[4], e->stream));
-  launch_pair_sweep(variant, e->d_sel.p, e->W, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_first.p,
+  launch_pair_sweep(variant, e->d_sel.p, R, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_first.p,
                     e->d_count.p, e->stream);
   HIPCHK(hipEventRecord(e->kev[5], e->stream));
   e->k_sweep_recorded = true;
   const uint32_t* chosen = e->d_first.p;  // PM_CHOOSE_FIRST: the first applicable task
   if (e->cfg.chooser == PM_CHOOSE_SEEDED) {
-    launch_chooser_rank(e->d_group_of.p, e->d_g_id.p, e->d_count.p, e->W, e->cfg.chooser_seed, e->d_rank.p,
+    launch_chooser_rank(e->d_group_of.p, e->d_g_id.p, e->d_count.p, R, rows, e->cfg.chooser_seed, e->d_rank.p,
                         e->stream);
-    launch_pair_select(variant, e->d_sel.p, e->W, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_rank.p,
+    launch_pair_select(variant, e->d_sel.p, R, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_rank.p,
                        e->d_chosen.p, e->stream);
     chosen = e->d_chosen.p;
   }
@@ -744,7 +814,8 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   const size_t G = e->d_n_groups;  // == groups.size() once the last carve is absorbed
   if (G) HIPCHK(hipMemcpyAsync(e->d_g_task_next.p, e->d_g_task.p, G * 4, hipMemcpyDeviceToDevice, e->stream));
   ClaimArgs c{};
-  c.W = e->W;
+  c.R = R;
+  c.rows = rows;
   c.group_of = e->d_group_of.p;
   c.g_n = e->d_g_n.p;
   c.g_off = e->d_g_off.p;
@@ -754,13 +825,13 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   c.chosen = chosen;
   c.rank_in_group = e->d_rank_in_group.p;
   c.by_rank = e->d_by_rank.p;
-  c.table = e->d_table.p;
+  c.table = dist ? e->d_table_x.p + size_t(e->dist_rank) * e->dist_cap_t : e->d_table.p;
   c.task_col = e->d_task_col.p;
   launch_claim_publish(c, e->stream);
   HIPCHK(hipGetLastError());
   if (want_count && count_out) {
-    count_out->resize(e->W);
-    HIPCHK(hipMemcpyAsync(count_out->data(), e->d_count.p, size_t(e->W) * 4, hipMemcpyDeviceToHost, e->stream));
+    count_out->resize(R);
+    HIPCHK(hipMemcpyAsync(count_out->data(), e->d_count.p, size_t(R) * 4, hipMemcpyDeviceToHost, e->stream));
   }
   return PM_OK;
 }
@@ -1056,6 +1127,7 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
     delete e;
     return set_error(PM_ENODEV, "hipStreamCreate failed");
   }
+  e->stream_owned = e->stream;
   for (auto& ev : e->ev)
     if (hipEventCreate(&ev) != hipSuccess) {
       delete e;
@@ -1088,12 +1160,13 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_rank_in_group.release(); e->d_g_id.release();
   e->d_order.release(); e->d_c_lat.release(); e->d_c_lon.release(); e->d_c_cos.release();
   e->d_cc_lat.release(); e->d_cc_lon.release(); e->d_cc_cos.release(); e->d_slot_pos.release(); e->d_slot_wid.release();
-  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop_n.release(); e->d_prop.release(); e->d_same_next.release();
+  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_same_next.release();
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
-  e->d_table.release(); e->d_task_col.release(); e->d_nb_idx.release(); e->d_nb_val.release();
+  e->d_table.release(); e->d_task_col.release(); e->d_shard.release(); e->d_own_rows.release(); e->d_xrow.release();
+  e->d_sel_own.release(); e->d_table_x.release(); e->d_nb_idx.release(); e->d_nb_val.release();
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
   if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
   if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
@@ -1104,7 +1177,8 @@ void pm_engine_destroy(pm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->kev)
     if (ev) (void)hipEventDestroy(ev);
-  if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stream_owned) (void)hipStreamDestroy(e->stream_owned);
+  delete e->form;
   delete e;
 }
 
@@ -1223,6 +1297,10 @@ int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_gr
   HIPCHK(hipSetDevice(e->cfg.device));
   if (keep_groups && e->have_workers && n != e->W)
     return set_error(PM_EINVAL, "keep_groups requires an unchanged worker count");
+  if (n != e->W && e->dist_world > 1) {  // ownership is per worker row: pm_dist_configure must follow
+    e->h_shard.clear();
+    e->h_own_rows.clear();
+  }
   e->W = n;
   e->h_flags.assign(w->flags, w->flags + n);
   e->h_gpu_count.assign(w->gpu_count, w->gpu_count + n);
@@ -1448,6 +1526,7 @@ int32_t pm_match(pm_engine* e, uint32_t* task_of_worker, uint32_t* applicable_co
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_world > 1) return set_error(PM_ESTATE, "multi-GPU engine: use the stepwise tick (pm_dist_tick_begin ...)");
   ABSORB_PENDING(e);
   std::vector<uint32_t> cnt;
   int32_t rc = run_match(e, applicable_count != nullptr, &cnt);
@@ -1460,10 +1539,9 @@ int32_t pm_match(pm_engine* e, uint32_t* task_of_worker, uint32_t* applicable_co
   return PM_OK;
 }
 
-int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candidate_count) {
-  if (!e) return set_error(PM_EINVAL, "null argument");
-  std::lock_guard<std::mutex> lk(e->mu);
-  HIPCHK(hipSetDevice(e->cfg.device));
+// north_star orientation: rows = tasks, swept axis = workers (the ones this rank owns in a multi-GPU set-up);
+// leaves first / count per task in d_first / d_count (worker indices are global: every rank holds the whole table)
+static int32_t run_match_per_task(pm_engine* e) {
   if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
   ABSORB_PENDING(e);
   int32_t rc = ensure_compat(e);
@@ -1475,7 +1553,8 @@ int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candida
   rc = ensure_sweep_outputs(e, e->T);
   if (rc) return rc;
   HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
-  launch_eligible_selector(e->d_flags.p, e->d_group_of.p, e->d_compat.p, e->enabled, e->W, e->d_sel.p, e->stream);
+  launch_eligible_selector(e->d_flags.p, e->d_group_of.p, e->d_compat.p, e->enabled, e->W,
+                           e->dist_world > 1 ? e->d_shard.p : nullptr, e->dist_rank, e->d_sel.p, e->stream);
   const uint64_t* cols = e->d_sel.p;
   if (e->any_price) {  // order the swept axis by (price, index) so "first hit" is the best bid
     HIPCHK(e->d_perm.ensure(e->W));
@@ -1496,6 +1575,15 @@ int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candida
   launch_pair_sweep(variant, e->d_tmask.p, e->T, cols, e->d_wplanes.p, e->W, n_planes, e->d_first.p, e->d_count.p,
                     e->stream);
   HIPCHK(hipGetLastError());
+  return PM_OK;
+}
+
+int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candidate_count) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int32_t rc = run_match_per_task(e);
+  if (rc) return rc;
   if (best_worker && e->T)
     HIPCHK(hipMemcpyAsync(best_worker, e->d_first.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
   if (candidate_count && e->T)
@@ -1504,6 +1592,20 @@ int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candida
   if (best_worker && e->any_price)
     for (uint32_t t = 0; t < e->T; ++t)
       if (best_worker[t] != PM_NONE) best_worker[t] = e->price_perm[best_worker[t]];
+  return PM_OK;
+}
+
+int32_t pm_match_per_task_device(pm_engine* e, uint64_t* best_ptr, uint64_t* count_ptr, uint32_t* n) {
+  if (!e || !best_ptr || !count_ptr || !n) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->any_price) return set_error(PM_ESTATE, "device-side bids are index-ordered: not available with a price column");
+  int32_t rc = run_match_per_task(e);
+  if (rc) return rc;
+  if (e->own_stream) HIPCHK(hipStreamSynchronize(e->stream));  // a caller-supplied stream orders the consumer itself
+  *best_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_first.p));
+  *count_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_count.p));
+  *n = e->T;
   return PM_OK;
 }
 
@@ -1537,17 +1639,50 @@ int32_t pm_newest_task(pm_engine* e, uint32_t* task_idx) {
   return PM_OK;
 }
 
+static void tick_reset(pm_engine* e) {
+  e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
+  e->tick_fast_steps = 0;
+  e->tick_cand_sum = 0;
+  e->k_ms_compat = e->k_ms_carve = e->k_ms_sweep = 0;
+  e->k_sweep_recorded = e->k_compat_recorded = false;
+}
+
+static int32_t tick_stats(pm_engine* e, pm_stats* stats, uint32_t n_formed, uint32_t n_merged) {
+  HIPCHK(hipEventRecord(e->ev[5], e->stream));
+  HIPCHK(hipEventSynchronize(e->ev[5]));
+  pm_stats s{};
+  HIPCHK(hipEventElapsedTime(&s.ms_compat, e->ev[0], e->ev[1]));
+  HIPCHK(hipEventElapsedTime(&s.ms_carve, e->ev[1], e->ev[2]));
+  HIPCHK(hipEventElapsedTime(&s.ms_merge, e->ev[2], e->ev[3]));
+  HIPCHK(hipEventElapsedTime(&s.ms_sweep, e->ev[3], e->ev[4]));
+  HIPCHK(hipEventElapsedTime(&s.ms_publish, e->ev[4], e->ev[5]));
+  HIPCHK(hipEventElapsedTime(&s.ms_total, e->ev[0], e->ev[5]));
+  if (e->k_compat_recorded) HIPCHK(hipEventElapsedTime(&s.ms_compat_kernel, e->kev[0], e->kev[1]));
+  if (e->k_sweep_recorded) HIPCHK(hipEventElapsedTime(&s.ms_sweep_kernel, e->kev[4], e->kev[5]));
+  s.ms_carve_kernel = e->k_ms_carve;
+  s.carve_cand_sum = e->tick_cand_sum;
+  s.n_groups = uint32_t(e->groups.size());
+  s.n_formed = n_formed;
+  s.n_merged = n_merged;
+  s.carve_steps = e->tick_carve_steps;
+  s.carve_fast_steps = e->tick_fast_steps;
+  s.host_resolved_steps = e->tick_host_resolved;
+  s.carve_launches = e->tick_carve_launches;
+  s.pair_evals = uint64_t(e->T) * uint64_t(e->W);
+  e->last_stats = s;
+  if (stats) *stats = s;
+  return PM_OK;
+}
+
 int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
   if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
     return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
-  e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
-  e->tick_fast_steps = 0;
-  e->tick_cand_sum = 0;
-  e->k_ms_compat = e->k_ms_carve = e->k_ms_sweep = 0;
-  e->k_sweep_recorded = e->k_compat_recorded = false;
+  if (e->dist_world > 1) return set_error(PM_ESTATE, "multi-GPU engine: use the stepwise tick (pm_dist_tick_begin ...)");
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  tick_reset(e);
   uint32_t n_formed = 0, n_merged = 0;
   HIPCHK(hipEventRecord(e->ev[0], e->stream));
   e->compat_dirty = true;  // a full-swarm match re-evaluates the W x C predicate, like mod.rs:511-515
@@ -1574,30 +1709,189 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   rc = publish(e);
   host_mark("tick: published");
   if (rc) return rc;
-  HIPCHK(hipEventRecord(e->ev[5], e->stream));
-  HIPCHK(hipEventSynchronize(e->ev[5]));
-  pm_stats s{};
-  HIPCHK(hipEventElapsedTime(&s.ms_compat, e->ev[0], e->ev[1]));
-  HIPCHK(hipEventElapsedTime(&s.ms_carve, e->ev[1], e->ev[2]));
-  HIPCHK(hipEventElapsedTime(&s.ms_merge, e->ev[2], e->ev[3]));
-  HIPCHK(hipEventElapsedTime(&s.ms_sweep, e->ev[3], e->ev[4]));
-  HIPCHK(hipEventElapsedTime(&s.ms_publish, e->ev[4], e->ev[5]));
-  HIPCHK(hipEventElapsedTime(&s.ms_total, e->ev[0], e->ev[5]));
-  if (e->k_compat_recorded) HIPCHK(hipEventElapsedTime(&s.ms_compat_kernel, e->kev[0], e->kev[1]));
-  if (e->k_sweep_recorded) HIPCHK(hipEventElapsedTime(&s.ms_sweep_kernel, e->kev[4], e->kev[5]));
-  s.ms_carve_kernel = e->k_ms_carve;
-  s.carve_cand_sum = e->tick_cand_sum;
-  s.n_groups = uint32_t(e->groups.size());
-  s.n_formed = n_formed;
-  s.n_merged = n_merged;
-  s.carve_steps = e->tick_carve_steps;
-  s.carve_fast_steps = e->tick_fast_steps;
-  s.host_resolved_steps = e->tick_host_resolved;
-  s.carve_launches = e->tick_carve_launches;
-  s.pair_evals = uint64_t(e->T) * uint64_t(e->W);
-  e->last_stats = s;
-  if (stats) *stats = s;
+  return tick_stats(e, stats, n_formed, n_merged);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: ownership, the stepwise tick and its two exchanges (see include/pm_engine.h)
+
+int32_t pm_set_stream(pm_engine* e, void* hip_stream) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (hip_stream) {
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    e->own_stream = false;
+  } else {
+    e->stream = e->stream_owned;
+    e->own_stream = true;
+  }
   return PM_OK;
+}
+
+static void dist_abort(pm_engine* e) {
+  delete e->form;
+  e->form = nullptr;
+  e->dist_phase = 0;
+}
+
+int32_t pm_dist_configure(pm_engine* e, uint32_t rank, uint32_t world, const uint8_t* shard_of_worker) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  if (world == 0 || world > 64 || rank >= world) return set_error(PM_EINVAL, "rank / world out of range (world <= 64)");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  if (world > 1 && !e->have_workers) return set_error(PM_ESTATE, "workers must be uploaded first");
+  if (world > 1 && e->W && !shard_of_worker) return set_error(PM_EINVAL, "null shard column");
+  e->dist_rank = world > 1 ? rank : 0;
+  e->dist_world = world;
+  e->h_shard.clear();
+  e->h_own_rows.clear();
+  e->dist_cap_t = 0;
+  if (world == 1) return PM_OK;
+  const uint32_t W = e->W;
+  for (uint32_t w = 0; w < W; ++w)
+    if (shard_of_worker[w] >= world) return set_error(PM_ERANGE, "shard index outside the world");
+  e->h_shard.assign(shard_of_worker, shard_of_worker + W);
+  std::vector<uint32_t> count(world, 0), xrow(W);
+  for (uint32_t w = 0; w < W; ++w) xrow[w] = count[e->h_shard[w]]++;  // index within the shard, in worker order
+  const uint32_t cap_t = std::max<uint32_t>(*std::max_element(count.begin(), count.end()), 1u);
+  for (uint32_t w = 0; w < W; ++w) {
+    xrow[w] += uint32_t(e->h_shard[w]) * cap_t;
+    if (e->h_shard[w] == rank) e->h_own_rows.push_back(w);
+  }
+  e->dist_cap_t = cap_t;
+  int32_t rc = upload(e->d_shard, e->h_shard.data(), W, e->stream);
+  if (rc) return rc;
+  rc = upload(e->d_own_rows, e->h_own_rows.data(), e->h_own_rows.size(), e->stream);
+  if (rc) return rc;
+  rc = upload(e->d_xrow, xrow.data(), W, e->stream);
+  if (rc) return rc;
+  HIPCHK(e->d_table_x.ensure(size_t(cap_t) * world));
+  HIPCHK(hipMemsetAsync(e->d_table_x.p, 0xFF, sizeof(pm_assignment) * size_t(cap_t) * world, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));  // the staging vectors die here
+  return PM_OK;
+}
+
+int32_t pm_dist_tick_begin(pm_engine* e) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
+    return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
+  if (e->dist_phase != 0) dist_abort(e);  // an abandoned stepwise tick
+  if (e->dist_world > 1 && e->h_shard.size() != e->W)
+    return set_error(PM_ESTATE, "the worker table changed size: call pm_dist_configure again");
+  tick_reset(e);
+  HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  e->compat_dirty = true;
+  int32_t rc = ensure_compat(e);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev[1], e->stream));
+  e->form = new (std::nothrow) FormRun();
+  if (!e->form) return set_error(PM_ENOMEM, "out of host memory");
+  rc = form_begin(e, e->form);
+  if (rc) {
+    dist_abort(e);
+    return rc;
+  }
+  e->dist_phase = 1;
+  return PM_OK;
+}
+
+int32_t pm_dist_carve_next(pm_engine* e, pm_dist_xfer* x, uint32_t* more) {
+  if (!e || !x || !more) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 1) return set_error(PM_ESTATE, "pm_dist_tick_begin first");
+  FormRun* r = e->form;
+  *more = 0;
+  std::memset(x, 0, sizeof(*x));
+  if (!r->nothing) {
+    int32_t rc = form_poll(e, r);
+    if (rc) {
+      dist_abort(e);
+      return rc;
+    }
+    if (r->st.state == CARVE_STATE_RUNNING && r->use_props) {
+      // a candidate list is prepared: this rank's share of the batch's neighbour lists
+      launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+      e->tick_carve_launches++;
+      HIPCHK(hipGetLastError());
+      x->send_ptr = uint64_t(reinterpret_cast<uintptr_t>(r->a.prop_send));
+      x->recv_ptr = uint64_t(reinterpret_cast<uintptr_t>(r->a.prop));
+      x->bytes_per_rank = r->st.prop_k ? uint64_t(r->st.rows_pr) * PM_PROP_ROW * 8u : 0u;
+      *more = 1;
+      return PM_OK;
+    }
+    if (r->st.state != CARVE_STATE_DONE) {
+      dist_abort(e);
+      return set_error(PM_ENODEV, "carve kernel did not complete");
+    }
+  }
+  e->dist_phase = 2;
+  return PM_OK;
+}
+
+int32_t pm_dist_carve_validate(pm_engine* e) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 1 || !e->form || e->form->nothing) return set_error(PM_ESTATE, "no proposal batch pending");
+  HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, e->form->lds, e->stream));
+  e->tick_carve_launches++;
+  return PM_OK;
+}
+
+int32_t pm_dist_match_begin(pm_engine* e, pm_dist_xfer* x) {
+  if (!e || !x) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 2) return set_error(PM_ESTATE, "the carve is not finished (pm_dist_carve_next until more == 0)");
+  std::memset(x, 0, sizeof(*x));
+  int32_t rc = form_finish(e, e->form, &e->dist_n_formed, /*defer_absorb=*/true);
+  delete e->form;
+  e->form = nullptr;
+  if (rc == PM_OK) {
+    HIPCHK(hipEventRecord(e->ev[2], e->stream));
+    rc = run_merge(e, &e->dist_n_merged);
+  }
+  if (rc == PM_OK) {
+    HIPCHK(hipEventRecord(e->ev[3], e->stream));
+    rc = run_match(e, false, nullptr, e->dist_world > 1);
+  }
+  if (rc) {
+    e->dist_phase = 0;
+    return rc;
+  }
+  HIPCHK(hipEventRecord(e->ev[4], e->stream));
+  if (e->dist_world > 1) {
+    x->recv_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_table_x.p));
+    x->send_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_table_x.p + size_t(e->dist_rank) * e->dist_cap_t));
+    x->bytes_per_rank = uint64_t(e->dist_cap_t) * sizeof(pm_assignment);
+  }
+  e->dist_phase = 3;
+  return PM_OK;
+}
+
+int32_t pm_dist_tick_end(pm_engine* e, pm_stats* stats) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 3) return set_error(PM_ESTATE, "pm_dist_match_begin first");
+  e->dist_phase = 0;
+  if (e->dist_world > 1) {
+    launch_table_scatter(e->d_table_x.p, e->d_xrow.p, e->W, e->d_table.p, e->d_task_col.p, e->d_g_task_next.p,
+                         e->stream);
+    HIPCHK(hipGetLastError());
+  }
+  int32_t rc = absorb_groups(e);
+  if (rc) return rc;
+  rc = publish(e);
+  if (rc) return rc;
+  return tick_stats(e, stats, e->dist_n_formed, e->dist_n_merged);
 }
 
 int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t worker, pm_assignment* out) {

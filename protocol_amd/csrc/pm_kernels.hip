@@ -288,38 +288,43 @@ __device__ __forceinline__ uint64_t splitmix64_mix(uint64_t x) {
   return z ^ (z >> 31);
 }
 
-// row selector of worker w = the configuration bit of its group (0 when not in a group).
+// row selector of worker w = the configuration bit of its group (0 when not in a group).  `rows` (optional):
+// the sweep's rows are the workers rows[0..R) — the ones this rank owns in a multi-GPU tick — instead of 0..R).
 __global__ __launch_bounds__(256) void worker_selector_kernel(const int32_t* __restrict__ group_of,
-                                                              const uint32_t* __restrict__ g_cfg, uint32_t W,
+                                                              const uint32_t* __restrict__ g_cfg, uint32_t R,
+                                                              const uint32_t* __restrict__ rows,
                                                               uint64_t* __restrict__ sel) {
-  const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-  if (w >= W) return;
-  const int32_t g = group_of[w];
-  sel[w] = g >= 0 ? (1ull << g_cfg[g]) : 0ull;
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= R) return;
+  const int32_t g = group_of[rows ? rows[r] : r];
+  sel[r] = g >= 0 ? (1ull << g_cfg[g]) : 0ull;
 }
 
 // rank of the chosen task inside the applicable list (PM_CHOOSE_SEEDED): mix(seed ^ group id) % n.
 __global__ __launch_bounds__(256) void chooser_rank_kernel(const int32_t* __restrict__ group_of,
                                                            const uint64_t* __restrict__ g_id,
-                                                           const uint32_t* __restrict__ count, uint32_t W,
-                                                           uint64_t seed, uint32_t* __restrict__ rank) {
-  const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-  if (w >= W) return;
-  const int32_t g = group_of[w];
-  const uint32_t n = count[w];
-  rank[w] = (g >= 0 && n) ? (uint32_t)(splitmix64_mix(seed ^ g_id[g]) % n) : PM_NONE;
+                                                           const uint32_t* __restrict__ count, uint32_t R,
+                                                           const uint32_t* __restrict__ rows, uint64_t seed,
+                                                           uint32_t* __restrict__ rank) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= R) return;
+  const int32_t g = group_of[rows ? rows[r] : r];
+  const uint32_t n = count[r];
+  rank[r] = (g >= 0 && n) ? (uint32_t)(splitmix64_mix(seed ^ g_id[g]) % n) : PM_NONE;
 }
 
 // Column mask of worker w for the per-task orientation: eligible (Healthy & p2p & unassigned,
 // mod.rs:492-497) ? compat & enabled : 0.
+// `shard` (optional): only the workers this rank owns bid (multi-GPU: the per-task bests are folded across ranks).
 __global__ __launch_bounds__(256) void eligible_selector_kernel(const uint32_t* __restrict__ wflags,
                                                                 const int32_t* __restrict__ group_of,
                                                                 const uint64_t* __restrict__ compat, uint64_t enabled,
-                                                                uint32_t W, uint64_t* __restrict__ sel) {
+                                                                uint32_t W, const uint8_t* __restrict__ shard,
+                                                                uint32_t my_rank, uint64_t* __restrict__ sel) {
   const uint32_t w = blockIdx.x * 256u + threadIdx.x;
   if (w >= W) return;
   const uint32_t f = wflags[w];
-  const bool e = (f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && group_of[w] < 0;
+  const bool e = (f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && group_of[w] < 0 && (!shard || shard[w] == my_rank);
   sel[w] = e ? (compat[w] & enabled) : 0ull;
 }
 
@@ -349,8 +354,9 @@ __global__ __launch_bounds__(256) void group_rank_kernel(const int32_t* __restri
 // Claim (SETNX, scheduler_impl.rs:74 / mod.rs:471-476) + publish row.  Every member of a group
 // computed the same choice, so the group's task word is written with the same value by all.
 __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
-  const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-  if (w >= p.W) return;
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= p.R) return;
+  const uint32_t w = p.rows ? p.rows[r] : r;
   const int32_t g = p.group_of[w];
   pm_assignment a;
   a.task = PM_NONE;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
   if (g >= 0) {
     uint32_t t = p.g_task[g];  // get_current_group_task (scheduler_impl.rs:33)
     if (t == PM_NONE) {
-      t = p.chosen[w];
+      t = p.chosen[r];
       if (t != PM_NONE) p.g_task_next[g] = t;  // same value from every member
     }
     const uint32_t n = p.g_n[g], off = p.g_off[g];
@@ -374,8 +380,28 @@ __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
     a.next_worker = p.by_rank[off + ((idx + 1u == n) ? 0u : idx + 1u)];  // (idx + 1) % n
     a.group_id = p.g_id[g];
   }
-  p.table[w] = a;
-  p.task_col[w] = a.task;
+  if (p.rows) {  // multi-GPU: this rank's rows, packed, into its segment of the exchange buffer
+    p.table[r] = a;
+  } else {
+    p.table[w] = a;
+    p.task_col[w] = a.task;
+  }
+}
+
+// Multi-GPU: the all-gathered segments ([world][cap_t] rows, xrow[w] = where worker w's row landed) -> the full
+// per-worker table, the compact task column and the groups' claimed-task words (every member of a group
+// carries the same task, whichever rank computed its row).
+__global__ __launch_bounds__(256) void table_scatter_kernel(const pm_assignment* __restrict__ x,
+                                                            const uint32_t* __restrict__ xrow, uint32_t W,
+                                                            pm_assignment* __restrict__ table,
+                                                            uint32_t* __restrict__ task_col,
+                                                            uint32_t* __restrict__ g_task_next) {
+  const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+  if (w >= W) return;
+  const pm_assignment a = x[xrow[w]];
+  table[w] = a;
+  task_col[w] = a.task;
+  if (a.group_slot != PM_NONE && a.task != PM_NONE) g_task_next[a.group_slot] = a.task;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -493,10 +519,11 @@ struct BlockRed {
   unsigned long long f_cand_sum;
   unsigned long long _spare0;
   uint32_t _spare1, _spare2;
-  // proposal rows staged in LDS (they alias the slow path's key array): slot and prop_n word per row
+  // proposal rows staged in LDS (they alias the slow path's key array): slot and row number (in the proposal
+  // buffer) per staged row; the row's flags word travels in its last entry (PM_PROP_META)
   uint32_t cache_n, cache_pad;
   uint32_t cache_slot[PM_CARVE_CACHE_ROWS];
-  uint32_t cache_meta[PM_CARVE_CACHE_ROWS];
+  uint32_t cache_row[PM_CARVE_CACHE_ROWS];
   uint32_t cache_next[PM_CARVE_CACHE_ROWS];  // same_next of the staged slot
 };
 
@@ -562,6 +589,7 @@ struct StepCtx {
   unsigned long long cand_sum;
   // proposals (0 = none)
   uint32_t prop_k, prop_limit;
+  uint32_t rows_pr;  // rows per rank in the proposal buffer for this batch: ceil(seeds / world)
   bool use_props;
   // packed-key geometry of the current list: low slot_bits of a key hold the slot; certificate band
   uint32_t slot_bits;
@@ -635,7 +663,6 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
   const lds_u64* const LOC = (const lds_u64*)l_loc;
   const lds_u64* const ROWS = (const lds_u64*)l_rows;
   const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
-  const lds_u32* const C_META = (const lds_u32*)red.cache_meta;
   const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
   const lds_u32* const WID3 = (const lds_u32*)l_wid;
   const lds_u32* const SITE3 = (const lds_u32*)l_site;
@@ -793,7 +820,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 
     FP_MARK(1);
     // ---- the seed's neighbour list (staged in LDS, row_ptr points at it): one packed key per lane, ascending
-    const uint32_t nk_word = C_META[row_ptr];
+    const uint32_t nk_word = (uint32_t)ROWS[row_ptr * PM_PROP_ROW + PM_PROP_META];  // the row's flags word
     const uint32_t n_k = nk_word & 0xFFu;
     const bool complete = (nk_word >> 31) != 0u;
     const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
@@ -910,7 +937,6 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   lds_u64* const A = (lds_u64*)l_alive;
   const lds_u64* const ROWS = (const lds_u64*)l_rows;
   const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
-  const lds_u32* const C_META = (const lds_u32*)red.cache_meta;
   const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
   const lds_u32* const WID3 = (const lds_u32*)l_wid;    // dereferenced only when !BIG
   const lds_u32* const SITE3 = (const lds_u32*)l_site;  // idem
@@ -1011,11 +1037,10 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
       seed = (uint32_t)__builtin_amdgcn_readlane((int)sl_l, (int)my_l);
       // every LDS read of the row is issued up front (they return in order, one latency for all)
       const uint64_t e = ROWS[my_row * PM_PROP_ROW + lane];
-      const uint32_t nk_raw = C_META[my_row];
       const uint32_t fs_raw = C_NEXT[my_row];
       seed_wid = wid_of(seed);
       const uint32_t slot = (uint32_t)(e & SLOT_MASK);
-      const uint32_t nk_word = UNI(nk_raw);
+      const uint32_t nk_word = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, (int)PM_PROP_META);  // flags word
       const uint32_t n_k = nk_word & 0xFFu;
       const bool alive = lane < n_k && alive_at(slot);
       const uint32_t first_same = want > 0 ? UNI(fs_raw) : PM_NONE;
@@ -1250,7 +1275,12 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
         // alias l_key, which only the slow sweep uses): wave 0 lists the slots, all waves copy the rows
         if (wave == 0) {
           // 64 bitmap words per pass, one word per lane; the non-empty ones are then visited in order with
-          // the whole wave looking at one word (lane = bit): rank within the word + running base = row
+          // the whole wave looking at one word (lane = bit): rank within the word + running base = row.
+          // The row a slot's proposal sits in is its rank among the batch's seeds (seed_map / seed_prefix:
+          // the live located slots below prop_limit at preparation time), dealt round-robin over the ranks.
+          const uint32_t world = p.dist_world, rows_pr = c.rows_pr;
+          const auto seed_map = G((const uint64_t*)p.seed_map);
+          const auto seed_prefix = G((const uint32_t*)p.seed_prefix);
           uint32_t base = 0;
           for (uint32_t j0 = 0; j0 < lw && base < PM_CARVE_CACHE_ROWS; j0 += 64u) {
             const uint32_t j = j0 + lane;
@@ -1258,15 +1288,25 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
             // proposals exist for slots below prop_limit only
             if (j * 64u + 64u > c.prop_limit)
               w = (j * 64u >= c.prop_limit) ? 0ull : (w & ((1ull << (c.prop_limit & 63u)) - 1ull));
+            const uint32_t jc = j < lw ? j : lw - 1u;  // unconditional loads (clamped), used only where w != 0
+            const uint64_t pm = seed_map[jc];
+            const uint32_t pf = seed_prefix[jc];
             uint64_t nz = __ballot(w != 0ull);
             while (nz && base < PM_CARVE_CACHE_ROWS) {
               const int src = __builtin_ctzll(nz);
               nz &= nz - 1ull;
               const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, src);
               const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), src);
+              const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pm, src);
+              const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pm >> 32), src);
+              const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)pf, src);
               const uint32_t bit = ((lane < 32u ? w_lo >> lane : w_hi >> (lane - 32u)) & 1u);
               const uint32_t r = base + __builtin_amdgcn_mbcnt_hi(w_hi, __builtin_amdgcn_mbcnt_lo(w_lo, 0u));
-              if (bit && r < PM_CARVE_CACHE_ROWS) red.cache_slot[r] = (j0 + (uint32_t)src) * 64u + lane;
+              if (bit && r < PM_CARVE_CACHE_ROWS) {
+                const uint32_t i = f0 + __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));  // seed number
+                red.cache_slot[r] = (j0 + (uint32_t)src) * 64u + lane;
+                red.cache_row[r] = world > 1u ? (i % world) * rows_pr + i / world : i;
+              }
               base += (uint32_t)__popc(w_lo) + (uint32_t)__popc(w_hi);
             }
           }
@@ -1280,23 +1320,16 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
 #pragma unroll
           for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
             const uint32_t r = wave + k * CARVE_WAVES;
-            rowv[k] = r < rows ? G(p.prop)[(size_t)red.cache_slot[r] * PM_PROP_ROW + lane] : ~0ull;
+            rowv[k] = r < rows ? G(p.prop)[(size_t)red.cache_row[r] * PM_PROP_ROW + lane] : ~0ull;
           }
-          uint32_t meta = 0, nx = PM_NONE;
-          if (tid < rows) {
-            const uint32_t sl = red.cache_slot[tid];
-            meta = G(p.prop_n)[sl];
-            nx = G(p.same_next)[sl];
-          }
+          uint32_t nx = PM_NONE;
+          if (tid < rows) nx = G(p.same_next)[red.cache_slot[tid]];
 #pragma unroll
           for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
             const uint32_t r = wave + k * CARVE_WAVES;
             if (r < rows) l_rows[r * PM_PROP_ROW + lane] = rowv[k];
           }
-          if (tid < rows) {
-            red.cache_meta[tid] = meta;
-            red.cache_next[tid] = nx < c.n_list ? nx : PM_NONE;
-          }
+          if (tid < rows) red.cache_next[tid] = nx < c.n_list ? nx : PM_NONE;
         }
         lds_barrier();
         cache_valid = true;
@@ -1905,6 +1938,10 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   if (st->state != CARVE_STATE_RUNNING) return;
   if (st->cur_ci >= p.n_avail) return;
   const uint32_t K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
+  const uint32_t world = p.dist_world, my_rank = p.dist_rank, rows_pr = st->rows_pr;
+  const auto seed_map = G((const uint64_t*)p.seed_map);
+  const auto seed_prefix = G((const uint32_t*)p.seed_prefix);
+  const auto prop_out = G(p.prop_send);
   if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
   const uint32_t SB = n_list > PM_CARVE_SLOTS ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   const double TIE_BAND = n_list > PM_CARVE_SLOTS ? PM_TIE_BAND_BIG : PM_TIE_BAND;
@@ -1958,6 +1995,11 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     }
 #endif
     if (s >= limit) continue;  // beyond this round's proposal batch
+    // seed number of this slot within the batch; the seeds are dealt round-robin over the ranks (every rank
+    // links same_next for the whole list above, but sweeps only for its own seeds)
+    const uint32_t seed_i = seed_prefix[s >> 6] + (uint32_t)__popcll(seed_map[s >> 6] & ((1ull << (s & 63u)) - 1ull));
+    if (world > 1u && seed_i % world != my_rank) continue;
+    const uint32_t out_row = world > 1u ? seed_i / world : seed_i;  // row in this rank's send segment
     const double slat = G(p.cc_lat)[s], slon = G(p.cc_lon)[s], scos = G(p.cc_cos)[s];
     const bool shared = (ssite & 0x80000000u) != 0u;
     TopN q;
@@ -2097,16 +2139,19 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       }
     }
 #endif
-    G(p.prop)[(size_t)s * PM_PROP_ROW + lane] = mine;
-    if (lane == 0) {
-      G(p.prop_n)[s] = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
-    }
+    // the row: K sorted entries, and the flags word in the last entry (PM_PROP_META)
+    const uint32_t meta = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
+    (void)rows_pr;
+    prop_out[(size_t)out_row * PM_PROP_ROW + lane] = lane == PM_PROP_META ? (uint64_t)meta : mine;
   }
 }
 
-// One proposal per located slot, at most PM_PROP_MAX_SEEDS per round: returns the slot after the word in
-// which the PM_PROP_MAX_SEEDS-th located slot falls (a later round covers the rest), or n_list.
-__device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& red, uint32_t n_list) {
+// One proposal per located slot, at most PM_PROP_MAX_SEEDS per batch.  Returns the slot after the word in which
+// the cap-th located slot falls (a later batch covers the rest), or n_list; *n_seeds = the located live slots
+// below it (the batch's seeds).  Also records, per bitmap word below the limit, the seed bitmap and the number of
+// seeds in front of the word (seed_map / seed_prefix): the rank of a slot among the seeds is the row its
+// proposal is stored in (proposer and validator derive it from these two words).
+__device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& red, uint32_t n_list, uint32_t* n_seeds) {
   // The configuration is re-prepared (and re-proposed) once half of its list is dead; by then the seed
   // pointer has advanced through roughly the first eighth of the slots (each group removes max_s slots
   // spread over the whole list), so later slots never consume this round's proposals: cap the batch.
@@ -2115,16 +2160,18 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
   uint32_t cap = n_list > PM_CARVE_SLOTS ? n_list / 10u : n_list / 5u;
   if (cap < 512u) cap = 512u;
   if (cap > PM_PROP_MAX_SEEDS) cap = PM_PROP_MAX_SEEDS;
-  if (n_list <= cap) return n_list;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (wave == 0) {
     const auto g_al = G((const uint64_t*)p.bits_scratch);
     const auto g_lc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
+    const auto seed_map = G(p.seed_map);
+    const auto seed_prefix = G(p.seed_prefix);
     const uint32_t lwp = (n_list + 63u) >> 6;
     uint32_t acc = 0, limit = n_list;
     for (uint32_t j0 = 0; j0 < lwp; j0 += 64u) {
       const uint32_t j = j0 + lane;
-      const uint32_t cnt = j < lwp ? (uint32_t)__popcll(g_al[j] & g_lc[j]) : 0u;
+      const uint64_t m = j < lwp ? (g_al[j] & g_lc[j]) : 0ull;  // bits beyond n_list are zero in both bitmaps
+      const uint32_t cnt = (uint32_t)__popcll(m);
       uint32_t incl = cnt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -2132,16 +2179,25 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
         if ((int)lane >= o) incl += up;
       }
       const uint64_t over = __ballot(acc + incl >= cap);
+      const uint32_t last = over ? (uint32_t)__builtin_ctzll(over) : 63u;  // last word of this pass inside the batch
+      if (j < lwp && lane <= last) {
+        seed_map[j] = m;
+        seed_prefix[j] = acc + incl - cnt;
+      }
+      acc += __shfl(incl, (int)last, 64);
       if (over) {
-        limit = (j0 + (uint32_t)__builtin_ctzll(over) + 1u) * 64u;
+        limit = (j0 + last + 1u) * 64u;
         break;
       }
-      acc += __shfl(incl, 63, 64);
     }
-    if (lane == 0) red.b[0] = limit < n_list ? limit : n_list;
+    if (lane == 0) {
+      red.b[0] = limit < n_list ? limit : n_list;
+      red.b[1] = acc;
+    }
   }
   __syncthreads();
   const uint32_t r = red.b[0];
+  *n_seeds = red.b[1];
   __syncthreads();
   return r;
 }
@@ -2258,6 +2314,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       c.n_list = 0;
       c.prop_k = 0;
       c.prop_limit = 0;
+      c.rows_pr = 0;
       for (; ci < p.n_avail; ++ci) {
         c.min_s = p.min_size[ci];
         c.max_s = p.max_size[ci];
@@ -2279,12 +2336,14 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         break;
       }
       // proposals: one neighbour list per located slot, K = (max - 1) + reserve entries
-      if ((flags & CARVE_F_PROPS) && p.proximity && c.n_list <= PM_CARVE_BIG_SLOTS && c.max_s - 1u < PM_PROP_ROW) {
+      if ((flags & CARVE_F_PROPS) && p.proximity && c.n_list <= PM_CARVE_BIG_SLOTS && c.max_s - 1u < PM_PROP_META) {
         const uint32_t k = c.max_s - 1u + PM_PROP_RESERVE;
-        c.prop_k = k < PM_PROP_ROW ? k : PM_PROP_ROW;
+        c.prop_k = k < PM_PROP_META ? k : PM_PROP_META;  // the last entry of a row carries its flags word
         // one proposal per located slot, at most PM_PROP_MAX_SEEDS per round: prop_limit = the slot after the
         // PM_PROP_MAX_SEEDS-th located one (a later round covers the rest)
-        c.prop_limit = carve_prop_limit(p, red, c.n_list);
+        uint32_t n_seeds = 0;
+        c.prop_limit = carve_prop_limit(p, red, c.n_list, &n_seeds);
+        c.rows_pr = (n_seeds + p.dist_world - 1u) / p.dist_world;
       }
       prepared = true;
       PROF_MARK(28);
@@ -2293,6 +2352,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       c.n_list = st->n_list;
       c.prop_k = st->prop_k;
       c.prop_limit = st->prop_limit;
+      c.rows_pr = st->rows_pr;
       c.min_s = p.min_size[ci];
       c.max_s = p.max_size[ci];
     }
@@ -2394,6 +2454,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     st->n_list = c.n_list;
     st->prop_k = c.prop_k;
     st->prop_limit = c.prop_limit;
+    st->rows_pr = c.rows_pr;
     st->total_available = c.total_available;
     st->fast_steps += c.fast_steps;
     st->slow_steps += c.steps - c.fast_steps;
@@ -2411,22 +2472,29 @@ void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s)
   if (W == 0) return;
   hipLaunchKernelGGL(coslat_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, lat, coslat, W);
 }
-void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t W, uint64_t* sel,
-                            hipStream_t s) {
-  if (W == 0) return;
-  hipLaunchKernelGGL(worker_selector_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, group_of, g_cfg, W, sel);
+void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t R, const uint32_t* rows,
+                            uint64_t* sel, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(worker_selector_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, group_of, g_cfg, R, rows, sel);
 }
-void launch_chooser_rank(const int32_t* group_of, const uint64_t* g_id, const uint32_t* count, uint32_t W,
-                         uint64_t seed, uint32_t* rank, hipStream_t s) {
-  if (W == 0) return;
-  hipLaunchKernelGGL(chooser_rank_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, group_of, g_id, count, W, seed,
-                     rank);
+void launch_chooser_rank(const int32_t* group_of, const uint64_t* g_id, const uint32_t* count, uint32_t R,
+                         const uint32_t* rows, uint64_t seed, uint32_t* rank, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(chooser_rank_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, group_of, g_id, count, R, rows,
+                     seed, rank);
 }
 void launch_eligible_selector(const uint32_t* wflags, const int32_t* group_of, const uint64_t* compat,
-                              uint64_t enabled, uint32_t W, uint64_t* sel, hipStream_t s) {
+                              uint64_t enabled, uint32_t W, const uint8_t* shard, uint32_t my_rank, uint64_t* sel,
+                              hipStream_t s) {
   if (W == 0) return;
   hipLaunchKernelGGL(eligible_selector_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, wflags, group_of, compat,
-                     enabled, W, sel);
+                     enabled, W, shard, my_rank, sel);
+}
+void launch_table_scatter(const pm_assignment* x, const uint32_t* xrow, uint32_t W, pm_assignment* table,
+                          uint32_t* task_col, uint32_t* g_task_next, hipStream_t s) {
+  if (W == 0) return;
+  hipLaunchKernelGGL(table_scatter_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, x, xrow, W, table, task_col,
+                     g_task_next);
 }
 void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint32_t* g_off, const uint32_t* members,
                        const uint32_t* addr_rank, uint32_t W, uint32_t* rank_in_group, uint32_t* by_rank,
@@ -2436,8 +2504,8 @@ void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint3
                      addr_rank, W, rank_in_group, by_rank);
 }
 void launch_claim_publish(const ClaimArgs& a, hipStream_t s) {
-  if (a.W == 0) return;
-  hipLaunchKernelGGL(claim_publish_kernel, dim3((a.W + 255u) / 256u), dim3(256), 0, s, a);
+  if (a.R == 0) return;
+  hipLaunchKernelGGL(claim_publish_kernel, dim3((a.R + 255u) / 256u), dim3(256), 0, s, a);
 }
 
 void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t n_planes, uint64_t* planes,

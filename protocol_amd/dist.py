@@ -1,16 +1,26 @@
-"""Hash-sharded swarm across ranks (one process per GPU) — SURVEY.md §8(e).
+"""Multi-GPU driver: one process per GPU, `torch.distributed` collectives (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" for the CPU tests and for several ranks sharing one GPU) — SURVEY.md §8(e), DESIGN.md §7.
 
-Workers are partitioned by  shard = splitmix64(address) % world ; configurations and tasks are replicated.
-Each shard is an independent carve domain (group formation never crosses shards — the same result as one
-reference orchestrator per shard), so the only data-path exchange is the one the north_star names: an
-all-gather of the per-task best bids followed by an identical deterministic fold on every rank, plus an
-all-gather of the published per-worker task columns when a rank must answer lookups for every worker.
+Every rank holds the WHOLE swarm (100k worker rows are 6 MB) and worker w is owned by
+    shard = splitmix64(address) % world                                   (shard_of)
+The reference carves from one pool (node_groups/mod.rs:492-503), so the carve domain is NOT split — a rank per
+shard carving on its own would form different groups than one orchestrator.  What is split is the parallel work:
 
-Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on MI355X; the same code runs
-on "gloo" for the CPU tests.  The local compute is whatever object implements `match_per_task()` /
-`task_column()` — libpm_engine.so in production.
+  * the neighbour-list proposals of a carve batch (the full-chip sweep that dominates at 100k workers) are dealt
+    round-robin over the ranks and ALL-GATHERED once per batch; the sequential validation chain runs replicated
+    on identical inputs, so every rank commits the identical groups;
+  * the pair sweep + chooser + claim run for the OWNED workers only; the published rows are ALL-GATHERED once per
+    tick and scattered into every rank's full table (any rank can answer any worker's heartbeat);
+  * per-task best bids (north_star orientation) are computed over the owned workers and folded across ranks
+    (min over the global worker index, sum over the counts) — on the device, no host round trip.
+
+`ShardedEngine.tick()` is the whole protocol; the local compute behind it is anything that implements the
+stepwise tick (`EngineLocal` = libpm_engine.so through the C ABI; the CPU tests plug in a numpy model).
+Nothing here touches oracle/.
 """
 from __future__ import annotations
+
+import contextlib
 
 import numpy as np
 import torch
@@ -19,74 +29,147 @@ import torch.distributed as dist
 from .swarm import mix64
 
 NONE = 0xFFFFFFFF
-_NO_BID = np.int64(2 ** 62)
+_NO_BID = 2 ** 62
 
 
 def shard_of(address: np.ndarray, world: int) -> np.ndarray:
-    """shard index of every worker: splitmix64 finaliser of the address, mod world."""
+    """owner rank of every worker: splitmix64 finaliser of the address, mod world."""
     return (mix64(np.asarray(address, dtype=np.uint64)) % np.uint64(world)).astype(np.int64)
 
 
-class ShardedMatcher:
-    """Cross-shard fold of per-task best bids and assembly of the global assignment table.
+class _DevMem:
+    """torch view of raw device memory (no copy) through __cuda_array_interface__"""
 
-    local        object with match_per_task() -> (best_local_worker u32[T], count u32[T])
-    global_index int64[W_local]: global worker index (position in the unsharded get_nodes order) of every
-                 local worker, ascending — so "first local hit" is the smallest global index of the shard
-    """
+    def __init__(self, ptr: int, n: int, typestr: str = "<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 3}
 
-    def __init__(self, local, global_index: np.ndarray, n_workers_global: int, *, device="cpu", group=None):
-        self.local = local
-        self.global_index = np.ascontiguousarray(global_index, dtype=np.int64)
-        assert np.all(np.diff(self.global_index) > 0), "shards keep the global worker order"
-        self.n_global = int(n_workers_global)
-        self.device = torch.device(device)
+
+class TorchExchanger:
+    """all-gather through torch.distributed.  CUDA tensors on a non-NCCL backend (gloo: CPU tests, several ranks
+    on one GPU) are staged through host memory; on nccl (= RCCL) the collective reads and writes HBM directly."""
+
+    def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
 
-    # ---- north_star orientation: per task, the best bid over ALL shards
-    def match_per_task(self):
-        best_local, count_local = self.local.match_per_task()
-        best_local = np.asarray(best_local, dtype=np.uint32)
-        has = best_local != NONE
-        # bid key = global worker index (price is the all-zero extension column in every parity run, so
-        # (price, index) order == index order); _NO_BID marks "no candidate in this shard"
-        key = np.full(best_local.shape, _NO_BID, dtype=np.int64)
-        key[has] = self.global_index[best_local[has].astype(np.int64)]
-        packed = np.stack([key, np.asarray(count_local, dtype=np.int64)], axis=0)  # (2, T)
+    def all_gather(self, recv: torch.Tensor, send: torch.Tensor):
         if self.world == 1:
-            folded_key, total = packed[0], packed[1]
+            if recv.data_ptr() != send.data_ptr():
+                recv.copy_(send)
+            return
+        if send.is_cuda and self.backend != "nccl":
+            send_h = send.cpu()
+            recv_h = torch.empty(recv.numel(), dtype=recv.dtype)
+            dist.all_gather_into_tensor(recv_h, send_h, group=self.group)
+            recv.copy_(recv_h)
         else:
-            mine = torch.from_numpy(packed).to(self.device).reshape(-1)
-            flat = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=self.device)
-            dist.all_gather_into_tensor(flat, mine, group=self.group)  # flat layout: same call on nccl and gloo
-            gathered = flat.view(self.world, 2, -1)
-            # identical deterministic fold on every rank: min over the bid keys, sum over the counts
-            folded_key = gathered[:, 0, :].amin(dim=0).cpu().numpy()
-            total = gathered[:, 1, :].sum(dim=0).cpu().numpy()
-        best = np.where(folded_key == _NO_BID, NONE, folded_key).astype(np.uint32)
-        return best, total.astype(np.uint32)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
 
-    # ---- reference orientation: every rank ends up with the whole per-worker task table
-    def gather_task_table(self, task_of_local_worker) -> np.ndarray:
-        col = np.asarray(task_of_local_worker, dtype=np.int64)
-        if self.world == 1:
-            out = np.full(self.n_global, NONE, dtype=np.int64)
-            out[self.global_index] = col
-            return out.astype(np.uint32)
-        n_local = torch.tensor([len(col)], dtype=torch.int64, device=self.device)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
-        dist.all_gather(sizes, n_local, group=self.group)
-        n_max = int(max(int(s.item()) for s in sizes))
-        pad = torch.full((2, n_max), -1, dtype=torch.int64, device=self.device)
-        pad[0, :len(col)] = torch.from_numpy(self.global_index).to(self.device)
-        pad[1, :len(col)] = torch.from_numpy(col).to(self.device)
-        flat = torch.empty(self.world * 2 * n_max, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(flat, pad.reshape(-1), group=self.group)
-        g = flat.view(self.world, 2, n_max).cpu().numpy()
-        out = np.full(self.n_global, NONE, dtype=np.int64)
-        for r in range(self.world):
-            ok = g[r, 0] >= 0
-            out[g[r, 0][ok]] = g[r, 1][ok]
-        return out.astype(np.uint32)
+
+class EngineLocal:
+    """The stepwise tick of libpm_engine.so as torch tensors.  The engine is switched to a torch stream so that its
+    kernels and the collectives (which torch orders against the current stream) need no host synchronisation."""
+
+    def __init__(self, engine, device: torch.device):
+        self.eng = engine
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        engine.set_stream(self.stream.cuda_stream)
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
+
+    def _tensors(self, x, world):
+        n = int(x.bytes_per_rank) // 8
+        if n == 0:
+            return None, None
+        send = torch.as_tensor(_DevMem(int(x.send_ptr), n), device=self.device)
+        recv = torch.as_tensor(_DevMem(int(x.recv_ptr), n * world), device=self.device)
+        return send, recv
+
+    def configure(self, rank, world, shard):
+        self.world = world
+        self.eng.dist_configure(rank, world, shard)
+
+    def tick_begin(self):
+        self.eng.dist_tick_begin()
+
+    def carve_next(self):
+        x, more = self.eng.dist_carve_next()
+        send, recv = self._tensors(x, self.world)
+        return more, send, recv
+
+    def carve_validate(self):
+        self.eng.dist_carve_validate()
+
+    def match_begin(self):
+        return self._tensors(self.eng.dist_match_begin(), self.world)
+
+    def tick_end(self):
+        return self.eng.dist_tick_end()
+
+    def match_per_task_device(self):
+        b, c, n = self.eng.match_per_task_device()
+        as_i32 = lambda p: torch.as_tensor(_DevMem(p, n, "<i4"), device=self.device)
+        return as_i32(b), as_i32(c)
+
+
+class ShardedEngine:
+    """One rank of the multi-GPU matcher.
+
+    local      the local compute: tick_begin / carve_next / carve_validate / match_begin / tick_end /
+               match_per_task_device (+ configure, stream_ctx) — EngineLocal in production
+    address    uint64[W]: the worker addresses (the same table on every rank); ownership = shard_of(address)
+    exchanger  object with all_gather(recv, send), world, rank — TorchExchanger by default
+    """
+
+    def __init__(self, local, address: np.ndarray, *, exchanger=None):
+        self.local = local
+        self.x = exchanger or TorchExchanger()
+        self.world, self.rank = self.x.world, self.x.rank
+        self.shard = shard_of(address, self.world).astype(np.uint8)
+        local.configure(self.rank, self.world, self.shard)
+        self.exchanges = 0
+
+    def _ctx(self):
+        f = getattr(self.local, "stream_ctx", None)
+        return f() if f else contextlib.nullcontext()
+
+    def tick(self) -> dict:
+        """one full-swarm match; every rank ends with the identical groups and the full published table"""
+        L = self.local
+        with self._ctx():
+            L.tick_begin()
+            while True:
+                more, send, recv = L.carve_next()
+                if not more:
+                    break
+                if send is not None:            # the batch's neighbour lists: every rank contributes its share
+                    self.x.all_gather(recv, send)
+                    self.exchanges += 1
+                L.carve_validate()
+            send, recv = L.match_begin()
+            if send is not None:                # the published rows of the owned workers
+                self.x.all_gather(recv, send)
+                self.exchanges += 1
+            return L.tick_end()
+
+    def match_per_task(self):
+        """north_star orientation: per task the best bid (smallest global worker index) and the number of bidders
+        over ALL ranks.  The fold runs where the local results live (HBM for EngineLocal)."""
+        with self._ctx():
+            best, count = self.local.match_per_task_device()      # int32 views; PM_NONE reads as -1
+            key = best.to(torch.int64)
+            key = torch.where(key < 0, torch.full_like(key, _NO_BID), key)
+            packed = torch.stack([key, count.to(torch.int64) & 0xFFFFFFFF]).reshape(-1)
+            if self.world > 1:
+                gathered = torch.empty(self.world * packed.numel(), dtype=torch.int64, device=packed.device)
+                self.x.all_gather(gathered, packed)
+                g = gathered.view(self.world, 2, -1)
+                key, total = g[:, 0, :].amin(dim=0), g[:, 1, :].sum(dim=0)   # identical on every rank
+            else:
+                key, total = packed.view(2, -1)[0], packed.view(2, -1)[1]
+            best_out = torch.where(key == _NO_BID, torch.full_like(key, NONE), key)
+        return best_out.cpu().numpy().astype(np.uint32), total.cpu().numpy().astype(np.uint32)

@@ -72,6 +72,11 @@ class GroupVars(C.Structure):
                 ("group_id", C.c_char_p), ("total_upload_count", C.c_char_p)]
 
 
+class DistXfer(C.Structure):
+    """pm_dist_xfer: device pointers + size of one all-gather (recv = [world][bytes_per_rank])."""
+    _fields_ = [("send_ptr", C.c_uint64), ("recv_ptr", C.c_uint64), ("bytes_per_rank", C.c_uint64)]
+
+
 class Assignment(C.Structure):
     _fields_ = [("task", C.c_uint32), ("group_slot", C.c_uint32), ("group_index", C.c_uint32),
                 ("group_size", C.c_uint32), ("next_worker", C.c_uint32), ("group_id", C.c_uint64)]
@@ -86,6 +91,8 @@ EXPORTS = [
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
+    "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
+    "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
 ]
 
 _lib = None
@@ -134,6 +141,14 @@ def lib() -> C.CDLL:
         L.pm_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pm_lookup_task_for_worker.argtypes = [vp, u32, C.POINTER(Assignment)]
         L.pm_device_task_column.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+        L.pm_set_stream.argtypes = [vp, vp]
+        L.pm_dist_configure.argtypes = [vp, u32, u32, vp]
+        L.pm_dist_tick_begin.argtypes = [vp]
+        L.pm_dist_carve_next.argtypes = [vp, C.POINTER(DistXfer), C.POINTER(u32)]
+        L.pm_dist_carve_validate.argtypes = [vp]
+        L.pm_dist_match_begin.argtypes = [vp, C.POINTER(DistXfer)]
+        L.pm_dist_tick_end.argtypes = [vp, C.POINTER(Stats)]
+        L.pm_match_per_task_device.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
         L.pm_host_parse_requirements.argtypes = [C.c_char_p, vp, vp, u32, C.c_char_p, C.c_size_t]
         L.pm_host_model_matches.argtypes = [C.c_char_p, C.c_char_p]
         L.pm_host_build_model_table.argtypes = [C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, vp]
@@ -327,6 +342,44 @@ class Engine:
         p, n = C.c_uint64(0), C.c_uint32(0)
         check(lib().pm_device_task_column(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    # ---- multi-GPU: ownership + the stepwise tick (the exchanges are the caller's, protocol_amd/dist.py)
+    def set_stream(self, hip_stream: int | None):
+        check(lib().pm_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def dist_configure(self, rank: int, world: int, shard_of_worker=None):
+        sh = None if shard_of_worker is None else _arr(shard_of_worker, np.uint8)
+        if sh is not None:
+            assert len(sh) == self.W
+        check(lib().pm_dist_configure(self._h, rank, world, sh.ctypes.data if sh is not None and len(sh) else None))
+
+    def dist_tick_begin(self):
+        check(lib().pm_dist_tick_begin(self._h))
+
+    def dist_carve_next(self):
+        """-> (DistXfer, more): more == False: the carve is done"""
+        x, more = DistXfer(), C.c_uint32(0)
+        check(lib().pm_dist_carve_next(self._h, C.byref(x), C.byref(more)))
+        return x, bool(more.value)
+
+    def dist_carve_validate(self):
+        check(lib().pm_dist_carve_validate(self._h))
+
+    def dist_match_begin(self) -> DistXfer:
+        x = DistXfer()
+        check(lib().pm_dist_match_begin(self._h, C.byref(x)))
+        return x
+
+    def dist_tick_end(self) -> dict:
+        s = Stats()
+        check(lib().pm_dist_tick_end(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def match_per_task_device(self):
+        """-> (device pointer of best u32[T], device pointer of count u32[T], T)"""
+        b, c, n = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        check(lib().pm_match_per_task_device(self._h, C.byref(b), C.byref(c), C.byref(n)))
+        return b.value, c.value, n.value
 
     def lookup(self, worker: int) -> Assignment:
         a = Assignment()
