@@ -175,11 +175,24 @@ int32_t pm_set_model_table(pm_engine*, const uint32_t* bits, uint32_t n_rows, ui
 /* "available_node_group_configs" (mod.rs:399-418, :1328-1348): bit c = config c enabled. */
 int32_t pm_set_enabled_mask(pm_engine*, uint64_t enabled);
 
-/* NodeStore::get_nodes snapshot (order significant). Resets group state iff keep_groups == 0. */
+/* NodeStore::get_nodes snapshot (order significant). Resets group state iff keep_groups == 0.
+ * keep_groups == 1 keeps the groups and their claimed tasks and therefore needs the SAME rows in the same order
+ * (groups are keyed by row index); anything else is a delta: */
 int32_t pm_upload_workers(pm_engine*, const pm_worker_soa* workers, uint32_t keep_groups);
-/* Churn: overwrite rows idx[0..rows->n) (discovery sync / status updater deltas).  A row that
- * loses PM_W_HEALTHY is NOT dissolved here; call pm_on_worker_status for Dead/LowBalance. */
+/* A node the discovery monitor sees for the first time (orchestrator/src/discovery/monitor.rs:236-420 ->
+ * NodeStore::add_node): rows are appended behind the existing ones (*first_index = index of the first new row),
+ * existing groups and claims are untouched, and the next pm_tick carves the newcomers together with the
+ * leftovers — the reference is incremental in exactly this way (node_groups/mod.rs:487-497, tests.rs:993-1213).
+ * The host keeps a stable address -> row index map; a node that leaves is tombstoned (pm_on_worker_status with
+ * PM_W_HEALTHY cleared), never removed, so indices stay valid.  Only the new rows travel to the GPU. */
+int32_t pm_append_workers(pm_engine*, const pm_worker_soa* rows, uint32_t* first_index);
+/* Churn: overwrite rows idx[0..rows->n) (discovery sync: specs / location / status of known nodes changed).
+ * Only these rows travel (one packed copy + a scatter kernel); groups are untouched.  A row that loses
+ * PM_W_HEALTHY is NOT dissolved here; call pm_on_worker_status for Dead/LowBalance. */
 int32_t pm_update_workers(pm_engine*, const uint32_t* idx, const pm_worker_soa* rows);
+/* GROUP_INDEX is the rank of address.to_string() inside the group (mod.rs:424-434).  Appending nodes shifts the
+ * global ranks of the others: the host re-ranks its address strings and replaces the whole column (4 B/worker). */
+int32_t pm_set_addr_ranks(pm_engine*, const uint32_t* addr_rank, uint32_t n_workers);
 /* TaskStore::get_all_tasks snapshot. Groups whose claimed task uid disappeared are dissolved
  * (on_task_deleted, mod.rs:1245-1288). */
 int32_t pm_upload_tasks(pm_engine*, const pm_task_soa* tasks);

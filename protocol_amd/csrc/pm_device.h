@@ -55,6 +55,15 @@ struct ClaimArgs {
   uint32_t* task_col;    // compact per-worker task column (device-side consumers; not written with `rows`)
 };
 
+// pm_update_workers / pm_append_workers: n packed rows (one H2D copy) scattered into the worker columns
+struct RowUpdateArgs {
+  uint32_t n;
+  const double *lat_in, *lon_in;  // [n] each
+  const uint32_t* u32_in;         // 10 columns of n: idx, flags, gpu_count, gpu_mem, gpu_cls, cpu_cores, ram, storage, addr_rank, site
+  uint32_t *flags, *gpu_count, *gpu_mem, *gpu_cls, *cpu_cores, *ram, *storage, *addr_rank, *site;
+  double *lat, *lon, *coslat;
+};
+
 enum { CARVE_MODE_FORM = 0, CARVE_MODE_MERGE = 1 };
 enum { CARVE_STATE_RUNNING = 0, CARVE_STATE_DONE = 1, CARVE_STATE_UNCERTAIN = 2, CARVE_STATE_OVERFLOW = 3 };
 // launch flags of carve_kernel
@@ -146,6 +155,7 @@ struct CarveArgs {
 
 void launch_compat(const CompatArgs& a, hipStream_t s);
 void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s);
+void launch_update_rows(const RowUpdateArgs& a, hipStream_t s);
 void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t R, const uint32_t* rows,
                             uint64_t* sel, hipStream_t s);
 void launch_eligible_selector(const uint32_t* wflags, const int32_t* group_of, const uint64_t* compat,

@@ -60,6 +60,26 @@ struct DevBuf {
     if (e == hipSuccess) cap = want;
     return e;
   }
+  // capacity for n elements, keeping the first `keep` (device-to-device copy on `s` when the buffer moves)
+  hipError_t grow_keep(size_t n, size_t keep, hipStream_t s) {
+    if (n <= cap) return hipSuccess;
+    size_t want = n + n / 4 + 64;
+    T* q = nullptr;
+    hipError_t e = hipMalloc((void**)&q, want * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);  // the old buffer is freed right below
+      if (e != hipSuccess) {
+        (void)hipFree(q);
+        return e;
+      }
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = want;
+    return hipSuccess;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -138,8 +158,20 @@ struct pm_engine {
   bool compat_dirty = true;
   std::vector<uint64_t> h_compat;
   bool h_compat_valid = false;
-  bool any_price = false;
-  std::vector<uint32_t> price_perm;  // workers sorted by (price, index)
+  bool any_price = false, price_dirty = true;
+  std::vector<uint32_t> price_perm;  // workers sorted by (price, index); rebuilt lazily (ensure_price_order)
+  // coordinates -> site id (identical bit patterns <=> identical id); located population per site; bit 31 of a
+  // worker's site word marks a site shared by >= 2 located workers (a hint for the carve: only those can have
+  // same-site neighbours).  The bits are refreshed for the whole column when a site crosses the 1 <-> 2 line.
+  struct SiteKeyHash {
+    size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
+      return size_t(splitmix64_mix(k.first ^ splitmix64_mix(k.second)));
+    }
+  };
+  std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, SiteKeyHash> site_map;
+  std::vector<uint32_t> site_pop;
+  bool site_bits_dirty = false;
+  DevBuf<unsigned char> d_row_stage;  // packed rows of pm_update_workers / pm_append_workers
 
   // ---- task table
   uint32_t T = 0;
@@ -1166,7 +1198,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
   e->d_table.release(); e->d_task_col.release(); e->d_shard.release(); e->d_own_rows.release(); e->d_xrow.release();
-  e->d_sel_own.release(); e->d_table_x.release(); e->d_nb_idx.release(); e->d_nb_val.release();
+  e->d_sel_own.release(); e->d_table_x.release(); e->d_row_stage.release(); e->d_nb_idx.release(); e->d_nb_val.release();
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
   if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
   if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
@@ -1232,6 +1264,29 @@ int32_t pm_set_enabled_mask(pm_engine* e, uint64_t enabled) {
   return PM_OK;
 }
 
+// ---- worker table ingestion.  Coordinates are interned into site ids (the carve certificate needs "same place"
+// as an exact integer compare); the map persists so that row deltas intern incrementally.
+
+static uint32_t site_of_row(pm_engine* e, size_t w) {
+  uint64_t a, b;
+  std::memcpy(&a, &e->h_lat[w], 8);
+  std::memcpy(&b, &e->h_lon[w], 8);
+  if (e->h_lat[w] == 0.0) a = 0;  // +0.0 and -0.0 compare equal in the reference's f64 arithmetic
+  if (e->h_lon[w] == 0.0) b = 0;
+  auto it = e->site_map.emplace(std::make_pair(a, b), uint32_t(e->site_map.size())).first;
+  if (it->second >= e->site_pop.size()) e->site_pop.push_back(0);
+  return it->second;
+}
+
+static void refresh_site_bits(pm_engine* e) {
+  for (size_t w = 0; w < e->W; ++w) {
+    const uint32_t id = e->h_site[w] & 0x7FFFFFFFu;
+    e->h_site[w] = id | (e->site_pop[id] >= 2 ? 0x80000000u : 0u);
+  }
+  e->site_bits_dirty = false;
+}
+
+// the whole table: host mirror -> HBM columns
 static int32_t upload_worker_columns(pm_engine* e) {
   const size_t W = e->W;
   int32_t rc;
@@ -1245,58 +1300,56 @@ static int32_t upload_worker_columns(pm_engine* e) {
   if ((rc = upload(e->d_addr_rank, e->h_addr_rank.data(), W, e->stream))) return rc;
   if ((rc = upload(e->d_lat, e->h_lat.data(), W, e->stream))) return rc;
   if ((rc = upload(e->d_lon, e->h_lon.data(), W, e->stream))) return rc;
-  {  // intern coordinates: the carve certificate needs "same place" as an exact integer compare
-    struct KeyHash {
-      size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
-        return size_t(splitmix64_mix(k.first ^ splitmix64_mix(k.second)));
-      }
-    };
-    std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> sites;
-    sites.reserve(W * 2);
-    e->h_site.resize(W);
-    std::vector<uint32_t> pop;
-    for (size_t w = 0; w < W; ++w) {
-      uint64_t a, b;
-      std::memcpy(&a, &e->h_lat[w], 8);
-      std::memcpy(&b, &e->h_lon[w], 8);
-      if (e->h_lat[w] == 0.0) a = 0;  // +0.0 and -0.0 compare equal in the reference's f64 arithmetic
-      if (e->h_lon[w] == 0.0) b = 0;
-      auto it = sites.emplace(std::make_pair(a, b), uint32_t(sites.size())).first;
-      e->h_site[w] = it->second;
-      if (it->second >= pop.size()) pop.push_back(0);
-      pop[it->second] += (e->h_flags[w] & PM_W_HAS_LOC) ? 1u : 0u;
-    }
-    // bit 31 marks a site shared by two or more located workers (only those can have same-site neighbours)
-    for (size_t w = 0; w < W; ++w)
-      if (pop[e->h_site[w]] >= 2) e->h_site[w] |= 0x80000000u;
+  e->site_map.clear();
+  e->site_map.reserve(W * 2);
+  e->site_pop.clear();
+  e->h_site.resize(W);
+  for (size_t w = 0; w < W; ++w) {
+    e->h_site[w] = site_of_row(e, w);
+    e->site_pop[e->h_site[w]] += (e->h_flags[w] & PM_W_HAS_LOC) ? 1u : 0u;
   }
+  refresh_site_bits(e);
   if ((rc = upload(e->d_site, e->h_site.data(), W, e->stream))) return rc;
   HIPCHK(e->d_coslat.ensure(W ? W : 1));
   launch_coslat(e->d_lat.p, e->d_coslat.p, uint32_t(W), e->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->flags_dirty = false;
+  e->price_dirty = true;
+  e->compat_dirty = true;
+  return PM_OK;
+}
+
+// (price, index) order of the swept axis for pm_match_per_task; rebuilt only when a price changed
+static void ensure_price_order(pm_engine* e) {
+  if (!e->price_dirty) return;
   e->any_price = std::any_of(e->h_price.begin(), e->h_price.end(), [](uint32_t p) { return p != 0; });
   e->price_perm.clear();
   if (e->any_price) {
-    e->price_perm.resize(W);
-    for (uint32_t i = 0; i < W; ++i) e->price_perm[i] = i;
+    e->price_perm.resize(e->W);
+    for (uint32_t i = 0; i < e->W; ++i) e->price_perm[i] = i;
     std::stable_sort(e->price_perm.begin(), e->price_perm.end(),
                      [&](uint32_t a, uint32_t b) { return e->h_price[a] < e->h_price[b]; });
   }
-  e->compat_dirty = true;
-  return PM_OK;
+  e->price_dirty = false;
+}
+
+static bool worker_soa_complete(const pm_worker_soa* w) {
+  return !w->n || (w->flags && w->gpu_count && w->gpu_mem_mb && w->gpu_model_class && w->cpu_cores && w->ram_mb &&
+                   w->storage_gb && w->lat && w->lon);
 }
 
 int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_groups) {
   if (!e || !w) return set_error(PM_EINVAL, "null argument");
   const uint32_t n = w->n;
-  if (n && (!w->flags || !w->gpu_count || !w->gpu_mem_mb || !w->gpu_model_class || !w->cpu_cores || !w->ram_mb ||
-            !w->storage_gb || !w->lat || !w->lon))
-    return set_error(PM_EINVAL, "null worker column");
+  if (!worker_soa_complete(w)) return set_error(PM_EINVAL, "null worker column");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  ABSORB_PENDING(e);
   if (keep_groups && e->have_workers && n != e->W)
-    return set_error(PM_EINVAL, "keep_groups requires an unchanged worker count");
+    return set_error(PM_EINVAL, "keep_groups requires the same rows in the same order (use pm_append_workers / "
+                                "pm_update_workers for deltas)");
   if (n != e->W && e->dist_world > 1) {  // ownership is per worker row: pm_dist_configure must follow
     e->h_shard.clear();
     e->h_own_rows.clear();
@@ -1326,18 +1379,20 @@ int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_gr
   return PM_OK;
 }
 
-int32_t pm_update_workers(pm_engine* e, const uint32_t* idx, const pm_worker_soa* rows) {
-  if (!e || !rows || (rows->n && !idx)) return set_error(PM_EINVAL, "null argument");
-  std::lock_guard<std::mutex> lk(e->mu);
-  if (!e->have_workers) return set_error(PM_ESTATE, "workers must be uploaded first");
-  if (rows->n && (!rows->flags || !rows->gpu_count || !rows->gpu_mem_mb || !rows->gpu_model_class ||
-                  !rows->cpu_cores || !rows->ram_mb || !rows->storage_gb || !rows->lat || !rows->lon))
-    return set_error(PM_EINVAL, "null worker column");
-  HIPCHK(hipSetDevice(e->cfg.device));
-  for (uint32_t k = 0; k < rows->n; ++k)
-    if (idx[k] >= e->W) return set_error(PM_ERANGE, "worker index out of range");
-  for (uint32_t k = 0; k < rows->n; ++k) {
+// Rows idx[0..n) <- rows: host mirror, incremental site interning, then ONE packed H2D copy and a scatter kernel
+// (update_rows_kernel also refreshes cos(lat)).  Shared by pm_update_workers and pm_append_workers.
+static int32_t scatter_rows(pm_engine* e, const uint32_t* idx, const pm_worker_soa* rows, uint32_t first_new) {
+  const uint32_t n = rows->n;
+  if (!n) return PM_OK;
+  for (uint32_t k = 0; k < n; ++k) {
     const uint32_t w = idx[k];
+    if (w < first_new) {  // an existing row leaves its old site (rows from first_new on are being appended)
+      const uint32_t old = e->h_site[w] & 0x7FFFFFFFu;
+      if ((e->h_flags[w] & PM_W_HAS_LOC) && old < e->site_pop.size()) {
+        if (e->site_pop[old] == 2) e->site_bits_dirty = true;
+        if (e->site_pop[old]) e->site_pop[old]--;
+      }
+    }
     e->h_flags[w] = rows->flags[k];
     e->h_gpu_count[w] = rows->gpu_count[k];
     e->h_gpu_mem[w] = rows->gpu_mem_mb[k];
@@ -1345,12 +1400,156 @@ int32_t pm_update_workers(pm_engine* e, const uint32_t* idx, const pm_worker_soa
     e->h_cpu_cores[w] = rows->cpu_cores[k];
     e->h_ram[w] = rows->ram_mb[k];
     e->h_storage[w] = rows->storage_gb[k];
-    if (rows->price) e->h_price[w] = rows->price[k];
+    if (rows->price) {
+      if (e->h_price[w] != rows->price[k]) e->price_dirty = true;
+      e->h_price[w] = rows->price[k];
+    }
     if (rows->addr_rank) e->h_addr_rank[w] = rows->addr_rank[k];
     e->h_lat[w] = rows->lat[k];
     e->h_lon[w] = rows->lon[k];
+    const uint32_t id = site_of_row(e, w);
+    if (rows->flags[k] & PM_W_HAS_LOC) {
+      if (e->site_pop[id] == 1) e->site_bits_dirty = true;
+      e->site_pop[id]++;
+    }
+    e->h_site[w] = id | (e->site_pop[id] >= 2 ? 0x80000000u : 0u);
   }
-  return upload_worker_columns(e);
+  // packed staging: [lat n][lon n] f64, then 10 u32 columns: idx, flags, gpu_count, gpu_mem, gpu_cls, cpu_cores,
+  // ram, storage, addr_rank, site
+  const size_t bytes = size_t(n) * (16 + 10 * 4);
+  std::vector<unsigned char> host(bytes);
+  double* hd = reinterpret_cast<double*>(host.data());
+  uint32_t* hu = reinterpret_cast<uint32_t*>(host.data() + size_t(n) * 16);
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t w = idx[k];
+    hd[k] = e->h_lat[w];
+    hd[n + k] = e->h_lon[w];
+    hu[0 * size_t(n) + k] = w;
+    hu[1 * size_t(n) + k] = e->h_flags[w];
+    hu[2 * size_t(n) + k] = e->h_gpu_count[w];
+    hu[3 * size_t(n) + k] = e->h_gpu_mem[w];
+    hu[4 * size_t(n) + k] = e->h_gpu_cls[w];
+    hu[5 * size_t(n) + k] = e->h_cpu_cores[w];
+    hu[6 * size_t(n) + k] = e->h_ram[w];
+    hu[7 * size_t(n) + k] = e->h_storage[w];
+    hu[8 * size_t(n) + k] = e->h_addr_rank[w];
+    hu[9 * size_t(n) + k] = e->h_site[w];
+  }
+  HIPCHK(e->d_row_stage.ensure(bytes));
+  HIPCHK(hipMemcpyAsync(e->d_row_stage.p, host.data(), bytes, hipMemcpyHostToDevice, e->stream));
+  RowUpdateArgs a{};
+  a.n = n;
+  a.lat_in = reinterpret_cast<const double*>(e->d_row_stage.p);
+  a.lon_in = a.lat_in + n;
+  a.u32_in = reinterpret_cast<const uint32_t*>(e->d_row_stage.p + size_t(n) * 16);
+  a.flags = e->d_flags.p;
+  a.gpu_count = e->d_gpu_count.p;
+  a.gpu_mem = e->d_gpu_mem.p;
+  a.gpu_cls = e->d_gpu_cls.p;
+  a.cpu_cores = e->d_cpu_cores.p;
+  a.ram = e->d_ram.p;
+  a.storage = e->d_storage.p;
+  a.addr_rank = e->d_addr_rank.p;
+  a.site = e->d_site.p;
+  a.lat = e->d_lat.p;
+  a.lon = e->d_lon.p;
+  a.coslat = e->d_coslat.p;
+  launch_update_rows(a, e->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));  // the staging vector dies here
+  if (e->site_bits_dirty) {  // a site crossed the one <-> two located workers line: refresh the hint bits
+    refresh_site_bits(e);
+    int32_t rc = upload(e->d_site, e->h_site.data(), e->W, e->stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  e->compat_dirty = true;
+  e->h_compat_valid = false;
+  return PM_OK;
+}
+
+int32_t pm_update_workers(pm_engine* e, const uint32_t* idx, const pm_worker_soa* rows) {
+  if (!e || !rows || (rows->n && !idx)) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->have_workers) return set_error(PM_ESTATE, "workers must be uploaded first");
+  if (!worker_soa_complete(rows)) return set_error(PM_EINVAL, "null worker column");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  for (uint32_t k = 0; k < rows->n; ++k)
+    if (idx[k] >= e->W) return set_error(PM_ERANGE, "worker index out of range");
+  int32_t rc = sync_flags(e);  // status-only changes made since the last upload go up first (whole column)
+  if (rc) return rc;
+  return scatter_rows(e, idx, rows, e->W);
+}
+
+int32_t pm_append_workers(pm_engine* e, const pm_worker_soa* rows, uint32_t* first_index) {
+  if (!e || !rows) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->have_workers) return set_error(PM_ESTATE, "workers must be uploaded first (an empty table is fine)");
+  if (!worker_soa_complete(rows)) return set_error(PM_EINVAL, "null worker column");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  ABSORB_PENDING(e);
+  const uint32_t w0 = e->W, n = rows->n;
+  if (first_index) *first_index = w0;
+  if (!n) return PM_OK;
+  if (uint64_t(w0) + n > 0x7FFFFFFFull) return set_error(PM_ERANGE, "worker table too large");
+  int32_t rc = sync_flags(e);
+  if (rc) return rc;
+  const size_t W1 = size_t(w0) + n;
+  HIPCHK(e->d_flags.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_gpu_count.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_gpu_mem.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_gpu_cls.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_cpu_cores.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_ram.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_storage.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_addr_rank.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_site.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_lat.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_lon.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_coslat.grow_keep(W1, w0, e->stream));
+  e->h_flags.resize(W1, 0);
+  e->h_gpu_count.resize(W1, 0);
+  e->h_gpu_mem.resize(W1, 0);
+  e->h_gpu_cls.resize(W1, 0);
+  e->h_cpu_cores.resize(W1, 0);
+  e->h_ram.resize(W1, 0);
+  e->h_storage.resize(W1, 0);
+  e->h_price.resize(W1, 0);
+  e->h_addr_rank.resize(W1, 0);
+  e->h_lat.resize(W1, 0.0);
+  e->h_lon.resize(W1, 0.0);
+  e->h_site.resize(W1, 0);
+  std::vector<uint32_t> idx(n);
+  for (uint32_t k = 0; k < n; ++k) {
+    idx[k] = w0 + k;
+    if (!rows->addr_rank) e->h_addr_rank[w0 + k] = w0 + k;
+  }
+  // a new row joins no group: the existing groups and their claimed tasks stay as they are (mod.rs:487-497)
+  e->h_group_of.resize(W1, -1);
+  e->W = uint32_t(W1);
+  rc = scatter_rows(e, idx.data(), rows, w0);
+  if (rc) return rc;
+  if (e->dist_world > 1) {  // ownership is per worker row: pm_dist_configure must follow
+    e->h_shard.clear();
+    e->h_own_rows.clear();
+  }
+  e->price_dirty = true;
+  e->groups_dirty = true;  // group_of and the group arrays are sized by W
+  return PM_OK;
+}
+
+int32_t pm_set_addr_ranks(pm_engine* e, const uint32_t* addr_rank, uint32_t n) {
+  if (!e || (n && !addr_rank)) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->have_workers || n != e->W) return set_error(PM_ERANGE, "one rank per worker row");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->h_addr_rank.assign(addr_rank, addr_rank + n);
+  int32_t rc = upload(e->d_addr_rank, e->h_addr_rank.data(), n, e->stream);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PM_OK;
 }
 
 int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
@@ -1553,6 +1752,7 @@ static int32_t run_match_per_task(pm_engine* e) {
   rc = ensure_sweep_outputs(e, e->T);
   if (rc) return rc;
   HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
+  ensure_price_order(e);
   launch_eligible_selector(e->d_flags.p, e->d_group_of.p, e->d_compat.p, e->enabled, e->W,
                            e->dist_world > 1 ? e->d_shard.p : nullptr, e->dist_rank, e->d_sel.p, e->stream);
   const uint64_t* cols = e->d_sel.p;
@@ -1599,6 +1799,7 @@ int32_t pm_match_per_task_device(pm_engine* e, uint64_t* best_ptr, uint64_t* cou
   if (!e || !best_ptr || !count_ptr || !n) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
+  ensure_price_order(e);
   if (e->any_price) return set_error(PM_ESTATE, "device-side bids are index-ordered: not available with a price column");
   int32_t rc = run_match_per_task(e);
   if (rc) return rc;

@@ -128,6 +128,28 @@ __global__ __launch_bounds__(256) void coslat_kernel(const double* __restrict__ 
   if (w < W) coslat[w] = cos(lat[w] * PM_RAD);
 }
 
+// Row deltas of the worker table (discovery sync / status updater, orchestrator/src/discovery/monitor.rs:236-420,
+// plugins/node_groups/status_update_impl.rs:8-39): n packed rows -> the SoA columns, cos(lat) refreshed.
+__global__ __launch_bounds__(256) void update_rows_kernel(RowUpdateArgs p) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= p.n) return;
+  const size_t n = p.n;
+  const uint32_t w = p.u32_in[k];
+  p.flags[w] = p.u32_in[1 * n + k];
+  p.gpu_count[w] = p.u32_in[2 * n + k];
+  p.gpu_mem[w] = p.u32_in[3 * n + k];
+  p.gpu_cls[w] = p.u32_in[4 * n + k];
+  p.cpu_cores[w] = p.u32_in[5 * n + k];
+  p.ram[w] = p.u32_in[6 * n + k];
+  p.storage[w] = p.u32_in[7 * n + k];
+  p.addr_rank[w] = p.u32_in[8 * n + k];
+  p.site[w] = p.u32_in[9 * n + k];
+  const double la = p.lat_in[k];
+  p.lat[w] = la;
+  p.lon[w] = p.lon_in[k];
+  p.coslat[w] = cos(la * PM_RAD);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Phase B.  hit(row, col) = (row_sel[row] & col_mask[col]) != 0; per row: first hit and hit count.
 // Both kernels split the swept axis over blockIdx.y so that a few thousand workgroups fill the chip, keep a
@@ -2471,6 +2493,10 @@ void launch_compat(const CompatArgs& a, hipStream_t s) {
 void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s) {
   if (W == 0) return;
   hipLaunchKernelGGL(coslat_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, lat, coslat, W);
+}
+void launch_update_rows(const RowUpdateArgs& a, hipStream_t s) {
+  if (a.n == 0) return;
+  hipLaunchKernelGGL(update_rows_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);
 }
 void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t R, const uint32_t* rows,
                             uint64_t* sel, hipStream_t s) {

@@ -91,7 +91,7 @@ EXPORTS = [
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
-    "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
+    "pm_append_workers", "pm_set_addr_ranks", "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
     "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
 ]
 
@@ -141,6 +141,8 @@ def lib() -> C.CDLL:
         L.pm_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pm_lookup_task_for_worker.argtypes = [vp, u32, C.POINTER(Assignment)]
         L.pm_device_task_column.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+        L.pm_append_workers.argtypes = [vp, C.POINTER(WorkerSoa), C.POINTER(u32)]
+        L.pm_set_addr_ranks.argtypes = [vp, vp, u32]
         L.pm_set_stream.argtypes = [vp, vp]
         L.pm_dist_configure.argtypes = [vp, u32, u32, vp]
         L.pm_dist_tick_begin.argtypes = [vp]
@@ -257,6 +259,18 @@ class Engine:
         soa, keep = self._worker_soa(cols)
         assert soa.n == len(idx)
         check(lib().pm_update_workers(self._h, idx.ctypes.data, C.byref(soa)))
+
+    def append_workers(self, cols: dict) -> int:
+        """-> index of the first appended row"""
+        soa, keep = self._worker_soa(cols)
+        first = C.c_uint32(0)
+        check(lib().pm_append_workers(self._h, C.byref(soa), C.byref(first)))
+        self.W += soa.n
+        return first.value
+
+    def set_addr_ranks(self, ranks):
+        r = _arr(ranks, np.uint32)
+        check(lib().pm_set_addr_ranks(self._h, r.ctypes.data if len(r) else None, len(r)))
 
     def upload_tasks(self, topo_mask, created_at, uid=None):
         tm, ca = _arr(topo_mask, np.uint64), _arr(created_at, np.int64)
