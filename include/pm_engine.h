@@ -196,6 +196,20 @@ int32_t pm_set_addr_ranks(pm_engine*, const uint32_t* addr_rank, uint32_t n_work
 /* TaskStore::get_all_tasks snapshot. Groups whose claimed task uid disappeared are dissolved
  * (on_task_deleted, mod.rs:1245-1288). */
 int32_t pm_upload_tasks(pm_engine*, const pm_task_soa* tasks);
+/* Task deltas — the observer-invalidated task cache of SURVEY section 8f row 2, replacing the per-heartbeat
+ * get_all_tasks (store/domains/task_store.rs:57-82) AND the re-upload of the snapshot:
+ *   pm_tasks_insert_front  on_task_created (mod.rs:1224-1243): rows in get_all_tasks order (created_at
+ *                          descending), every one of them strictly newer than the newest task of the table, so they
+ *                          sort in front of it (task_store.rs:79); PM_EINVAL otherwise -> fall back to
+ *                          pm_upload_tasks.  Only the new rows travel, the bit planes are patched in the words
+ *                          they fall into, and every claimed task keeps its binding.
+ *   pm_tasks_delete        on_task_deleted (mod.rs:1245-1325) by task id (needs pm_task_soa.uid): the rows leave
+ *                          the list, groups that had claimed one of them are dissolved; unknown ids are ignored.
+ * Task indices reported by the engine (pm_assignment.task, pm_group.task, pm_match*, pm_newest_task) are always
+ * positions in the caller's CURRENT list: after an insertion of n rows every older task's index is n higher,
+ * after a deletion the later ones move up — exactly as in the caller's own Vec<Task>. */
+int32_t pm_tasks_insert_front(pm_engine*, const pm_task_soa* rows);
+int32_t pm_tasks_delete(pm_engine*, const uint64_t* uids, uint32_t n, uint32_t* n_deleted);
 
 /* StatusUpdatePlugin::handle_status_change (status_update_impl.rs:8-39): dead != 0 means the new
  * status is Dead or LowBalance => dissolve the worker's whole group. */

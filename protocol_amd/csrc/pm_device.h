@@ -51,6 +51,8 @@ struct ClaimArgs {
   const uint32_t* chosen;         // per row
   const uint32_t* rank_in_group;  // per worker
   const uint32_t* by_rank;        // per member slot: worker of that rank
+  const uint64_t* t_live;     // task table: live bitmap and live-prefix per word (handle -> published position)
+  const uint32_t* t_prefix;
   pm_assignment* table;  // per worker; with `rows`: per row (this rank's segment of the exchange buffer)
   uint32_t* task_col;    // compact per-worker task column (device-side consumers; not written with `rows`)
 };
@@ -164,21 +166,28 @@ void launch_eligible_selector(const uint32_t* wflags, const int32_t* group_of, c
 void launch_chooser_rank(const int32_t* group_of, const uint64_t* g_id, const uint32_t* count, uint32_t R,
                          const uint32_t* rows, uint64_t seed, uint32_t* rank, hipStream_t s);
 void launch_table_scatter(const pm_assignment* x, const uint32_t* xrow, uint32_t W, pm_assignment* table,
-                          uint32_t* task_col, uint32_t* g_task_next, hipStream_t s);
+                          uint32_t* task_col, uint32_t* g_task_next, const uint64_t* t_live, const uint32_t* t_prefix,
+                          hipStream_t s);
 void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint32_t* g_off, const uint32_t* members,
                        const uint32_t* addr_rank, uint32_t W, uint32_t* rank_in_group, uint32_t* by_rank,
                        hipStream_t s);
 void launch_claim_publish(const ClaimArgs& a, hipStream_t s);
-void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t n_planes, uint64_t* planes,
-                         hipStream_t s);
+void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t c_begin, uint32_t c_end, uint32_t stride,
+                         uint32_t n_planes, uint64_t* planes, hipStream_t s);
 void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
-                       const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, uint32_t* first, uint32_t* count,
-                       hipStream_t s);
+                       const uint64_t* planes, uint32_t c_begin, uint32_t c_end, uint32_t stride, uint32_t n_planes,
+                       uint32_t* first, uint32_t* count, hipStream_t s);
 void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
-                        const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, const uint32_t* rank,
-                        uint32_t* out, hipStream_t s);
-void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block, long long* val_by_block,
-                   uint32_t n_blocks, hipStream_t s);
+                        const uint64_t* planes, uint32_t c_begin, uint32_t c_end, uint32_t stride, uint32_t n_planes,
+                        const uint32_t* rank, uint32_t* out, hipStream_t s);
+void launch_task_prefix(const uint64_t* live, uint32_t w_begin, uint32_t w_end, uint32_t* prefix, hipStream_t s);
+void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, long long* created, uint64_t* live,
+                        uint64_t* planes, uint32_t stride, uint32_t n_planes, hipStream_t s);
+void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint32_t u_begin, uint32_t u_end,
+                         const uint64_t* live, const uint32_t* prefix, uint32_t* first_out, uint32_t* count_out,
+                         hipStream_t s);
+void launch_newest(const int64_t* created_at, uint32_t t_begin, uint32_t t_end, uint32_t* idx_by_block,
+                   long long* val_by_block, uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);

@@ -174,14 +174,28 @@ struct pm_engine {
   DevBuf<unsigned char> d_row_stage;  // packed rows of pm_update_workers / pm_append_workers
 
   // ---- task table
-  uint32_t T = 0;
+  // The table lives in a fixed-capacity index space [0, t_cap) and is filled from the TOP: the used part is
+  // [t_lo, t_cap), ascending index u = get_all_tasks order (created_at desc).  New tasks are the newest, so they
+  // go in FRONT — at lower indices — without moving anything (pm_tasks_insert_front); a deleted task leaves a
+  // tombstone (mask 0, not live).  A task's index u is therefore a stable HANDLE (what groups store as their
+  // claim); its position in the caller's current list — what the ABI reports — is the number of live tasks in
+  // front of it (live bitmap + per-word prefix, on the device and lazily on the host).
+  uint32_t T = 0;  // live tasks
+  uint32_t t_cap = 0, t_lo = 0, t_dead = 0;
   bool have_tasks = false;
-  std::vector<uint64_t> h_tmask, h_tuid;
+  std::vector<uint64_t> h_tmask, h_tuid, h_tlive;  // indexed by u (h_tlive: bitmap words)
   std::vector<int64_t> h_created;
+  std::vector<uint32_t> h_tprefix;
+  bool h_tprefix_valid = false;
   bool tasks_have_uid = false;
-  DevBuf<uint64_t> d_tmask, d_tplanes;
+  std::unordered_map<uint64_t, uint32_t> uid_to_u;  // built on the first pm_tasks_delete
+  bool uid_map_valid = false;
+  uint32_t cfg_app_count[PM_MAX_CONFIGS]{};         // live tasks applicable per configuration (merge path)
+  bool cfg_app_valid = false;
+  DevBuf<uint64_t> d_tmask, d_tplanes, d_tlive;
   DevBuf<int64_t> d_created;
-  bool tplanes_dirty = true;
+  DevBuf<uint32_t> d_tprefix, d_first_c, d_count_c, d_tdel;
+  bool tplanes_dirty = true, tprefix_dirty = true;
 
   // ---- groups: the host vector is the source of truth between calls; device arrays mirror it
   std::vector<Group> groups;
@@ -762,14 +776,39 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
 
 static int32_t ensure_task_planes(pm_engine* e) {
   if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
-  if (!e->tplanes_dirty) return PM_OK;
   const uint32_t n_planes = uint32_t(e->cfgs.size());
-  const size_t n_words = (size_t(e->T) + 63) / 64;
-  HIPCHK(e->d_tplanes.ensure(std::max<size_t>(n_words * n_planes, 1)));
-  launch_build_planes(e->d_tmask.p, e->T, n_planes, e->d_tplanes.p, e->stream);
-  HIPCHK(hipGetLastError());
-  e->tplanes_dirty = false;
+  const uint32_t stride = e->t_cap / 64u;
+  if (e->tplanes_dirty) {  // whole table (upload, capacity change, new configurations); deltas patch the planes
+    HIPCHK(e->d_tplanes.ensure(std::max<size_t>(size_t(stride) * n_planes, 1)));
+    launch_build_planes(e->d_tmask.p, e->t_cap, e->t_lo, e->t_cap, stride, n_planes, e->d_tplanes.p, e->stream);
+    HIPCHK(hipGetLastError());
+    e->tplanes_dirty = false;
+  }
+  if (e->tprefix_dirty) {
+    launch_task_prefix(e->d_tlive.p, e->t_lo / 64u, stride, e->d_tprefix.p, e->stream);
+    HIPCHK(hipGetLastError());
+    e->tprefix_dirty = false;
+  }
   return PM_OK;
+}
+
+// handle -> position in the caller's current get_all_tasks list (host side; the device does the same in
+// claim_publish_kernel)
+static uint32_t task_position(pm_engine* e, uint32_t u) {
+  if (u == PM_NONE || u < e->t_lo || u >= e->t_cap) return PM_NONE;
+  if (!e->h_tprefix_valid) {
+    const uint32_t stride = e->t_cap / 64u;
+    e->h_tprefix.assign(stride, 0);
+    uint32_t acc = 0;
+    for (uint32_t j = e->t_lo / 64u; j < stride; ++j) {
+      e->h_tprefix[j] = acc;
+      acc += uint32_t(__builtin_popcountll(e->h_tlive[j]));
+    }
+    e->h_tprefix_valid = true;
+  }
+  const uint64_t w = e->h_tlive[u >> 6];
+  if (!((w >> (u & 63u)) & 1ull)) return PM_NONE;
+  return e->h_tprefix[u >> 6] + uint32_t(__builtin_popcountll(w & ((1ull << (u & 63u)) - 1ull)));
 }
 
 static int32_t ensure_sweep_outputs(pm_engine* e, uint32_t R) {
@@ -785,18 +824,29 @@ static int32_t ensure_sweep_outputs(pm_engine* e, uint32_t R) {
 static int32_t pick_task_for_config(pm_engine* e, uint32_t cfg, uint64_t group_id, uint32_t* task_out) {
   *task_out = PM_NONE;
   if (!e->have_tasks || e->T == 0) return PM_OK;
-  // The applicable list depends only on the configuration bit: evaluate it on the host mirror — this is
-  // a T-length scan on a rare path (a merge actually happened), not the pair sweep.
-  const uint64_t bit = 1ull << cfg;
-  uint32_t n_app = 0;
-  for (uint32_t t = 0; t < e->T; ++t) n_app += (e->h_tmask[t] & bit) != 0;
+  // The applicable list depends only on the configuration bit.  Per-configuration counts are kept per version
+  // of the task table (one pass), so a merge costs one early-exit scan to the chosen task — not two passes over
+  // a million rows.
+  if (!e->cfg_app_valid) {
+    std::memset(e->cfg_app_count, 0, sizeof(e->cfg_app_count));
+    for (uint32_t u = e->t_lo; u < e->t_cap; ++u) {
+      uint64_t m = e->h_tmask[u];  // 0 for tombstones
+      while (m) {
+        e->cfg_app_count[__builtin_ctzll(m)]++;
+        m &= m - 1;
+      }
+    }
+    e->cfg_app_valid = true;
+  }
+  const uint32_t n_app = e->cfg_app_count[cfg];
   if (!n_app) return PM_OK;
+  const uint64_t bit = 1ull << cfg;
   uint32_t r = 0;
   if (e->cfg.chooser == PM_CHOOSE_SEEDED) r = uint32_t(splitmix64_mix(e->cfg.chooser_seed ^ group_id) % n_app);
-  for (uint32_t t = 0; t < e->T; ++t)
-    if (e->h_tmask[t] & bit) {
+  for (uint32_t u = e->t_lo; u < e->t_cap; ++u)
+    if (e->h_tmask[u] & bit) {
       if (r == 0) {
-        *task_out = t;
+        *task_out = u;  // the handle
         return PM_OK;
       }
       --r;
@@ -812,10 +862,8 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   int32_t rc = push_groups(e);
   if (rc) return rc;
   const int variant = int(e->cfg.sweep_variant);
-  if (variant != 1) {
-    rc = ensure_task_planes(e);
-    if (rc) return rc;
-  }
+  rc = ensure_task_planes(e);  // (also the live prefix the published positions come from)
+  if (rc) return rc;
   const uint32_t R = dist ? uint32_t(e->h_own_rows.size()) : e->W;
   const uint32_t* rows = dist ? e->d_own_rows.p : nullptr;
   rc = ensure_sweep_outputs(e, R);
@@ -829,16 +877,17 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   host_mark("match: selector launch");
   launch_worker_selector(e->d_group_of.p, e->d_g_cfg.p, R, rows, e->d_sel.p, e->stream);
   HIPCHK(hipEventRecord(e->kev[4], e->stream));
-  launch_pair_sweep(variant, e->d_sel.p, R, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_first.p,
-                    e->d_count.p, e->stream);
+  const uint32_t t_stride = e->t_cap / 64u;
+  launch_pair_sweep(variant, e->d_sel.p, R, e->d_tmask.p, e->d_tplanes.p, e->t_lo, e->t_cap, t_stride, n_planes,
+                    e->d_first.p, e->d_count.p, e->stream);
   HIPCHK(hipEventRecord(e->kev[5], e->stream));
   e->k_sweep_recorded = true;
   const uint32_t* chosen = e->d_first.p;  // PM_CHOOSE_FIRST: the first applicable task
   if (e->cfg.chooser == PM_CHOOSE_SEEDED) {
     launch_chooser_rank(e->d_group_of.p, e->d_g_id.p, e->d_count.p, R, rows, e->cfg.chooser_seed, e->d_rank.p,
                         e->stream);
-    launch_pair_select(variant, e->d_sel.p, R, e->d_tmask.p, e->d_tplanes.p, e->T, n_planes, e->d_rank.p,
-                       e->d_chosen.p, e->stream);
+    launch_pair_select(variant, e->d_sel.p, R, e->d_tmask.p, e->d_tplanes.p, e->t_lo, e->t_cap, t_stride, n_planes,
+                       e->d_rank.p, e->d_chosen.p, e->stream);
     chosen = e->d_chosen.p;
   }
   launch_group_rank(e->d_group_of.p, e->d_g_n.p, e->d_g_off.p, e->d_members.p, e->d_addr_rank.p, e->W,
@@ -857,6 +906,8 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   c.chosen = chosen;
   c.rank_in_group = e->d_rank_in_group.p;
   c.by_rank = e->d_by_rank.p;
+  c.t_live = e->d_tlive.p;
+  c.t_prefix = e->d_tprefix.p;
   c.table = dist ? e->d_table_x.p + size_t(e->dist_rank) * e->dist_cap_t : e->d_table.p;
   c.task_col = e->d_task_col.p;
   launch_claim_publish(c, e->stream);
@@ -894,7 +945,7 @@ static int32_t publish(pm_engine* e) {
   HIPCHK(hipStreamSynchronize(e->stream));
   for (size_t g = 0; g < G; ++g) {
     e->groups[g].task = g_task[g];
-    e->groups[g].task_uid = (g_task[g] != PM_NONE && e->tasks_have_uid) ? e->h_tuid[g_task[g]] : g_task[g];
+    e->groups[g].task_uid = g_task[g] == PM_NONE ? 0 : (e->tasks_have_uid ? e->h_tuid[g_task[g]] : task_position(e, g_task[g]));
   }
   std::swap(e->d_g_task, e->d_g_task_next);
   // swap in the new snapshot (see PubTable)
@@ -1101,7 +1152,7 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
       gr.task_uid = 0;
       rc = pick_task_for_config(e, cfg, gr.id, &gr.task);  // find_best_task_for_group, mod.rs:896
       if (rc) return rc;
-      if (gr.task != PM_NONE) gr.task_uid = e->tasks_have_uid ? e->h_tuid[gr.task] : gr.task;
+      if (gr.task != PM_NONE) gr.task_uid = e->tasks_have_uid ? e->h_tuid[gr.task] : task_position(e, gr.task);
       std::vector<uint32_t> old_slots;
       for (uint32_t w : b) old_slots.push_back(uint32_t(e->h_group_of[w]));
       std::sort(old_slots.rbegin(), old_slots.rend());
@@ -1186,7 +1237,8 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_flags.release(); e->d_gpu_count.release(); e->d_gpu_mem.release(); e->d_gpu_cls.release();
   e->d_cpu_cores.release(); e->d_ram.release(); e->d_storage.release(); e->d_addr_rank.release();
   e->d_lat.release(); e->d_lon.release(); e->d_coslat.release(); e->d_compat.release();
-  e->d_tmask.release(); e->d_tplanes.release(); e->d_created.release();
+  e->d_tmask.release(); e->d_tplanes.release(); e->d_created.release(); e->d_tlive.release(); e->d_tprefix.release();
+  e->d_first_c.release(); e->d_count_c.release(); e->d_tdel.release();
   e->d_group_of.release(); e->d_g_cfg.release(); e->d_g_n.release(); e->d_g_off.release();
   e->d_g_task.release(); e->d_g_task_next.release(); e->d_members.release(); e->d_by_rank.release();
   e->d_rank_in_group.release(); e->d_g_id.release();
@@ -1552,24 +1604,94 @@ int32_t pm_set_addr_ranks(pm_engine* e, const uint32_t* addr_rank, uint32_t n) {
   return PM_OK;
 }
 
+// (Re)allocate the task index space with capacity `cap` (a multiple of 64) and move the used part to its top.
+// Handles shift by (cap - old cap): the groups' claims are shifted with them.
+static int32_t tasks_set_capacity(pm_engine* e, uint32_t cap, bool keep) {
+  const uint32_t old_cap = e->t_cap, used = keep ? old_cap - e->t_lo : 0u;
+  const uint32_t new_lo = cap - used;
+  std::vector<uint64_t> tmask(cap, 0), tuid, tlive(cap / 64u, 0);
+  std::vector<int64_t> created(cap, INT64_MIN);
+  if (e->tasks_have_uid) tuid.assign(cap, 0);
+  if (used) {
+    std::copy(e->h_tmask.begin() + e->t_lo, e->h_tmask.end(), tmask.begin() + new_lo);
+    std::copy(e->h_created.begin() + e->t_lo, e->h_created.end(), created.begin() + new_lo);
+    if (e->tasks_have_uid) std::copy(e->h_tuid.begin() + e->t_lo, e->h_tuid.end(), tuid.begin() + new_lo);
+    for (uint32_t u = e->t_lo; u < old_cap; ++u)
+      if ((e->h_tlive[u >> 6] >> (u & 63u)) & 1ull) {
+        const uint32_t v = u - e->t_lo + new_lo;
+        tlive[v >> 6] |= 1ull << (v & 63u);
+      }
+    const uint32_t shift = new_lo - e->t_lo;  // cap grows: handles move up
+    for (Group& g : e->groups)
+      if (g.task != PM_NONE) g.task += shift;
+    e->groups_dirty = true;
+    if (e->uid_map_valid)
+      for (auto& kv : e->uid_to_u) kv.second += shift;
+  }
+  e->h_tmask.swap(tmask);
+  e->h_created.swap(created);
+  e->h_tuid.swap(tuid);
+  e->h_tlive.swap(tlive);
+  e->t_cap = cap;
+  e->t_lo = new_lo;
+  e->h_tprefix_valid = false;
+  HIPCHK(e->d_tmask.ensure(cap));
+  HIPCHK(e->d_created.ensure(cap));
+  HIPCHK(e->d_tlive.ensure(cap / 64u));
+  HIPCHK(e->d_tprefix.ensure(cap / 64u));
+  // the whole index space goes up: unused and dead entries are mask 0 / not live / created_at = INT64_MIN
+  HIPCHK(hipMemcpyAsync(e->d_tmask.p, e->h_tmask.data(), size_t(cap) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_created.p, e->h_created.data(), size_t(cap) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_tlive.p, e->h_tlive.data(), size_t(cap / 64u) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->tplanes_dirty = true;
+  e->tprefix_dirty = true;
+  return PM_OK;
+}
+
+static uint32_t task_capacity_for(uint32_t n) {  // room for about as many insertions as there are tasks
+  const uint64_t want = uint64_t(n) * 2 + 65536;
+  return uint32_t(std::min<uint64_t>((want + 63) & ~uint64_t(63), 0xFFFFFFC0ull));
+}
+
 int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
   if (!e || !t) return set_error(PM_EINVAL, "null argument");
   if (t->n && (!t->topo_mask || !t->created_at)) return set_error(PM_EINVAL, "null task column");
+  if (t->n > 0x7FFFFFFFu) return set_error(PM_ERANGE, "task table too large");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   ABSORB_PENDING(e);
-  e->T = t->n;
-  e->h_tmask.assign(t->topo_mask, t->topo_mask + t->n);
-  e->h_created.assign(t->created_at, t->created_at + t->n);
+  const uint32_t n = t->n;
   e->tasks_have_uid = t->uid != nullptr;
-  if (t->uid) e->h_tuid.assign(t->uid, t->uid + t->n); else e->h_tuid.clear();
-  int32_t rc = upload(e->d_tmask, e->h_tmask.data(), e->T, e->stream);
+  e->uid_to_u.clear();
+  e->uid_map_valid = false;
+  e->cfg_app_valid = false;
+  uint32_t cap = e->t_cap;
+  if (cap < n + 64u || uint64_t(cap) > uint64_t(n) * 8 + (1u << 20)) cap = task_capacity_for(n);
+  e->t_cap = 0;  // nothing to keep
+  e->t_lo = 0;
+  {  // host mirror in table order: position i -> index lo + i
+    const uint32_t lo = cap - n;
+    e->h_tmask.assign(cap, 0);
+    e->h_created.assign(cap, INT64_MIN);
+    e->h_tlive.assign(cap / 64u, 0);
+    if (t->uid) e->h_tuid.assign(cap, 0); else e->h_tuid.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t u = lo + i;
+      e->h_tmask[u] = t->topo_mask[i];
+      e->h_created[u] = t->created_at[i];
+      if (t->uid) e->h_tuid[u] = t->uid[i];
+      e->h_tlive[u >> 6] |= 1ull << (u & 63u);
+    }
+    e->t_cap = cap;
+    e->t_lo = lo;
+  }
+  e->T = n;
+  e->t_dead = 0;
+  int32_t rc = tasks_set_capacity(e, cap, /*keep=*/true);  // same capacity: uploads the columns as they are
   if (rc) return rc;
-  rc = upload(e->d_created, e->h_created.data(), e->T, e->stream);
-  if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(e->stream));
   e->have_tasks = true;
-  e->tplanes_dirty = true;
   // re-bind claimed tasks by identity; groups whose task vanished are dissolved (on_task_deleted,
   // mod.rs:1259-1288)
   // Only the claimed tasks have to be found again: an open-addressing table of their ids (a few thousand
@@ -1577,43 +1699,176 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
   size_t n_claim = 0;
   for (const Group& g : e->groups) n_claim += (!g.dead && g.task != PM_NONE);
   if (n_claim) {
-    size_t cap = 64;
-    while (cap < n_claim * 4) cap <<= 1;
+    size_t hcap = 64;
+    while (hcap < n_claim * 4) hcap <<= 1;
     const uint64_t EMPTY = ~0ull;  // a task id of all ones simply stays unresolved in the table path below
-    std::vector<uint64_t> keys(cap, EMPTY);
-    std::vector<uint32_t> vals(cap, PM_NONE);
+    std::vector<uint64_t> keys(hcap, EMPTY);
+    std::vector<uint32_t> vals(hcap, PM_NONE);
     auto slot_of = [&](uint64_t k) {
-      size_t h = size_t(splitmix64_mix(k)) & (cap - 1);
-      while (keys[h] != EMPTY && keys[h] != k) h = (h + 1) & (cap - 1);
+      size_t h = size_t(splitmix64_mix(k)) & (hcap - 1);
+      while (keys[h] != EMPTY && keys[h] != k) h = (h + 1) & (hcap - 1);
       return h;
     };
     if (e->tasks_have_uid) {
       for (const Group& g : e->groups)
         if (!g.dead && g.task != PM_NONE && g.task_uid != EMPTY) keys[slot_of(g.task_uid)] = g.task_uid;
-      for (uint32_t i = 0; i < e->T; ++i) {
-        const uint64_t k = e->h_tuid[i];
-        size_t h = size_t(splitmix64_mix(k)) & (cap - 1);
-        while (keys[h] != EMPTY && keys[h] != k) h = (h + 1) & (cap - 1);
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t k = t->uid[i];
+        size_t h = size_t(splitmix64_mix(k)) & (hcap - 1);
+        while (keys[h] != EMPTY && keys[h] != k) h = (h + 1) & (hcap - 1);
         if (keys[h] == k && vals[h] == PM_NONE) vals[h] = i;  // first occurrence, like a map's emplace
       }
     }
     for (size_t g = e->groups.size(); g-- > 0;) {
       Group& gr = e->groups[g];
       if (gr.dead || gr.task == PM_NONE) continue;
-      uint32_t ni = PM_NONE;
+      uint32_t ni = PM_NONE;  // position in the new list
       if (e->tasks_have_uid) {
         if (gr.task_uid != EMPTY) ni = vals[slot_of(gr.task_uid)];
-      } else if (gr.task_uid < e->T) {
-        ni = uint32_t(gr.task_uid);
+      } else if (gr.task_uid < n) {
+        ni = uint32_t(gr.task_uid);  // without ids the identity of a task is its position
       }
       if (ni == PM_NONE) {
         dissolve_locked(e, uint32_t(g));
-      } else if (ni != gr.task) {
-        gr.task = ni;
+      } else if (e->t_lo + ni != gr.task) {
+        gr.task = e->t_lo + ni;
         e->groups_dirty = true;
       }
     }
   }
+  return PM_OK;
+}
+
+// on_task_created (node_groups/mod.rs:1224-1243) + TaskStore::add_task (store/domains/task_store.rs:33-55): new
+// tasks are the newest, i.e. they sort in FRONT of get_all_tasks (:79, created_at desc).  Only the new rows
+// travel; the bit planes are patched in the words they fall into; nothing else moves, so every claimed task
+// keeps its handle.
+int32_t pm_tasks_insert_front(pm_engine* e, const pm_task_soa* t) {
+  if (!e || !t) return set_error(PM_EINVAL, "null argument");
+  if (t->n && (!t->topo_mask || !t->created_at)) return set_error(PM_EINVAL, "null task column");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first (an empty table is fine)");
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  if ((t->uid != nullptr) != e->tasks_have_uid && (e->T || e->t_dead))
+    return set_error(PM_EINVAL, "the table was uploaded with / without task ids: the new rows must match");
+  const uint32_t n = t->n;
+  if (!n) return PM_OK;
+  for (uint32_t i = 1; i < n; ++i)
+    if (t->created_at[i] > t->created_at[i - 1])
+      return set_error(PM_EINVAL, "rows must be in get_all_tasks order (created_at descending)");
+  for (uint32_t u = e->t_lo; u < e->t_cap; ++u)  // the newest live task of the table
+    if ((e->h_tlive[u >> 6] >> (u & 63u)) & 1ull) {
+      // an equal timestamp would sort BEHIND the older task (stable sort, task_store.rs:79): not a front insertion
+      if (t->created_at[n - 1] <= e->h_created[u])
+        return set_error(PM_EINVAL, "not newer than the newest task of the table: use pm_upload_tasks");
+      break;
+    }
+  ABSORB_PENDING(e);
+  if (!e->T && !e->t_dead) e->tasks_have_uid = t->uid != nullptr;
+  if (e->t_lo < n) {  // out of room in front: a larger index space, everything moves to its top
+    if (e->tasks_have_uid && e->h_tuid.size() != e->t_cap) e->h_tuid.assign(e->t_cap, 0);
+    int32_t rc = tasks_set_capacity(e, task_capacity_for(e->t_cap - e->t_lo + n), /*keep=*/true);
+    if (rc) return rc;
+  }
+  if (e->tasks_have_uid && e->h_tuid.size() != e->t_cap) e->h_tuid.assign(e->t_cap, 0);
+  const uint32_t lo = e->t_lo - n;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t u = lo + i;
+    e->h_tmask[u] = t->topo_mask[i];
+    e->h_created[u] = t->created_at[i];
+    if (t->uid) {
+      e->h_tuid[u] = t->uid[i];
+      if (e->uid_map_valid) e->uid_to_u.emplace(t->uid[i], u);
+    }
+    e->h_tlive[u >> 6] |= 1ull << (u & 63u);
+    if (e->cfg_app_valid) {
+      uint64_t m = t->topo_mask[i];
+      while (m) {
+        e->cfg_app_count[__builtin_ctzll(m)]++;
+        m &= m - 1;
+      }
+    }
+  }
+  const uint32_t w0 = lo / 64u, w1 = (e->t_lo + 63u) / 64u;  // bitmap / plane words the new rows fall into
+  HIPCHK(hipMemcpyAsync(e->d_tmask.p + lo, e->h_tmask.data() + lo, size_t(n) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_created.p + lo, e->h_created.data() + lo, size_t(n) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_tlive.p + w0, e->h_tlive.data() + w0, size_t(w1 - w0) * 8, hipMemcpyHostToDevice, e->stream));
+  if (!e->tplanes_dirty && e->d_tplanes.p)  // patch the planes: the touched words are rebuilt from the masks
+    launch_build_planes(e->d_tmask.p, e->t_cap, lo, e->t_lo, e->t_cap / 64u, uint32_t(e->cfgs.size()), e->d_tplanes.p,
+                        e->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));  // pageable sources
+  e->t_lo = lo;
+  e->T += n;
+  e->tprefix_dirty = true;
+  e->h_tprefix_valid = false;
+  return PM_OK;
+}
+
+// on_task_deleted (node_groups/mod.rs:1245-1325): the tasks leave the table (tombstones: nothing moves) and every
+// group that had claimed one of them is dissolved (:1259-1288).  Unknown ids are ignored.
+int32_t pm_tasks_delete(pm_engine* e, const uint64_t* uids, uint32_t n, uint32_t* n_deleted) {
+  if (!e || (n && !uids)) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (n_deleted) *n_deleted = 0;
+  if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
+  if (!e->tasks_have_uid) return set_error(PM_ESTATE, "the task table carries no ids (pm_task_soa.uid)");
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  ABSORB_PENDING(e);
+  if (!e->uid_map_valid) {
+    e->uid_to_u.clear();
+    e->uid_to_u.reserve(size_t(e->T) * 2);
+    for (uint32_t u = e->t_cap; u-- > e->t_lo;)  // descending: the first occurrence in list order wins
+      if ((e->h_tlive[u >> 6] >> (u & 63u)) & 1ull) e->uid_to_u[e->h_tuid[u]] = u;
+    e->uid_map_valid = true;
+  }
+  std::vector<uint32_t> slots;
+  for (uint32_t k = 0; k < n; ++k) {
+    auto it = e->uid_to_u.find(uids[k]);
+    if (it == e->uid_to_u.end()) continue;
+    const uint32_t u = it->second;
+    e->uid_to_u.erase(it);
+    if (e->cfg_app_valid) {
+      uint64_t m = e->h_tmask[u];
+      while (m) {
+        e->cfg_app_count[__builtin_ctzll(m)]--;
+        m &= m - 1;
+      }
+    }
+    e->h_tmask[u] = 0;
+    e->h_created[u] = INT64_MIN;
+    e->h_tlive[u >> 6] &= ~(1ull << (u & 63u));
+    slots.push_back(u);
+  }
+  if (slots.empty()) return PM_OK;
+  std::vector<uint32_t> sorted = slots;
+  std::sort(sorted.begin(), sorted.end());
+  for (size_t g = e->groups.size(); g-- > 0;) {
+    const Group& gr = e->groups[g];
+    if (!gr.dead && gr.task != PM_NONE && std::binary_search(sorted.begin(), sorted.end(), gr.task))
+      dissolve_locked(e, uint32_t(g));
+  }
+  HIPCHK(e->d_tdel.ensure(slots.size()));
+  HIPCHK(hipMemcpyAsync(e->d_tdel.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, e->stream));
+  if (e->tplanes_dirty || !e->d_tplanes.p) {  // no planes yet: only the columns need the update
+    int32_t rc = ensure_task_planes(e);
+    if (rc) return rc;
+  }
+  launch_task_delete(e->d_tdel.p, uint32_t(slots.size()), e->d_tmask.p, reinterpret_cast<long long*>(e->d_created.p),
+                     e->d_tlive.p, e->d_tplanes.p, e->t_cap / 64u, uint32_t(e->cfgs.size()), e->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->T -= uint32_t(slots.size());
+  e->t_dead += uint32_t(slots.size());
+  while (e->t_lo < e->t_cap && !((e->h_tlive[e->t_lo >> 6] >> (e->t_lo & 63u)) & 1ull)) {  // dead rows in front
+    e->t_lo++;
+    e->t_dead--;
+  }
+  e->tprefix_dirty = true;
+  e->h_tprefix_valid = false;
+  if (n_deleted) *n_deleted = uint32_t(slots.size());
   return PM_OK;
 }
 
@@ -1709,7 +1964,7 @@ int32_t pm_get_groups(pm_engine* e, int32_t* group_of_worker, pm_group* groups, 
       groups[g].config = gr.cfg;
       groups[g].n_members = uint32_t(gr.members.size());
       groups[g].member_begin = off;
-      groups[g].task = gr.task;
+      groups[g].task = task_position(e, gr.task);
     }
     if (members) {
       std::vector<uint32_t> m = gr.members;  // BTreeSet<String> order = address rank
@@ -1749,8 +2004,13 @@ static int32_t run_match_per_task(pm_engine* e) {
   if (rc) return rc;
   const int variant = int(e->cfg.sweep_variant);
   const uint32_t n_planes = uint32_t(e->cfgs.size());
-  rc = ensure_sweep_outputs(e, e->T);
+  rc = ensure_task_planes(e);  // (the live prefix: results are reported by list position)
   if (rc) return rc;
+  const uint32_t R = e->t_cap - e->t_lo;  // rows of the sweep: the used part of the table, tombstones included
+  rc = ensure_sweep_outputs(e, R);
+  if (rc) return rc;
+  HIPCHK(e->d_first_c.ensure(std::max<uint32_t>(e->T, 1)));
+  HIPCHK(e->d_count_c.ensure(std::max<uint32_t>(e->T, 1)));
   HIPCHK(e->d_sel.ensure(std::max<uint32_t>(e->W, 1)));
   ensure_price_order(e);
   launch_eligible_selector(e->d_flags.p, e->d_group_of.p, e->d_compat.p, e->enabled, e->W,
@@ -1770,10 +2030,12 @@ static int32_t run_match_per_task(pm_engine* e) {
   if (variant != 1) {
     const size_t n_words = (size_t(e->W) + 63) / 64;
     HIPCHK(e->d_wplanes.ensure(std::max<size_t>(n_words * n_planes, 1)));
-    launch_build_planes(cols, e->W, n_planes, e->d_wplanes.p, e->stream);
+    launch_build_planes(cols, e->W, 0, e->W, uint32_t(n_words), n_planes, e->d_wplanes.p, e->stream);
   }
-  launch_pair_sweep(variant, e->d_tmask.p, e->T, cols, e->d_wplanes.p, e->W, n_planes, e->d_first.p, e->d_count.p,
-                    e->stream);
+  launch_pair_sweep(variant, e->d_tmask.p + e->t_lo, R, cols, e->d_wplanes.p, 0, e->W, uint32_t((size_t(e->W) + 63) / 64),
+                    n_planes, e->d_first.p, e->d_count.p, e->stream);
+  launch_task_compact(e->d_first.p, e->d_count.p, e->t_lo, e->t_cap, e->d_tlive.p, e->d_tprefix.p, e->d_first_c.p,
+                      e->d_count_c.p, e->stream);
   HIPCHK(hipGetLastError());
   return PM_OK;
 }
@@ -1785,9 +2047,9 @@ int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candida
   int32_t rc = run_match_per_task(e);
   if (rc) return rc;
   if (best_worker && e->T)
-    HIPCHK(hipMemcpyAsync(best_worker, e->d_first.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(best_worker, e->d_first_c.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
   if (candidate_count && e->T)
-    HIPCHK(hipMemcpyAsync(candidate_count, e->d_count.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(candidate_count, e->d_count_c.p, size_t(e->T) * 4, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   if (best_worker && e->any_price)
     for (uint32_t t = 0; t < e->T; ++t)
@@ -1804,8 +2066,8 @@ int32_t pm_match_per_task_device(pm_engine* e, uint64_t* best_ptr, uint64_t* cou
   int32_t rc = run_match_per_task(e);
   if (rc) return rc;
   if (e->own_stream) HIPCHK(hipStreamSynchronize(e->stream));  // a caller-supplied stream orders the consumer itself
-  *best_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_first.p));
-  *count_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_count.p));
+  *best_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_first_c.p));
+  *count_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_count_c.p));
   *n = e->T;
   return PM_OK;
 }
@@ -1817,10 +2079,10 @@ int32_t pm_newest_task(pm_engine* e, uint32_t* task_idx) {
   if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
   *task_idx = PM_NONE;
   if (e->T == 0) return PM_OK;
-  const uint32_t nb = std::min<uint32_t>(1024, (e->T + 255u) / 256u);
+  const uint32_t nb = std::min<uint32_t>(1024, (e->t_cap - e->t_lo + 255u) / 256u);
   HIPCHK(e->d_nb_idx.ensure(nb));
   HIPCHK(e->d_nb_val.ensure(nb));
-  launch_newest(e->d_created.p, e->T, e->d_nb_idx.p, e->d_nb_val.p, nb, e->stream);
+  launch_newest(e->d_created.p, e->t_lo, e->t_cap, e->d_nb_idx.p, e->d_nb_val.p, nb, e->stream);
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> bi(nb);
   std::vector<long long> bv(nb);
@@ -1836,7 +2098,7 @@ int32_t pm_newest_task(pm_engine* e, uint32_t* task_idx) {
       bval = bv[k];
     }
   }
-  *task_idx = best;
+  *task_idx = task_position(e, best);
   return PM_OK;
 }
 
@@ -2085,7 +2347,7 @@ int32_t pm_dist_tick_end(pm_engine* e, pm_stats* stats) {
   e->dist_phase = 0;
   if (e->dist_world > 1) {
     launch_table_scatter(e->d_table_x.p, e->d_xrow.p, e->W, e->d_table.p, e->d_task_col.p, e->d_g_task_next.p,
-                         e->stream);
+                         e->d_tlive.p, e->d_tprefix.p, e->stream);
     HIPCHK(hipGetLastError());
   }
   int32_t rc = absorb_groups(e);

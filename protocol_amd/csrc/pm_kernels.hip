@@ -181,12 +181,12 @@ __device__ __forceinline__ void pair_fold(uint32_t* __restrict__ first, uint32_t
 // compare.  Kept as the straightforward kernel the bit-sliced one is checked against.
 __global__ __launch_bounds__(256) void pair_sweep_scalar_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                 const uint64_t* __restrict__ col_mask,
-                                                                uint32_t n_cols, uint32_t chunk,
+                                                                uint32_t c_begin, uint32_t c_end, uint32_t chunk,
                                                                 uint32_t* __restrict__ first_out,
                                                                 uint32_t* __restrict__ count_out, uint32_t atomic) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t c0 = blockIdx.y * chunk;
-  const uint32_t c1 = min(n_cols, c0 + chunk);
+  const uint32_t c0 = c_begin + blockIdx.y * chunk;
+  const uint32_t c1 = min(c_end, c0 + chunk);
   const uint64_t sel = r < R ? row_sel[r] : 0ull;
   uint32_t first = PM_NONE, cnt = 0;
   for (uint32_t c = c0; c < c1; ++c) {
@@ -201,13 +201,14 @@ __global__ __launch_bounds__(256) void pair_sweep_scalar_kernel(const uint64_t* 
 // rank-th hit of a row (seeded chooser): second pass over the same pairs.
 __global__ __launch_bounds__(256) void pair_select_scalar_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                  const uint64_t* __restrict__ col_mask,
-                                                                 uint32_t n_cols, const uint32_t* __restrict__ rank,
+                                                                 uint32_t c_begin, uint32_t c_end,
+                                                                 const uint32_t* __restrict__ rank,
                                                                  uint32_t* __restrict__ out) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   const uint64_t sel = r < R ? row_sel[r] : 0ull;
   uint32_t want = r < R ? rank[r] : PM_NONE;
   uint32_t res = PM_NONE, seen = 0;
-  for (uint32_t c = 0; c < n_cols; ++c) {
+  for (uint32_t c = c_begin; c < c_end; ++c) {
     const bool hit = (col_mask[c] & sel) != 0ull;
     res = (hit && seen == want) ? c : res;
     seen += hit;
@@ -220,18 +221,21 @@ __global__ __launch_bounds__(256) void pair_select_scalar_kernel(const uint64_t*
 // bit c of the masks of columns 64j..64j+63, so one 64-bit AND/OR evaluates 64 (row, col) pairs.
 // rows live in lanes; the plane words of a chunk are staged in LDS and read as broadcasts.
 
+// The swept axis lives in a fixed-capacity index space (the task table grows downwards from its capacity, see
+// pm_engine.cpp): plane b is planes[b * stride .. ), word j holds columns 64j..64j+63; kernels work on a word
+// range [w_begin, w_end) and report absolute column indices.
 __global__ __launch_bounds__(256) void build_planes_kernel(const uint64_t* __restrict__ col_mask, uint32_t n_cols,
-                                                           uint32_t n_words, uint32_t n_planes,
-                                                           uint64_t* __restrict__ planes) {
+                                                           uint32_t w_begin, uint32_t w_end, uint32_t stride,
+                                                           uint32_t n_planes, uint64_t* __restrict__ planes) {
   // one wave per 64-column word; lane l owns column 64*j + l; __ballot gives the plane word.
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t j = (blockIdx.x * 256u + threadIdx.x) >> 6;
-  if (j >= n_words) return;
+  const uint32_t j = w_begin + ((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (j >= w_end) return;
   const uint32_t c = j * 64u + lane;
   const uint64_t m = c < n_cols ? col_mask[c] : 0ull;
   for (uint32_t b = 0; b < n_planes; ++b) {
     const uint64_t word = __ballot((m >> b) & 1ull);
-    if (lane == 0) planes[(size_t)b * n_words + j] = word;
+    if (lane == 0) planes[(size_t)b * stride + j] = word;
   }
 }
 
@@ -239,21 +243,22 @@ __global__ __launch_bounds__(256) void build_planes_kernel(const uint64_t* __res
 // [y * words_per_split, (y + 1) * words_per_split), staged through LDS in pieces of words_per_piece.
 __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                 const uint64_t* __restrict__ planes,
-                                                                uint32_t n_words, uint32_t n_planes,
-                                                                uint32_t words_per_split, uint32_t words_per_piece,
+                                                                uint32_t stride, uint32_t w_begin, uint32_t w_end,
+                                                                uint32_t n_planes, uint32_t words_per_split,
+                                                                uint32_t words_per_piece,
                                                                 uint32_t* __restrict__ first_out,
                                                                 uint32_t* __restrict__ count_out, uint32_t atomic) {
   extern __shared__ uint64_t s_pl[];  // [n_planes][words_per_piece]
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t w0 = blockIdx.y * words_per_split;
-  const uint32_t w1 = min(n_words, w0 + words_per_split);
+  const uint32_t w0 = w_begin + blockIdx.y * words_per_split;
+  const uint32_t w1 = min(w_end, w0 + words_per_split);
   const uint64_t sel = r < R ? row_sel[r] : 0ull;
   uint32_t first = PM_NONE, cnt = 0;
   for (uint32_t j0 = w0; j0 < w1; j0 += words_per_piece) {
     const uint32_t nj = min(words_per_piece, w1 - j0);
     __syncthreads();  // the previous piece has been consumed
     for (uint32_t b = 0; b < n_planes; ++b)
-      for (uint32_t j = threadIdx.x; j < nj; j += 256u) s_pl[b * words_per_piece + j] = planes[(size_t)b * n_words + j0 + j];
+      for (uint32_t j = threadIdx.x; j < nj; j += 256u) s_pl[b * words_per_piece + j] = planes[(size_t)b * stride + j0 + j];
     __syncthreads();
     for (uint32_t j = 0; j < nj; ++j) {
       uint64_t hits = 0;
@@ -272,8 +277,8 @@ __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* 
 
 __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                  const uint64_t* __restrict__ planes,
-                                                                 uint32_t n_words, uint32_t n_planes,
-                                                                 const uint32_t* __restrict__ rank,
+                                                                 uint32_t stride, uint32_t w_begin, uint32_t w_end,
+                                                                 uint32_t n_planes, const uint32_t* __restrict__ rank,
                                                                  uint32_t* __restrict__ out) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= R) return;
@@ -281,12 +286,12 @@ __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t*
   uint32_t want = rank[r];
   uint32_t res = PM_NONE;
   if (want != PM_NONE) {
-    for (uint32_t j = 0; j < n_words; ++j) {
+    for (uint32_t j = w_begin; j < w_end; ++j) {
       uint64_t hits = 0, s = sel;
       while (s) {
         const uint32_t b = __builtin_ctzll(s);
         s &= s - 1;
-        if (b < n_planes) hits |= planes[(size_t)b * n_words + j];
+        if (b < n_planes) hits |= planes[(size_t)b * stride + j];
       }
       const uint32_t pc = __popcll(hits);
       if (want < pc) {
@@ -298,6 +303,55 @@ __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t*
     }
   }
   out[r] = res;
+}
+
+// ---- task table deltas (the table grows downwards: new tasks sit in front of the old ones)
+// live prefix: prefix[j] = live tasks in words [w_begin, j); one workgroup, 64-word passes
+__global__ __launch_bounds__(64) void task_prefix_kernel(const uint64_t* __restrict__ live, uint32_t w_begin,
+                                                         uint32_t w_end, uint32_t* __restrict__ prefix) {
+  const uint32_t lane = threadIdx.x;
+  uint32_t acc = 0;
+  for (uint32_t j0 = w_begin; j0 < w_end; j0 += 64u) {
+    const uint32_t j = j0 + lane;
+    const uint32_t cnt = j < w_end ? (uint32_t)__popcll(live[j]) : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if ((int)lane >= o) incl += up;
+    }
+    if (j < w_end) prefix[j] = acc + incl - cnt;
+    acc += __shfl(incl, 63, 64);
+  }
+}
+// deleted tasks: clear the mask, the live bit, the created_at key and the task's bit in every plane
+__global__ __launch_bounds__(256) void task_delete_kernel(const uint32_t* __restrict__ slots, uint32_t n,
+                                                          uint64_t* __restrict__ tmask, long long* __restrict__ created,
+                                                          uint64_t* __restrict__ live, uint64_t* __restrict__ planes,
+                                                          uint32_t stride, uint32_t n_planes) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t u = slots[k];
+  const uint64_t bit = 1ull << (u & 63u);
+  tmask[u] = 0ull;
+  created[u] = INT64_MIN;
+  atomicAnd((unsigned long long*)&live[u >> 6], ~bit);
+  for (uint32_t b = 0; b < n_planes; ++b) atomicAnd((unsigned long long*)&planes[(size_t)b * stride + (u >> 6)], ~bit);
+}
+// per-task results of the north_star orientation, from table slots to positions in get_all_tasks order
+__global__ __launch_bounds__(256) void task_compact_kernel(const uint32_t* __restrict__ first_u,
+                                                           const uint32_t* __restrict__ count_u, uint32_t u_begin,
+                                                           uint32_t u_end, const uint64_t* __restrict__ live,
+                                                           const uint32_t* __restrict__ prefix,
+                                                           uint32_t* __restrict__ first_out,
+                                                           uint32_t* __restrict__ count_out) {
+  const uint32_t u = u_begin + blockIdx.x * 256u + threadIdx.x;
+  if (u >= u_end) return;
+  const uint64_t w = live[u >> 6];
+  if (!((w >> (u & 63u)) & 1ull)) return;
+  const uint32_t pos = prefix[u >> 6] + (uint32_t)__popcll(w & ((1ull << (u & 63u)) - 1ull));
+  first_out[pos] = first_u[u - u_begin];
+  count_out[pos] = count_u[u - u_begin];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,6 +427,11 @@ __global__ __launch_bounds__(256) void group_rank_kernel(const int32_t* __restri
   by_rank[off + idx] = w;
 }
 
+__device__ __forceinline__ uint32_t task_position(const uint64_t* __restrict__ live, const uint32_t* __restrict__ prefix,
+                                                  uint32_t u) {
+  return prefix[u >> 6] + (uint32_t)__popcll(live[u >> 6] & ((1ull << (u & 63u)) - 1ull));
+}
+
 // Claim (SETNX, scheduler_impl.rs:74 / mod.rs:471-476) + publish row.  Every member of a group
 // computed the same choice, so the group's task word is written with the same value by all.
 __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
@@ -395,7 +454,9 @@ __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
     }
     const uint32_t n = p.g_n[g], off = p.g_off[g];
     const uint32_t idx = p.rank_in_group[w];
-    a.task = t;
+    // published: the task's position in get_all_tasks order (live tasks in front of it in the table); a row that
+    // goes into the multi-GPU exchange keeps the handle — table_scatter_kernel needs it for the group's claim
+    a.task = (t == PM_NONE || p.rows) ? t : task_position(p.t_live, p.t_prefix, t);
     a.group_slot = (uint32_t)g;
     a.group_index = idx;
     a.group_size = n;
@@ -417,19 +478,22 @@ __global__ __launch_bounds__(256) void table_scatter_kernel(const pm_assignment*
                                                             const uint32_t* __restrict__ xrow, uint32_t W,
                                                             pm_assignment* __restrict__ table,
                                                             uint32_t* __restrict__ task_col,
-                                                            uint32_t* __restrict__ g_task_next) {
+                                                            uint32_t* __restrict__ g_task_next,
+                                                            const uint64_t* __restrict__ t_live,
+                                                            const uint32_t* __restrict__ t_prefix) {
   const uint32_t w = blockIdx.x * 256u + threadIdx.x;
   if (w >= W) return;
-  const pm_assignment a = x[xrow[w]];
+  pm_assignment a = x[xrow[w]];
+  if (a.group_slot != PM_NONE && a.task != PM_NONE) g_task_next[a.group_slot] = a.task;  // exchanged rows carry handles
+  if (a.task != PM_NONE) a.task = task_position(t_live, t_prefix, a.task);
   table[w] = a;
   task_col[w] = a.task;
-  if (a.group_slot != PM_NONE && a.task != PM_NONE) g_task_next[a.group_slot] = a.task;
 }
 
 // ------------------------------------------------------------------------------------------------
 // NewestTaskPlugin: argmax (created_at, index) — LDS-staged wavefront argmax, last max wins.
 
-__global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__ created_at, uint32_t T,
+__global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__ created_at, uint32_t t_begin, uint32_t T,
                                                      unsigned long long* __restrict__ best_key,
                                                      uint32_t* __restrict__ best_idx_by_block,
                                                      long long* __restrict__ best_val_by_block) {
@@ -437,8 +501,9 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
   __shared__ uint32_t s_i[4];
   long long bv = INT64_MIN;
   uint32_t bi = PM_NONE;
-  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < T; t += gridDim.x * 256u) {
+  for (uint32_t t = t_begin + blockIdx.x * 256u + threadIdx.x; t < T; t += gridDim.x * 256u) {
     const long long v = created_at[t];
+    if (v == INT64_MIN) continue;    // a deleted / unused table slot
     if (bi == PM_NONE || v >= bv) {  // ascending t within a thread: >= keeps the last max
       bv = v;
       bi = t;
@@ -2517,10 +2582,11 @@ void launch_eligible_selector(const uint32_t* wflags, const int32_t* group_of, c
                      enabled, W, shard, my_rank, sel);
 }
 void launch_table_scatter(const pm_assignment* x, const uint32_t* xrow, uint32_t W, pm_assignment* table,
-                          uint32_t* task_col, uint32_t* g_task_next, hipStream_t s) {
+                          uint32_t* task_col, uint32_t* g_task_next, const uint64_t* t_live, const uint32_t* t_prefix,
+                          hipStream_t s) {
   if (W == 0) return;
   hipLaunchKernelGGL(table_scatter_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, x, xrow, W, table, task_col,
-                     g_task_next);
+                     g_task_next, t_live, t_prefix);
 }
 void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint32_t* g_off, const uint32_t* members,
                        const uint32_t* addr_rank, uint32_t W, uint32_t* rank_in_group, uint32_t* by_rank,
@@ -2534,37 +2600,39 @@ void launch_claim_publish(const ClaimArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(claim_publish_kernel, dim3((a.R + 255u) / 256u), dim3(256), 0, s, a);
 }
 
-void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t n_planes, uint64_t* planes,
-                         hipStream_t s) {
-  const uint32_t n_words = (n_cols + 63u) / 64u;
-  if (n_words == 0) return;
-  hipLaunchKernelGGL(build_planes_kernel, dim3((n_words * 64u + 255u) / 256u), dim3(256), 0, s, col_mask, n_cols,
-                     n_words, n_planes, planes);
+// A swept axis is the column range [c_begin, c_end) of an index space of n_cols columns whose bit planes have a
+// stride of `stride` words (c_begin need not be word-aligned: the bits below it are zero in every plane).
+void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t c_begin, uint32_t c_end, uint32_t stride,
+                         uint32_t n_planes, uint64_t* planes, hipStream_t s) {
+  const uint32_t w0 = c_begin / 64u, w1 = (c_end + 63u) / 64u;
+  if (w1 <= w0) return;
+  hipLaunchKernelGGL(build_planes_kernel, dim3(((w1 - w0) * 64u + 255u) / 256u), dim3(256), 0, s, col_mask, n_cols, w0,
+                     w1, stride, n_planes, planes);
 }
 
-// Pair sweep: rows x cols -> first hit + hit count per row.
+// Pair sweep: rows x cols -> first hit (absolute column index) + hit count per row.
 void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
-                       const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, uint32_t* first, uint32_t* count,
-                       hipStream_t s) {
+                       const uint64_t* planes, uint32_t c_begin, uint32_t c_end, uint32_t stride, uint32_t n_planes,
+                       uint32_t* first, uint32_t* count, hipStream_t s) {
   if (R == 0) return;
   const uint32_t rb = (R + 255u) / 256u;
   // enough workgroups to cover 256 CUs several times over
   const uint32_t want_split = (2048u + rb - 1u) / rb;
-  if (variant == 1) {
-    uint32_t n_split = want_split < (n_cols ? n_cols : 1u) ? want_split : (n_cols ? n_cols : 1u);
-    uint32_t chunk = (n_cols + n_split - 1u) / n_split;
-    if (chunk == 0) chunk = 1;
-    n_split = n_cols ? (n_cols + chunk - 1u) / chunk : 1u;
-    if (n_split > 1u) hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
-    hipLaunchKernelGGL(pair_sweep_scalar_kernel, dim3(rb, n_split), dim3(256), 0, s, row_sel, R, col_mask, n_cols,
-                       chunk, first, count, n_split > 1u ? 1u : 0u);
-    return;
-  }
-  const uint32_t n_words = (n_cols + 63u) / 64u;
-  if (n_words == 0) {
+  const uint32_t n_cols = c_end > c_begin ? c_end - c_begin : 0u;
+  if (n_cols == 0) {
     hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
     return;
   }
+  if (variant == 1) {
+    uint32_t n_split = want_split < n_cols ? want_split : n_cols;
+    const uint32_t chunk = (n_cols + n_split - 1u) / n_split;
+    n_split = (n_cols + chunk - 1u) / chunk;
+    if (n_split > 1u) hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
+    hipLaunchKernelGGL(pair_sweep_scalar_kernel, dim3(rb, n_split), dim3(256), 0, s, row_sel, R, col_mask, c_begin,
+                       c_end, chunk, first, count, n_split > 1u ? 1u : 0u);
+    return;
+  }
+  const uint32_t w0 = c_begin / 64u, w1 = (c_end + 63u) / 64u, n_words = w1 - w0;
   uint32_t n_split = want_split < n_words ? want_split : n_words;
   const uint32_t wps = (n_words + n_split - 1u) / n_split;
   n_split = (n_words + wps - 1u) / wps;
@@ -2572,28 +2640,46 @@ void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const u
   const uint32_t wpp = wps < lds_cap_words ? wps : lds_cap_words;
   const size_t lds = (size_t)n_planes * wpp * sizeof(uint64_t);
   if (n_split > 1u) hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
-  hipLaunchKernelGGL(pair_sweep_planes_kernel, dim3(rb, n_split), dim3(256), lds, s, row_sel, R, planes, n_words,
-                     n_planes, wps, wpp, first, count, n_split > 1u ? 1u : 0u);
+  hipLaunchKernelGGL(pair_sweep_planes_kernel, dim3(rb, n_split), dim3(256), lds, s, row_sel, R, planes, stride, w0,
+                     w1, n_planes, wps, wpp, first, count, n_split > 1u ? 1u : 0u);
 }
 
 void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
-                        const uint64_t* planes, uint32_t n_cols, uint32_t n_planes, const uint32_t* rank,
-                        uint32_t* out, hipStream_t s) {
+                        const uint64_t* planes, uint32_t c_begin, uint32_t c_end, uint32_t stride, uint32_t n_planes,
+                        const uint32_t* rank, uint32_t* out, hipStream_t s) {
   if (R == 0) return;
   const uint32_t rb = (R + 255u) / 256u;
   if (variant == 1) {
-    hipLaunchKernelGGL(pair_select_scalar_kernel, dim3(rb), dim3(256), 0, s, row_sel, R, col_mask, n_cols, rank, out);
+    hipLaunchKernelGGL(pair_select_scalar_kernel, dim3(rb), dim3(256), 0, s, row_sel, R, col_mask, c_begin, c_end,
+                       rank, out);
   } else {
-    const uint32_t n_words = (n_cols + 63u) / 64u;
-    hipLaunchKernelGGL(pair_select_planes_kernel, dim3(rb), dim3(256), 0, s, row_sel, R, planes, n_words,
-                       n_planes, rank, out);
+    hipLaunchKernelGGL(pair_select_planes_kernel, dim3(rb), dim3(256), 0, s, row_sel, R, planes, stride,
+                       c_begin / 64u, (c_end + 63u) / 64u, n_planes, rank, out);
   }
 }
 
-void launch_newest(const int64_t* created_at, uint32_t T, uint32_t* idx_by_block, long long* val_by_block,
-                   uint32_t n_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(newest_kernel, dim3(n_blocks), dim3(256), 0, s, created_at, T, (unsigned long long*)nullptr,
-                     idx_by_block, val_by_block);
+void launch_task_prefix(const uint64_t* live, uint32_t w_begin, uint32_t w_end, uint32_t* prefix, hipStream_t s) {
+  if (w_end <= w_begin) return;
+  hipLaunchKernelGGL(task_prefix_kernel, dim3(1), dim3(64), 0, s, live, w_begin, w_end, prefix);
+}
+void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, long long* created, uint64_t* live,
+                        uint64_t* planes, uint32_t stride, uint32_t n_planes, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(task_delete_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, slots, n, tmask, created, live,
+                     planes, stride, n_planes);
+}
+void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint32_t u_begin, uint32_t u_end,
+                         const uint64_t* live, const uint32_t* prefix, uint32_t* first_out, uint32_t* count_out,
+                         hipStream_t s) {
+  if (u_end <= u_begin) return;
+  hipLaunchKernelGGL(task_compact_kernel, dim3((u_end - u_begin + 255u) / 256u), dim3(256), 0, s, first_u, count_u,
+                     u_begin, u_end, live, prefix, first_out, count_out);
+}
+
+void launch_newest(const int64_t* created_at, uint32_t t_begin, uint32_t t_end, uint32_t* idx_by_block,
+                   long long* val_by_block, uint32_t n_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(newest_kernel, dim3(n_blocks), dim3(256), 0, s, created_at, t_begin, t_end,
+                     (unsigned long long*)nullptr, idx_by_block, val_by_block);
 }
 
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s) {

@@ -91,7 +91,7 @@ EXPORTS = [
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
-    "pm_append_workers", "pm_set_addr_ranks", "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
+    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_delete", "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
     "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
 ]
 
@@ -143,6 +143,8 @@ def lib() -> C.CDLL:
         L.pm_device_task_column.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
         L.pm_append_workers.argtypes = [vp, C.POINTER(WorkerSoa), C.POINTER(u32)]
         L.pm_set_addr_ranks.argtypes = [vp, vp, u32]
+        L.pm_tasks_insert_front.argtypes = [vp, C.POINTER(TaskSoa)]
+        L.pm_tasks_delete.argtypes = [vp, vp, u32, C.POINTER(u32)]
         L.pm_set_stream.argtypes = [vp, vp]
         L.pm_dist_configure.argtypes = [vp, u32, u32, vp]
         L.pm_dist_tick_begin.argtypes = [vp]
@@ -272,18 +274,36 @@ class Engine:
         r = _arr(ranks, np.uint32)
         check(lib().pm_set_addr_ranks(self._h, r.ctypes.data if len(r) else None, len(r)))
 
-    def upload_tasks(self, topo_mask, created_at, uid=None):
+    @staticmethod
+    def _task_soa(topo_mask, created_at, uid):
         tm, ca = _arr(topo_mask, np.uint64), _arr(created_at, np.int64)
         soa = TaskSoa()
         soa.n = len(tm)
-        soa.topo_mask = tm.ctypes.data
-        soa.created_at = ca.ctypes.data
+        soa.topo_mask = tm.ctypes.data if len(tm) else None
+        soa.created_at = ca.ctypes.data if len(ca) else None
         u = None
         if uid is not None:
             u = _arr(uid, np.uint64)
-            soa.uid = u.ctypes.data
+            soa.uid = u.ctypes.data if len(u) else None
+        return soa, (tm, ca, u)
+
+    def upload_tasks(self, topo_mask, created_at, uid=None):
+        soa, keep = self._task_soa(topo_mask, created_at, uid)
         check(lib().pm_upload_tasks(self._h, C.byref(soa)))
         self.T = soa.n
+
+    def tasks_insert_front(self, topo_mask, created_at, uid=None):
+        """new tasks, newest first; they sort in front of the table (on_task_created)"""
+        soa, keep = self._task_soa(topo_mask, created_at, uid)
+        check(lib().pm_tasks_insert_front(self._h, C.byref(soa)))
+        self.T += soa.n
+
+    def tasks_delete(self, uids) -> int:
+        u = _arr(uids, np.uint64)
+        n = C.c_uint32(0)
+        check(lib().pm_tasks_delete(self._h, u.ctypes.data if len(u) else None, len(u), C.byref(n)))
+        self.T -= n.value
+        return n.value
 
     # ---- events
     def on_worker_status(self, worker: int, flags_new: int, dead: bool):

@@ -451,8 +451,11 @@ def test_engine_argument_errors():
     eng.close()
 
 
-def test_streaming_churn_parity():
-    """BASELINE configs[4] in miniature: every tick new tasks arrive (newest first), ~1 % of the workers die
+@pytest.mark.parametrize("deltas", [False, True])
+def test_streaming_churn_parity(deltas):
+    """(deltas: the task table is maintained with pm_tasks_insert_front / pm_tasks_delete instead of re-uploading
+    the snapshot every tick — same results, and claimed tasks keep their binding without any look-up)
+    BASELINE configs[4] in miniature: every tick new tasks arrive (newest first), ~1 % of the workers die
     (whole group dissolved) or join, one old task is deleted (its groups dissolve); the engine's incremental
     state must track the oracle's tick by tick — existing groups are sticky (Appendix A)."""
     rng = np.random.default_rng(42)
@@ -480,6 +483,7 @@ def test_streaming_churn_parity():
             if claimed:
                 keep[claimed[tick % len(claimed)]] = False
         old_to_new = np.where(keep, n_new + np.cumsum(keep) - 1, -1)
+        uid_prev = uid
         tasks = np.concatenate([new_rows, tasks[keep]])
         masks = np.concatenate([masks[pick], masks[keep]])
         created = np.concatenate([new_rows["created_at"], created[keep]])
@@ -487,7 +491,13 @@ def test_streaming_churn_parity():
         next_uid += n_new
         st.set_tasks(tasks)
         st.remap_tasks(old_to_new)
-        eng.upload_tasks(masks, created, uid)
+        if deltas:
+            if not keep.all():
+                assert eng.tasks_delete(uid_prev[~keep]) == int((~keep).sum())
+            eng.tasks_insert_front(masks[:n_new], created[:n_new], uid[:n_new])
+            assert eng.T == len(masks)
+        else:
+            eng.upload_tasks(masks, created, uid)
         # ---- worker churn: ~0.5 % die, ~0.5 % join
         alive = np.nonzero(st.nodes["status"] == 2)[0]
         for w in rng.choice(alive, size=15, replace=False):
@@ -510,3 +520,49 @@ def test_streaming_churn_parity():
         assert sorted(oracle_groups(st)) == sorted(engine_groups(eng)), f"tick {tick}"
         assert s["host_resolved_steps"] == 0
     eng.close()
+
+
+def test_task_deltas_equal_a_fresh_upload():
+    """pm_tasks_insert_front / pm_tasks_delete against an engine that re-uploads the whole snapshot: the same
+    published table (task positions in the CURRENT list), the same groups, the same per-task bids and newest task —
+    through several rounds, including a growth of the table's index space and deletions at the front."""
+    rng = np.random.default_rng(77)
+    sw = make_swarm(15, 3000, 1500)
+    a, b = E.Engine(), E.Engine()
+    host.load_swarm(a, sw)
+    host.load_swarm(b, sw)
+    masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+    next_uid = 1 << 41
+    with pytest.raises(E.EngineError):                       # not newer than the newest task: not a front insertion
+        a.tasks_insert_front(masks[:1], created[:1], np.array([7], dtype=np.uint64))
+    for rnd in range(6):
+        a.tick()
+        b.tick()
+        ta = [a.lookup(w).task for w in range(sw.W)]
+        assert ta == [b.lookup(w).task for w in range(sw.W)], rnd
+        assert engine_groups(a) == engine_groups(b), rnd
+        assert a.newest_task() == b.newest_task()
+        ba, ca = a.match_per_task()
+        bb, cb = b.match_per_task()
+        assert np.array_equal(ba, bb) and np.array_equal(ca, cb), rnd
+        # ---- delta: delete a few tasks (some claimed, the two in front), insert a batch of newer ones
+        claimed = sorted(set(t for t in ta if t != NONE))
+        kill = set(int(x) for x in rng.choice(len(masks), size=25, replace=False)) | {0, 1} | set(claimed[:3])
+        keep = np.ones(len(masks), dtype=bool)
+        keep[list(kill)] = False
+        n_new = 70000 if rnd == 2 else 40                     # round 2 outgrows the index space of the table
+        pick = rng.integers(0, len(masks), n_new)
+        new_masks = masks[pick]
+        new_created = int(created.max()) + 1 + np.arange(n_new)[::-1]
+        new_uid = np.arange(next_uid, next_uid + n_new, dtype=np.uint64)
+        next_uid += n_new
+        assert a.tasks_delete(uid[~keep]) == int((~keep).sum())
+        assert a.tasks_delete(uid[~keep]) == 0               # unknown ids are ignored
+        a.tasks_insert_front(new_masks, new_created, new_uid)
+        masks = np.concatenate([new_masks, masks[keep]])
+        created = np.concatenate([new_created, created[keep]])
+        uid = np.concatenate([new_uid, uid[keep]])
+        b.upload_tasks(masks, created, uid)
+        assert a.T == b.T == len(masks)
+    a.close()
+    b.close()
