@@ -5,22 +5,24 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): 100k tasks x 10k workers per GPU, mixed gpu/mem/storage/cpu
-constraints, seeded synthetic swarm (protocol_amd/swarm.py), tables resident in HBM before the timed
-region.  One step = one full-swarm match from a cold group state through the C ABI (pm_tick):
-compat sweep (W x C) -> greedy proximity carve -> solo merge -> T x W pair sweep + claim -> published
-assignment table.  For N > 1 the swarm is N x 10k workers hash-sharded by address (splitmix64(address)
-% N), tasks replicated, each shard an independent carve domain, and every step ends with the one
-exchange the path has: an RCCL all-gather of the per-worker task table shards.
+One step = one full-swarm match from a cold group state through the C ABI: compat sweep (W x C) -> greedy
+proximity carve -> solo merge -> T x W pair sweep + claim -> published assignment table, tables resident in HBM
+before the timed region.   value = task x worker pair-evals per second = T * W * K / t  (max over ranks).
 
-value = whole-job task x worker pair-evals per second = N * T * W_local * K / t  (max over ranks).
-The JSON line also carries:
-  roofline     — the dominant kernel (carve_kernel) against the HBM roofline with the algorithmic-bytes
-                 convention of SURVEY.md §8(d) (W_remaining*20 + 8 bytes per carve step), duration from
-                 hipEvents recorded around the launches on the engine's own stream;
-  kernels      — the same for the compat sweep and the pair sweep (+ VALU ceiling for the sweep);
-  cpu_baseline — the C oracle (a port of the reference path; oracle/) timed on this box's host cores,
-                 rank 0, N=1 only, on a stated sample.
+N = 1   BASELINE.json configs[1]: 100k tasks x 10k workers, mixed gpu/mem/storage/cpu constraints (pm_tick).
+        The line also carries, each from a few extra steps:
+          configs2   configs[2] (1M tasks x 100k workers, Zipf): ms per match, carve / proposer / sweep split, the
+                     proposer against the FP64 vector peak, the sweep against the VALU ceiling
+          churn      configs[4] on one GPU: 100k workers, per tick +10k tasks (pm_tasks_insert_front), 1 % of the
+                     workers leave (pm_on_worker_status) and 1 % brand-new ones join (pm_append_workers)
+          per_task   the north_star orientation (pm_match_per_task) timed
+          roofline   the dominant kernel sequence (carve) with SURVEY section 8(d)'s algorithmic bytes against HBM —
+                     and, because the carve is a dependent chain, `chain`: achieved time per step against a floor
+          cpu_baseline  the C oracle (a port of the reference path) on this box's host cores: reference-shaped on
+                     one thread, the pair sweep on all cores, and a best-effort CPU variant
+N > 1   BASELINE.json configs[3]: the SAME 1M x 100k swarm on every rank (strong scaling).  Workers are owned by
+        hash(address) % N; the validation chain is replicated, the proposal sweeps and the pair sweep are sharded,
+        two kinds of RCCL all-gather per tick (protocol_amd/dist.py).  Every rank ends with identical groups.
 """
 from __future__ import annotations
 
@@ -36,27 +38,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9    # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = lane-ops per second
+OPS_PER_PAIR_EVAL = 20.0                # ~20 integer ops per (task, worker) predicate + fold
+FP64_VECTOR_TFLOPS = 78.6               # half the FP32 vector rate (157.3 TFLOPS spec)
+FLOP_PER_KEY = 70.0                     # one Haversine term: 2 polynomial sines (fma chains) + products
+LDS_ROUND_TRIP_CYC, CLOCK_GHZ = 50.0, 2.4   # MI355X_MICROARCH.md: ds_read issue->use ~50 cycles
 
 
-def shard_swarm(sw, rank: int, world: int):
-    """hash-shard the workers: shard = splitmix64(address) % world (protocol_amd/dist.py)."""
-    from protocol_amd.dist import shard_of
-    if world == 1:
-        return sw, np.arange(sw.W)
-    idx = np.nonzero(shard_of(sw.address, world) == rank)[0]
-    import copy
-    s = copy.copy(sw)
-    for k in ("address", "status", "has_p2p", "has_specs", "has_gpu", "gpu_count_some", "gpu_mem_some",
-              "gpu_model_some", "has_cpu", "cpu_cores_some", "ram_some", "storage_some", "gpu_count", "gpu_mem_mb",
-              "gpu_model_id", "cpu_cores", "ram_mb", "storage_gb", "price", "has_loc", "lat", "lon"):
-        setattr(s, k, getattr(sw, k)[idx])
-    return s, idx
+def med(stats, k):
+    return statistics.median(s[k] for s in stats)
 
 
-def cpu_baseline(sw, budget_s: float = 30.0) -> dict:
-    """Time the oracle (kind "port": C restatement of the reference path, single thread) on this host."""
+def cpu_baseline(sw, budget_s: float = 25.0) -> dict:
+    """Time the oracle (kind "port": C restatement of the reference path) on this host."""
     from oracle import oracle_ffi as orc
     nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
     st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=True)
@@ -96,6 +91,29 @@ def cpu_baseline(sw, budget_s: float = 30.0) -> dict:
                  "sample": (f"pair sweep on {n_thr} threads ({t_mt} of {sw.T} tasks, scaled: {t_sweep_mt:.2f} s) + the "
                             f"sequential compat/carve/merge of the 1-thread run ({t_compat + t_carve:.2f} s)"),
                  "seconds_full_match_est": t_full_mt}
+    # best-effort CPU (so the GPU speed-up is not overstated): predicate evaluated once per
+    # (configuration, node), distances cached per seed, and the pair sweep on interned masks — first applicable task
+    # and count per configuration bit (a group's selector has one bit), then one look-up per worker
+    st2 = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False)
+    t0 = time.perf_counter()
+    st2.try_form_new_groups()
+    st2.try_merge_solo_groups()
+    t_carve_be = time.perf_counter() - t0
+    tm = sw.task_masks()
+    t0 = time.perf_counter()
+    first = np.full(len(sw.configs), 0xFFFFFFFF, dtype=np.uint32)
+    for c in range(len(sw.configs)):
+        hit = np.nonzero(tm & (np.uint64(1) << np.uint64(c)))[0]
+        if len(hit):
+            first[c] = hit[0]
+    _task = np.where(cfg_of_node >= 0, first[np.maximum(cfg_of_node, 0)], 0xFFFFFFFF)
+    t_sweep_be = time.perf_counter() - t0
+    t_be = t_compat + t_carve_be + t_sweep_be
+    best_effort = {"value": sw.T * sw.W / t_be, "unit": "pair-evals/s", "cores": 1,
+                   "sample": (f"full match, 1 thread: compat {t_compat:.3f} s + carve/merge with the predicate evaluated "
+                              f"once per (config, node) and cached distances {t_carve_be:.2f} s + mask-interned sweep "
+                              f"{t_sweep_be:.3f} s (numpy)"),
+                   "seconds_full_match": t_be}
     return {
         "value": sw.T * sw.W / t_full, "unit": "pair-evals/s", "cores": 1, "kind": "port",
         "sample": (f"oracle/pm_oracle.c -O2, 1 thread of {os.cpu_count()} host cores: compat sweep + reference-shaped "
@@ -104,18 +122,175 @@ def cpu_baseline(sw, budget_s: float = 30.0) -> dict:
                    f"reference excluded"),
         "seconds_full_match_est": t_full,
         "all_cores": all_cores,
+        "best_effort": best_effort,
     }
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per full-swarm match from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json,
-    FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_match")
-    except Exception:
-        return None
+    """HBM bytes per full-swarm match from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate runs of this same command, newest round first).  A constant read from a
+    committed profile, not a measurement of this run; None if absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                v = json.load(f).get(kernel, {}).get("hbm_bytes_per_match")
+            if v is not None:
+                return v, os.path.basename(path)
+        except Exception:
+            pass
+    return None, None
+
+
+def proposer_split(E, host, sw, seed, steps=3):
+    """The proposer's share of the carve: a separate engine whose proposer launches are bracketed by their own
+    hipEvents (pm_engine_config.time_proposer).  The events break the back-to-back dispatch of the launch sequence
+    (~0.5 ms per match at configs[1]), so the headline loop runs without them."""
+    eng = E.Engine(group_id_seed=seed, time_proposer=True)
+    host.load_swarm(eng, sw)
+    st = []
+    for k in range(steps + 1):
+        eng.reset_groups()
+        s = eng.tick()
+        if k:
+            st.append(s)
+    eng.close()
+    return {"ms": med(st, "ms_propose_kernel"), "proposals": med(st, "proposals"), "keys": med(st, "propose_keys"),
+            "ms_carve_kernel_with_events": med(st, "ms_carve_kernel")}
+
+
+def kernel_table(sw, stats, T, W, prop):
+    n_cfgs, n_alts = len(sw.configs), sum(1 for c in sw.configs if c[3]) * 2
+    carve_ms = med(stats, "ms_carve_kernel")
+    carve_bytes = 20.0 * med(stats, "carve_cand_sum") + 8.0 * med(stats, "carve_steps")
+    compat_bytes = W * 32 + n_cfgs * 32 + n_alts * 32 + W * 8
+    sweep_bytes = T * 16 + W * 16 + W * 8          # per-worker orientation: (16T + 24W)
+    compat_ms, sweep_ms = med(stats, "ms_compat_kernel"), med(stats, "ms_sweep_kernel")
+    prop_ms, keys = prop["ms"], prop["keys"]
+    gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else None
+    pair_rate = T * W / (sweep_ms * 1e-3) if sweep_ms > 0 else None
+    steps = max(med(stats, "carve_steps"), 1)
+    return {
+        "compat_kernel": {"ms": compat_ms, "alg_bytes": compat_bytes, "GB/s": gbs(compat_bytes, compat_ms)},
+        "pair_sweep": {"ms": sweep_ms, "alg_bytes": sweep_bytes, "GB/s": gbs(sweep_bytes, sweep_ms),
+                       "pair_evals_per_s": pair_rate,
+                       "valu_ceiling_pair_evals_per_s": VALU_LANE_OPS / OPS_PER_PAIR_EVAL,
+                       "valu_frac": pair_rate / (VALU_LANE_OPS / OPS_PER_PAIR_EVAL) if pair_rate else None,
+                       "note": ("bit-sliced: one 64-bit op evaluates 64 pairs, so the fraction of the one-pair-per-lane-op "
+                                "ceiling (SURVEY 8d: CUs x lanes x clk / 20 ops) can exceed 1")},
+        "carve": {"ms": carve_ms, "alg_bytes": carve_bytes, "GB/s": gbs(carve_bytes, carve_ms),
+                  "steps": steps, "fast_steps": med(stats, "carve_fast_steps"), "us_per_step": 1e3 * carve_ms / steps,
+                  "launches": med(stats, "carve_launches")},
+        "carve_propose_kernel": {"ms": prop_ms, "proposals": prop["proposals"], "keys": keys,
+                                 "timing": "separate pass with hipEvents around every proposer launch",
+                                 "TFLOP/s": keys * FLOP_PER_KEY / (prop_ms * 1e-3) / 1e12 if prop_ms > 0 else None,
+                                 "fp64_vector_peak_TFLOP/s": FP64_VECTOR_TFLOPS,
+                                 "fp64_frac": (keys * FLOP_PER_KEY / (prop_ms * 1e-3) / 1e12 / FP64_VECTOR_TFLOPS)
+                                 if prop_ms > 0 else None},
+    }
+
+
+def chain_model(steps, carve_ms, prop_ms):
+    floor_us = 3.0 * LDS_ROUND_TRIP_CYC / (CLOCK_GHZ * 1e3)
+    val_ms = max(carve_ms - prop_ms, 0.0)
+    return {"model": ("group g+1's seed depends on what group g removed: a chain of dependent steps; floor per step = 3 "
+                      "dependent LDS round trips (row -> live bits -> kill) of ~50 cycles at 2.4 GHz; the proposer "
+                      "launches between the validation launches are on the chain too"),
+            "steps": steps, "floor_us_per_step": floor_us, "achieved_us_per_step": 1e3 * carve_ms / max(steps, 1),
+            "validate_only_us_per_step": 1e3 * val_ms / max(steps, 1),
+            "frac": floor_us / (1e3 * carve_ms / max(steps, 1)) if carve_ms > 0 else None}
+
+
+def run_extra_configs2(E, host, seed):
+    from protocol_amd.swarm import baseline_config
+    sw = baseline_config(2, seed=seed)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    stats = []
+    for k in range(4):
+        eng.reset_groups()
+        s = eng.tick()
+        if k:
+            stats.append(s)
+    prop = proposer_split(E, host, sw, seed, steps=2)
+    kt = kernel_table(sw, stats, sw.T, sw.W, prop)
+    out = {"workload": "BASELINE configs[2]: 1M tasks x 100k workers, Zipf-skewed topologies, cold match",
+           "steps": len(stats), "ms_per_match": med(stats, "ms_total"), "groups": int(stats[-1]["n_groups"]),
+           "pair_evals_per_s": sw.T * sw.W / (med(stats, "ms_total") * 1e-3),
+           "carve_ms": med(stats, "ms_carve"), "propose_ms": prop["ms"],
+           "validate_ms": prop["ms_carve_kernel_with_events"] - prop["ms"],
+           "sweep_ms": med(stats, "ms_sweep"), "compat_ms": med(stats, "ms_compat"), "publish_ms": med(stats, "ms_publish"),
+           "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
+           "roofline": {"bound": "fp64-valu", "kernel": "carve_propose_kernel",
+                        "achieved": kt["carve_propose_kernel"]["TFLOP/s"], "peak": FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                        "frac": kt["carve_propose_kernel"]["fp64_frac"],
+                        "note": f"keys x {FLOP_PER_KEY:.0f} flop per Haversine term / summed proposer launch time"},
+           "kernels": kt,
+           "chain": chain_model(kt["carve"]["steps"], kt["carve"]["ms"], kt["carve_propose_kernel"]["ms"])}
+    # the north_star orientation at this size
+    t0 = time.perf_counter()
+    eng.match_per_task()
+    out["per_task_ms"] = 1e3 * (time.perf_counter() - t0)
+    eng.close()
+    return out
+
+
+def run_extra_churn(E, host, seed, ticks=6):
+    """BASELINE configs[4] on one GPU (the 8-GPU form is `--gpus 8`): 100k workers; per tick 10k tasks arrive, 1 % of
+    the workers die and 1 % brand-new workers join; one incremental match on the standing groups."""
+    from protocol_amd.swarm import make_swarm
+    W0, n_churn, n_new = 100_000, 1000, 10_000
+    sw_all = make_swarm(seed + 4, 10_000, W0 + n_churn * (ticks + 2))
+    packed = host.pack_workers(sw_all)
+    rows = lambda idx: {k: np.ascontiguousarray(v[idx]) for k, v in packed.items()}
+    eng = E.Engine()
+    cfg_rows, alt_rows, req_models = host.pack_configs(sw_all.configs)
+    eng.set_configs(cfg_rows, alt_rows)
+    eng.set_model_table(host.build_model_table(req_models, sw_all.model_names), len(req_models), len(sw_all.model_names))
+    eng.upload_workers(rows(np.arange(W0)))
+    masks, created, uid = sw_all.task_masks(), sw_all.created_at.copy(), sw_all.task_uid.copy()
+    eng.upload_tasks(masks, created, uid)
+    eng.set_enabled_mask(sw_all.enabled_mask())
+    s0 = eng.tick()
+    rng = np.random.default_rng(seed)
+    flags = packed["flags"].astype(np.int64)
+    alive = set(np.nonzero((sw_all.status[:W0] == 2))[0].tolist())
+    W, next_uid, t_max = W0, 1 << 40, int(created.max())
+    out_ticks = []
+    for t in range(ticks + 2):
+        t0 = time.perf_counter()
+        leave = rng.choice(np.fromiter(alive, dtype=np.int64), size=n_churn, replace=False)
+        for w in leave:
+            eng.on_worker_status(int(w), int(flags[w] & ~E.W_HEALTHY), True)
+            alive.discard(int(w))
+        t1 = time.perf_counter()
+        idx_new = np.arange(W, W + n_churn)
+        eng.append_workers(rows(idx_new))
+        alive.update(int(w) for w in idx_new if sw_all.status[w] == 2)
+        W += n_churn
+        t2 = time.perf_counter()
+        pick = rng.integers(0, len(masks), n_new)
+        eng.tasks_insert_front(masks[pick], t_max + 1 + np.arange(n_new)[::-1],
+                               np.arange(next_uid, next_uid + n_new, dtype=np.uint64))
+        t_max += n_new
+        next_uid += n_new
+        t3 = time.perf_counter()
+        s = eng.tick()
+        t4 = time.perf_counter()
+        if t >= 2:
+            out_ticks.append({"status_ms": 1e3 * (t1 - t0), "append_ms": 1e3 * (t2 - t1), "tasks_ms": 1e3 * (t3 - t2),
+                              "match_ms": 1e3 * (t4 - t3), "carve_ms": s["ms_carve"], "sweep_ms": s["ms_sweep"],
+                              "publish_ms": s["ms_publish"], "formed": s["n_formed"], "groups": s["n_groups"]})
+    eng.close()
+    m = lambda k: statistics.median(x[k] for x in out_ticks)
+    return {"workload": ("BASELINE configs[4] on one GPU: 100k workers, per tick +10k tasks (pm_tasks_insert_front), 1% "
+                         "workers die (pm_on_worker_status x1000), 1% brand-new workers (pm_append_workers), incremental "
+                         "pm_tick on the standing groups"),
+            "ticks": len(out_ticks), "cold_match_ms": s0["ms_total"],
+            "ms_per_tick": m("status_ms") + m("append_ms") + m("tasks_ms") + m("match_ms"),
+            "split_ms_p50": {k: m(k) for k in ("status_ms", "append_ms", "tasks_ms", "match_ms", "carve_ms", "sweep_ms",
+                                               "publish_ms")},
+            "formed_per_tick_p50": m("formed"), "groups": out_ticks[-1]["groups"]}
 
 
 def main() -> int:
@@ -123,11 +298,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=21)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index (default 1: 100k x 10k)")
+    ap.add_argument("--config", type=int, default=None,
+                    help="BASELINE.json configs index (default: 1 on one GPU, 3 on several)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--sweep-variant", type=int, default=0)
     ap.add_argument("--carve-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs2 / churn / per_task sub-objects")
     ap.add_argument("--check", action="store_true", help="also verify the groups against the oracle (slow)")
     args = ap.parse_args()
 
@@ -141,7 +318,7 @@ def main() -> int:
         print("bench.py needs an MI355X (the engine has no CPU fallback)", file=sys.stderr)
         return 2
     # PM_BENCH_BACKEND=gloo + PM_BENCH_SHARE_DEVICE=1: plumbing check of the N>1 path on a 1-GPU box (all ranks
-    # on device 0, collectives on host tensors).  The real path is nccl (= RCCL over xGMI), one GPU per rank.
+    # on device 0, collectives staged through the host).  The real path is nccl (= RCCL over xGMI), one GPU per rank.
     backend = os.environ.get("PM_BENCH_BACKEND", "nccl")
     if os.environ.get("PM_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
@@ -157,106 +334,108 @@ def main() -> int:
     from protocol_amd import engine as E, host
     from protocol_amd.swarm import baseline_config, make_swarm
 
-    # global swarm: weak scaling — per-GPU work is fixed (tasks replicated, W_local ~ 10k workers per rank)
-    if args.config == 1:
-        sw_global = make_swarm(args.seed, 100_000, 10_000 * world)
-        workload = f"100k tasks x {10_000 * world} workers, mixed gpu/mem/storage/cpu constraints (BASELINE configs[1])"
-    else:
-        sw_global = baseline_config(args.config, seed=args.seed)
-        workload = f"BASELINE configs[{args.config}]"
-    sw, shard_idx = shard_swarm(sw_global, rank, world)
+    cfg_index = args.config if args.config is not None else (1 if world == 1 else 3)
+    sw = baseline_config(cfg_index, seed=args.seed)          # the SAME swarm on every rank (strong scaling for N > 1)
+    names = {1: "100k tasks x 10000 workers, mixed gpu/mem/storage/cpu constraints (BASELINE configs[1])",
+             2: "1M tasks x 100k workers, Zipf-skewed topologies (BASELINE configs[2])",
+             3: ("1M tasks x 100k workers, Zipf-skewed topologies, worker ownership hash-sharded across the ranks with RCCL "
+                 "all-gathers (BASELINE configs[3])")}
+    workload = names.get(cfg_index, f"BASELINE configs[{cfg_index}]")
 
     eng = E.Engine(device=local_rank, sweep_variant=args.sweep_variant, carve_variant=args.carve_variant,
-                   group_id_seed=args.seed + rank)
+                   group_id_seed=args.seed)
     host.load_swarm(eng, sw)
+    sharded = None
     if world > 1:
-        w_counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
-        dist.all_gather(w_counts, torch.tensor([sw.W], dtype=torch.int64, device=coll_dev))
-        w_counts = [int(x.item()) for x in w_counts]
-        w_max = max(w_counts)
-        gather_out = torch.empty(world * w_max, dtype=torch.int32, device=coll_dev)
-        local_tbl = torch.full((w_max,), -1, dtype=torch.int32, device=coll_dev)
-    else:
-        w_counts = [sw.W]
+        from protocol_amd.dist import EngineLocal, ShardedEngine
+        sharded = ShardedEngine(EngineLocal(eng, dev), sw.address)
 
-    class _DevCol:  # torch view of the engine's device-resident task column (no copy)
-        def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 3}
-
-    def step_fast():
+    def step():
         eng.reset_groups()
-        s = eng.tick()
-        if world > 1:  # the one exchange step: all-gather the published table shards over RCCL/xGMI
-            ptr, n = eng.device_task_column()
-            local_tbl[:n].copy_(torch.as_tensor(_DevCol(ptr, n), device=dev))   # stays on the GPU for nccl
-            dist.all_gather_into_tensor(gather_out, local_tbl)
-        return s
+        return sharded.tick() if sharded else eng.tick()
 
     for _ in range(args.warmup):
-        step_fast()
+        step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stats = []
     for _ in range(args.steps):
-        stats.append(step_fast())
+        stats.append(step())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ranks_seen, own = 1, sw.W
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the gathered table must hold every shard's published column
-        got = gather_out.view(world, w_max).cpu().numpy()
-        ptr, n = eng.device_task_column()
-        mine = torch.as_tensor(_DevCol(ptr, n), device=dev).cpu().numpy()
-        assert (got[rank, :n] == mine).all(), "all-gathered table does not contain this rank's column"
+        # every rank must hold the same groups and the same full table: compare a digest across the ranks
+        import hashlib
+        _, groups, members = eng.get_groups()
+        h = hashlib.sha256(groups.tobytes() + members.tobytes()).digest()[:8]
+        mine = torch.tensor([int.from_bytes(h, "little") >> 1, len(groups)],
+                            dtype=torch.int64, device=coll_dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        assert all(bool((v == mine).all()) for v in allv), "ranks disagree on the groups they formed"
+        ranks_seen = len(allv)
+        own = int((sharded.shard == rank).sum())
 
-    T = sw.T
-    total_pairs = float(T) * float(sum(w_counts)) * args.steps
-    value = total_pairs / elapsed
+    T, W = sw.T, sw.W
+    value = float(T) * float(W) * args.steps / elapsed
     ms = [s["ms_total"] for s in stats]
-    med = lambda k: statistics.median(s[k] for s in stats)
-
-    # ---- roofline of the dominant kernel (carve) with the algorithmic-bytes convention
-    carve_ms = med("ms_carve_kernel")
-    carve_bytes = 20.0 * med("carve_cand_sum") + 8.0 * med("carve_steps")
-    carve_gbs = carve_bytes / (carve_ms * 1e-3) / 1e9 if carve_ms > 0 else 0.0
-    n_cfgs, n_alts = len(sw.configs), sum(1 for c in sw.configs if c[3]) * 2
-    compat_bytes = sw.W * 32 + n_cfgs * 32 + n_alts * 32 + sw.W * 8
-    sweep_bytes = T * 16 + sw.W * 16 + sw.W * 8          # per-worker orientation: (16T + 24W)
-    compat_ms, sweep_ms = med("ms_compat_kernel"), med("ms_sweep_kernel")
-    kernels = {
-        "compat_kernel": {"ms": compat_ms, "alg_bytes": compat_bytes,
-                          "GB/s": compat_bytes / (compat_ms * 1e-3) / 1e9 if compat_ms > 0 else None},
-        "pair_sweep": {"ms": sweep_ms, "alg_bytes": sweep_bytes,
-                       "GB/s": sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None,
-                       "pair_evals_per_s": T * sw.W / (sweep_ms * 1e-3) if sweep_ms > 0 else None},
-        "carve_kernel": {"ms": carve_ms, "alg_bytes": carve_bytes, "GB/s": carve_gbs,
-                         "steps": med("carve_steps"), "fast_steps": med("carve_fast_steps"),
-                         "us_per_step": 1e3 * carve_ms / max(med("carve_steps"), 1)},
-    }
+    prop = proposer_split(E, host, sw, args.seed) if (world == 1 and not args.no_extras) else \
+        {"ms": 0.0, "proposals": med(stats, "proposals"), "keys": med(stats, "propose_keys"),
+         "ms_carve_kernel_with_events": 0.0}
+    kt = kernel_table(sw, stats, T, W, prop)
+    carve = kt["carve"]
+    traffic, traffic_src = pmc_traffic("carve")
     out = {
         "metric": "task x worker pair-evals/sec (full-swarm match)", "value": value, "unit": "pair-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": workload, "tasks": T, "workers_per_gpu": sw.W, "workers_total": sum(w_counts),
-                   "configs": n_cfgs, "seed": args.seed, "sharding": "hash(address) % n_gpus" if world > 1 else "none",
+        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": workload, "tasks": T, "workers": W, "workers_total": W, "configs": len(sw.configs),
+                   "seed": args.seed,
+                   "sharding": ("none" if world == 1 else
+                                "ownership = splitmix64(address) % n_gpus; proposals + pair sweep sharded, chain replicated"),
                    "sweep_variant": args.sweep_variant, "carve_variant": args.carve_variant},
         "p50_match_latency_ms": statistics.median(ms),
         "match_latency_ms": {"min": min(ms), "p50": statistics.median(ms), "max": max(ms)},
-        "phase_ms_p50": {k: med(k) for k in ("ms_compat", "ms_carve", "ms_merge", "ms_sweep", "ms_publish")},
+        "phase_ms_p50": {k: med(stats, k) for k in ("ms_compat", "ms_carve", "ms_merge", "ms_sweep", "ms_publish")},
         "groups": int(stats[-1]["n_groups"]), "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
         "roofline": {"bound": "hbm", "kernel": "carve (carve_propose_kernel + carve_kernel launch sequence)",
-                     "achieved": carve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": carve_gbs / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("carve"),
-                     "note": "dependent chain of ~2k carve steps: latency-bound by construction, see DESIGN.md §6"},
-        "kernels": kernels,
+                     "achieved": carve["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (carve["GB/s"] or 0.0) / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": (f"profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                            f"of this command, a committed constant — not measured in this run")
+                     if traffic_src else None,
+                     "note": ("SURVEY 8(d) accounting (W_remaining*20+8 bytes per step); the sequence is a dependent chain, "
+                              "not a bandwidth-shaped scan: see `chain`"),
+                     "chain": chain_model(carve["steps"], carve["ms"], kt["carve_propose_kernel"]["ms"])},
+        "kernels": kt,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if world > 1:
+        out["ranks_seen"] = ranks_seen
+        out["dist"] = {"workers_owned_by_rank0": own, "exchanges_per_tick": sharded.exchanges / (args.steps + args.warmup),
+                       "backend": backend, "identical_groups_on_all_ranks": True}
+    single = rank == 0 and world == 1
+    if single and not args.no_extras:
+        try:
+            out["hbm_triad_gbs_measured"] = eng.hbm_triad_gbs()
+        except Exception as ex:  # never lose the line over the microbench
+            out["hbm_triad_gbs_measured"] = None
+            out["hbm_triad_error"] = repr(ex)
+        t0 = time.perf_counter()
+        eng.match_per_task()
+        t_pt = time.perf_counter() - t0
+        out["per_task"] = {"ms": 1e3 * t_pt, "pair_evals_per_s": T * W / t_pt,
+                           "note": "north_star orientation (pm_match_per_task): per task best bid + bidder count, "
+                                   "incl. the D2H copy of both columns"}
+    if single and not args.no_cpu_baseline:
         # PCIe-inclusive rate, reported beside (never as) `value`: the same match when the worker and task
         # columns arrive as host buffers through the C ABI (pm_upload_workers + pm_upload_tasks) every time
         packed = host.pack_workers(sw)
@@ -271,27 +450,30 @@ def main() -> int:
             eng.tick()
             t_up.append(time.perf_counter() - u0)
         up = sorted(t_up)[len(t_up) // 2]
-        out["pcie_inclusive"] = {"ms_per_match": up * 1e3, "value": float(sw.T) * float(sw.W) / up,
-                                 "unit": "pair-evals/s",
+        out["pcie_inclusive"] = {"ms_per_match": up * 1e3, "value": float(T) * float(W) / up, "unit": "pair-evals/s",
                                  "note": "host SoA columns -> HBM (workers + tasks) + match, p50 of 5"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sw)
     else:
         out["cpu_baseline"] = None
     if args.check and rank == 0:
         from oracle import oracle_ffi as orc
         nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
-        st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False,
-                       group_id_seed=args.seed + rank)
+        st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False, group_id_seed=args.seed)
         st.try_form_new_groups()
         st.try_merge_solo_groups()
         _, groups, members = eng.get_groups()
         got = [(int(g["id"]), int(g["config"]),
                 members[int(g["member_begin"]):int(g["member_begin"]) + int(g["n_members"])].tolist()) for g in groups]
         out["parity_vs_oracle"] = got == [(gid, c, m) for (_s, gid, c, m, _t) in st.groups()]
+    eng.close()
+    if single and not args.no_extras:
+        for key, fn in (("configs2", run_extra_configs2), ("churn", run_extra_churn)):
+            try:
+                out[key] = fn(E, host, args.seed)
+            except Exception as ex:
+                out[key] = {"error": repr(ex)}
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
     return 0

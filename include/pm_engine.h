@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 1
+#define PM_ABI_VERSION 2
 
 enum {
   PM_OK = 0,
@@ -153,7 +153,7 @@ typedef struct {
                                     in-order validation rounds),
                                     1 = single-workgroup sequential exact sweep only (the straightforward kernel),
                                     2 = proposals with single-wave sequential validation (no speculative rounds) */
-  uint32_t _reserved;
+  uint32_t time_proposer;        /* bench: hipEvents around every proposer launch (pm_stats.ms_propose_kernel) */
 } pm_engine_config;
 
 void pm_engine_config_default(pm_engine_config*);
@@ -268,6 +268,11 @@ typedef struct {
   uint32_t carve_launches;
   uint64_t pair_evals;          /* T x W of the sweep */
   uint64_t carve_cand_sum;      /* sum over carve steps of the remaining candidates scanned (roofline bytes) */
+  /* proposer (carve_propose_kernel): summed launch durations (hipEvents around every launch; 0 when the launches
+   * are not timed individually), neighbour lists computed by this rank, Haversine keys their sweeps evaluated */
+  float ms_propose_kernel;
+  uint32_t proposals;
+  uint64_t propose_keys;
 } pm_stats;
 
 /* One full-swarm match on one GPU (a multi-GPU engine uses the stepwise tick below): compat masks -> form groups

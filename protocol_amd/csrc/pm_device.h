@@ -96,7 +96,8 @@ struct CarveStatus {
   uint32_t fast_steps;   // steps committed from proposals
   uint32_t slow_steps;   // steps that needed the full key sweep
   uint32_t n_solo;       // single-node groups carved (the merge pass only runs when there are two or more)
-  uint32_t _pad_solo;
+  uint32_t n_props;      // neighbour lists computed by this rank's proposer
+  unsigned long long prop_keys;  // keys (Haversine terms) those sweeps evaluated
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
@@ -143,6 +144,7 @@ struct CarveArgs {
   uint64_t* seed_map;      // per bitmap word below prop_limit: the batch's seeds (live & located at preparation)
   uint32_t* seed_prefix;   // per bitmap word: seeds in front of the word
   uint32_t dist_rank, dist_world;
+  uint32_t count_keys, _pad_ck;  // proposer: count the keys it sweeps (bench bookkeeping)
   uint32_t* same_next;     // next located slot at the same site (identical coordinates), PM_NONE = none
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
@@ -157,6 +159,7 @@ struct CarveArgs {
 
 void launch_compat(const CompatArgs& a, hipStream_t s);
 void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s);
+void launch_triad(const double* b, const double* c, double* a, size_t n, hipStream_t s);
 void launch_update_rows(const RowUpdateArgs& a, hipStream_t s);
 void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t R, const uint32_t* rows,
                             uint64_t* sel, hipStream_t s);
@@ -181,13 +184,13 @@ void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const 
                         const uint64_t* planes, uint32_t c_begin, uint32_t c_end, uint32_t stride, uint32_t n_planes,
                         const uint32_t* rank, uint32_t* out, hipStream_t s);
 void launch_task_prefix(const uint64_t* live, uint32_t w_begin, uint32_t w_end, uint32_t* prefix, hipStream_t s);
-void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, long long* created, uint64_t* live,
-                        uint64_t* planes, uint32_t stride, uint32_t n_planes, hipStream_t s);
+void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, uint64_t* live, uint64_t* planes,
+                        uint32_t stride, uint32_t n_planes, hipStream_t s);
 void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint32_t u_begin, uint32_t u_end,
                          const uint64_t* live, const uint32_t* prefix, uint32_t* first_out, uint32_t* count_out,
                          hipStream_t s);
-void launch_newest(const int64_t* created_at, uint32_t t_begin, uint32_t t_end, uint32_t* idx_by_block,
-                   long long* val_by_block, uint32_t n_blocks, hipStream_t s);
+void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_begin, uint32_t t_end,
+                   uint32_t* idx_by_block, long long* val_by_block, uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);

@@ -254,6 +254,11 @@ struct pm_engine {
   int dist_phase = 0;                  // 0 idle, 1 carving, 2 carve done, 3 match queued
   uint32_t dist_n_formed = 0, dist_n_merged = 0;
   uint32_t tick_host_resolved = 0, tick_carve_launches = 0, tick_carve_steps = 0;
+  uint32_t tick_props = 0;
+  uint64_t tick_prop_keys = 0;
+  float k_ms_propose = 0;
+  std::vector<hipEvent_t> prop_ev;  // (start, stop) pairs of the proposer launches of the current poll interval
+  size_t prop_ev_used = 0;
 };
 
 namespace pm {
@@ -490,6 +495,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->seed_prefix = e->d_seed_prefix.p;
   a->dist_rank = e->dist_rank;
   a->dist_world = e->dist_world;
+  a->count_keys = e->cfg.time_proposer ? 1u : 0u;
   a->same_next = e->d_same_next.p;
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
   a->bits_stride = stride;
@@ -661,11 +667,30 @@ static int32_t form_begin(pm_engine* e, FormRun* r) {
   return form_queue_init(e, r);  // prepares the first candidate list (all of it when there are no proposals)
 }
 
+// the proposer launch, bracketed by its own hipEvents when pm_engine_config.time_proposer asks for the split
+static int32_t launch_propose_timed(pm_engine* e) {
+  if (!e->cfg.time_proposer) {
+    launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+    return PM_OK;
+  }
+  while (e->prop_ev.size() < e->prop_ev_used + 2) {
+    hipEvent_t x = nullptr;
+    HIPCHK(hipEventCreate(&x));
+    e->prop_ev.push_back(x);
+  }
+  HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used], e->stream));
+  launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+  HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used + 1], e->stream));
+  e->prop_ev_used += 2;
+  return PM_OK;
+}
+
 // (propose, validate) pairs: one per configuration plus one per re-proposal round; launches queued behind a
 // finished carve return immediately
 static int32_t form_queue_pairs(pm_engine* e, FormRun* r, uint32_t count) {
   for (uint32_t k = 0; k < count; ++k) {
-    launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+    int32_t rc = launch_propose_timed(e);
+    if (rc) return rc;
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, r->lds, e->stream));
     e->tick_carve_launches += 2;
   }
@@ -684,6 +709,11 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
       HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
       e->k_ms_carve += ms;
       HIPCHK(hipEventRecord(e->kev[2], e->stream));
+      for (size_t k = 0; k + 1 < e->prop_ev_used; k += 2) {
+        HIPCHK(hipEventElapsedTime(&ms, e->prop_ev[k], e->prop_ev[k + 1]));
+        e->k_ms_propose += ms;
+      }
+      e->prop_ev_used = 0;
     }
     if (r->st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
     if (r->st.state != CARVE_STATE_UNCERTAIN) return PM_OK;
@@ -706,6 +736,8 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   e->tick_fast_steps += st.fast_steps;
   e->tick_carve_steps += st.steps_total;
   e->tick_cand_sum += st.cand_sum;
+  e->tick_props += st.n_props;
+  e->tick_prop_keys += st.prop_keys;
   std::memcpy(e->carve_prof, st.prof, sizeof(st.prof));
 
   // The new group records stay in HBM for the match; their ids (generate_group_id stream) and empty task
@@ -1261,6 +1293,7 @@ void pm_engine_destroy(pm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->kev)
     if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t x : e->prop_ev) (void)hipEventDestroy(x);
   if (e->stream_owned) (void)hipStreamDestroy(e->stream_owned);
   delete e->form;
   delete e;
@@ -1604,48 +1637,69 @@ int32_t pm_set_addr_ranks(pm_engine* e, const uint32_t* addr_rank, uint32_t n) {
   return PM_OK;
 }
 
-// (Re)allocate the task index space with capacity `cap` (a multiple of 64) and move the used part to its top.
-// Handles shift by (cap - old cap): the groups' claims are shifted with them.
-static int32_t tasks_set_capacity(pm_engine* e, uint32_t cap, bool keep) {
-  const uint32_t old_cap = e->t_cap, used = keep ? old_cap - e->t_lo : 0u;
-  const uint32_t new_lo = cap - used;
-  std::vector<uint64_t> tmask(cap, 0), tuid, tlive(cap / 64u, 0);
-  std::vector<int64_t> created(cap, INT64_MIN);
-  if (e->tasks_have_uid) tuid.assign(cap, 0);
-  if (used) {
-    std::copy(e->h_tmask.begin() + e->t_lo, e->h_tmask.end(), tmask.begin() + new_lo);
-    std::copy(e->h_created.begin() + e->t_lo, e->h_created.end(), created.begin() + new_lo);
-    if (e->tasks_have_uid) std::copy(e->h_tuid.begin() + e->t_lo, e->h_tuid.end(), tuid.begin() + new_lo);
-    for (uint32_t u = e->t_lo; u < old_cap; ++u)
-      if ((e->h_tlive[u >> 6] >> (u & 63u)) & 1ull) {
-        const uint32_t v = u - e->t_lo + new_lo;
-        tlive[v >> 6] |= 1ull << (v & 63u);
-      }
-    const uint32_t shift = new_lo - e->t_lo;  // cap grows: handles move up
-    for (Group& g : e->groups)
-      if (g.task != PM_NONE) g.task += shift;
-    e->groups_dirty = true;
-    if (e->uid_map_valid)
-      for (auto& kv : e->uid_to_u) kv.second += shift;
-  }
-  e->h_tmask.swap(tmask);
-  e->h_created.swap(created);
-  e->h_tuid.swap(tuid);
-  e->h_tlive.swap(tlive);
+// A fresh, empty task index space of capacity `cap` (a multiple of 64): host mirror and device columns zeroed.
+static int32_t tasks_alloc(pm_engine* e, uint32_t cap) {
+  e->h_tmask.assign(cap, 0);
+  e->h_created.assign(cap, 0);
+  e->h_tlive.assign(cap / 64u, 0);
+  if (e->tasks_have_uid) e->h_tuid.assign(cap, 0); else e->h_tuid.clear();
   e->t_cap = cap;
-  e->t_lo = new_lo;
+  e->t_lo = cap;
+  e->T = e->t_dead = 0;
   e->h_tprefix_valid = false;
   HIPCHK(e->d_tmask.ensure(cap));
   HIPCHK(e->d_created.ensure(cap));
   HIPCHK(e->d_tlive.ensure(cap / 64u));
   HIPCHK(e->d_tprefix.ensure(cap / 64u));
-  // the whole index space goes up: unused and dead entries are mask 0 / not live / created_at = INT64_MIN
-  HIPCHK(hipMemcpyAsync(e->d_tmask.p, e->h_tmask.data(), size_t(cap) * 8, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d_created.p, e->h_created.data(), size_t(cap) * 8, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d_tlive.p, e->h_tlive.data(), size_t(cap / 64u) * 8, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemsetAsync(e->d_tmask.p, 0, size_t(cap) * 8, e->stream));
+  HIPCHK(hipMemsetAsync(e->d_tlive.p, 0, size_t(cap / 64u) * 8, e->stream));
   e->tplanes_dirty = true;
   e->tprefix_dirty = true;
+  return PM_OK;
+}
+
+// Host range [u0, u1) of the table -> HBM (masks, created_at, the live words it touches)
+static int32_t tasks_push_range(pm_engine* e, uint32_t u0, uint32_t u1) {
+  if (u1 <= u0) return PM_OK;
+  const uint32_t w0 = u0 / 64u, w1 = (u1 + 63u) / 64u;
+  HIPCHK(hipMemcpyAsync(e->d_tmask.p + u0, e->h_tmask.data() + u0, size_t(u1 - u0) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_created.p + u0, e->h_created.data() + u0, size_t(u1 - u0) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_tlive.p + w0, e->h_tlive.data() + w0, size_t(w1 - w0) * 8, hipMemcpyHostToDevice, e->stream));
+  return PM_OK;
+}
+
+// The table outgrew the room in front of it: a larger index space, the used part moves to its top.  Handles
+// shift by (new capacity - old capacity): the groups' claims are shifted with them.
+static int32_t tasks_grow(pm_engine* e, uint32_t cap) {
+  const uint32_t old_cap = e->t_cap, old_lo = e->t_lo, used = old_cap - old_lo, new_lo = cap - used;
+  const uint32_t shift = new_lo - old_lo;
+  std::vector<uint64_t> tmask(e->h_tmask.begin() + old_lo, e->h_tmask.end());
+  std::vector<int64_t> created(e->h_created.begin() + old_lo, e->h_created.end());
+  std::vector<uint64_t> tuid;
+  if (e->tasks_have_uid) tuid.assign(e->h_tuid.begin() + old_lo, e->h_tuid.end());
+  std::vector<uint64_t> live_old = e->h_tlive;
+  const uint32_t T = e->T, dead = e->t_dead;
+  int32_t rc = tasks_alloc(e, cap);
+  if (rc) return rc;
+  std::copy(tmask.begin(), tmask.end(), e->h_tmask.begin() + new_lo);
+  std::copy(created.begin(), created.end(), e->h_created.begin() + new_lo);
+  if (e->tasks_have_uid) std::copy(tuid.begin(), tuid.end(), e->h_tuid.begin() + new_lo);
+  for (uint32_t u = old_lo; u < old_cap; ++u)
+    if ((live_old[u >> 6] >> (u & 63u)) & 1ull) {
+      const uint32_t v = u + shift;
+      e->h_tlive[v >> 6] |= 1ull << (v & 63u);
+    }
+  e->t_lo = new_lo;
+  e->T = T;
+  e->t_dead = dead;
+  for (Group& g : e->groups)
+    if (g.task != PM_NONE) g.task += shift;
+  e->groups_dirty = true;
+  if (e->uid_map_valid)
+    for (auto& kv : e->uid_to_u) kv.second += shift;
+  rc = tasks_push_range(e, new_lo, cap);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
   return PM_OK;
 }
 
@@ -1663,34 +1717,34 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
   if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   ABSORB_PENDING(e);
   const uint32_t n = t->n;
+  const bool had_uid = e->tasks_have_uid;
   e->tasks_have_uid = t->uid != nullptr;
   e->uid_to_u.clear();
   e->uid_map_valid = false;
   e->cfg_app_valid = false;
-  uint32_t cap = e->t_cap;
-  if (cap < n + 64u || uint64_t(cap) > uint64_t(n) * 8 + (1u << 20)) cap = task_capacity_for(n);
-  e->t_cap = 0;  // nothing to keep
-  e->t_lo = 0;
-  {  // host mirror in table order: position i -> index lo + i
-    const uint32_t lo = cap - n;
-    e->h_tmask.assign(cap, 0);
-    e->h_created.assign(cap, INT64_MIN);
-    e->h_tlive.assign(cap / 64u, 0);
-    if (t->uid) e->h_tuid.assign(cap, 0); else e->h_tuid.clear();
-    for (uint32_t i = 0; i < n; ++i) {
-      const uint32_t u = lo + i;
-      e->h_tmask[u] = t->topo_mask[i];
-      e->h_created[u] = t->created_at[i];
-      if (t->uid) e->h_tuid[u] = t->uid[i];
-      e->h_tlive[u >> 6] |= 1ull << (u & 63u);
-    }
-    e->t_cap = cap;
-    e->t_lo = lo;
+  int32_t rc;
+  if (e->t_cap < n + 64u || uint64_t(e->t_cap) > uint64_t(n) * 8 + (1u << 20) || had_uid != e->tasks_have_uid) {
+    rc = tasks_alloc(e, task_capacity_for(n));
+    if (rc) return rc;
   }
+  // the snapshot replaces the used part: position i of the caller's list -> index lo + i; whatever the old table
+  // had in front of the new one is cleared (only the rows that changed hands travel)
+  const uint32_t cap = e->t_cap, old_lo = e->t_lo, lo = cap - n, clear_from = std::min(old_lo, lo);
+  for (uint32_t u = clear_from; u < lo; ++u) e->h_tmask[u] = 0;
+  for (uint32_t w = clear_from / 64u; w < cap / 64u; ++w) e->h_tlive[w] = 0;
+  std::memcpy(e->h_tmask.data() + lo, t->topo_mask, size_t(n) * 8);
+  std::memcpy(e->h_created.data() + lo, t->created_at, size_t(n) * 8);
+  if (t->uid) std::memcpy(e->h_tuid.data() + lo, t->uid, size_t(n) * 8);
+  for (uint32_t u = lo; u < cap; ++u) e->h_tlive[u >> 6] |= 1ull << (u & 63u);
+  e->t_lo = lo;
   e->T = n;
   e->t_dead = 0;
-  int32_t rc = tasks_set_capacity(e, cap, /*keep=*/true);  // same capacity: uploads the columns as they are
+  e->h_tprefix_valid = false;
+  rc = tasks_push_range(e, clear_from, cap);
   if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));  // pageable sources
+  e->tplanes_dirty = true;
+  e->tprefix_dirty = true;
   e->have_tasks = true;
   // re-bind claimed tasks by identity; groups whose task vanished are dissolved (on_task_deleted,
   // mod.rs:1259-1288)
@@ -1768,7 +1822,7 @@ int32_t pm_tasks_insert_front(pm_engine* e, const pm_task_soa* t) {
   if (!e->T && !e->t_dead) e->tasks_have_uid = t->uid != nullptr;
   if (e->t_lo < n) {  // out of room in front: a larger index space, everything moves to its top
     if (e->tasks_have_uid && e->h_tuid.size() != e->t_cap) e->h_tuid.assign(e->t_cap, 0);
-    int32_t rc = tasks_set_capacity(e, task_capacity_for(e->t_cap - e->t_lo + n), /*keep=*/true);
+    int32_t rc = tasks_grow(e, task_capacity_for(e->t_cap - e->t_lo + n));
     if (rc) return rc;
   }
   if (e->tasks_have_uid && e->h_tuid.size() != e->t_cap) e->h_tuid.assign(e->t_cap, 0);
@@ -1790,10 +1844,10 @@ int32_t pm_tasks_insert_front(pm_engine* e, const pm_task_soa* t) {
       }
     }
   }
-  const uint32_t w0 = lo / 64u, w1 = (e->t_lo + 63u) / 64u;  // bitmap / plane words the new rows fall into
-  HIPCHK(hipMemcpyAsync(e->d_tmask.p + lo, e->h_tmask.data() + lo, size_t(n) * 8, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d_created.p + lo, e->h_created.data() + lo, size_t(n) * 8, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d_tlive.p + w0, e->h_tlive.data() + w0, size_t(w1 - w0) * 8, hipMemcpyHostToDevice, e->stream));
+  {
+    int32_t rcp = tasks_push_range(e, lo, e->t_lo);
+    if (rcp) return rcp;
+  }
   if (!e->tplanes_dirty && e->d_tplanes.p)  // patch the planes: the touched words are rebuilt from the masks
     launch_build_planes(e->d_tmask.p, e->t_cap, lo, e->t_lo, e->t_cap / 64u, uint32_t(e->cfgs.size()), e->d_tplanes.p,
                         e->stream);
@@ -1838,7 +1892,6 @@ int32_t pm_tasks_delete(pm_engine* e, const uint64_t* uids, uint32_t n, uint32_t
       }
     }
     e->h_tmask[u] = 0;
-    e->h_created[u] = INT64_MIN;
     e->h_tlive[u >> 6] &= ~(1ull << (u & 63u));
     slots.push_back(u);
   }
@@ -1856,8 +1909,8 @@ int32_t pm_tasks_delete(pm_engine* e, const uint64_t* uids, uint32_t n, uint32_t
     int32_t rc = ensure_task_planes(e);
     if (rc) return rc;
   }
-  launch_task_delete(e->d_tdel.p, uint32_t(slots.size()), e->d_tmask.p, reinterpret_cast<long long*>(e->d_created.p),
-                     e->d_tlive.p, e->d_tplanes.p, e->t_cap / 64u, uint32_t(e->cfgs.size()), e->stream);
+  launch_task_delete(e->d_tdel.p, uint32_t(slots.size()), e->d_tmask.p, e->d_tlive.p, e->d_tplanes.p, e->t_cap / 64u,
+                     uint32_t(e->cfgs.size()), e->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
   e->T -= uint32_t(slots.size());
@@ -2082,7 +2135,7 @@ int32_t pm_newest_task(pm_engine* e, uint32_t* task_idx) {
   const uint32_t nb = std::min<uint32_t>(1024, (e->t_cap - e->t_lo + 255u) / 256u);
   HIPCHK(e->d_nb_idx.ensure(nb));
   HIPCHK(e->d_nb_val.ensure(nb));
-  launch_newest(e->d_created.p, e->t_lo, e->t_cap, e->d_nb_idx.p, e->d_nb_val.p, nb, e->stream);
+  launch_newest(e->d_created.p, e->d_tlive.p, e->t_lo, e->t_cap, e->d_nb_idx.p, e->d_nb_val.p, nb, e->stream);
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> bi(nb);
   std::vector<long long> bv(nb);
@@ -2106,6 +2159,10 @@ static void tick_reset(pm_engine* e) {
   e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
   e->tick_fast_steps = 0;
   e->tick_cand_sum = 0;
+  e->tick_props = 0;
+  e->tick_prop_keys = 0;
+  e->k_ms_propose = 0;
+  e->prop_ev_used = 0;
   e->k_ms_compat = e->k_ms_carve = e->k_ms_sweep = 0;
   e->k_sweep_recorded = e->k_compat_recorded = false;
 }
@@ -2124,6 +2181,9 @@ static int32_t tick_stats(pm_engine* e, pm_stats* stats, uint32_t n_formed, uint
   if (e->k_sweep_recorded) HIPCHK(hipEventElapsedTime(&s.ms_sweep_kernel, e->kev[4], e->kev[5]));
   s.ms_carve_kernel = e->k_ms_carve;
   s.carve_cand_sum = e->tick_cand_sum;
+  s.ms_propose_kernel = e->k_ms_propose;
+  s.proposals = e->tick_props;
+  s.propose_keys = e->tick_prop_keys;
   s.n_groups = uint32_t(e->groups.size());
   s.n_formed = n_formed;
   s.n_merged = n_merged;
@@ -2280,7 +2340,11 @@ int32_t pm_dist_carve_next(pm_engine* e, pm_dist_xfer* x, uint32_t* more) {
     }
     if (r->st.state == CARVE_STATE_RUNNING && r->use_props) {
       // a candidate list is prepared: this rank's share of the batch's neighbour lists
-      launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+      int32_t rcp = launch_propose_timed(e);
+      if (rcp) {
+        dist_abort(e);
+        return rcp;
+      }
       e->tick_carve_launches++;
       HIPCHK(hipGetLastError());
       x->send_ptr = uint64_t(reinterpret_cast<uintptr_t>(r->a.prop_send));
@@ -2395,6 +2459,37 @@ int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap)
   std::lock_guard<std::mutex> lk(e->mu);
   const uint32_t n = std::min<uint32_t>(cap, uint32_t(sizeof(e->carve_prof) / sizeof(e->carve_prof[0])));
   std::memcpy(out, e->carve_prof, size_t(n) * sizeof(unsigned long long));
+  return PM_OK;
+}
+
+// debug (pm_internal.h): stream triad over 3 x n_doubles f64 on the engine's stream, best of `reps` -> GB/s
+int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s) {
+  if (!e || !gb_per_s || !n_doubles) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  double *a = nullptr, *b = nullptr, *c = nullptr;
+  HIPCHK(hipMalloc((void**)&a, n_doubles * 8));
+  if (hipMalloc((void**)&b, n_doubles * 8) != hipSuccess || hipMalloc((void**)&c, n_doubles * 8) != hipSuccess) {
+    (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return set_error(PM_ENOMEM, "triad buffers");
+  }
+  (void)hipMemsetAsync(b, 0, n_doubles * 8, e->stream);
+  (void)hipMemsetAsync(c, 0, n_doubles * 8, e->stream);
+  float best = 1e30f;
+  for (uint32_t r = 0; r < reps + 1; ++r) {
+    (void)hipEventRecord(e->kev[0], e->stream);
+    launch_triad(b, c, a, size_t(n_doubles), e->stream);
+    (void)hipEventRecord(e->kev[1], e->stream);
+    (void)hipEventSynchronize(e->kev[1]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e->kev[0], e->kev[1]);
+    if (r > 0 && ms < best) best = ms;
+  }
+  (void)hipFree(a);
+  (void)hipFree(b);
+  (void)hipFree(c);
+  *gb_per_s = double(n_doubles) * 24.0 / (double(best) * 1e-3) / 1e9;
   return PM_OK;
 }
 

@@ -121,6 +121,13 @@ __global__ __launch_bounds__(256) void compat_kernel(CompatArgs p) {
   p.compat[w] = mask;
 }
 
+// stream triad a = b + 3 c over f64 (3 x 8 bytes per element): the measured HBM rate bench.py cites next to the
+// nominal 8 TB/s
+__global__ __launch_bounds__(256) void triad_kernel(const double* __restrict__ b, const double* __restrict__ c,
+                                                    double* __restrict__ a, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) a[i] = b[i] + 3.0 * c[i];
+}
+
 // cos(lat * pi/180) per worker, consumed by the Haversine term of the carve kernel.
 __global__ __launch_bounds__(256) void coslat_kernel(const double* __restrict__ lat, double* __restrict__ coslat,
                                                      uint32_t W) {
@@ -324,9 +331,9 @@ __global__ __launch_bounds__(64) void task_prefix_kernel(const uint64_t* __restr
     acc += __shfl(incl, 63, 64);
   }
 }
-// deleted tasks: clear the mask, the live bit, the created_at key and the task's bit in every plane
+// deleted tasks: clear the mask, the live bit and the task's bit in every plane
 __global__ __launch_bounds__(256) void task_delete_kernel(const uint32_t* __restrict__ slots, uint32_t n,
-                                                          uint64_t* __restrict__ tmask, long long* __restrict__ created,
+                                                          uint64_t* __restrict__ tmask,
                                                           uint64_t* __restrict__ live, uint64_t* __restrict__ planes,
                                                           uint32_t stride, uint32_t n_planes) {
   const uint32_t k = blockIdx.x * 256u + threadIdx.x;
@@ -334,7 +341,6 @@ __global__ __launch_bounds__(256) void task_delete_kernel(const uint32_t* __rest
   const uint32_t u = slots[k];
   const uint64_t bit = 1ull << (u & 63u);
   tmask[u] = 0ull;
-  created[u] = INT64_MIN;
   atomicAnd((unsigned long long*)&live[u >> 6], ~bit);
   for (uint32_t b = 0; b < n_planes; ++b) atomicAnd((unsigned long long*)&planes[(size_t)b * stride + (u >> 6)], ~bit);
 }
@@ -493,7 +499,8 @@ __global__ __launch_bounds__(256) void table_scatter_kernel(const pm_assignment*
 // ------------------------------------------------------------------------------------------------
 // NewestTaskPlugin: argmax (created_at, index) — LDS-staged wavefront argmax, last max wins.
 
-__global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__ created_at, uint32_t t_begin, uint32_t T,
+__global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__ created_at,
+                                                     const uint64_t* __restrict__ live, uint32_t t_begin, uint32_t T,
                                                      unsigned long long* __restrict__ best_key,
                                                      uint32_t* __restrict__ best_idx_by_block,
                                                      long long* __restrict__ best_val_by_block) {
@@ -502,8 +509,8 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
   long long bv = INT64_MIN;
   uint32_t bi = PM_NONE;
   for (uint32_t t = t_begin + blockIdx.x * 256u + threadIdx.x; t < T; t += gridDim.x * 256u) {
+    if (!((live[t >> 6] >> (t & 63u)) & 1ull)) continue;  // a deleted task's slot
     const long long v = created_at[t];
-    if (v == INT64_MIN) continue;    // a deleted / unused table slot
     if (bi == PM_NONE || v >= bv) {  // ascending t within a thread: >= keeps the last max
       bv = v;
       bi = t;
@@ -2226,6 +2233,13 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       }
     }
 #endif
+    if (p.count_keys) {  // bookkeeping for the roofline of this kernel (bench only): keys this sweep evaluated
+      const uint32_t swept = wave_sum(n_mine);
+      if (lane == 0) {
+        atomicAdd((unsigned long long*)&p.status->prop_keys, (unsigned long long)swept);
+        atomicAdd(&p.status->n_props, 1u);
+      }
+    }
     // the row: K sorted entries, and the flags word in the last entry (PM_PROP_META)
     const uint32_t meta = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
     (void)rows_pr;
@@ -2555,6 +2569,9 @@ void launch_compat(const CompatArgs& a, hipStream_t s) {
   if (a.W == 0) return;
   hipLaunchKernelGGL(compat_kernel, dim3((a.W + 255u) / 256u), dim3(256), 0, s, a);
 }
+void launch_triad(const double* b, const double* c, double* a, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(triad_kernel, dim3(256 * 32), dim3(256), 0, s, b, c, a, n);
+}
 void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s) {
   if (W == 0) return;
   hipLaunchKernelGGL(coslat_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, lat, coslat, W);
@@ -2662,11 +2679,11 @@ void launch_task_prefix(const uint64_t* live, uint32_t w_begin, uint32_t w_end, 
   if (w_end <= w_begin) return;
   hipLaunchKernelGGL(task_prefix_kernel, dim3(1), dim3(64), 0, s, live, w_begin, w_end, prefix);
 }
-void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, long long* created, uint64_t* live,
-                        uint64_t* planes, uint32_t stride, uint32_t n_planes, hipStream_t s) {
+void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, uint64_t* live, uint64_t* planes,
+                        uint32_t stride, uint32_t n_planes, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(task_delete_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, slots, n, tmask, created, live,
-                     planes, stride, n_planes);
+  hipLaunchKernelGGL(task_delete_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, slots, n, tmask, live, planes,
+                     stride, n_planes);
 }
 void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint32_t u_begin, uint32_t u_end,
                          const uint64_t* live, const uint32_t* prefix, uint32_t* first_out, uint32_t* count_out,
@@ -2676,9 +2693,9 @@ void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint3
                      u_begin, u_end, live, prefix, first_out, count_out);
 }
 
-void launch_newest(const int64_t* created_at, uint32_t t_begin, uint32_t t_end, uint32_t* idx_by_block,
-                   long long* val_by_block, uint32_t n_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(newest_kernel, dim3(n_blocks), dim3(256), 0, s, created_at, t_begin, t_end,
+void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_begin, uint32_t t_end,
+                   uint32_t* idx_by_block, long long* val_by_block, uint32_t n_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(newest_kernel, dim3(n_blocks), dim3(256), 0, s, created_at, live, t_begin, t_end,
                      (unsigned long long*)nullptr, idx_by_block, val_by_block);
 }
 

@@ -51,7 +51,7 @@ class EngineConfig(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("proximity_enabled", C.c_uint32),
                 ("switching_enabled", C.c_uint32), ("prefer_larger_groups", C.c_uint32), ("chooser", C.c_uint32),
                 ("chooser_seed", C.c_uint64), ("group_id_seed", C.c_uint64), ("debug_uncertain_every", C.c_uint32),
-                ("sweep_variant", C.c_uint32), ("carve_variant", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("sweep_variant", C.c_uint32), ("carve_variant", C.c_uint32), ("time_proposer", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -61,7 +61,8 @@ class Stats(C.Structure):
                 ("n_formed", C.c_uint32), ("n_merged", C.c_uint32), ("carve_steps", C.c_uint32),
                 ("carve_fast_steps", C.c_uint32),
                 ("host_resolved_steps", C.c_uint32), ("carve_launches", C.c_uint32), ("pair_evals", C.c_uint64),
-                ("carve_cand_sum", C.c_uint64)]
+                ("carve_cand_sum", C.c_uint64), ("ms_propose_kernel", C.c_float), ("proposals", C.c_uint32),
+                ("propose_keys", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -187,7 +188,7 @@ class Engine:
 
     def __init__(self, *, device: int = 0, proximity=True, switching=True, prefer_larger=True,
                  chooser=CHOOSE_FIRST, chooser_seed=0, group_id_seed=1, debug_uncertain_every=0, sweep_variant=0,
-                 carve_variant=0):
+                 carve_variant=0, time_proposer=False):
         L = lib()
         cfg = EngineConfig()
         L.pm_engine_config_default(C.byref(cfg))
@@ -201,6 +202,7 @@ class Engine:
         cfg.debug_uncertain_every = debug_uncertain_every
         cfg.sweep_variant = sweep_variant
         cfg.carve_variant = carve_variant
+        cfg.time_proposer = int(time_proposer)
         self._h = C.c_void_p()
         check(L.pm_engine_create(C.byref(cfg), C.byref(self._h)))
         self.W = 0
@@ -414,6 +416,15 @@ class Engine:
         b, c, n = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
         check(lib().pm_match_per_task_device(self._h, C.byref(b), C.byref(c), C.byref(n)))
         return b.value, c.value, n.value
+
+    def hbm_triad_gbs(self, n_doubles: int = 1 << 27, reps: int = 5) -> float:
+        """measured HBM rate (stream triad over 3 x n_doubles f64) — a debug export, not part of the ABI header"""
+        L = lib()
+        L.pm_debug_hbm_triad.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+        L.pm_debug_hbm_triad.restype = C.c_int32
+        out = C.c_double(0)
+        check(L.pm_debug_hbm_triad(self._h, n_doubles, reps, C.byref(out)))
+        return out.value
 
     def lookup(self, worker: int) -> Assignment:
         a = Assignment()

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in pm_engine.h but not exported"
     assert declared == set(E.EXPORTS)
-    assert L.pm_abi_version() == 1
+    assert L.pm_abi_version() == 2
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="this check is for boxes without a GPU")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Collect the per-round profile artefacts on the GPU box (run through gpurun), into gpurun_out/<tag>/:
 
-  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2`
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2 --no-extras` (12 matches)
+  <tag>_cfg2_kernel_stats.csv  the same for `--config 2 --steps 3 --warmup 1` (BASELINE configs[2], 4 matches)
   <tag>_timeline.txt       per-launch timeline of the last match of that run
   <tag>_bench.json         the bench line of the default `bench.py` command (with the CPU baseline)
   <tag>_pmc_traffic.json   HBM bytes per match from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes
@@ -43,10 +44,15 @@ def main():
     # 1. kernel trace
     d = os.path.join(out, "trace")
     run(f"cd /tmp && rocprofv3 --kernel-trace --stats -d {d} -o t -- {py} {bench} --steps 10 --warmup 2 "
-        f"--no-cpu-baseline > {out}/trace_bench.log 2>&1", env=env)
+        f"--no-cpu-baseline --no-extras > {out}/trace_bench.log 2>&1", env=env)
     db = os.path.join(d, "t_results.db")
     run(f"{py} {ROOT}/tools/rocpd_summary.py {db} {out}/{tag}_kernel_stats.csv")
     run(f"{py} {ROOT}/tools/tick_timeline.py {db} --all > {out}/{tag}_timeline.txt")
+    # 1b. the same for BASELINE configs[2] (1M tasks x 100k workers): 4 matches
+    d2 = os.path.join(out, "trace_cfg2")
+    run(f"cd /tmp && rocprofv3 --kernel-trace --stats -d {d2} -o t -- {py} {bench} --config 2 --steps 3 --warmup 1 "
+        f"--no-cpu-baseline --no-extras > {out}/trace_cfg2_bench.log 2>&1", env=env)
+    run(f"{py} {ROOT}/tools/rocpd_summary.py {os.path.join(d2, 't_results.db')} {out}/{tag}_cfg2_kernel_stats.csv")
 
     # 2. PMC passes (counters on their own, no trace domains besides the kernel trace)
     matches = 4  # --steps 3 --warmup 1
@@ -54,14 +60,14 @@ def main():
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         dd = os.path.join(out, "pmc_" + counter)
         run(f"cd /tmp && rocprofv3 --pmc {counter} -d {dd} -o p -- {py} {bench} --steps 3 --warmup 1 "
-            f"--no-cpu-baseline > {out}/pmc_{counter}.log 2>&1", env=env)
+            f"--no-cpu-baseline --no-extras > {out}/pmc_{counter}.log 2>&1", env=env)
         try:
             sums[counter] = pmc_sum(os.path.join(dd, "p_results.db"), counter)
         except Exception as ex:  # noqa: BLE001
             print("pmc pass failed:", counter, ex)
             sums[counter] = {}
     groups = {"carve": ("carve_kernel", "carve_propose_kernel"),
-              "pair_sweep": ("pair_sweep", "pair_combine", "build_planes"),
+              "pair_sweep": ("pair_sweep", "pair_init", "build_planes"),
               "compat_kernel": ("compat_kernel",)}
     traffic = {}
     for g, pats in groups.items():
@@ -87,7 +93,7 @@ def main():
             fh.write((line[-1] if line else r.stdout + r.stderr) + "\n")
         print(line[-1] if line else r.stdout[-2000:] + r.stderr[-2000:])
     # drop the bulky raw databases, keep the summaries
-    run(f"rm -rf {out}/trace {out}/pmc_FETCH_SIZE {out}/pmc_WRITE_SIZE")
+    run(f"rm -rf {out}/trace {out}/trace_cfg2 {out}/pmc_FETCH_SIZE {out}/pmc_WRITE_SIZE")
 
 
 if __name__ == "__main__":
