@@ -74,6 +74,7 @@ enum {
   CARVE_F_RUN = 1u << 1,    // process the prepared configuration
   CARVE_F_ALL = 1u << 2,    // keep going through every configuration in this launch (no proposals)
   CARVE_F_PROPS = 1u << 3,  // neighbour-list proposals of carve_propose_kernel are available
+  CARVE_F_EXTPREP = 1u << 4 // the candidate lists are prepared by carve_prep_*_kernel between the launches
 };
 // Device-resident state of one carve (try_form_new_groups / one merge configuration); it persists across
 // the launches of the propose / validate sequence.
@@ -97,6 +98,9 @@ struct CarveStatus {
   uint32_t slow_steps;   // steps that needed the full key sweep
   uint32_t n_solo;       // single-node groups carved (the merge pass only runs when there are two or more)
   uint32_t n_props;      // neighbour lists computed by this rank's proposer
+  uint32_t need_prep;    // (external preparation) the next candidate list has not been prepared yet
+  uint32_t g_lo, g_hi;   // groups appended by the last validation launch (their group_of is written by the prep kernels)
+  uint32_t _pad_prep;
   unsigned long long prop_keys;  // keys (Haversine terms) those sweeps evaluated
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
@@ -145,6 +149,8 @@ struct CarveArgs {
   uint32_t* seed_prefix;   // per bitmap word: seeds in front of the word
   uint32_t dist_rank, dist_world;
   uint32_t count_keys, _pad_ck;  // proposer: count the keys it sweeps (bench bookkeeping)
+  uint32_t* prep_block_counts;   // [blocks][PM_MAX_CONFIGS] live compatible positions per block and configuration
+  uint32_t* prep_counts;         // [PM_MAX_CONFIGS] totals, [PM_MAX_CONFIGS] = finished-blocks ticket
   uint32_t* same_next;     // next located slot at the same site (identical coordinates), PM_NONE = none
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
@@ -193,6 +199,8 @@ void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_b
                    uint32_t* idx_by_block, long long* val_by_block, uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
+void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s);
+void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 
 }  // namespace pm

@@ -149,7 +149,7 @@ struct pm_engine {
       h_addr_rank;
   std::vector<double> h_lat, h_lon;
   std::vector<uint32_t> h_site;  // equal (lat, lon) bit patterns <=> equal site id
-  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_same_next, d_seed_prefix;
+  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_same_next, d_seed_prefix, d_prep_block_counts, d_prep_counts;
   DevBuf<uint64_t> d_prop, d_prop_send, d_seed_map;
   uint32_t tick_fast_steps = 0;
   DevBuf<uint32_t> d_flags, d_gpu_count, d_gpu_mem, d_gpu_cls, d_cpu_cores, d_ram, d_storage, d_addr_rank;
@@ -455,6 +455,8 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     if (world > 1) HIPCHK(e->d_prop_send.ensure(rows_pr * PM_PROP_ROW));
     HIPCHK(e->d_seed_map.ensure((cap + 63) / 64 + 64));
     HIPCHK(e->d_seed_prefix.ensure((cap + 63) / 64 + 64));
+    HIPCHK(e->d_prep_block_counts.ensure(((cap + 255) / 256 + 1) * PM_MAX_CONFIGS));
+    HIPCHK(e->d_prep_counts.ensure(PM_MAX_CONFIGS + 8));
   }
   HIPCHK(e->d_status.ensure(1));
   HIPCHK(e->d_carve_args.ensure(1));
@@ -496,6 +498,8 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->dist_rank = e->dist_rank;
   a->dist_world = e->dist_world;
   a->count_keys = e->cfg.time_proposer ? 1u : 0u;
+  a->prep_block_counts = e->d_prep_block_counts.p;
+  a->prep_counts = e->d_prep_counts.p;
   a->same_next = e->d_same_next.p;
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
   a->bits_stride = stride;
@@ -619,9 +623,11 @@ struct FormRun {
 
 static int32_t form_queue_init(pm_engine* e, FormRun* r) {
   HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
-  if (r->use_props)
-    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS, r->start_ci, r->lds, e->stream));
-  else
+  if (r->use_props) {
+    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS | CARVE_F_EXTPREP, r->start_ci, r->lds, e->stream));
+    launch_carve_prep(e->d_carve_args.p, e->W, e->stream);  // the first candidate list
+    e->tick_carve_launches += 2;
+  } else
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, r->start_ci, r->lds, e->stream));
   e->tick_carve_launches++;
   return PM_OK;
@@ -691,8 +697,9 @@ static int32_t form_queue_pairs(pm_engine* e, FormRun* r, uint32_t count) {
   for (uint32_t k = 0; k < count; ++k) {
     int32_t rc = launch_propose_timed(e);
     if (rc) return rc;
-    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, r->lds, e->stream));
-    e->tick_carve_launches += 2;
+    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, r->lds, e->stream));
+    launch_carve_prep(e->d_carve_args.p, e->W, e->stream);  // group_of of the new groups + the next candidate list
+    e->tick_carve_launches += 4;
   }
   return PM_OK;
 }
@@ -786,7 +793,10 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   if (rc) return rc;
   if (!r.nothing) {
     uint32_t batch = r.a.n_avail + 3u;
-    for (;;) {
+    for (uint32_t spins = 0;; ++spins) {
+      // every poll either ends the carve or follows launches that formed at least one group or moved on to the
+      // next configuration: far fewer rounds than this, or the device side is stuck — fail instead of hanging
+      if (spins > 4096u + e->W / 8u) return set_error(PM_ENODEV, "carve made no progress");
       if (r.use_props) {
         rc = form_queue_pairs(e, &r, batch);
         if (rc) return rc;
@@ -1276,7 +1286,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_rank_in_group.release(); e->d_g_id.release();
   e->d_order.release(); e->d_c_lat.release(); e->d_c_lon.release(); e->d_c_cos.release();
   e->d_cc_lat.release(); e->d_cc_lon.release(); e->d_cc_cos.release(); e->d_slot_pos.release(); e->d_slot_wid.release();
-  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_same_next.release();
+  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_prep_block_counts.release(); e->d_prep_counts.release(); e->d_same_next.release();
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
@@ -2367,8 +2377,9 @@ int32_t pm_dist_carve_validate(pm_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
   if (e->dist_phase != 1 || !e->form || e->form->nothing) return set_error(PM_ESTATE, "no proposal batch pending");
-  HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS, 0, e->form->lds, e->stream));
-  e->tick_carve_launches++;
+  HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, e->form->lds, e->stream));
+  launch_carve_prep(e->d_carve_args.p, e->W, e->stream);
+  e->tick_carve_launches += 3;
   return PM_OK;
 }
 

@@ -2252,7 +2252,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
 // below it (the batch's seeds).  Also records, per bitmap word below the limit, the seed bitmap and the number of
 // seeds in front of the word (seed_map / seed_prefix): the rank of a slot among the seeds is the row its
 // proposal is stored in (proposer and validator derive it from these two words).
-__device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& red, uint32_t n_list, uint32_t* n_seeds) {
+// (one wave; the results are valid in every lane)
+__device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_list, uint32_t lane, uint32_t* limit_out,
+                                                uint32_t* n_seeds_out) {
   // The configuration is re-prepared (and re-proposed) once half of its list is dead; by then the seed
   // pointer has advanced through roughly the first eighth of the slots (each group removes max_s slots
   // spread over the whole list), so later slots never consume this round's proposals: cap the batch.
@@ -2261,38 +2263,45 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
   uint32_t cap = n_list > PM_CARVE_SLOTS ? n_list / 10u : n_list / 5u;
   if (cap < 512u) cap = 512u;
   if (cap > PM_PROP_MAX_SEEDS) cap = PM_PROP_MAX_SEEDS;
+  const auto g_al = G((const uint64_t*)p.bits_scratch);
+  const auto g_lc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
+  const auto seed_map = G(p.seed_map);
+  const auto seed_prefix = G(p.seed_prefix);
+  const uint32_t lwp = (n_list + 63u) >> 6;
+  uint32_t acc = 0, limit = n_list;
+  for (uint32_t j0 = 0; j0 < lwp; j0 += 64u) {
+    const uint32_t j = j0 + lane;
+    const uint64_t m = j < lwp ? (g_al[j] & g_lc[j]) : 0ull;  // bits beyond n_list are zero in both bitmaps
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if ((int)lane >= o) incl += up;
+    }
+    const uint64_t over = __ballot(acc + incl >= cap);
+    const uint32_t last = over ? (uint32_t)__builtin_ctzll(over) : 63u;  // last word of this pass inside the batch
+    if (j < lwp && lane <= last) {
+      seed_map[j] = m;
+      seed_prefix[j] = acc + incl - cnt;
+    }
+    acc += __shfl(incl, (int)last, 64);
+    if (over) {
+      limit = (j0 + last + 1u) * 64u;
+      break;
+    }
+  }
+  *limit_out = limit < n_list ? limit : n_list;
+  *n_seeds_out = acc;
+}
+
+__device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& red, uint32_t n_list, uint32_t* n_seeds) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (wave == 0) {
-    const auto g_al = G((const uint64_t*)p.bits_scratch);
-    const auto g_lc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
-    const auto seed_map = G(p.seed_map);
-    const auto seed_prefix = G(p.seed_prefix);
-    const uint32_t lwp = (n_list + 63u) >> 6;
-    uint32_t acc = 0, limit = n_list;
-    for (uint32_t j0 = 0; j0 < lwp; j0 += 64u) {
-      const uint32_t j = j0 + lane;
-      const uint64_t m = j < lwp ? (g_al[j] & g_lc[j]) : 0ull;  // bits beyond n_list are zero in both bitmaps
-      const uint32_t cnt = (uint32_t)__popcll(m);
-      uint32_t incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += up;
-      }
-      const uint64_t over = __ballot(acc + incl >= cap);
-      const uint32_t last = over ? (uint32_t)__builtin_ctzll(over) : 63u;  // last word of this pass inside the batch
-      if (j < lwp && lane <= last) {
-        seed_map[j] = m;
-        seed_prefix[j] = acc + incl - cnt;
-      }
-      acc += __shfl(incl, (int)last, 64);
-      if (over) {
-        limit = (j0 + last + 1u) * 64u;
-        break;
-      }
-    }
+    uint32_t limit, acc;
+    prop_limit_scan(p, n_list, lane, &limit, &acc);
     if (lane == 0) {
-      red.b[0] = limit < n_list ? limit : n_list;
+      red.b[0] = limit;
       red.b[1] = acc;
     }
   }
@@ -2301,6 +2310,166 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
   *n_seeds = red.b[1];
   __syncthreads();
   return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Full-chip preparation of the next candidate list (proposal-driven FORM carve).  The validator is one
+// workgroup; compacting a 100 k-entry eligible list (and scattering group_of for the groups it just formed) on
+// one CU took a third of its time.  Between two validation launches run, on every CU:
+//   carve_prep_count_kernel   group_of for the groups of the last launch; per block, per remaining configuration,
+//                             the number of live compatible positions (+ global totals); clears the slot loc bitmap
+//   carve_prep_place_kernel   every block picks the same next configuration from the totals (mod.rs:505-519: the
+//                             first whose loop would be entered), derives its offset from the per-block counts
+//                             and places its candidates (stable: slot order = input order); the block that
+//                             finishes last computes the proposal batch (prop_limit_scan) and publishes the status
+// One 64-position word per wave, four waves per block.
+
+#define PREP_WAVES 4
+
+__global__ __launch_bounds__(256) void carve_prep_count_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;
+  const auto st = G(p.status);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t wave_g = blockIdx.x * PREP_WAVES + wave, n_waves = gridDim.x * PREP_WAVES;
+  // group_of for the groups the last validation launch appended (idempotent; also runs after the carve ended)
+  {
+    const uint32_t g_lo = st->g_lo, g_hi = st->g_hi;
+    for (uint32_t g = g_lo + wave_g; g < g_hi; g += n_waves) {
+      const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
+      for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
+    }
+  }
+  if (st->state != CARVE_STATE_RUNNING || !st->need_prep || st->cur_ci >= p.n_avail) return;
+  __shared__ uint32_t s_cnt[PREP_WAVES][PM_MAX_CONFIGS];
+  const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6, ci0 = st->cur_ci;
+  const uint32_t j = wave_g;  // this wave's word of the position space
+  uint64_t m = 0;
+  if (j < n_words) {
+    const uint32_t i = j * 64u + lane;
+    const bool alive = i < n && ((G(p.alive_g)[j] >> lane) & 1ull);
+    m = alive ? G((const uint64_t*)p.c_compat)[i] : 0ull;
+    if (lane == 0) G(p.bits_scratch)[p.bits_stride + j] = 0ull;  // slot loc bitmap: the placement ORs its bits in
+  }
+  for (uint32_t ci = ci0; ci < p.n_avail; ++ci) {
+    const uint32_t cnt = (uint32_t)__popcll(__ballot((m >> p.avail_cfg[ci]) & 1ull));
+    if (lane == 0) s_cnt[wave][ci] = cnt;
+  }
+  __syncthreads();
+  if (tid >= ci0 && tid < p.n_avail) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < PREP_WAVES; ++w) sum += s_cnt[w][tid];
+    G(p.prep_block_counts)[(size_t)blockIdx.x * PM_MAX_CONFIGS + tid] = sum;
+    if (sum) atomicAdd(&p.prep_counts[tid], sum);
+  }
+}
+
+__global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;
+  const auto st = G(p.status);
+  // (a carve whose last configuration has just been exhausted arrives here with cur_ci == n_avail: the selection
+  // below finds nothing and the last block reports DONE)
+  if (st->state != CARVE_STATE_RUNNING || !st->need_prep) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  __shared__ uint32_t s_red[PREP_WAVES + 4];
+  __shared__ uint32_t s_bits[PREP_WAVES][64];
+  const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6;
+  const uint32_t total_available = st->total_available;
+  // ---- the next configuration whose loop would be entered (mod.rs:505-519), the same in every block
+  uint32_t ci = st->cur_ci, n_list = 0;
+  for (; ci < p.n_avail; ++ci) {
+    const uint32_t min_s = p.min_size[ci];
+    if (total_available < min_s) continue;             // `while` never entered (:507)
+    n_list = G((const uint32_t*)p.prep_counts)[ci];
+    if (n_list < min_s || n_list == 0) continue;       // :517-519
+    break;
+  }
+  const bool none = ci >= p.n_avail;
+  if (!none) {
+    const uint64_t cbit = 1ull << p.avail_cfg[ci];
+    // ---- this block's first slot: candidates of the blocks in front of it
+    uint32_t part = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += 256u) part += G((const uint32_t*)p.prep_block_counts)[(size_t)b * PM_MAX_CONFIGS + ci];
+    part = wave_sum(part);
+    if (lane == 0) s_red[wave] = part;
+    // ---- this wave's word: candidates, their ranks
+    const uint32_t j = blockIdx.x * PREP_WAVES + wave;
+    const uint32_t i = j * 64u + lane;
+    const uint32_t ic = i < n ? i : (n ? n - 1u : 0u);
+    const uint64_t aw = j < n_words ? G(p.alive_g)[j] : 0ull;
+    const uint64_t lg = j < n_words ? G(p.loc_g)[j] : 0ull;
+    const uint64_t cm = n ? G((const uint64_t*)p.c_compat)[ic] : 0ull;
+    const uint32_t ow = n ? G(p.order)[ic] : 0u;
+    const uint32_t os = n ? G(p.c_site)[ic] : 0u;
+    const double la = n ? G(p.c_lat)[ic] : 0.0, lo = n ? G(p.c_lon)[ic] : 0.0, co = n ? G(p.c_cos)[ic] : 0.0;
+    const bool c = i < n && ((aw >> lane) & 1ull) && (cm & cbit) != 0ull;
+    const uint64_t bal = __ballot(c);
+    const uint32_t cnt = (uint32_t)__popcll(bal);
+    if (lane == 0) s_red[PREP_WAVES + wave] = cnt;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < PREP_WAVES; ++w) off += s_red[w];
+    for (uint32_t w = 0; w < wave; ++w) off += s_red[PREP_WAVES + w];
+    const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    const uint32_t has_loc = (uint32_t)(lg >> lane) & 1u;
+    if (c) {
+      const uint32_t s = off + rank;
+      G(p.slot_pos)[s] = i | (has_loc << 31);  // bit 31: has a location
+      G(p.slot_wid)[s] = ow;
+      G(p.cc_lat)[s] = la;
+      G(p.cc_lon)[s] = lo;
+      G(p.cc_cos)[s] = co;
+      G(p.cc_site)[s] = os;
+      s_bits[wave][rank] = has_loc;
+    }
+    // the located bits of this wave's slots [off, off + cnt): compacted by rank, ORed into the slot loc bitmap
+    // (cleared by carve_prep_count_kernel); at most two words
+    __syncthreads();
+    const uint64_t locm = __ballot(lane < cnt && s_bits[wave][lane] != 0u);
+    if (lane == 0 && locm) {
+      const auto loc = (unsigned long long*)(p.bits_scratch + p.bits_stride);
+      const uint32_t sh = off & 63u;
+      atomicOr(&loc[off >> 6], (unsigned long long)(locm << sh));
+      if (sh && (locm >> (64u - sh))) atomicOr(&loc[(off >> 6) + 1u], (unsigned long long)(locm >> (64u - sh)));
+    }
+  }
+  // ---- the block that finishes last completes the list and publishes it
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_red[0] = atomicAdd(&p.prep_counts[PM_MAX_CONFIGS], 1u);
+  __syncthreads();
+  if (s_red[0] != gridDim.x - 1u) return;
+  __threadfence();
+  if (none) {
+    if (tid == 0) {
+      st->state = CARVE_STATE_DONE;
+      st->cur_ci = p.n_avail;
+      st->need_prep = 0;
+    }
+    return;
+  }
+  const uint32_t lw = (n_list + 63u) >> 6;
+  const auto alive = G(p.bits_scratch);
+  for (uint32_t w = tid; w < lw; w += 256u)  // slot alive bitmap: every slot of the fresh list
+    alive[w] = (w + 1u < lw || (n_list & 63u) == 0u) ? ~0ull : ((1ull << (n_list & 63u)) - 1ull);
+  __threadfence();
+  __syncthreads();
+  uint32_t prop_k = 0, limit = 0, n_seeds = 0;
+  const uint32_t max_s = p.max_size[ci];
+  if (p.proximity && n_list <= PM_CARVE_BIG_SLOTS && max_s - 1u < PM_PROP_META) {
+    const uint32_t k = max_s - 1u + PM_PROP_RESERVE;
+    prop_k = k < PM_PROP_META ? k : PM_PROP_META;
+    if (wave == 0) prop_limit_scan(p, n_list, lane, &limit, &n_seeds);
+  }
+  if (tid == 0) {
+    st->cur_ci = ci;
+    st->n_list = n_list;
+    st->prop_k = prop_k;
+    st->prop_limit = limit;
+    st->rows_pr = (n_seeds + p.dist_world - 1u) / p.dist_world;
+    st->need_prep = 0;
+  }
 }
 
 __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* __restrict__ pa, uint32_t flags_in,
@@ -2393,7 +2562,19 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     c.total_available = n;  // mod.rs:503
     ci = start_ci;
     prepared = false;
+    if (flags & CARVE_F_EXTPREP) {  // the lists are prepared by carve_prep_*_kernel on the whole chip
+      if (tid <= PM_MAX_CONFIGS) p.prep_counts[tid] = 0u;
+      if (tid == 0) {
+        st->n_eligible = n;
+        st->total_available = n;
+        st->cur_ci = start_ci;
+        st->need_prep = 1u;
+        st->g_lo = st->g_hi = st->n_groups;
+      }
+      return;
+    }
   } else {
+    if ((flags & CARVE_F_EXTPREP) && st->need_prep) return;  // nothing prepared (no configuration left, or stopped)
     n = st->n_eligible;
     c.total_available = st->total_available;
     ci = st->cur_ci;
@@ -2529,18 +2710,23 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     }
     prepared = false;
     if (rc == STEP_BREAK) ++ci;  // configuration exhausted; STEP_CONTINUE => re-prepare the same configuration
+    if (flags & CARVE_F_EXTPREP) break;  // the next list is prepared on the whole chip (carve_prep_*_kernel)
     if (!(flags & CARVE_F_ALL)) flags &= ~CARVE_F_RUN;  // per-configuration launch: prepare the next list, leave
   }
 
-  // group_of for everything carved by this launch (FORM), one parallel pass at the end
+  // group_of for everything carved by this launch (FORM), one parallel pass at the end — or, with the external
+  // preparation, left to carve_prep_count_kernel (every CU); single-node groups are counted here either way
+  const bool ext = (flags_in & CARVE_F_EXTPREP) != 0u;
   if (p.mode == CARVE_MODE_FORM) {
     __syncthreads();
     for (uint32_t g = groups_at_entry + wave; g < c.n_groups; g += CARVE_WAVES) {
       const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
-      for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
+      if (!ext)
+        for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
       if (gn == 1u && lane == 0) atomicAdd(&p.status->n_solo, 1u);  // rare
     }
   }
+  if (ext && tid <= PM_MAX_CONFIGS) p.prep_counts[tid] = 0u;  // totals + ticket of the next preparation
   __syncthreads();
   PROF_MARK(14);
   if (tid == 0) {
@@ -2557,6 +2743,11 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     st->prop_limit = c.prop_limit;
     st->rows_pr = c.rows_pr;
     st->total_available = c.total_available;
+    if (ext) {
+      st->need_prep = exit_state == CARVE_STATE_RUNNING ? 1u : 0u;
+      st->g_lo = groups_at_entry;
+      st->g_hi = c.n_groups;
+    }
     st->fast_steps += c.fast_steps;
     st->slow_steps += c.steps - c.fast_steps;
   }
@@ -2722,6 +2913,20 @@ __global__ __launch_bounds__(256) void group_ids_kernel(uint64_t* __restrict__ g
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(group_ids_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, g_id, g_task, n, rng_state);
+}
+
+// the two full-chip kernels that prepare the next candidate list: one 64-position word per wave
+void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
+  uint32_t blocks = ((W + 63u) / 64u + PREP_WAVES - 1u) / PREP_WAVES;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(carve_prep_count_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+  hipLaunchKernelGGL(carve_prep_place_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+}
+// group_of for the groups of the last validation launch (the count kernel's first half), e.g. after the carve ended
+void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
+  uint32_t blocks = ((W + 63u) / 64u + PREP_WAVES - 1u) / PREP_WAVES;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(carve_prep_count_kernel, dim3(blocks), dim3(256), 0, s, d_args);
 }
 
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s) {

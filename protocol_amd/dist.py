@@ -142,7 +142,7 @@ class ShardedEngine:
         L = self.local
         with self._ctx():
             L.tick_begin()
-            while True:
+            for _batch in range(1 << 20):        # (bounded: a stuck carve must fail, not hang the job)
                 more, send, recv = L.carve_next()
                 if not more:
                     break
@@ -150,6 +150,8 @@ class ShardedEngine:
                     self.x.all_gather(recv, send)
                     self.exchanges += 1
                 L.carve_validate()
+            else:
+                raise RuntimeError("the carve did not finish")
             send, recv = L.match_begin()
             if send is not None:                # the published rows of the owned workers
                 self.x.all_gather(recv, send)
