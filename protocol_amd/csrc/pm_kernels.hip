@@ -2100,16 +2100,15 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
 #pragma unroll
     for (int i = 0; i < PM_TOPN; ++i) q.r[i] = ~0ull;
     uint32_t n_mine = 0;
-    // The sweep is a chain of L2-latency loads with ~70 f64 operations per key in between.  One wave per SIMD
-    // has nobody to hide that latency behind, so the loop is software-pipelined: the loads of the next four
-    // 64-slot strides are in flight while the keys of the current four are computed (two register sets).
-    SweepBatch ba, bb;
-    sweep_load(p, alive, loc, lw, n_list, 0u, lane, shared, ba);
-    for (uint32_t j0 = 0; j0 < lw; j0 += 8u) {
-      sweep_load(p, alive, loc, lw, n_list, j0 + 4u, lane, shared, bb);
+    // The sweep: L2-latency loads with ~70 f64 operations + an 8-deep insertion per key in between (about 375
+    // instructions per 64-slot stride: the kernel is issue-bound once enough seeds are in flight).
+    // One register set of four strides per step.  (A software-pipelined variant with two register sets needs 213
+    // VGPRs = 2 waves per SIMD; this one needs 159 = 3 waves, and the extra wave hides more latency than the
+    // explicit prefetch did: 9.2 -> 8.4 ms of proposals per match at 1M x 100k.)
+    SweepBatch ba;
+    for (uint32_t j0 = 0; j0 < lw; j0 += 4u) {
+      sweep_load(p, alive, loc, lw, n_list, j0, lane, shared, ba);
       sweep_keys(ba, lw, j0, lane, s, shared, ssite, slat, slon, scos, SB, q, n_mine);
-      sweep_load(p, alive, loc, lw, n_list, j0 + 8u, lane, shared, ba);
-      sweep_keys(bb, lw, j0 + 4u, lane, s, shared, ssite, slat, slon, scos, SB, q, n_mine);
     }
     PP_MARK(pt_sweep);
     uint32_t popped = 0, n_k = 0;
