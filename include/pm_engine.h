@@ -22,8 +22,10 @@
  *     fallback.
  *
  * Threading (orchestrator/src/plugins/mod.rs:66-78 is called concurrently from actix workers):
- *   pm_lookup_* are wait-free reads of the last published assignment table and may be called from
- *   any thread at any time; every other call takes the engine's single-writer mutex.
+ *   pm_lookup_task_for_worker may be called from any thread at any time, also while pm_tick runs: the published
+ *   table is double-buffered behind a sequence counter (seqlock) — no lock, no HIP call, no allocation; a reader
+ *   retries only if two publishes complete during its 32-byte row copy.  Every other call takes the engine's
+ *   single-writer mutex.
  */
 #ifndef PM_ENGINE_H
 #define PM_ENGINE_H
@@ -293,7 +295,7 @@ typedef struct {
 } pm_assignment;
 
 /* Scheduler::get_task_for_node (scheduler/mod.rs:26-36) served from the table published by the last
- * pm_tick / pm_match: wait-free, no HIP call. */
+ * pm_tick / pm_match: lock-free (seqlock over two buffers), no HIP call. */
 int32_t pm_lookup_task_for_worker(pm_engine*, uint32_t worker, pm_assignment* out);
 
 /* Device-resident view of the last published per-worker task column (u32 task index or PM_NONE, W

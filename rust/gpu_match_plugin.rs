@@ -1,4 +1,4 @@
-//! GpuMatchPlugin — the third `SchedulerPlugin` variant: binds libpm_engine.so (include/pm_engine.h).
+//! GpuMatchPlugin — the third `SchedulerPlugin` variant: binds libpm_engine.so (include/pm_engine.h, ABI v2).
 //!
 //! SOURCE ONLY: this image has no cargo/rustc, so this file has never been compiled.  It is the binding a
 //! maintainer adds under crates/orchestrator/src/plugins/gpu_match/mod.rs, next to
@@ -6,9 +6,18 @@
 //!
 //! The plugin owns an opaque `pm_engine*`.  The group-management loop calls `tick()` instead of
 //! `try_form_new_groups` + `try_merge_solo_groups` (node_groups/mod.rs:180-203); `filter_tasks` becomes a
-//! wait-free lookup of the table published by the last tick (scheduler_impl.rs:11-110).
+//! lock-free lookup of the table published by the last tick (scheduler_impl.rs:11-110).
+//!
+//! Row identity.  The engine keys workers, groups and claims by ROW INDEX.  `NodeStore::get_nodes` is Redis
+//! SMEMBERS order followed by a status sort (node_store.rs:195-206), so the position of a node in that Vec moves
+//! whenever anybody's status changes.  The plugin therefore keeps a stable `address -> row` map: a node seen for the
+//! first time is APPENDED (pm_append_workers), a known node whose projection changed is rewritten in place
+//! (pm_update_workers), a node that left the store is tombstoned (PM_W_HEALTHY cleared + dissolve, never removed).
+//! The order in which nodes first appear is the engine's input order (the reference's own tie-break is the
+//! unspecified SMEMBERS order).
 #![allow(non_camel_case_types, dead_code)]
 
+use std::collections::HashMap;
 use std::ffi::{c_char, CStr, CString};
 use std::os::raw::c_void;
 
@@ -21,6 +30,8 @@ use crate::models::node::{NodeStatus, OrchestratorNode};
 use crate::plugins::node_groups::NodeGroupConfiguration;
 
 pub const PM_NONE: u32 = 0xFFFF_FFFF;
+pub const PM_ABI_VERSION: u32 = 2;
+const PM_EINVAL: i32 = -1;
 
 #[repr(C)]
 pub struct pm_engine_config {
@@ -35,7 +46,7 @@ pub struct pm_engine_config {
     pub debug_uncertain_every: u32,
     pub sweep_variant: u32,
     pub carve_variant: u32,
-    pub _reserved: u32,
+    pub time_proposer: u32,
 }
 
 #[repr(C)]
@@ -106,6 +117,7 @@ pub struct pm_stats {
     pub ms_total: f32, pub ms_compat_kernel: f32, pub ms_carve_kernel: f32, pub ms_sweep_kernel: f32,
     pub n_groups: u32, pub n_formed: u32, pub n_merged: u32, pub carve_steps: u32, pub carve_fast_steps: u32,
     pub host_resolved_steps: u32, pub carve_launches: u32, pub pair_evals: u64, pub carve_cand_sum: u64,
+    pub ms_propose_kernel: f32, pub proposals: u32, pub propose_keys: u64,
 }
 
 #[repr(C)]
@@ -115,6 +127,15 @@ pub struct pm_group_vars {
     pub next_p2p_address: *const c_char,
     pub group_id: *const c_char,
     pub total_upload_count: *const c_char,
+}
+
+/// One all-gather of the multi-GPU tick (device pointers; recv = [world][bytes_per_rank]).
+#[repr(C)]
+#[derive(Default)]
+pub struct pm_dist_xfer {
+    pub send_ptr: u64,
+    pub recv_ptr: u64,
+    pub bytes_per_rank: u64,
 }
 
 #[link(name = "pm_engine")]
@@ -127,16 +148,27 @@ extern "C" {
     fn pm_set_model_table(e: *mut c_void, bits: *const u32, n_rows: u32, n_classes: u32) -> i32;
     fn pm_set_enabled_mask(e: *mut c_void, enabled: u64) -> i32;
     fn pm_upload_workers(e: *mut c_void, w: *const pm_worker_soa, keep_groups: u32) -> i32;
+    fn pm_append_workers(e: *mut c_void, rows: *const pm_worker_soa, first_index: *mut u32) -> i32;
+    fn pm_update_workers(e: *mut c_void, idx: *const u32, rows: *const pm_worker_soa) -> i32;
+    fn pm_set_addr_ranks(e: *mut c_void, ranks: *const u32, n: u32) -> i32;
     fn pm_upload_tasks(e: *mut c_void, t: *const pm_task_soa) -> i32;
+    fn pm_tasks_insert_front(e: *mut c_void, rows: *const pm_task_soa) -> i32;
+    fn pm_tasks_delete(e: *mut c_void, uids: *const u64, n: u32, n_deleted: *mut u32) -> i32;
     fn pm_on_worker_status(e: *mut c_void, worker: u32, flags_new: u32, dead: u32) -> i32;
     fn pm_tick(e: *mut c_void, stats: *mut pm_stats) -> i32;
     fn pm_lookup_task_for_worker(e: *mut c_void, worker: u32, out: *mut pm_assignment) -> i32;
     fn pm_host_group_vars(input: *const c_char, v: *const pm_group_vars, out: *mut c_char, cap: usize, needed: *mut usize) -> i32;
     fn pm_host_volume_vars(input: *const c_char, group_id: *const c_char, out: *mut c_char, cap: usize, needed: *mut usize) -> i32;
-    fn pm_host_parse_requirements(s: *const c_char, cfg: *mut pm_config_row, alts: *mut pm_gpu_alt_row,
-                                  alt_cap: u32, models_out: *mut c_char, models_cap: usize) -> i32;
     fn pm_host_build_model_table(req_models: *const *const c_char, n_rows: u32,
                                  spec_models: *const *const c_char, n_classes: u32, bits_out: *mut u32) -> i32;
+    // multi-GPU (one process per GPU; the all-gathers are ncclAllGather on the stream handed to pm_set_stream)
+    fn pm_set_stream(e: *mut c_void, hip_stream: *mut c_void) -> i32;
+    fn pm_dist_configure(e: *mut c_void, rank: u32, world: u32, shard_of_worker: *const u8) -> i32;
+    fn pm_dist_tick_begin(e: *mut c_void) -> i32;
+    fn pm_dist_carve_next(e: *mut c_void, x: *mut pm_dist_xfer, more: *mut u32) -> i32;
+    fn pm_dist_carve_validate(e: *mut c_void) -> i32;
+    fn pm_dist_match_begin(e: *mut c_void, x: *mut pm_dist_xfer) -> i32;
+    fn pm_dist_tick_end(e: *mut c_void, stats: *mut pm_stats) -> i32;
 }
 
 // worker flag bits (include/pm_engine.h)
@@ -144,6 +176,11 @@ const W_HAS_SPECS: u32 = 1 << 0; const W_HAS_GPU: u32 = 1 << 1; const W_GPU_COUN
 const W_GPU_MEM: u32 = 1 << 3; const W_GPU_MODEL: u32 = 1 << 4; const W_HAS_CPU: u32 = 1 << 5;
 const W_CPU_CORES: u32 = 1 << 6; const W_RAM: u32 = 1 << 7; const W_STORAGE: u32 = 1 << 8;
 const W_HEALTHY: u32 = 1 << 9; const W_HAS_P2P: u32 = 1 << 10; const W_HAS_LOC: u32 = 1 << 11;
+// requirement flag bits
+const R_HAS_REQ: u32 = 1 << 0; const R_CPU: u32 = 1 << 1; const R_CPU_CORES: u32 = 1 << 2;
+const R_RAM: u32 = 1 << 3; const R_STORAGE: u32 = 1 << 4;
+const G_COUNT: u32 = 1 << 0; const G_MODEL: u32 = 1 << 1; const G_MEM: u32 = 1 << 2; const G_MEM_MIN: u32 = 1 << 3;
+const G_MEM_MAX: u32 = 1 << 4; const G_TOT_MIN: u32 = 1 << 5; const G_TOT_MAX: u32 = 1 << 6;
 
 fn check(rc: i32) -> Result<()> {
     if rc == 0 { return Ok(()); }
@@ -151,47 +188,66 @@ fn check(rc: i32) -> Result<()> {
     Err(anyhow!("pm_engine error {rc}: {msg}"))
 }
 
-/// Projection of one `OrchestratorNode` (orchestrator/src/models/node.rs:11-37) into the SoA row.
-fn worker_flags(n: &OrchestratorNode) -> u32 {
-    let mut f = 0;
-    if n.status == NodeStatus::Healthy { f |= W_HEALTHY; }
-    if n.p2p_id.is_some() { f |= W_HAS_P2P; }
-    if n.location.is_some() { f |= W_HAS_LOC; }
-    if let Some(s) = &n.compute_specs {
-        f |= W_HAS_SPECS;
-        if let Some(g) = &s.gpu {
-            f |= W_HAS_GPU;
-            if g.count.is_some() { f |= W_GPU_COUNT; }
-            if g.memory_mb.is_some() { f |= W_GPU_MEM; }
-            if g.model.is_some() { f |= W_GPU_MODEL; }
-        }
-        if let Some(c) = &s.cpu {
-            f |= W_HAS_CPU;
-            if c.cores.is_some() { f |= W_CPU_CORES; }
-        }
-        if s.ram_mb.is_some() { f |= W_RAM; }
-        if s.storage_gb.is_some() { f |= W_STORAGE; }
+/// One worker row as the engine sees it; `PartialEq` is what decides whether a known node is rewritten.
+#[derive(Clone, PartialEq, Default)]
+struct Row {
+    flags: u32, gpu_count: u32, gpu_mem: u32, gpu_class: u32, cpu_cores: u32, ram: u32, storage: u32,
+    lat: f64, lon: f64,
+}
+
+/// Columns of a batch of rows, kept alive for the duration of one FFI call.
+#[derive(Default)]
+struct RowColumns {
+    flags: Vec<u32>, gpu_count: Vec<u32>, gpu_mem: Vec<u32>, gpu_class: Vec<u32>, cpu_cores: Vec<u32>,
+    ram: Vec<u32>, storage: Vec<u32>, addr_rank: Vec<u32>, lat: Vec<f64>, lon: Vec<f64>,
+}
+impl RowColumns {
+    fn push(&mut self, r: &Row, rank: u32) {
+        self.flags.push(r.flags); self.gpu_count.push(r.gpu_count); self.gpu_mem.push(r.gpu_mem);
+        self.gpu_class.push(r.gpu_class); self.cpu_cores.push(r.cpu_cores); self.ram.push(r.ram);
+        self.storage.push(r.storage); self.addr_rank.push(rank); self.lat.push(r.lat); self.lon.push(r.lon);
     }
-    f
+    fn soa(&self) -> pm_worker_soa {
+        pm_worker_soa { n: self.flags.len() as u32, flags: self.flags.as_ptr(), gpu_count: self.gpu_count.as_ptr(),
+            gpu_mem_mb: self.gpu_mem.as_ptr(), gpu_model_class: self.gpu_class.as_ptr(),
+            cpu_cores: self.cpu_cores.as_ptr(), ram_mb: self.ram.as_ptr(), storage_gb: self.storage.as_ptr(),
+            price: std::ptr::null(), addr_rank: self.addr_rank.as_ptr(), lat: self.lat.as_ptr(), lon: self.lon.as_ptr() }
+    }
+}
+
+/// The plugin's mirror of the engine's worker table (rows never move, never disappear).
+#[derive(Default)]
+struct NodeTable {
+    index: HashMap<Address, u32>,
+    addresses: Vec<Address>,
+    address_strings: Vec<String>,   // address.to_string(): GROUP_INDEX is the rank of this string (mod.rs:424-434)
+    p2p_ids: Vec<String>,           // node.p2p_id.unwrap_or_default() (scheduler_impl.rs:118-128)
+    rows: Vec<Row>,
+    present: Vec<bool>,             // still in the node store
+    spec_models: Vec<String>,       // interned gpu.model strings; the index is gpu_model_class
+    spec_model_index: HashMap<String, u32>,
 }
 
 pub struct GpuMatchPlugin {
     engine: *mut c_void,
     config_names: Vec<String>,
-    /// worker index = position in the last `NodeStore::get_nodes()` snapshot given to `sync_nodes`
-    addresses: parking_lot::RwLock<Vec<Address>>,
-    /// p2p id per worker index (node.p2p_id.unwrap_or_default(), scheduler_impl.rs:118-128)
-    p2p_ids: parking_lot::RwLock<Vec<String>>,
-    tasks: parking_lot::RwLock<Vec<Task>>,
+    req_models: Vec<CString>,       // requirement model strings, one per pm_gpu_alt_row.model_row
+    nodes: parking_lot::RwLock<NodeTable>,
+    tasks: parking_lot::RwLock<Vec<Task>>,   // get_all_tasks order: the engine reports positions in this Vec
+    /// `upload:<node>:<group>:*` key count (scheduler_impl.rs:130-153): stays with the Redis store
+    upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>,
 }
 
 unsafe impl Send for GpuMatchPlugin {}
 unsafe impl Sync for GpuMatchPlugin {}
 
+fn task_uid(t: &Task) -> u64 { t.id.as_u64_pair().1 }
+
 impl GpuMatchPlugin {
-    /// Same contract as NodeGroupsPlugin::new (node_groups/mod.rs:113-175): duplicate names or
-    /// max < min panic, exactly like the reference constructor.
-    pub fn new(templates: Vec<NodeGroupConfiguration>, device: i32) -> Self {
+    /// Same contract as NodeGroupsPlugin::new (node_groups/mod.rs:113-175): duplicate names or max < min panic,
+    /// exactly like the reference constructor (the engine answers PM_EINVAL for the latter).
+    pub fn new(templates: Vec<NodeGroupConfiguration>, device: i32,
+               upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>) -> Self {
         let mut cfg: pm_engine_config = unsafe { std::mem::zeroed() };
         unsafe { pm_engine_config_default(&mut cfg) };
         cfg.device = device;
@@ -199,64 +255,177 @@ impl GpuMatchPlugin {
         check(unsafe { pm_engine_create(&cfg, &mut engine) }).expect("pm_engine_create");
         let mut seen = std::collections::HashSet::new();
         for t in &templates {
-            if !seen.insert(t.name.clone()) { panic!("Configuration names must be unique"); }
+            if !seen.insert(t.name.clone()) { panic!("Configuration names must be unique"); }   // mod.rs:142-144
         }
-        // requirement strings were parsed by serde into ComputeRequirements; re-serialise the fields into
-        // pm_config_row / pm_gpu_alt_row here (omitted: field-by-field copy), intern requirement model
-        // strings, and call pm_set_configs — PM_EINVAL maps to the reference's "Plugin configuration is invalid".
-        let this = Self { engine, config_names: templates.iter().map(|t| t.name.clone()).collect(),
-                          addresses: Default::default(), p2p_ids: Default::default(), tasks: Default::default() };
+        let mut this = Self { engine, config_names: templates.iter().map(|t| t.name.clone()).collect(),
+                              req_models: Vec::new(), nodes: Default::default(), tasks: Default::default(),
+                              upload_counter };
         this.set_configs(&templates);
+        // an empty worker / task table, so that the delta calls have something to extend
+        let empty = RowColumns::default();
+        check(unsafe { pm_upload_workers(this.engine, &empty.soa(), 0) }).expect("pm_upload_workers");
+        let t = pm_task_soa { n: 0, topo_mask: std::ptr::null(), created_at: std::ptr::null(), uid: [0u64; 0].as_ptr() };
+        check(unsafe { pm_upload_tasks(this.engine, &t) }).expect("pm_upload_tasks");
         this
     }
 
-    fn set_configs(&self, _templates: &[NodeGroupConfiguration]) { /* pack rows + pm_set_configs + pm_set_model_table */ }
+    /// NodeGroupConfiguration (mod.rs:30-37) + ComputeRequirements / GpuRequirements (shared/models/node.rs:49-70)
+    /// -> pm_config_row / pm_gpu_alt_row.  The requirement strings were already parsed by
+    /// `ComputeRequirements::from_str` (serde), so this is a field-by-field projection.
+    fn set_configs(&mut self, templates: &[NodeGroupConfiguration]) {
+        let mut rows = Vec::with_capacity(templates.len());
+        let mut alts: Vec<pm_gpu_alt_row> = Vec::new();
+        let opt = |v: Option<u32>, bit: u32, flags: &mut u32| -> u32 { if v.is_some() { *flags |= bit; } v.unwrap_or(0) };
+        for t in templates {
+            let mut row = pm_config_row { min_group_size: t.min_group_size as u32, max_group_size: t.max_group_size as u32,
+                                          ..Default::default() };
+            if let Some(req) = &t.compute_requirements {
+                row.flags |= R_HAS_REQ;
+                if let Some(cpu) = &req.cpu {
+                    row.flags |= R_CPU;
+                    row.cpu_cores = opt(cpu.cores, R_CPU_CORES, &mut row.flags);
+                }
+                row.ram_mb = opt(req.ram_mb, R_RAM, &mut row.flags);
+                row.storage_gb = opt(req.storage_gb, R_STORAGE, &mut row.flags);
+                row.alt_begin = alts.len() as u32;
+                row.alt_count = req.gpu.len() as u32;
+                for g in &req.gpu {
+                    let mut a = pm_gpu_alt_row::default();
+                    a.count = opt(g.count, G_COUNT, &mut a.flags);
+                    a.memory_mb = opt(g.memory_mb, G_MEM, &mut a.flags);
+                    a.memory_mb_min = opt(g.memory_mb_min, G_MEM_MIN, &mut a.flags);
+                    a.memory_mb_max = opt(g.memory_mb_max, G_MEM_MAX, &mut a.flags);
+                    a.total_memory_min = opt(g.total_memory_min, G_TOT_MIN, &mut a.flags);
+                    a.total_memory_max = opt(g.total_memory_max, G_TOT_MAX, &mut a.flags);
+                    if let Some(m) = &g.model {
+                        a.flags |= G_MODEL;
+                        a.model_row = self.req_models.len() as u32;
+                        self.req_models.push(CString::new(m.as_str()).expect("model string"));
+                    }
+                    alts.push(a);
+                }
+            }
+            rows.push(row);
+        }
+        let rc = unsafe { pm_set_configs(self.engine, rows.as_ptr(), rows.len() as u32, alts.as_ptr(), alts.len() as u32) };
+        if rc == PM_EINVAL { panic!("Plugin configuration is invalid"); }                                   // mod.rs:145-147
+        check(rc).expect("pm_set_configs");
+        self.push_model_table(&NodeTable::default());
+    }
 
-    /// Number of `upload:<node>:<group>:*` keys (scheduler_impl.rs:130-153): stays with the Redis store.
-    fn upload_count(&self, _node: &Address, _group_id: u64) -> usize { 0 /* store.scan_match(pattern).count() */ }
+    /// The substring rule of GpuSpecs::meets (shared/models/node.rs:463-484), evaluated once per
+    /// (requirement model, interned spec model) pair by the library; re-sent whenever a new spec model shows up.
+    fn push_model_table(&self, nodes: &NodeTable) {
+        let spec: Vec<CString> = nodes.spec_models.iter().map(|s| CString::new(s.as_str()).unwrap()).collect();
+        let spec_p: Vec<*const c_char> = spec.iter().map(|s| s.as_ptr()).collect();
+        let req_p: Vec<*const c_char> = self.req_models.iter().map(|s| s.as_ptr()).collect();
+        let words = (spec.len() + 31) / 32;
+        let mut bits = vec![0u32; (self.req_models.len() * words).max(1)];
+        check(unsafe { pm_host_build_model_table(req_p.as_ptr(), req_p.len() as u32, spec_p.as_ptr(), spec_p.len() as u32,
+                                                 bits.as_mut_ptr()) }).expect("pm_host_build_model_table");
+        check(unsafe { pm_set_model_table(self.engine, bits.as_ptr(), req_p.len() as u32, spec_p.len() as u32) })
+            .expect("pm_set_model_table");
+    }
 
-    /// Called with the snapshot of `store_context.node_store.get_nodes()` (node_store.rs:163-209); the
-    /// ORDER of that Vec is the tie-break of the reference and is passed through unchanged.
-    pub fn sync_nodes(&self, nodes: &[OrchestratorNode]) -> Result<()> {
-        let n = nodes.len();
-        let flags: Vec<u32> = nodes.iter().map(worker_flags).collect();
-        let col = |f: &dyn Fn(&ComputeSpecs) -> Option<u32>| -> Vec<u32> {
-            nodes.iter().map(|x| x.compute_specs.as_ref().and_then(|s| f(s)).unwrap_or(0)).collect()
-        };
-        let gpu_count = col(&|s| s.gpu.as_ref().and_then(|g| g.count));
-        let gpu_mem = col(&|s| s.gpu.as_ref().and_then(|g| g.memory_mb));
-        let cpu_cores = col(&|s| s.cpu.as_ref().and_then(|c| c.cores));
-        let ram = col(&|s| s.ram_mb);
-        let storage = col(&|s| s.storage_gb);
-        let gpu_class: Vec<u32> = vec![0; n]; // index into the interned spec model strings (set_model_table)
-        let lat: Vec<f64> = nodes.iter().map(|x| x.location.as_ref().map(|l| l.latitude).unwrap_or(0.0)).collect();
-        let lon: Vec<f64> = nodes.iter().map(|x| x.location.as_ref().map(|l| l.longitude).unwrap_or(0.0)).collect();
-        // GROUP_INDEX is the rank of address.to_string() inside the group's BTreeSet<String> (mod.rs:424-434)
-        let mut order: Vec<usize> = (0..n).collect();
-        order.sort_by_key(|&i| nodes[i].address.to_string());
-        let mut addr_rank = vec![0u32; n];
-        for (r, &i) in order.iter().enumerate() { addr_rank[i] = r as u32; }
-        let soa = pm_worker_soa { n: n as u32, flags: flags.as_ptr(), gpu_count: gpu_count.as_ptr(),
-            gpu_mem_mb: gpu_mem.as_ptr(), gpu_model_class: gpu_class.as_ptr(), cpu_cores: cpu_cores.as_ptr(),
-            ram_mb: ram.as_ptr(), storage_gb: storage.as_ptr(), price: std::ptr::null(),
-            addr_rank: addr_rank.as_ptr(), lat: lat.as_ptr(), lon: lon.as_ptr() };
-        check(unsafe { pm_upload_workers(self.engine, &soa, 1) })?;
-        *self.addresses.write() = nodes.iter().map(|x| x.address).collect();
-        *self.p2p_ids.write() = nodes.iter().map(|x| x.p2p_id.clone().unwrap_or_default()).collect();
+    /// Projection of one `OrchestratorNode` (orchestrator/src/models/node.rs:11-37) into the SoA row.
+    fn project(node: &OrchestratorNode, table: &mut NodeTable, new_model: &mut bool) -> Row {
+        let mut r = Row::default();
+        if node.status == NodeStatus::Healthy { r.flags |= W_HEALTHY; }
+        if node.p2p_id.is_some() { r.flags |= W_HAS_P2P; }
+        if let Some(l) = &node.location { r.flags |= W_HAS_LOC; r.lat = l.latitude; r.lon = l.longitude; }
+        if let Some(s) = &node.compute_specs {
+            let s: &ComputeSpecs = s;
+            r.flags |= W_HAS_SPECS;
+            if let Some(g) = &s.gpu {
+                r.flags |= W_HAS_GPU;
+                if let Some(c) = g.count { r.flags |= W_GPU_COUNT; r.gpu_count = c; }
+                if let Some(m) = g.memory_mb { r.flags |= W_GPU_MEM; r.gpu_mem = m; }
+                if let Some(m) = &g.model {
+                    r.flags |= W_GPU_MODEL;
+                    r.gpu_class = *table.spec_model_index.entry(m.clone()).or_insert_with(|| {
+                        *new_model = true;
+                        table.spec_models.push(m.clone());
+                        (table.spec_models.len() - 1) as u32
+                    });
+                }
+            }
+            if let Some(c) = &s.cpu {
+                r.flags |= W_HAS_CPU;
+                if let Some(n) = c.cores { r.flags |= W_CPU_CORES; r.cpu_cores = n; }
+            }
+            if let Some(v) = s.ram_mb { r.flags |= W_RAM; r.ram = v; }
+            if let Some(v) = s.storage_gb { r.flags |= W_STORAGE; r.storage = v; }
+        }
+        r
+    }
+
+    /// Called every management interval with `store_context.node_store.get_nodes()` (node_store.rs:163-209).
+    /// Sends only what changed: new nodes are appended, changed rows rewritten, departed nodes tombstoned.
+    pub fn sync_nodes(&self, snapshot: &[OrchestratorNode]) -> Result<()> {
+        let mut t = self.nodes.write();
+        let mut new_model = false;
+        let mut seen = vec![false; t.rows.len()];
+        let mut appended = RowColumns::default();
+        let (mut upd_idx, mut updated) = (Vec::<u32>::new(), RowColumns::default());
+        for node in snapshot {
+            let row = Self::project(node, &mut t, &mut new_model);
+            match t.index.get(&node.address).copied() {
+                Some(i) => {
+                    let i = i as usize;
+                    seen[i] = true;
+                    t.p2p_ids[i] = node.p2p_id.clone().unwrap_or_default();
+                    if t.rows[i] != row || !t.present[i] {
+                        t.rows[i] = row.clone();
+                        t.present[i] = true;
+                        upd_idx.push(i as u32);
+                        updated.push(&row, 0);          // ranks are replaced wholesale below when they change
+                    }
+                }
+                None => {
+                    let i = t.rows.len() as u32;
+                    t.index.insert(node.address, i);
+                    t.addresses.push(node.address);
+                    t.address_strings.push(node.address.to_string());
+                    t.p2p_ids.push(node.p2p_id.clone().unwrap_or_default());
+                    t.rows.push(row.clone());
+                    t.present.push(true);
+                    appended.push(&row, i);
+                }
+            }
+        }
+        if new_model { self.push_model_table(&t); }
+        // nodes that left the store: tombstone (their group dissolves, like a death; status_update_impl.rs:17-29)
+        for i in 0..seen.len() {
+            if !seen[i] && t.present[i] {
+                t.present[i] = false;
+                t.rows[i].flags &= !W_HEALTHY;
+                check(unsafe { pm_on_worker_status(self.engine, i as u32, t.rows[i].flags, 1) })?;
+            }
+        }
+        if !upd_idx.is_empty() {
+            // keep the ranks the engine already has for rewritten rows
+            let ranks = Self::address_ranks(&t.address_strings[..seen.len()]);
+            for (k, &i) in upd_idx.iter().enumerate() { updated.addr_rank[k] = ranks[i as usize]; }
+            check(unsafe { pm_update_workers(self.engine, upd_idx.as_ptr(), &updated.soa()) })?;
+        }
+        if !appended.flags.is_empty() {
+            let mut first = 0u32;
+            check(unsafe { pm_append_workers(self.engine, &appended.soa(), &mut first) })?;
+            debug_assert_eq!(first as usize, seen.len());
+            // a new address shifts the global ranks of the others: GROUP_INDEX only needs the relative order
+            let ranks = Self::address_ranks(&t.address_strings);
+            check(unsafe { pm_set_addr_ranks(self.engine, ranks.as_ptr(), ranks.len() as u32) })?;
+        }
         Ok(())
     }
 
-    /// Called with `task_store.get_all_tasks()` (task_store.rs:57-82, already created_at-desc).
-    pub fn sync_tasks(&self, tasks: Vec<Task>) -> Result<()> {
-        let masks: Vec<u64> = tasks.iter().map(|t| self.topology_mask(t)).collect();
-        let created: Vec<i64> = tasks.iter().map(|t| t.created_at).collect();
-        let uid: Vec<u64> = tasks.iter().map(|t| t.id.as_u64_pair().1).collect();
-        let soa = pm_task_soa { n: tasks.len() as u32, topo_mask: masks.as_ptr(), created_at: created.as_ptr(), uid: uid.as_ptr() };
-        check(unsafe { pm_upload_tasks(self.engine, &soa) })?;
-        let enabled = masks.iter().filter(|m| **m != u64::MAX).fold(0u64, |a, m| a | m); // on_task_created, mod.rs:1224-1243
-        check(unsafe { pm_set_enabled_mask(self.engine, enabled) })?;
-        *self.tasks.write() = tasks;
-        Ok(())
+    /// rank of address.to_string() in byte order (BTreeSet<String>, mod.rs:424-434)
+    fn address_ranks(strings: &[String]) -> Vec<u32> {
+        let mut order: Vec<usize> = (0..strings.len()).collect();
+        order.sort_by(|&a, &b| strings[a].cmp(&strings[b]));
+        let mut rank = vec![0u32; strings.len()];
+        for (r, &i) in order.iter().enumerate() { rank[i] = r as u32; }
+        rank
     }
 
     /// scheduler_impl.rs:44-59: any None on the way => every configuration allowed.
@@ -266,6 +435,46 @@ impl GpuMatchPlugin {
         list.iter().filter_map(|name| self.config_names.iter().position(|c| c == name)).fold(0, |m, i| m | (1u64 << i))
     }
 
+    fn push_enabled(&self, tasks: &[Task]) -> Result<()> {
+        // available_node_group_configs: every topology some task names (on_task_created, mod.rs:1224-1243)
+        let enabled = tasks.iter().map(|t| self.topology_mask(t)).filter(|m| *m != u64::MAX).fold(0u64, |a, m| a | m);
+        check(unsafe { pm_set_enabled_mask(self.engine, enabled) })
+    }
+
+    /// Full snapshot: `task_store.get_all_tasks()` (task_store.rs:57-82, already created_at-desc).  Start-up and
+    /// the fallback when a delta does not apply.
+    pub fn sync_tasks(&self, tasks: Vec<Task>) -> Result<()> {
+        let masks: Vec<u64> = tasks.iter().map(|t| self.topology_mask(t)).collect();
+        let created: Vec<i64> = tasks.iter().map(|t| t.created_at).collect();
+        let uid: Vec<u64> = tasks.iter().map(task_uid).collect();
+        let soa = pm_task_soa { n: tasks.len() as u32, topo_mask: masks.as_ptr(), created_at: created.as_ptr(), uid: uid.as_ptr() };
+        check(unsafe { pm_upload_tasks(self.engine, &soa) })?;
+        self.push_enabled(&tasks)?;
+        *self.tasks.write() = tasks;
+        Ok(())
+    }
+
+    /// TaskStore observer (task_store.rs:46-52 -> on_task_created, mod.rs:1224-1243): the new task is the newest, so
+    /// it goes in front; only this row travels to the GPU.  Equal or older timestamps fall back to the snapshot.
+    pub fn on_task_created(&self, task: &Task, all_tasks: impl FnOnce() -> Vec<Task>) -> Result<()> {
+        let (mask, created, uid) = (self.topology_mask(task), task.created_at, task_uid(task));
+        let soa = pm_task_soa { n: 1, topo_mask: &mask, created_at: &created, uid: &uid };
+        if unsafe { pm_tasks_insert_front(self.engine, &soa) } != 0 { return self.sync_tasks(all_tasks()); }
+        let mut tasks = self.tasks.write();
+        tasks.insert(0, task.clone());
+        self.push_enabled(&tasks)
+    }
+
+    /// on_task_deleted (mod.rs:1245-1325): the engine dissolves every group that had claimed the task.
+    pub fn on_task_deleted(&self, task: &Task) -> Result<()> {
+        let uid = task_uid(task);
+        let mut n = 0u32;
+        check(unsafe { pm_tasks_delete(self.engine, &uid, 1, &mut n) })?;
+        let mut tasks = self.tasks.write();
+        tasks.retain(|t| t.id != task.id);
+        self.push_enabled(&tasks)
+    }
+
     /// One body of run_group_management_loop (mod.rs:180-203) + every worker's filter_tasks.
     pub fn tick(&self) -> Result<pm_stats> {
         let mut s = pm_stats::default();
@@ -273,44 +482,59 @@ impl GpuMatchPlugin {
         Ok(s)
     }
 
-    /// SchedulerPlugin::filter_tasks (plugins/mod.rs:66-78): wait-free lookup + the `${...}` templating the
-    /// reference does at scheduler_impl.rs:112-205 (GROUP_INDEX, GROUP_SIZE, NEXT_P2P_ADDRESS, GROUP_ID).
+    fn render(f: impl Fn(*mut c_char, usize, *mut usize) -> i32) -> Result<String> {
+        let mut need = 0usize;
+        check(f(std::ptr::null_mut(), 0, &mut need))?;
+        let mut buf = vec![0u8; need];
+        check(f(buf.as_mut_ptr() as *mut c_char, need, &mut need))?;
+        buf.pop();
+        Ok(String::from_utf8(buf)?)
+    }
+
+    /// SchedulerPlugin::filter_tasks (plugins/mod.rs:66-78): lock-free lookup + the `${...}` templating the
+    /// reference does at scheduler_impl.rs:112-205 (GROUP_INDEX, GROUP_SIZE, NEXT_P2P_ADDRESS, GROUP_ID, upload count).
     pub(crate) fn filter_tasks(&self, _tasks: &[Task], node_address: &Address) -> Result<Vec<Task>> {
-        let Some(w) = self.addresses.read().iter().position(|a| a == node_address) else { return Ok(vec![]) };
+        let nodes = self.nodes.read();
+        let Some(&w) = nodes.index.get(node_address) else { return Ok(vec![]) };
         let mut a = pm_assignment::default();
-        if unsafe { pm_lookup_task_for_worker(self.engine, w as u32, &mut a) } != 0 || a.task == PM_NONE {
+        if unsafe { pm_lookup_task_for_worker(self.engine, w, &mut a) } != 0 || a.task == PM_NONE {
             return Ok(vec![]);
         }
-        let mut task = self.tasks.read()[a.task as usize].clone();
-        // group variables (scheduler_impl.rs:155-200) through the library's helpers — the same chained
-        // replace order as the reference; the upload count still comes from the `upload:<node>:<group>:*` scan
-        let gid = CString::new(format!("{:x}", a.group_id))?;
-        let next = CString::new(self.p2p_ids.read().get(a.next_worker as usize).cloned().unwrap_or_default())?;
-        let count = CString::new(self.upload_count(node_address, a.group_id).to_string())?;
+        let Some(mut task) = self.tasks.read().get(a.task as usize).cloned() else { return Ok(vec![]) };
+        let group_id = format!("{:x}", a.group_id);                                   // generate_group_id, mod.rs:1489-1493
+        let gid = CString::new(group_id.as_str())?;
+        let next = CString::new(nodes.p2p_ids.get(a.next_worker as usize).cloned().unwrap_or_default())?;
+        let count = CString::new((self.upload_counter)(node_address, &group_id).to_string())?;
         let vars = pm_group_vars { group_index: a.group_index, group_size: a.group_size,
             next_p2p_address: next.as_ptr(), group_id: gid.as_ptr(), total_upload_count: count.as_ptr() };
-        let render = |s: &str| -> Result<String> {
+        let group_vars = |s: &str| -> Result<String> {
             let cin = CString::new(s)?;
-            let mut need = 0usize;
-            check(unsafe { pm_host_group_vars(cin.as_ptr(), &vars, std::ptr::null_mut(), 0, &mut need) })?;
-            let mut buf = vec![0u8; need];
-            check(unsafe { pm_host_group_vars(cin.as_ptr(), &vars, buf.as_mut_ptr() as *mut c_char, need, &mut need) })?;
-            buf.pop();
-            Ok(String::from_utf8(buf)?)
+            Self::render(|o, c, n| unsafe { pm_host_group_vars(cin.as_ptr(), &vars, o, c, n) })
         };
         let env = task.env_vars.get_or_insert_with(Default::default);
-        env.insert("GROUP_INDEX".to_string(), a.group_index.to_string());
-        for (_, v) in env.iter_mut() { *v = render(v)?; }
-        if let Some(cmd) = task.cmd.as_mut() { for arg in cmd.iter_mut() { *arg = render(arg)?; } }
-        // volume mounts: pm_host_volume_vars on host_path / container_path (same calling convention)
+        env.insert("GROUP_INDEX".to_string(), a.group_index.to_string());             // scheduler_impl.rs:161
+        for (_, v) in env.iter_mut() { *v = group_vars(v)?; }
+        if let Some(cmd) = task.cmd.as_mut() { for arg in cmd.iter_mut() { *arg = group_vars(arg)?; } }
+        if let Some(mounts) = task.volume_mounts.as_mut() {                           // scheduler_impl.rs:185-200
+            for m in mounts.iter_mut() {
+                for path in [&mut m.host_path, &mut m.container_path] {
+                    let cin = CString::new(path.as_str())?;
+                    *path = Self::render(|o, c, n| unsafe { pm_host_volume_vars(cin.as_ptr(), gid.as_ptr(), o, c, n) })?;
+                }
+            }
+        }
         Ok(vec![task])
     }
 
     /// StatusUpdatePlugin::handle_status_change (status_update_impl.rs:8-39).
     pub(crate) fn handle_status_change(&self, node: &OrchestratorNode) -> Result<()> {
-        let Some(w) = self.addresses.read().iter().position(|a| *a == node.address) else { return Ok(()) };
+        let mut t = self.nodes.write();
+        let Some(&w) = t.index.get(&node.address) else { return Ok(()) };
+        let mut flags = t.rows[w as usize].flags & !W_HEALTHY;
+        if node.status == NodeStatus::Healthy { flags |= W_HEALTHY; }
+        t.rows[w as usize].flags = flags;
         let dead = matches!(node.status, NodeStatus::Dead | NodeStatus::LowBalance) as u32;
-        check(unsafe { pm_on_worker_status(self.engine, w as u32, worker_flags(node), dead) })
+        check(unsafe { pm_on_worker_status(self.engine, w, flags, dead) })
     }
 }
 
