@@ -821,7 +821,7 @@ static int32_t ensure_task_planes(pm_engine* e) {
   const uint32_t n_planes = uint32_t(e->cfgs.size());
   const uint32_t stride = e->t_cap / 64u;
   if (e->tplanes_dirty) {  // whole table (upload, capacity change, new configurations); deltas patch the planes
-    HIPCHK(e->d_tplanes.ensure(std::max<size_t>(size_t(stride) * n_planes, 1)));
+    HIPCHK(e->d_tplanes.ensure(std::max<size_t>(size_t(stride) * (n_planes + 1), 1)));  // + the OR plane
     launch_build_planes(e->d_tmask.p, e->t_cap, e->t_lo, e->t_cap, stride, n_planes, e->d_tplanes.p, e->stream);
     HIPCHK(hipGetLastError());
     e->tplanes_dirty = false;
@@ -2092,7 +2092,7 @@ static int32_t run_match_per_task(pm_engine* e) {
   }
   if (variant != 1) {
     const size_t n_words = (size_t(e->W) + 63) / 64;
-    HIPCHK(e->d_wplanes.ensure(std::max<size_t>(n_words * n_planes, 1)));
+    HIPCHK(e->d_wplanes.ensure(std::max<size_t>(n_words * (n_planes + 1), 1)));  // + the OR plane
     launch_build_planes(cols, e->W, 0, e->W, uint32_t(n_words), n_planes, e->d_wplanes.p, e->stream);
   }
   launch_pair_sweep(variant, e->d_tmask.p + e->t_lo, R, cols, e->d_wplanes.p, 0, e->W, uint32_t((size_t(e->W) + 63) / 64),

@@ -244,6 +244,11 @@ __global__ __launch_bounds__(256) void build_planes_kernel(const uint64_t* __res
     const uint64_t word = __ballot((m >> b) & 1ull);
     if (lane == 0) planes[(size_t)b * stride + j] = word;
   }
+  // plane n_planes: the OR of all of them — what a row that selects every plane (a task without topology
+  // restriction: mask ~0) hits, in one read instead of n_planes
+  const uint64_t valid = n_planes >= 64u ? ~0ull : ((1ull << n_planes) - 1ull);
+  const uint64_t any = __ballot((m & valid) != 0ull);
+  if (lane == 0) planes[(size_t)n_planes * stride + j] = any;
 }
 
 // grid = (ceil(R / 256), n_split): workgroup (x, y) sweeps its 256 rows over the plane words
@@ -255,17 +260,22 @@ __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* 
                                                                 uint32_t words_per_piece,
                                                                 uint32_t* __restrict__ first_out,
                                                                 uint32_t* __restrict__ count_out, uint32_t atomic) {
-  extern __shared__ uint64_t s_pl[];  // [n_planes][words_per_piece]
+  extern __shared__ uint64_t s_pl[];  // [n_planes + 1][lds_stride]: the planes of a piece and their OR
+  // The lanes of a wave read DIFFERENT planes at the same word j: with a plane stride that is a multiple of the 64
+  // LDS banks (x 4 B) all of those reads would land in one bank.  An odd stride (in 8-byte words) spreads them.
+  const uint32_t lds_stride = words_per_piece | 1u;
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   const uint32_t w0 = w_begin + blockIdx.y * words_per_split;
   const uint32_t w1 = min(w_end, w0 + words_per_split);
-  const uint64_t sel = r < R ? row_sel[r] : 0ull;
+  const uint64_t valid = n_planes >= 64u ? ~0ull : ((1ull << n_planes) - 1ull);
+  uint64_t sel = r < R ? (row_sel[r] & valid) : 0ull;
+  if (sel == valid && n_planes > 1u && n_planes < 64u) sel = 1ull << n_planes;  // every plane selected: read their OR
   uint32_t first = PM_NONE, cnt = 0;
   for (uint32_t j0 = w0; j0 < w1; j0 += words_per_piece) {
     const uint32_t nj = min(words_per_piece, w1 - j0);
     __syncthreads();  // the previous piece has been consumed
-    for (uint32_t b = 0; b < n_planes; ++b)
-      for (uint32_t j = threadIdx.x; j < nj; j += 256u) s_pl[b * words_per_piece + j] = planes[(size_t)b * stride + j0 + j];
+    for (uint32_t b = 0; b <= n_planes; ++b)
+      for (uint32_t j = threadIdx.x; j < nj; j += 256u) s_pl[b * lds_stride + j] = planes[(size_t)b * stride + j0 + j];
     __syncthreads();
     for (uint32_t j = 0; j < nj; ++j) {
       uint64_t hits = 0;
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* 
       while (s) {  // OR the planes this row selects; rows of one group share the selector
         const uint32_t b = __builtin_ctzll(s);
         s &= s - 1;
-        if (b < n_planes) hits |= s_pl[b * words_per_piece + j];
+        hits |= s_pl[b * lds_stride + j];
       }
       cnt += __popcll(hits);
       if (hits && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(hits);
@@ -289,7 +299,8 @@ __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t*
                                                                  uint32_t* __restrict__ out) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= R) return;
-  const uint64_t sel = row_sel[r];
+  const uint64_t valid = n_planes >= 64u ? ~0ull : ((1ull << n_planes) - 1ull);
+  const uint64_t sel = row_sel[r] & valid;
   uint32_t want = rank[r];
   uint32_t res = PM_NONE;
   if (want != PM_NONE) {
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t*
       while (s) {
         const uint32_t b = __builtin_ctzll(s);
         s &= s - 1;
-        if (b < n_planes) hits |= planes[(size_t)b * stride + j];
+        hits |= planes[(size_t)b * stride + j];
       }
       const uint32_t pc = __popcll(hits);
       if (want < pc) {
@@ -342,7 +353,8 @@ __global__ __launch_bounds__(256) void task_delete_kernel(const uint32_t* __rest
   const uint64_t bit = 1ull << (u & 63u);
   tmask[u] = 0ull;
   atomicAnd((unsigned long long*)&live[u >> 6], ~bit);
-  for (uint32_t b = 0; b < n_planes; ++b) atomicAnd((unsigned long long*)&planes[(size_t)b * stride + (u >> 6)], ~bit);
+  for (uint32_t b = 0; b <= n_planes; ++b)  // (plane n_planes is the OR of the others)
+    atomicAnd((unsigned long long*)&planes[(size_t)b * stride + (u >> 6)], ~bit);
 }
 // per-task results of the north_star orientation, from table slots to positions in get_all_tasks order
 __global__ __launch_bounds__(256) void task_compact_kernel(const uint32_t* __restrict__ first_u,
@@ -2843,9 +2855,9 @@ void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const u
   uint32_t n_split = want_split < n_words ? want_split : n_words;
   const uint32_t wps = (n_words + n_split - 1u) / n_split;
   n_split = (n_words + wps - 1u) / wps;
-  const uint32_t lds_cap_words = (48u * 1024u / 8u) / (n_planes ? n_planes : 1u);
+  const uint32_t lds_cap_words = ((48u * 1024u / 8u) / (n_planes + 1u)) - 1u;  // n_planes + 1 planes, padded stride
   const uint32_t wpp = wps < lds_cap_words ? wps : lds_cap_words;
-  const size_t lds = (size_t)n_planes * wpp * sizeof(uint64_t);
+  const size_t lds = (size_t)(n_planes + 1u) * (wpp | 1u) * sizeof(uint64_t);
   if (n_split > 1u) hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
   hipLaunchKernelGGL(pair_sweep_planes_kernel, dim3(rb, n_split), dim3(256), lds, s, row_sel, R, planes, stride, w0,
                      w1, n_planes, wps, wpp, first, count, n_split > 1u ? 1u : 0u);
