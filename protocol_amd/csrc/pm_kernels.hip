@@ -271,22 +271,47 @@ __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* 
   uint64_t sel = r < R ? (row_sel[r] & valid) : 0ull;
   if (sel == valid && n_planes > 1u && n_planes < 64u) sel = 1ull << n_planes;  // every plane selected: read their OR
   uint32_t first = PM_NONE, cnt = 0;
+  // wave-uniform: does any row of this wave select more than one plane?
+  const bool single = __ballot((sel & (sel - 1ull)) != 0ull) == 0ull;
+  const uint32_t my_plane = sel ? (uint32_t)__builtin_ctzll(sel) : 0u;
+  const uint64_t keep = sel ? ~0ull : 0ull;  // rows without a selector (workers outside groups) hit nothing
   for (uint32_t j0 = w0; j0 < w1; j0 += words_per_piece) {
     const uint32_t nj = min(words_per_piece, w1 - j0);
     __syncthreads();  // the previous piece has been consumed
     for (uint32_t b = 0; b <= n_planes; ++b)
       for (uint32_t j = threadIdx.x; j < nj; j += 256u) s_pl[b * lds_stride + j] = planes[(size_t)b * stride + j0 + j];
     __syncthreads();
-    for (uint32_t j = 0; j < nj; ++j) {
-      uint64_t hits = 0;
-      uint64_t s = sel;
-      while (s) {  // OR the planes this row selects; rows of one group share the selector
-        const uint32_t b = __builtin_ctzll(s);
-        s &= s - 1;
-        hits |= s_pl[b * lds_stride + j];
+    if (single) {
+      // every row of this wave selects at most one plane (the reference orientation: a group's configuration
+      // bit): one LDS read per word, no selector loop; four words per step keep the reads in flight
+      const uint64_t* pl = s_pl + my_plane * lds_stride;
+      uint32_t j = 0;
+      for (; j + 4u <= nj; j += 4u) {
+        const uint64_t h0 = pl[j] & keep, h1 = pl[j + 1u] & keep, h2 = pl[j + 2u] & keep, h3 = pl[j + 3u] & keep;
+        cnt += __popcll(h0) + __popcll(h1) + __popcll(h2) + __popcll(h3);
+        if (first == PM_NONE && (h0 | h1 | h2 | h3)) {
+          const uint32_t u = h0 ? 0u : (h1 ? 1u : (h2 ? 2u : 3u));
+          const uint64_t h = h0 ? h0 : (h1 ? h1 : (h2 ? h2 : h3));
+          first = (j0 + j + u) * 64u + __builtin_ctzll(h);
+        }
       }
-      cnt += __popcll(hits);
-      if (hits && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(hits);
+      for (; j < nj; ++j) {
+        const uint64_t h = pl[j] & keep;
+        cnt += __popcll(h);
+        if (h && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(h);
+      }
+    } else {
+      for (uint32_t j = 0; j < nj; ++j) {
+        uint64_t hits = 0;
+        uint64_t s = sel;
+        while (s) {  // OR the planes this row selects
+          const uint32_t b = __builtin_ctzll(s);
+          s &= s - 1;
+          hits |= s_pl[b * lds_stride + j];
+        }
+        cnt += __popcll(hits);
+        if (hits && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(hits);
+      }
     }
   }
   if (r < R) pair_fold(first_out, count_out, r, first, cnt, atomic != 0u);
