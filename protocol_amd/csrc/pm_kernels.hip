@@ -2088,6 +2088,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     // shared by several workers (bit 31 of the interned id) can have one
 #ifdef PM_CARVE_PROF
     uint64_t pt = __builtin_amdgcn_s_memtime(), pt_same = 0, pt_sweep = 0, pt_pop = 0, pt_flags = 0, n_resweep = 0;
+    (void)pt_same; (void)pt_sweep; (void)pt_pop; (void)pt_flags;
 #define PP_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - pt; pt = t_; } while (0)
 #else
 #define PP_MARK(var)
@@ -2120,10 +2121,12 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     if (lane == 0) G(p.same_next)[s] = same;
     PP_MARK(pt_same);
 #ifdef PM_CARVE_PROF
+#ifndef PM_CARVE_PROF_FINE
     if (s >= limit && lane == 0) {
       atomicAdd((unsigned long long*)&p.status->prof[5], (unsigned long long)pt_same);
       atomicMax((unsigned long long*)&p.status->prof[23], (unsigned long long)pt_same);
     }
+#endif
 #endif
     if (s >= limit) continue;  // beyond this round's proposal batch
     // seed number of this slot within the batch; the seeds are dealt round-robin over the ranks (every rank
@@ -2259,13 +2262,15 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       const uint64_t any_re = __ballot(n_resweep != 0);
       if (lane == 0) {
         unsigned long long* pr = (unsigned long long*)p.status->prof;
+#ifndef PM_CARVE_PROF_FINE  // (the fine build uses these slots for the validator's round phases)
         atomicAdd(&pr[5], (unsigned long long)pt_same);
         atomicAdd(&pr[6], (unsigned long long)pt_sweep);
         atomicAdd(&pr[7], (unsigned long long)pt_pop);
         atomicAdd(&pr[8], (unsigned long long)pt_flags);
+        atomicMax(&pr[23], (unsigned long long)(pt_same + pt_sweep + pt_pop + pt_flags));
+#endif
         atomicAdd(&pr[24], 1ull);
         atomicAdd(&pr[25], any_re ? 1ull : 0ull);
-        atomicMax(&pr[23], (unsigned long long)(pt_same + pt_sweep + pt_pop + pt_flags));
       }
     }
 #endif

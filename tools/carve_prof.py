@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from protocol_amd import build as B
 
 prof_lib = os.path.join(ROOT, "protocol_amd", "libpm_engine_prof.so")
-B.build(force=True, defines=["PM_CARVE_PROF"], out=prof_lib)
+B.build(force=True, defines=["PM_CARVE_PROF"] + (["PM_CARVE_PROF_FINE"] if os.environ.get("PM_PROF_FINE") else []), out=prof_lib)
 B.LIB_PATH = prof_lib
 B.needs_build = lambda: False
 from protocol_amd import engine as E, host
