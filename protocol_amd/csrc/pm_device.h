@@ -12,6 +12,9 @@ namespace pm {
 static constexpr double PM_RAD = 3.14159265358979323846 / 180.0;  // f64::to_radians factor
 static constexpr uint64_t PM_KEY_NOLOC = 0x7FEFFFFFFFFFFFFFull;   // bits of f64::MAX (mod.rs:244,249)
 static constexpr double PM_A_MAX_SAFE = 1.0 - 1.0 / 1048576.0;    // near-antipodal => settle on host
+// below this Haversine term (about 10 km) the chord-length form of the key is not accurate enough for the
+// certificate band and the proposer evaluates the sine form instead (see prox_key in pm_kernels.hip)
+static constexpr double PM_A_CHORD_MIN = 6.2e-7;
 // carve kernel geometry
 static constexpr uint32_t PM_CARVE_SLOTS = 8192;       // candidate slots with positions/bitmaps in LDS, keys in VGPRs
 static constexpr uint32_t PM_CARVE_PART = 64;          // per-wave partial selection capacity (max_group_size - 1)
@@ -64,6 +67,7 @@ struct RowUpdateArgs {
   const uint32_t* u32_in;         // 10 columns of n: idx, flags, gpu_count, gpu_mem, gpu_cls, cpu_cores, ram, storage, addr_rank, site
   uint32_t *flags, *gpu_count, *gpu_mem, *gpu_cls, *cpu_cores, *ram, *storage, *addr_rank, *site;
   double *lat, *lon, *coslat;
+  double *ux, *uy, *uz;  // unit vector of the location (cos lat cos lon, cos lat sin lon, sin lat)
 };
 
 enum { CARVE_MODE_FORM = 0, CARVE_MODE_MERGE = 1 };
@@ -92,7 +96,7 @@ struct CarveStatus {
   uint32_t prop_k;       // entries per proposal for the prepared configuration (0 = no proposals)
   uint32_t prop_limit;   // proposals exist for located slots below this slot number
   uint32_t rows_pr;      // rows per rank of this batch in the proposal buffer: ceil(seeds / world)
-  uint32_t _pad_rows;
+  uint32_t n_seeds;      // seeds of the batch
   uint32_t total_available;
   uint32_t fast_steps;   // steps committed from proposals
   uint32_t slow_steps;   // steps that needed the full key sweep
@@ -115,6 +119,7 @@ struct CarveArgs {
   // worker columns
   const uint32_t* wflags;
   const double *lat, *lon, *coslat;
+  const double *ux, *uy, *uz;  // unit vectors: the proposer's chord-length key (see prox_key)
   const uint32_t* site;  // equal (lat, lon) bit patterns <=> equal site id (host-interned)
   const uint64_t* compat;
   int32_t* group_of;  // FORM: read (eligibility) and written (commit)
@@ -125,11 +130,13 @@ struct CarveArgs {
   uint32_t _pad2;
   // scratch (capacity W each): columns indexed by position in the eligible list ...
   double *c_lat, *c_lon, *c_cos;
+  double *c_ux, *c_uy, *c_uz;
   uint32_t* c_site;
   uint64_t* c_compat;
   uint64_t *alive_g, *loc_g;  // bitmaps over positions (bits_stride words each)
   // ... and by candidate slot of the prepared configuration
   double *cc_lat, *cc_lon, *cc_cos;
+  double *cc_ux, *cc_uy, *cc_uz;
   uint32_t* cc_site;
   uint32_t* slot_pos;      // slot -> position (for the alive_g write-back)
   uint32_t* slot_wid;      // slot -> worker id
@@ -147,6 +154,7 @@ struct CarveArgs {
   uint64_t* prop_send;
   uint64_t* seed_map;      // per bitmap word below prop_limit: the batch's seeds (live & located at preparation)
   uint32_t* seed_prefix;   // per bitmap word: seeds in front of the word
+  uint32_t* seed_slots;    // seed number -> slot (PM_PROP_MAX_SEEDS + 64 entries)
   uint32_t dist_rank, dist_world;
   uint32_t count_keys, _pad_ck;  // proposer: count the keys it sweeps (bench bookkeeping)
   uint32_t* prep_block_counts;   // [blocks][PM_MAX_CONFIGS] live compatible positions per block and configuration
@@ -164,7 +172,8 @@ struct CarveArgs {
 };
 
 void launch_compat(const CompatArgs& a, hipStream_t s);
-void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s);
+void launch_geo(const double* lat, const double* lon, double* coslat, double* ux, double* uy, double* uz, uint32_t W,
+                hipStream_t s);
 void launch_triad(const double* b, const double* c, double* a, size_t n, hipStream_t s);
 void launch_update_rows(const RowUpdateArgs& a, hipStream_t s);
 void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t R, const uint32_t* rows,

@@ -149,11 +149,11 @@ struct pm_engine {
       h_addr_rank;
   std::vector<double> h_lat, h_lon;
   std::vector<uint32_t> h_site;  // equal (lat, lon) bit patterns <=> equal site id
-  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_same_next, d_seed_prefix, d_prep_block_counts, d_prep_counts;
+  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_same_next, d_seed_prefix, d_seed_slots, d_prep_block_counts, d_prep_counts;
   DevBuf<uint64_t> d_prop, d_prop_send, d_seed_map;
   uint32_t tick_fast_steps = 0;
   DevBuf<uint32_t> d_flags, d_gpu_count, d_gpu_mem, d_gpu_cls, d_cpu_cores, d_ram, d_storage, d_addr_rank;
-  DevBuf<double> d_lat, d_lon, d_coslat;
+  DevBuf<double> d_lat, d_lon, d_coslat, d_ux, d_uy, d_uz;
   DevBuf<uint64_t> d_compat;
   bool compat_dirty = true;
   std::vector<uint64_t> h_compat;
@@ -211,7 +211,7 @@ struct pm_engine {
 
   // ---- carve scratch
   DevBuf<uint32_t> d_order;
-  DevBuf<double> d_c_lat, d_c_lon, d_c_cos, d_cc_lat, d_cc_lon, d_cc_cos;
+  DevBuf<double> d_c_lat, d_c_lon, d_c_cos, d_cc_lat, d_cc_lon, d_cc_cos, d_c_u[3], d_cc_u[3];
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
   DevBuf<uint32_t> d_slot_pos, d_slot_wid;
   DevBuf<CarveStatus> d_status;
@@ -441,6 +441,10 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_cc_lat.ensure(cap));
   HIPCHK(e->d_cc_lon.ensure(cap));
   HIPCHK(e->d_cc_cos.ensure(cap));
+  for (int k = 0; k < 3; ++k) {
+    HIPCHK(e->d_c_u[k].ensure(cap));
+    HIPCHK(e->d_cc_u[k].ensure(cap));
+  }
   HIPCHK(e->d_c_compat.ensure(cap));
   HIPCHK(e->d_keys.ensure(cap));
   HIPCHK(e->d_slot_pos.ensure(cap));
@@ -455,6 +459,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     if (world > 1) HIPCHK(e->d_prop_send.ensure(rows_pr * PM_PROP_ROW));
     HIPCHK(e->d_seed_map.ensure((cap + 63) / 64 + 64));
     HIPCHK(e->d_seed_prefix.ensure((cap + 63) / 64 + 64));
+    HIPCHK(e->d_seed_slots.ensure(size_t(PM_PROP_MAX_SEEDS) + 128));
     HIPCHK(e->d_prep_block_counts.ensure(((cap + 255) / 256 + 1) * PM_MAX_CONFIGS));
     HIPCHK(e->d_prep_counts.ensure(PM_MAX_CONFIGS + 8));
   }
@@ -472,6 +477,9 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->lat = e->d_lat.p;
   a->lon = e->d_lon.p;
   a->coslat = e->d_coslat.p;
+  a->ux = e->d_ux.p;
+  a->uy = e->d_uy.p;
+  a->uz = e->d_uz.p;
   a->compat = e->d_compat.p;
   a->group_of = e->d_group_of.p;
   a->order = e->d_order.p;
@@ -479,12 +487,18 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->c_lat = e->d_c_lat.p;
   a->c_lon = e->d_c_lon.p;
   a->c_cos = e->d_c_cos.p;
+  a->c_ux = e->d_c_u[0].p;
+  a->c_uy = e->d_c_u[1].p;
+  a->c_uz = e->d_c_u[2].p;
   a->c_compat = e->d_c_compat.p;
   a->alive_g = e->d_bits.p;
   a->loc_g = e->d_bits.p + stride;
   a->cc_lat = e->d_cc_lat.p;
   a->cc_lon = e->d_cc_lon.p;
   a->cc_cos = e->d_cc_cos.p;
+  a->cc_ux = e->d_cc_u[0].p;
+  a->cc_uy = e->d_cc_u[1].p;
+  a->cc_uz = e->d_cc_u[2].p;
   a->keys = e->d_keys.p;
   a->slot_pos = e->d_slot_pos.p;
   a->slot_wid = e->d_slot_wid.p;
@@ -495,6 +509,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->prop_send = e->dist_world > 1 ? e->d_prop_send.p : e->d_prop.p;
   a->seed_map = e->d_seed_map.p;
   a->seed_prefix = e->d_seed_prefix.p;
+  a->seed_slots = e->d_seed_slots.p;
   a->dist_rank = e->dist_rank;
   a->dist_world = e->dist_world;
   a->count_keys = e->cfg.time_proposer ? 1u : 0u;
@@ -1279,6 +1294,8 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_flags.release(); e->d_gpu_count.release(); e->d_gpu_mem.release(); e->d_gpu_cls.release();
   e->d_cpu_cores.release(); e->d_ram.release(); e->d_storage.release(); e->d_addr_rank.release();
   e->d_lat.release(); e->d_lon.release(); e->d_coslat.release(); e->d_compat.release();
+  e->d_ux.release(); e->d_uy.release(); e->d_uz.release();
+  for (int k = 0; k < 3; ++k) { e->d_c_u[k].release(); e->d_cc_u[k].release(); }
   e->d_tmask.release(); e->d_tplanes.release(); e->d_created.release(); e->d_tlive.release(); e->d_tprefix.release();
   e->d_first_c.release(); e->d_count_c.release(); e->d_tdel.release();
   e->d_group_of.release(); e->d_g_cfg.release(); e->d_g_n.release(); e->d_g_off.release();
@@ -1286,7 +1303,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_rank_in_group.release(); e->d_g_id.release();
   e->d_order.release(); e->d_c_lat.release(); e->d_c_lon.release(); e->d_c_cos.release();
   e->d_cc_lat.release(); e->d_cc_lon.release(); e->d_cc_cos.release(); e->d_slot_pos.release(); e->d_slot_wid.release();
-  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_prep_block_counts.release(); e->d_prep_counts.release(); e->d_same_next.release();
+  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_seed_slots.release(); e->d_prep_block_counts.release(); e->d_prep_counts.release(); e->d_same_next.release();
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
@@ -1406,7 +1423,10 @@ static int32_t upload_worker_columns(pm_engine* e) {
   refresh_site_bits(e);
   if ((rc = upload(e->d_site, e->h_site.data(), W, e->stream))) return rc;
   HIPCHK(e->d_coslat.ensure(W ? W : 1));
-  launch_coslat(e->d_lat.p, e->d_coslat.p, uint32_t(W), e->stream);
+  HIPCHK(e->d_ux.ensure(W ? W : 1));
+  HIPCHK(e->d_uy.ensure(W ? W : 1));
+  HIPCHK(e->d_uz.ensure(W ? W : 1));
+  launch_geo(e->d_lat.p, e->d_lon.p, e->d_coslat.p, e->d_ux.p, e->d_uy.p, e->d_uz.p, uint32_t(W), e->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
   e->flags_dirty = false;
@@ -1549,6 +1569,9 @@ static int32_t scatter_rows(pm_engine* e, const uint32_t* idx, const pm_worker_s
   a.lat = e->d_lat.p;
   a.lon = e->d_lon.p;
   a.coslat = e->d_coslat.p;
+  a.ux = e->d_ux.p;
+  a.uy = e->d_uy.p;
+  a.uz = e->d_uz.p;
   launch_update_rows(a, e->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));  // the staging vector dies here
@@ -1604,6 +1627,9 @@ int32_t pm_append_workers(pm_engine* e, const pm_worker_soa* rows, uint32_t* fir
   HIPCHK(e->d_lat.grow_keep(W1, w0, e->stream));
   HIPCHK(e->d_lon.grow_keep(W1, w0, e->stream));
   HIPCHK(e->d_coslat.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_ux.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_uy.grow_keep(W1, w0, e->stream));
+  HIPCHK(e->d_uz.grow_keep(W1, w0, e->stream));
   e->h_flags.resize(W1, 0);
   e->h_gpu_count.resize(W1, 0);
   e->h_gpu_mem.resize(W1, 0);

@@ -128,11 +128,20 @@ __global__ __launch_bounds__(256) void triad_kernel(const double* __restrict__ b
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) a[i] = b[i] + 3.0 * c[i];
 }
 
-// cos(lat * pi/180) per worker, consumed by the Haversine term of the carve kernel.
-__global__ __launch_bounds__(256) void coslat_kernel(const double* __restrict__ lat, double* __restrict__ coslat,
-                                                     uint32_t W) {
+// Per worker: cos(lat * pi/180) for the Haversine term, and the unit vector of the location for its chord form.
+__device__ __forceinline__ void geo_of(double la, double lo, double* coslat, double* ux, double* uy, double* uz) {
+  const double phi = la * PM_RAD, lam = lo * PM_RAD;
+  const double c = cos(phi);
+  *coslat = c;
+  *ux = c * cos(lam);
+  *uy = c * sin(lam);
+  *uz = sin(phi);
+}
+__global__ __launch_bounds__(256) void geo_kernel(const double* __restrict__ lat, const double* __restrict__ lon,
+                                                  double* __restrict__ coslat, double* __restrict__ ux,
+                                                  double* __restrict__ uy, double* __restrict__ uz, uint32_t W) {
   const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-  if (w < W) coslat[w] = cos(lat[w] * PM_RAD);
+  if (w < W) geo_of(lat[w], lon[w], &coslat[w], &ux[w], &uy[w], &uz[w]);
 }
 
 // Row deltas of the worker table (discovery sync / status updater, orchestrator/src/discovery/monitor.rs:236-420,
@@ -151,10 +160,10 @@ __global__ __launch_bounds__(256) void update_rows_kernel(RowUpdateArgs p) {
   p.storage[w] = p.u32_in[7 * n + k];
   p.addr_rank[w] = p.u32_in[8 * n + k];
   p.site[w] = p.u32_in[9 * n + k];
-  const double la = p.lat_in[k];
+  const double la = p.lat_in[k], lo = p.lon_in[k];
   p.lat[w] = la;
-  p.lon[w] = p.lon_in[k];
-  p.coslat[w] = cos(la * PM_RAD);
+  p.lon[w] = lo;
+  geo_of(la, lo, &p.coslat[w], &p.ux[w], &p.uy[w], &p.uz[w]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -685,6 +694,24 @@ __device__ __forceinline__ double hav_a(double lat1, double lon1, double cos1, d
   return s1 * s1 + cos1 * cos2 * (s2 * s2);
 }
 
+// The proposer's Haversine term.  a = sin^2(dphi/2) + cos cos sin^2(dlam/2) is, exactly, a quarter of the squared
+// chord between the two unit vectors: a = |u1 - u2|^2 / 4 — three subtractions, a multiply and two fma instead of
+// two sine polynomials.  The unit vectors carry an absolute error of ~2e-16 per component, so the chord form has a
+// relative error of ~7e-16 / sqrt(a): under 1e-12 — a fifteenth of the certificate band (2^-36) — for a >=
+// PM_A_CHORD_MIN (about 10 km), and that is where it is used; nearer candidates (rare: a handful per seed) take the
+// sine form, whose error is independent of the distance.  Every path of the proposer goes through this one
+// function, so a candidate's key is the same bit pattern whenever it is recomputed (re-sweeps compare keys).
+struct SeedGeo {
+  double lat, lon, cos, ux, uy, uz;
+};
+template <typename DP>
+__device__ __forceinline__ double prox_a(const SeedGeo& s, double ux, double uy, double uz, DP lat, DP lon, DP cs, uint32_t t) {
+  const double dx = ux - s.ux, dy = uy - s.uy, dz = uz - s.uz;
+  const double a = 0.25 * fma(dx, dx, fma(dy, dy, dz * dz));
+  if (a >= PM_A_CHORD_MIN) return a;
+  return hav_a(s.lat, s.lon, s.cos, lat[t], lon[t], cs[t]);
+}
+
 template <typename P>
 __device__ __forceinline__ bool bit_at(P b, uint32_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }
 
@@ -721,6 +748,7 @@ struct StepCtx {
   // proposals (0 = none)
   uint32_t prop_k, prop_limit;
   uint32_t rows_pr;  // rows per rank in the proposal buffer for this batch: ceil(seeds / world)
+  uint32_t n_seeds;  // seeds of the batch
   bool use_props;
   // packed-key geometry of the current list: low slot_bits of a key hold the slot; certificate band
   uint32_t slot_bits;
@@ -2006,10 +2034,12 @@ __device__ __forceinline__ void topn_insert(uint64_t k, TopN& q) {
     q.r[PM_TOPN - 1] = k;
 #pragma unroll
     for (int i = PM_TOPN - 1; i > 0; --i) {
-      const uint64_t lo = q.r[i] < q.r[i - 1] ? q.r[i] : q.r[i - 1];
-      const uint64_t hi = q.r[i] < q.r[i - 1] ? q.r[i - 1] : q.r[i];
-      q.r[i - 1] = lo;
-      q.r[i] = hi;
+      // one 64-bit compare per level, four selects (written as min / max the compiler compares twice)
+      const bool sw = q.r[i] < q.r[i - 1];
+      const uint32_t a_lo = (uint32_t)q.r[i], a_hi = (uint32_t)(q.r[i] >> 32);
+      const uint32_t b_lo = (uint32_t)q.r[i - 1], b_hi = (uint32_t)(q.r[i - 1] >> 32);
+      q.r[i - 1] = ((uint64_t)(sw ? a_hi : b_hi) << 32) | (sw ? a_lo : b_lo);
+      q.r[i] = ((uint64_t)(sw ? b_hi : a_hi) << 32) | (sw ? b_lo : a_lo);
     }
   }
 }
@@ -2019,47 +2049,87 @@ __device__ __forceinline__ void topn_pop(TopN& q) {
   q.r[PM_TOPN - 1] = ~0ull;
 }
 
-struct SweepBatch {
-  uint64_t aw[4], lwd[4];  // alive / located words of the four strides (lane = bit)
-  double tla[4], tlo[4], tco[4];
-  uint32_t tsi[4];
+// The candidate columns of a tile of PROP_TILE slots, staged in LDS and shared by the four waves (= four seeds) of a
+// workgroup: the sweep of a seed is then a chain of LDS reads (~64 cycles) instead of L2 round trips (~500), the
+// next tile's global loads are in flight while the current one is consumed (two buffers), and every candidate
+// row is fetched once per workgroup instead of once per seed.
+#define PROP_TILE 512u
+struct TileBuf {
+  double x[PROP_TILE], y[PROP_TILE], z[PROP_TILE];  // unit vectors
+  uint32_t site[PROP_TILE];
+  uint64_t alive[PROP_TILE / 64u], loc[PROP_TILE / 64u];
 };
-// Loads of four 64-slot strides starting at word j0.  Every load is unconditional (indices clamped into the
-// list) and independent of the others — a load guarded by the bitmap word would wait for that word first —
-// so a whole batch is in flight at once; the bitmaps are applied when the keys are formed.
+struct TileRegs {  // one thread's share of a tile on its way from HBM/L2 to LDS: slots tid and tid + 256
+  double x[2], y[2], z[2];
+  uint32_t site[2];
+  uint64_t bm;
+};
 template <typename BP>
-__device__ __forceinline__ void sweep_load(const CarveArgs& p, BP alive, BP loc, uint32_t lw, uint32_t n_list,
-                                           uint32_t j0, uint32_t lane, bool shared, SweepBatch& b) {
+__device__ __forceinline__ void tile_fetch(const CarveArgs& p, BP alive, BP loc, uint32_t lw, uint32_t n_list,
+                                           uint32_t tile, uint32_t tid, TileRegs& r) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const uint32_t j = j0 + (uint32_t)u;
-    const uint32_t jc = j < lw ? j : lw - 1u;
-    const uint32_t t = j * 64u + lane;
-    const uint32_t tc = t < n_list ? t : n_list - 1u;
-    b.aw[u] = alive[jc];
-    b.lwd[u] = loc[jc];
-    b.tla[u] = G(p.cc_lat)[tc];
-    b.tlo[u] = G(p.cc_lon)[tc];
-    b.tco[u] = G(p.cc_cos)[tc];
-    b.tsi[u] = shared ? G(p.cc_site)[tc] : 0u;
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t t = tile * PROP_TILE + (uint32_t)h * 256u + tid;
+    const uint32_t tc = t < n_list ? t : n_list - 1u;  // unconditional loads; the bitmaps are zero beyond the list
+    r.x[h] = G(p.cc_ux)[tc];
+    r.y[h] = G(p.cc_uy)[tc];
+    r.z[h] = G(p.cc_uz)[tc];
+    r.site[h] = G(p.cc_site)[tc];
   }
+  const uint32_t j = tile * (PROP_TILE / 64u) + (tid & 7u);
+  r.bm = (tid < 16u && j < lw) ? (tid < 8u ? alive[j] : loc[j]) : 0ull;
 }
-__device__ __forceinline__ void sweep_keys(const SweepBatch& b, uint32_t lw, uint32_t j0, uint32_t lane, uint32_t s,
-                                           bool shared, uint32_t ssite, double slat, double slon, double scos,
-                                           uint32_t SB, TopN& q, uint32_t& n_mine) {
+__device__ __forceinline__ void tile_store(TileBuf& tb, uint32_t tid, const TileRegs& r) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const uint32_t j = j0 + (uint32_t)u;
-    const uint32_t t = j * 64u + lane;
-    if (j >= lw || !((b.aw[u] >> lane) & 1ull) || t == s) continue;
-    const bool located = (b.lwd[u] >> lane) & 1ull;
-    // candidates at the seed's own (shared) site are not listed: the validator takes them from the
-    // same_next chain, ahead of everything in the row
-    if (shared && located && b.tsi[u] == ssite) continue;
-    const uint64_t k = located ? pack_key((uint64_t)__double_as_longlong(hav_a(slat, slon, scos, b.tla[u], b.tlo[u], b.tco[u])), t, SB)
-                               : pack_key(PM_KEY_NOLOC, t, SB);
-    topn_insert(k, q);
-    ++n_mine;
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t o = (uint32_t)h * 256u + tid;
+    tb.x[o] = r.x[h];
+    tb.y[o] = r.y[h];
+    tb.z[o] = r.z[h];
+    tb.site[o] = r.site[h];
+  }
+  if (tid < 8u) tb.alive[tid] = r.bm;
+  else if (tid < 16u) tb.loc[tid - 8u] = r.bm;
+}
+// keys of one seed against a staged tile: lane l owns the slots t = l (mod 64), as everywhere in this kernel.
+// Straight-line code: every LDS read of four strides is issued up front, the chord key is computed for every lane,
+// and a slot that does not count (dead, the seed itself, same shared site) becomes the key ~0, which the
+// insertion ignores — a `continue` per condition would put an LDS round trip and a branch between each of them.
+__device__ __forceinline__ void tile_keys(const CarveArgs& p, const TileBuf& tb, uint32_t tile, uint32_t lane, uint32_t s,
+                                          bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, TopN& q,
+                                          uint32_t& n_mine) {
+#pragma unroll
+  for (uint32_t h = 0; h < PROP_TILE / 256u; ++h) {
+    double x[4], y[4], z[4];
+    uint32_t si[4];
+    uint64_t aw[4], lwd[4];
+#pragma unroll
+    for (uint32_t v = 0; v < 4u; ++v) {
+      const uint32_t u = h * 4u + v, o = u * 64u + lane;
+      aw[v] = tb.alive[u];
+      lwd[v] = tb.loc[u];
+      x[v] = tb.x[o];
+      y[v] = tb.y[o];
+      z[v] = tb.z[o];
+      si[v] = tb.site[o];
+    }
+#pragma unroll
+    for (uint32_t v = 0; v < 4u; ++v) {
+      const uint32_t u = h * 4u + v, t = tile * PROP_TILE + u * 64u + lane;
+      const bool located = (lwd[v] >> lane) & 1ull;
+      // candidates at the seed's own (shared) site are not listed: the validator takes them from the
+      // same_next chain, ahead of everything in the row
+      const bool counts = ((aw[v] >> lane) & 1ull) && t != s && !(shared && located && si[v] == ssite);
+      const double dx = x[v] - sg.ux, dy = y[v] - sg.uy, dz = z[v] - sg.uz;
+      double a = 0.25 * fma(dx, dx, fma(dy, dy, dz * dz));
+      const bool near = counts && located && a < PM_A_CHORD_MIN;  // (see prox_a: the sine form below ~10 km)
+      if (__ballot(near)) {
+        if (near) a = hav_a(sg.lat, sg.lon, sg.cos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t]);
+      }
+      const uint64_t kl = pack_key(located ? (uint64_t)__double_as_longlong(a) : PM_KEY_NOLOC, t, SB);
+      topn_insert(counts ? kl : ~0ull, q);
+      n_mine += counts ? 1u : 0u;
+    }
   }
 }
 
@@ -2068,10 +2138,8 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   const auto st = G((const CarveStatus*)p.status);
   if (st->state != CARVE_STATE_RUNNING) return;
   if (st->cur_ci >= p.n_avail) return;
-  const uint32_t K = st->prop_k, n_list = st->n_list, limit = st->prop_limit;
-  const uint32_t world = p.dist_world, my_rank = p.dist_rank, rows_pr = st->rows_pr;
-  const auto seed_map = G((const uint64_t*)p.seed_map);
-  const auto seed_prefix = G((const uint32_t*)p.seed_prefix);
+  const uint32_t K = st->prop_k, n_list = st->n_list;
+  const uint32_t world = p.dist_world, my_rank = p.dist_rank;
   const auto prop_out = G(p.prop_send);
   if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
   const uint32_t SB = n_list > PM_CARVE_SLOTS ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
@@ -2081,22 +2149,15 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   const auto alive = G((const uint64_t*)p.bits_scratch);
   const auto loc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
   const uint32_t lw = (n_list + 63u) >> 6;
+  // ---- phase 1: same-site links for every located live slot (the validator's same-site shortcut walks them);
+  // only sites shared by several workers (bit 31 of the interned id) can have one.  One wave per slot.
   for (uint32_t s = wave_g; s < n_list; s += n_waves) {
     if (!(bit_at(alive, s) && bit_at(loc, s))) continue;  // wave-uniform
     const uint32_t ssite = G(p.cc_site)[s];
-    // next located slot at the same site (the validator's same-site shortcut walks these links); only sites
-    // shared by several workers (bit 31 of the interned id) can have one
-#ifdef PM_CARVE_PROF
-    uint64_t pt = __builtin_amdgcn_s_memtime(), pt_same = 0, pt_sweep = 0, pt_pop = 0, pt_flags = 0, n_resweep = 0;
-    (void)pt_same; (void)pt_sweep; (void)pt_pop; (void)pt_flags;
-#define PP_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - pt; pt = t_; } while (0)
-#else
-#define PP_MARK(var)
-#endif
     uint32_t same = PM_NONE;
     if (ssite & 0x80000000u) {
-      // eight strides per step, every load unconditional and independent (see sweep_load): the last member
-      // of a site scans to the end of the list, and a load per step would make that wave the launch's tail
+      // eight strides per step, every load unconditional and independent: the last member of a site scans to
+      // the end of the list, and a load per step would make that wave the launch's tail
       for (uint32_t j0 = s >> 6; j0 < lw && same == PM_NONE; j0 += 8u) {
         uint32_t si[8];
         uint64_t m[8];
@@ -2119,41 +2180,52 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       }
     }
     if (lane == 0) G(p.same_next)[s] = same;
-    PP_MARK(pt_same);
+  }
+  // ---- phase 2: the neighbour rows.  Four seeds per workgroup (one per wave) sweep the candidate list together,
+  // tile by tile through LDS.  The seeds of the batch are dealt round-robin over the ranks: this rank computes
+  // seed numbers my_rank, my_rank + world, ... (every rank linked same_next for the whole list above).
+  __shared__ TileBuf tiles[2];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t n_seeds = st->n_seeds;
+  const uint32_t n_my = world > 1u ? (n_seeds > my_rank ? (n_seeds - my_rank + world - 1u) / world : 0u) : n_seeds;
+  const uint32_t n_tiles = (n_list + PROP_TILE - 1u) / PROP_TILE;
+  const auto seed_slots = G((const uint32_t*)p.seed_slots);
+  for (uint32_t k0 = blockIdx.x * 4u; k0 < n_my; k0 += gridDim.x * 4u) {
+    const uint32_t out_row = k0 + wave;  // row in this rank's send segment
+    const bool valid = out_row < n_my;
+    const uint32_t s = valid ? seed_slots[world > 1u ? my_rank + world * out_row : out_row] : 0u;
+    const uint32_t ssite = G(p.cc_site)[s];
 #ifdef PM_CARVE_PROF
-#ifndef PM_CARVE_PROF_FINE
-    if (s >= limit && lane == 0) {
-      atomicAdd((unsigned long long*)&p.status->prof[5], (unsigned long long)pt_same);
-      atomicMax((unsigned long long*)&p.status->prof[23], (unsigned long long)pt_same);
-    }
+    uint64_t pt = __builtin_amdgcn_s_memtime(), pt_same = 0, pt_sweep = 0, pt_pop = 0, pt_flags = 0, n_resweep = 0;
+    (void)pt_same; (void)pt_sweep; (void)pt_pop; (void)pt_flags;
+#define PP_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - pt; pt = t_; } while (0)
+#else
+#define PP_MARK(var)
 #endif
-#endif
-    if (s >= limit) continue;  // beyond this round's proposal batch
-    // seed number of this slot within the batch; the seeds are dealt round-robin over the ranks (every rank
-    // links same_next for the whole list above, but sweeps only for its own seeds)
-    const uint32_t seed_i = seed_prefix[s >> 6] + (uint32_t)__popcll(seed_map[s >> 6] & ((1ull << (s & 63u)) - 1ull));
-    if (world > 1u && seed_i % world != my_rank) continue;
-    const uint32_t out_row = world > 1u ? seed_i / world : seed_i;  // row in this rank's send segment
-    const double slat = G(p.cc_lat)[s], slon = G(p.cc_lon)[s], scos = G(p.cc_cos)[s];
+    const SeedGeo sg = {G(p.cc_lat)[s], G(p.cc_lon)[s], G(p.cc_cos)[s], G(p.cc_ux)[s], G(p.cc_uy)[s], G(p.cc_uz)[s]};
     const bool shared = (ssite & 0x80000000u) != 0u;
     TopN q;
 #pragma unroll
     for (int i = 0; i < PM_TOPN; ++i) q.r[i] = ~0ull;
     uint32_t n_mine = 0;
-    // The sweep: L2-latency loads with ~70 f64 operations + an 8-deep insertion per key in between (about 375
-    // instructions per 64-slot stride: the kernel is issue-bound once enough seeds are in flight).
-    // One register set of four strides per step.  (A software-pipelined variant with two register sets needs 213
-    // VGPRs = 2 waves per SIMD; this one needs 159 = 3 waves, and the extra wave hides more latency than the
-    // explicit prefetch did: 9.2 -> 8.4 ms of proposals per match at 1M x 100k.)
-    SweepBatch ba;
-    for (uint32_t j0 = 0; j0 < lw; j0 += 4u) {
-      sweep_load(p, alive, loc, lw, n_list, j0, lane, shared, ba);
-      sweep_keys(ba, lw, j0, lane, s, shared, ssite, slat, slon, scos, SB, q, n_mine);
+    {
+      TileRegs tr;
+      tile_fetch(p, alive, loc, lw, n_list, 0u, tid, tr);
+      tile_store(tiles[0], tid, tr);
+      __syncthreads();
+      for (uint32_t t = 0; t < n_tiles; ++t) {
+        const bool more = t + 1u < n_tiles;
+        if (more) tile_fetch(p, alive, loc, lw, n_list, t + 1u, tid, tr);  // in flight while this tile is consumed
+        if (valid) tile_keys(p, tiles[t & 1u], t, lane, s, shared, ssite, sg, SB, q, n_mine);
+        if (more) tile_store(tiles[(t + 1u) & 1u], tid, tr);
+        __syncthreads();
+      }
     }
     PP_MARK(pt_sweep);
+    // ---- the K nearest in (key, slot) order: K + 1 rounds of wave-wide argmin over the lanes' sorted registers
     uint32_t popped = 0, n_k = 0;
     uint64_t mine = ~0ull, beyond = ~0ull;  // beyond = the (K+1)-th key, if any
-    while (n_k <= K) {
+    while (valid && n_k <= K) {
       const uint64_t v = wave_min_u64(q.r[0]);
       if (v == ~0ull) break;
       if (n_k == K) {
@@ -2175,7 +2247,8 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
             if (shared && ((loc[j] >> lane) & 1ull) && G(p.cc_site)[t] == ssite) continue;  // not listed
             const uint64_t k = ((loc[j] >> lane) & 1ull)
                                    ? pack_key((uint64_t)__double_as_longlong(
-                                                  hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB)
+                                                  prox_a(sg, G(p.cc_ux)[t], G(p.cc_uy)[t], G(p.cc_uz)[t], G(p.cc_lat),
+                                                         G(p.cc_lon), G(p.cc_cos), t)), t, SB)
                                    : pack_key(PM_KEY_NOLOC, t, SB);
             if (k > v) topn_insert(k, q);
           }
@@ -2190,7 +2263,11 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     //  tail_clear — the first candidate NOT in the row is further than the band from the last entry
     //  tail_ok    — otherwise: everything unlisted within the band of the last entry sits at that entry's site
     uint32_t clean = 1, tail_clear = 0, tail_ok = 0;
-    {
+    int tail_bad = 0, need_pass2 = 0;  // pass 2: a second sweep of the list that settles tail_ok (see below)
+    uint64_t e_last = 0;
+    double a_last = 0.0, band2 = 0.0;
+    uint32_t site_last = 0;
+    if (valid) {
       const uint64_t kb = (mine >> SB) << SB;
       const uint32_t my_site = (lane < n_k && kb != noloc_kb) ? G(p.cc_site)[(uint32_t)(mine & ((1ull << SB) - 1ull))] : 0u;
       const uint64_t nkb_lo = __shfl_down((uint32_t)kb, 1, 64), nkb_hi = __shfl_down((uint32_t)(kb >> 32), 1, 64);
@@ -2203,9 +2280,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       }
       clean = __ballot(bad) == 0ull;
     }
-    if (n_k == K) {
-      const uint64_t e_last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 1) << 32) |
-                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 1);
+    if (valid && n_k == K) {
+      e_last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 1) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 1);
       const uint64_t kb_last = (e_last >> SB) << SB;
       const uint64_t kb_beyond = (beyond >> SB) << SB;
       if (beyond == ~0ull || kb_last == noloc_kb) {
@@ -2213,17 +2290,19 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       } else if (kb_beyond == noloc_kb) {
         tail_clear = 1;
       } else {
-        const double a_last = __longlong_as_double((long long)kb_last);
+        a_last = __longlong_as_double((long long)kb_last);
         const double a_b = __longlong_as_double((long long)kb_beyond);
         if (a_b - a_last > a_b * (4.0 * TIE_BAND) + 1e-300) {
           tail_clear = 1;
         } else {
-          const uint32_t site_last = G(p.cc_site)[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
-          const double band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
+          site_last = G(p.cc_site)[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
+          band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
           // The unlisted candidates closest to the last entry are still in the lanes' registers (ascending):
-          // check those within the band; only a lane whose registers are all within the band AND that dropped
-          // candidates during the sweep cannot tell, and falls back to a re-sweep of its own slots.
-          int bad = 0;
+          // check those within the band.  A lane whose registers are ALL within the band and that dropped
+          // candidates during the sweep cannot tell (a city of a thousand co-located workers just beyond the row
+          // does this to every lane): then the list is swept a second time — by the whole workgroup, through the
+          // same LDS tiles, not lane by lane through L2 — looking only for an unlisted in-band candidate of
+          // another site.
           bool unknown = false;
           uint32_t in_regs = 0;
 #pragma unroll
@@ -2235,27 +2314,45 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
             if (kb2 == noloc_kb) continue;
             const double a = __longlong_as_double((long long)kb2);
             if (a - a_last <= band2) {
-              if (G(p.cc_site)[(uint32_t)(k & ((1ull << SB) - 1ull))] != site_last) bad = 1;
+              if (G(p.cc_site)[(uint32_t)(k & ((1ull << SB) - 1ull))] != site_last) tail_bad = 1;
               if (i == PM_TOPN - 1) unknown = true;
             }
           }
           unknown = unknown && (n_mine - popped > in_regs);
-          if (__ballot(unknown)) {
-            for (uint32_t j = 0; j < lw; ++j) {
-              const uint32_t t = j * 64u + lane;
-              if (!unknown || !((alive[j] >> lane) & 1ull) || t == s || !((loc[j] >> lane) & 1ull)) continue;
-              if (shared && G(p.cc_site)[t] == ssite) continue;  // same-site candidates never enter the row
-              const uint64_t k = pack_key((uint64_t)__double_as_longlong(
-                                              hav_a(slat, slon, scos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t])), t, SB);
-              if (k <= e_last) continue;  // listed
-              const double a = __longlong_as_double((long long)((k >> SB) << SB));
-              if (a - a_last <= band2 && G(p.cc_site)[t] != site_last) bad = 1;
-            }
-          }
-          tail_ok = __ballot(bad) == 0ull;
+          need_pass2 = __ballot(unknown) != 0ull && __ballot(tail_bad) == 0ull;
+          if (!need_pass2) tail_ok = __ballot(tail_bad) == 0ull;
         }
       }
     }
+    if (__syncthreads_or(need_pass2)) {  // uniform in the workgroup: every wave helps to stage the tiles
+      TileRegs tr;
+      tile_fetch(p, alive, loc, lw, n_list, 0u, tid, tr);
+      tile_store(tiles[0], tid, tr);
+      __syncthreads();
+      for (uint32_t t = 0; t < n_tiles; ++t) {
+        const bool more = t + 1u < n_tiles;
+        if (more) tile_fetch(p, alive, loc, lw, n_list, t + 1u, tid, tr);
+        if (need_pass2) {
+          const TileBuf& tb = tiles[t & 1u];
+#pragma unroll
+          for (uint32_t u = 0; u < PROP_TILE / 64u; ++u) {
+            const uint32_t o = u * 64u + lane, tt = t * PROP_TILE + o;
+            if (!((tb.alive[u] >> lane) & 1ull) || tt == s || !((tb.loc[u] >> lane) & 1ull)) continue;
+            const uint32_t st_site = tb.site[o];
+            if (st_site == site_last || (shared && st_site == ssite)) continue;  // (same-site candidates never enter the row)
+            const uint64_t k = pack_key((uint64_t)__double_as_longlong(prox_a(sg, tb.x[o], tb.y[o], tb.z[o], G(p.cc_lat),
+                                                                               G(p.cc_lon), G(p.cc_cos), tt)), tt, SB);
+            if (k <= e_last) continue;  // listed
+            const double a = __longlong_as_double((long long)((k >> SB) << SB));
+            if (a - a_last <= band2) tail_bad = 1;
+          }
+        }
+        if (more) tile_store(tiles[(t + 1u) & 1u], tid, tr);
+        __syncthreads();
+      }
+      if (need_pass2) tail_ok = __ballot(tail_bad) == 0ull;
+    }
+    if (!valid) continue;  // (the workgroup's last seeds may be fewer than four)
     PP_MARK(pt_flags);
 #ifdef PM_CARVE_PROF
     {
@@ -2270,7 +2367,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         atomicMax(&pr[23], (unsigned long long)(pt_same + pt_sweep + pt_pop + pt_flags));
 #endif
         atomicAdd(&pr[24], 1ull);
-        atomicAdd(&pr[25], any_re ? 1ull : 0ull);
+        atomicAdd(&pr[25], (any_re || need_pass2) ? 1ull : 0ull);
       }
     }
 #endif
@@ -2283,7 +2380,6 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     }
     // the row: K sorted entries, and the flags word in the last entry (PM_PROP_META)
     const uint32_t meta = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
-    (void)rows_pr;
     prop_out[(size_t)out_row * PM_PROP_ROW + lane] = lane == PM_PROP_META ? (uint64_t)meta : mine;
   }
 }
@@ -2308,6 +2404,7 @@ __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_l
   const auto g_lc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
   const auto seed_map = G(p.seed_map);
   const auto seed_prefix = G(p.seed_prefix);
+  const auto seed_slots = G(p.seed_slots);
   const uint32_t lwp = (n_list + 63u) >> 6;
   uint32_t acc = 0, limit = n_list;
   for (uint32_t j0 = 0; j0 < lwp; j0 += 64u) {
@@ -2325,6 +2422,8 @@ __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_l
     if (j < lwp && lane <= last) {
       seed_map[j] = m;
       seed_prefix[j] = acc + incl - cnt;
+      uint32_t o = acc + incl - cnt;  // seed number -> slot (the proposer takes its seeds from this list)
+      for (uint64_t mm = m; mm; mm &= mm - 1ull) seed_slots[o++] = j * 64u + (uint32_t)__builtin_ctzll(mm);
     }
     acc += __shfl(incl, (int)last, 64);
     if (over) {
@@ -2443,6 +2542,7 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     const uint32_t ow = n ? G(p.order)[ic] : 0u;
     const uint32_t os = n ? G(p.c_site)[ic] : 0u;
     const double la = n ? G(p.c_lat)[ic] : 0.0, lo = n ? G(p.c_lon)[ic] : 0.0, co = n ? G(p.c_cos)[ic] : 0.0;
+    const double vx = n ? G(p.c_ux)[ic] : 0.0, vy = n ? G(p.c_uy)[ic] : 0.0, vz = n ? G(p.c_uz)[ic] : 0.0;
     const bool c = i < n && ((aw >> lane) & 1ull) && (cm & cbit) != 0ull;
     const uint64_t bal = __ballot(c);
     const uint32_t cnt = (uint32_t)__popcll(bal);
@@ -2461,6 +2561,9 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
       G(p.cc_lat)[s] = la;
       G(p.cc_lon)[s] = lo;
       G(p.cc_cos)[s] = co;
+      G(p.cc_ux)[s] = vx;
+      G(p.cc_uy)[s] = vy;
+      G(p.cc_uz)[s] = vz;
       G(p.cc_site)[s] = os;
       s_bits[wave][rank] = has_loc;
     }
@@ -2509,6 +2612,7 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     st->prop_k = prop_k;
     st->prop_limit = limit;
     st->rows_pr = (n_seeds + p.dist_world - 1u) / p.dist_world;
+    st->n_seeds = n_seeds;
     st->need_prep = 0;
   }
 }
@@ -2589,6 +2693,9 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         G(p.c_lat)[i] = G(p.lat)[w];
         G(p.c_lon)[i] = G(p.lon)[w];
         G(p.c_cos)[i] = G(p.coslat)[w];
+        G(p.c_ux)[i] = G(p.ux)[w];
+        G(p.c_uy)[i] = G(p.uy)[w];
+        G(p.c_uz)[i] = G(p.uz)[w];
         G(p.c_site)[i] = G(p.site)[w];
         G(p.c_compat)[i] = G(p.compat)[w];
       }
@@ -2638,6 +2745,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       c.prop_k = 0;
       c.prop_limit = 0;
       c.rows_pr = 0;
+      c.n_seeds = 0;
       for (; ci < p.n_avail; ++ci) {
         c.min_s = p.min_size[ci];
         c.max_s = p.max_size[ci];
@@ -2667,6 +2775,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         uint32_t n_seeds = 0;
         c.prop_limit = carve_prop_limit(p, red, c.n_list, &n_seeds);
         c.rows_pr = (n_seeds + p.dist_world - 1u) / p.dist_world;
+        c.n_seeds = n_seeds;
       }
       prepared = true;
       PROF_MARK(28);
@@ -2676,6 +2785,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       c.prop_k = st->prop_k;
       c.prop_limit = st->prop_limit;
       c.rows_pr = st->rows_pr;
+      c.n_seeds = st->n_seeds;
       c.min_s = p.min_size[ci];
       c.max_s = p.max_size[ci];
     }
@@ -2783,6 +2893,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     st->prop_k = c.prop_k;
     st->prop_limit = c.prop_limit;
     st->rows_pr = c.rows_pr;
+    st->n_seeds = c.n_seeds;
     st->total_available = c.total_available;
     if (ext) {
       st->need_prep = exit_state == CARVE_STATE_RUNNING ? 1u : 0u;
@@ -2804,9 +2915,10 @@ void launch_compat(const CompatArgs& a, hipStream_t s) {
 void launch_triad(const double* b, const double* c, double* a, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(triad_kernel, dim3(256 * 32), dim3(256), 0, s, b, c, a, n);
 }
-void launch_coslat(const double* lat, double* coslat, uint32_t W, hipStream_t s) {
+void launch_geo(const double* lat, const double* lon, double* coslat, double* ux, double* uy, double* uz, uint32_t W,
+                hipStream_t s) {
   if (W == 0) return;
-  hipLaunchKernelGGL(coslat_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, lat, coslat, W);
+  hipLaunchKernelGGL(geo_kernel, dim3((W + 255u) / 256u), dim3(256), 0, s, lat, lon, coslat, ux, uy, uz, W);
 }
 void launch_update_rows(const RowUpdateArgs& a, hipStream_t s) {
   if (a.n == 0) return;
