@@ -2021,32 +2021,83 @@ __device__ __noinline__ void carve_compact_place(const CarveArgs& p, BlockRed& r
   __syncthreads();
 }
 
-// Proposal generator: one wave per located live slot of the prepared configuration.  The wave sweeps the
-// whole candidate list (coalesced 64-slot strides), every lane keeps its PM_TOPN smallest keys in registers,
-// and K rounds of DPP argmin pop the K nearest in (key, slot) order.  A lane whose PM_TOPN entries are all
-// consumed re-sweeps its own slots for keys beyond the last one popped.
-#define PM_TOPN 8  // smallest keys each lane keeps (a lane holding more than that of the K nearest re-sweeps)
-struct TopN {
-  uint64_t r[PM_TOPN];  // ascending; ~0 = empty
+// Proposal generator: one wave per located live slot of the prepared configuration.  The wave sweeps the whole
+// candidate list and keeps its 64 smallest keys SORTED ACROSS ITS LANES (lane i = the i-th nearest so far).  A
+// candidate enters only if it beats lane 63 (one compare against a wave-uniform threshold; after the first few
+// hundred slots almost nothing does: 64 (1 + ln(n / 64)) insertions over a list of n), and an insertion is a
+// wave-wide shift by one lane (DPP wave_shr) from the insertion point — so the sweep's inner loop is the key
+// arithmetic alone, and the finished register IS the row: no per-lane queues, no pop rounds, no re-sweeps.
+struct NearRow {
+  uint64_t key;     // ascending over the lanes; ~0 = empty
+  uint64_t tau;     // lane 63's key (wave-uniform): what a candidate has to beat
+  uint64_t tau_hi;  // keys in (tau, tau_hi) may end up within the certificate band of the row's last entry
+  // the unlisted candidates that came that close (rejected at the threshold, or pushed out of lane 63 later):
+  // the smallest key and its site, and the smallest key at any OTHER site — enough to answer, at the end, "is
+  // there an unlisted candidate within the band of the last entry that does not sit at that entry's site?"
+  uint64_t m1, m2;
+  uint32_t s1;
 };
-__device__ __forceinline__ void topn_insert(uint64_t k, TopN& q) {
-  if (k < q.r[PM_TOPN - 1]) {
-    q.r[PM_TOPN - 1] = k;
-#pragma unroll
-    for (int i = PM_TOPN - 1; i > 0; --i) {
-      // one 64-bit compare per level, four selects (written as min / max the compiler compares twice)
-      const bool sw = q.r[i] < q.r[i - 1];
-      const uint32_t a_lo = (uint32_t)q.r[i], a_hi = (uint32_t)(q.r[i] >> 32);
-      const uint32_t b_lo = (uint32_t)q.r[i - 1], b_hi = (uint32_t)(q.r[i - 1] >> 32);
-      q.r[i - 1] = ((uint64_t)(sw ? a_hi : b_hi) << 32) | (sw ? a_lo : b_lo);
-      q.r[i] = ((uint64_t)(sw ? b_hi : a_hi) << 32) | (sw ? b_lo : a_lo);
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {  // lane i <- lane i - 1, lane 0 <- 0
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+}
+// Upper end of the window behind the threshold.  The row's last entry (the K-th nearest, K <= 63) never lies
+// beyond lane 63, and lane 63 only ever moves inwards, so a candidate that finishes within the band
+// (a <= a_last (1 + 4 band) + 1e-300) of the last entry is, whenever it is looked at, fewer than 4 band 2^53 ulps
+// above the threshold's `a` (or below 1e-290): in integer terms — keys are the bit patterns of positive doubles —
+// below tau + ulps.  `ulps` = 2^20 / 2^25 (twice what the band needs; the key truncation is 2^13 / 2^18).
+// Location-less thresholds, and a row that is not full yet, have no window.
+__device__ __forceinline__ uint64_t near_window(uint64_t tau, uint32_t SB, uint64_t ulps) {
+  if (tau >= ((PM_KEY_NOLOC >> SB) << SB)) return tau;
+  const uint64_t hi = tau + ulps, floor_bits = 0x03B8F2B061AEA073ull;  // bits of 1e-290, rounded up
+  return (hi > floor_bits ? hi : floor_bits) | ((1ull << SB) - 1ull);
+}
+__device__ __forceinline__ void near_track(NearRow& r, uint64_t k, uint32_t site, bool cand) {
+  uint64_t chg = __ballot(cand && (k < r.m1 || (site != r.s1 && k < r.m2)));
+  while (chg) {  // (a city of co-located workers: the first one sets m1 / s1, the others change nothing)
+    const uint32_t l = (uint32_t)__builtin_ctzll(chg);
+    chg &= chg - 1ull;
+    const uint64_t kk = readlane_u64(k, l);
+    const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)site, (int)l);
+    if (kk < r.m1) {
+      if (ss != r.s1) r.m2 = r.m1;
+      r.m1 = kk;
+      r.s1 = ss;
+    } else if (ss != r.s1 && kk < r.m2) {
+      r.m2 = kk;
     }
   }
 }
-__device__ __forceinline__ void topn_pop(TopN& q) {
-#pragma unroll
-  for (int i = 0; i + 1 < PM_TOPN; ++i) q.r[i] = q.r[i + 1];
-  q.r[PM_TOPN - 1] = ~0ull;
+// the candidates of one 64-slot stride (k = ~0 where the lane has none; site = the candidate's site) against the row
+template <typename SP>
+__device__ __forceinline__ void near_row_offer(NearRow& r, uint64_t k, uint32_t site, SP cc_site, uint32_t SB, uint64_t ulps) {
+  if (!__ballot(k < r.tau_hi)) return;
+  uint64_t m = __ballot(k < r.tau);
+  if (m) {
+    const uint64_t old = r.key;
+    do {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1ull;
+      const uint64_t kk = readlane_u64(k, l);  // wave-uniform
+      const uint64_t prev = wave_shr1_u64(r.key);
+      const bool gt = r.key > kk, pgt = prev > kk;  // keys are distinct (the slot is in the low bits)
+      r.key = gt ? (pgt ? prev : kk) : r.key;     // (a key that no longer beats lane 63 changes nothing)
+    } while (m);
+    r.tau = readlane_u64(r.key, 63u);
+    r.tau_hi = near_window(r.tau, SB, ulps);
+    const bool ev = old > r.tau && old < r.tau_hi;  // pushed out of the row, still near
+    if (__ballot(ev)) {
+      const uint32_t es = ev ? cc_site[(uint32_t)(old & ((1ull << SB) - 1ull))] : 0u;
+      near_track(r, old, es, ev);
+    }
+  }
+  const bool nm = k > r.tau && k < r.tau_hi;  // not (or no longer) in the row, but near
+  if (__ballot(nm)) near_track(r, k, site, nm);
 }
 
 // The candidate columns of a tile of PROP_TILE slots, staged in LDS and shared by the four waves (= four seeds) of a
@@ -2093,11 +2144,11 @@ __device__ __forceinline__ void tile_store(TileBuf& tb, uint32_t tid, const Tile
 }
 // keys of one seed against a staged tile: lane l owns the slots t = l (mod 64), as everywhere in this kernel.
 // Straight-line code: every LDS read of four strides is issued up front, the chord key is computed for every lane,
-// and a slot that does not count (dead, the seed itself, same shared site) becomes the key ~0, which the
-// insertion ignores — a `continue` per condition would put an LDS round trip and a branch between each of them.
+// and a slot that does not count (dead, the seed itself, same shared site) becomes the key ~0, which never beats
+// the row's threshold — a `continue` per condition would put an LDS round trip and a branch between each of them.
 __device__ __forceinline__ void tile_keys(const CarveArgs& p, const TileBuf& tb, uint32_t tile, uint32_t lane, uint32_t s,
-                                          bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, TopN& q,
-                                          uint32_t& n_mine) {
+                                          bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps,
+                                          NearRow& q, uint32_t& n_mine) {
 #pragma unroll
   for (uint32_t h = 0; h < PROP_TILE / 256u; ++h) {
     double x[4], y[4], z[4];
@@ -2127,7 +2178,7 @@ __device__ __forceinline__ void tile_keys(const CarveArgs& p, const TileBuf& tb,
         if (near) a = hav_a(sg.lat, sg.lon, sg.cos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t]);
       }
       const uint64_t kl = pack_key(located ? (uint64_t)__double_as_longlong(a) : PM_KEY_NOLOC, t, SB);
-      topn_insert(counts ? kl : ~0ull, q);
+      near_row_offer(q, counts ? kl : ~0ull, si[v], G(p.cc_site), SB, ulps);
       n_mine += counts ? 1u : 0u;
     }
   }
@@ -2144,11 +2195,15 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
   const uint32_t SB = n_list > PM_CARVE_SLOTS ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   const double TIE_BAND = n_list > PM_CARVE_SLOTS ? PM_TIE_BAND_BIG : PM_TIE_BAND;
+  const uint64_t WINDOW_ULPS = n_list > PM_CARVE_SLOTS ? (1ull << 25) : (1ull << 20);  // 8 band 2^53 (see near_window)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_g = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
   const auto alive = G((const uint64_t*)p.bits_scratch);
   const auto loc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
   const uint32_t lw = (n_list + 63u) >> 6;
+#ifdef PM_CARVE_PROF
+  const uint64_t prof_k0 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- phase 1: same-site links for every located live slot (the validator's same-site shortcut walks them);
   // only sites shared by several workers (bit 31 of the interned id) can have one.  One wave per slot.
   for (uint32_t s = wave_g; s < n_list; s += n_waves) {
@@ -2156,13 +2211,13 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     const uint32_t ssite = G(p.cc_site)[s];
     uint32_t same = PM_NONE;
     if (ssite & 0x80000000u) {
-      // eight strides per step, every load unconditional and independent: the last member of a site scans to
+      // sixteen strides per step, every load unconditional and independent: the last member of a site scans to
       // the end of the list, and a load per step would make that wave the launch's tail
-      for (uint32_t j0 = s >> 6; j0 < lw && same == PM_NONE; j0 += 8u) {
-        uint32_t si[8];
-        uint64_t m[8];
+      for (uint32_t j0 = s >> 6; j0 < lw && same == PM_NONE; j0 += 16u) {
+        uint32_t si[16];
+        uint64_t m[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
           const uint32_t j = j0 + (uint32_t)u;
           const uint32_t jc = j < lw ? j : lw - 1u;
           const uint32_t t = j * 64u + lane;
@@ -2170,7 +2225,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
           m[u] = alive[jc] & loc[jc];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
           const uint32_t j = j0 + (uint32_t)u;
           const uint32_t t = j * 64u + lane;
           const bool hit = j < lw && t > s && t < n_list && ((m[u] >> lane) & 1ull) && si[u] == ssite;
@@ -2181,6 +2236,17 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     }
     if (lane == 0) G(p.same_next)[s] = same;
   }
+#ifdef PM_CARVE_PROF
+#ifndef PM_CARVE_PROF_FINE
+  {
+    const uint64_t dt1 = __builtin_amdgcn_s_memtime() - prof_k0;
+    if (lane == 0) {
+      atomicAdd(&((unsigned long long*)p.status->prof)[5], (unsigned long long)dt1);
+      atomicMax(&((unsigned long long*)p.status->prof)[31], (unsigned long long)dt1);
+    }
+  }
+#endif
+#endif
   // ---- phase 2: the neighbour rows.  Four seeds per workgroup (one per wave) sweep the candidate list together,
   // tile by tile through LDS.  The seeds of the batch are dealt round-robin over the ranks: this rank computes
   // seed numbers my_rank, my_rank + world, ... (every rank linked same_next for the whole list above).
@@ -2196,7 +2262,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     const uint32_t s = valid ? seed_slots[world > 1u ? my_rank + world * out_row : out_row] : 0u;
     const uint32_t ssite = G(p.cc_site)[s];
 #ifdef PM_CARVE_PROF
-    uint64_t pt = __builtin_amdgcn_s_memtime(), pt_same = 0, pt_sweep = 0, pt_pop = 0, pt_flags = 0, n_resweep = 0;
+    uint64_t pt = __builtin_amdgcn_s_memtime(), pt_same = 0, pt_sweep = 0, pt_pop = 0, pt_flags = 0;
     (void)pt_same; (void)pt_sweep; (void)pt_pop; (void)pt_flags;
 #define PP_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - pt; pt = t_; } while (0)
 #else
@@ -2204,9 +2270,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
 #endif
     const SeedGeo sg = {G(p.cc_lat)[s], G(p.cc_lon)[s], G(p.cc_cos)[s], G(p.cc_ux)[s], G(p.cc_uy)[s], G(p.cc_uz)[s]};
     const bool shared = (ssite & 0x80000000u) != 0u;
-    TopN q;
-#pragma unroll
-    for (int i = 0; i < PM_TOPN; ++i) q.r[i] = ~0ull;
+    NearRow q = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, 0xFFFFFFFFu};
     uint32_t n_mine = 0;
     {
       TileRegs tr;
@@ -2216,45 +2280,17 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       for (uint32_t t = 0; t < n_tiles; ++t) {
         const bool more = t + 1u < n_tiles;
         if (more) tile_fetch(p, alive, loc, lw, n_list, t + 1u, tid, tr);  // in flight while this tile is consumed
-        if (valid) tile_keys(p, tiles[t & 1u], t, lane, s, shared, ssite, sg, SB, q, n_mine);
+        if (valid) tile_keys(p, tiles[t & 1u], t, lane, s, shared, ssite, sg, SB, WINDOW_ULPS, q, n_mine);
         if (more) tile_store(tiles[(t + 1u) & 1u], tid, tr);
         __syncthreads();
       }
     }
     PP_MARK(pt_sweep);
-    // ---- the K nearest in (key, slot) order: K + 1 rounds of wave-wide argmin over the lanes' sorted registers
-    uint32_t popped = 0, n_k = 0;
-    uint64_t mine = ~0ull, beyond = ~0ull;  // beyond = the (K+1)-th key, if any
-    while (valid && n_k <= K) {
-      const uint64_t v = wave_min_u64(q.r[0]);
-      if (v == ~0ull) break;
-      if (n_k == K) {
-        beyond = v;
-        break;
-      }
-      if (lane == n_k) mine = v;
-      ++n_k;
-      if (q.r[0] == v) {
-        topn_pop(q);
-        ++popped;
-#ifdef PM_CARVE_PROF
-        if (q.r[0] == ~0ull && popped < n_mine) n_resweep = 1;
-#endif
-        if (q.r[0] == ~0ull && popped < n_mine) {  // entries were dropped: re-sweep this lane's slots beyond v
-          for (uint32_t j = 0; j < lw; ++j) {
-            const uint32_t t = j * 64u + lane;
-            if (!((alive[j] >> lane) & 1ull) || t == s) continue;
-            if (shared && ((loc[j] >> lane) & 1ull) && G(p.cc_site)[t] == ssite) continue;  // not listed
-            const uint64_t k = ((loc[j] >> lane) & 1ull)
-                                   ? pack_key((uint64_t)__double_as_longlong(
-                                                  prox_a(sg, G(p.cc_ux)[t], G(p.cc_uy)[t], G(p.cc_uz)[t], G(p.cc_lat),
-                                                         G(p.cc_lon), G(p.cc_cos), t)), t, SB)
-                                   : pack_key(PM_KEY_NOLOC, t, SB);
-            if (k > v) topn_insert(k, q);
-          }
-        }
-      }
-    }
+    // ---- the K nearest in (key, slot) order are lanes 0 .. K-1 of the row; lane K holds the first unlisted one
+    const uint32_t n_tot = valid ? (uint32_t)__popcll(__ballot(q.key != ~0ull)) : 0u;
+    const uint32_t n_k = n_tot < K ? n_tot : K;
+    const uint64_t beyond = n_tot > K ? readlane_u64(q.key, K) : ~0ull;
+    const uint64_t mine = lane < n_k ? q.key : ~0ull;
     PP_MARK(pt_pop);
     const uint64_t noloc_kb = (PM_KEY_NOLOC >> SB) << SB;
     // row certificates the validator can rely on instead of re-deriving them at every step:
@@ -2263,7 +2299,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     //  tail_clear — the first candidate NOT in the row is further than the band from the last entry
     //  tail_ok    — otherwise: everything unlisted within the band of the last entry sits at that entry's site
     uint32_t clean = 1, tail_clear = 0, tail_ok = 0;
-    int tail_bad = 0, need_pass2 = 0;  // pass 2: a second sweep of the list that settles tail_ok (see below)
+    int tail_bad = 0;
     uint64_t e_last = 0;
     double a_last = 0.0, band2 = 0.0;
     uint32_t site_last = 0;
@@ -2297,66 +2333,26 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         } else {
           site_last = G(p.cc_site)[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
           band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
-          // The unlisted candidates closest to the last entry are still in the lanes' registers (ascending):
-          // check those within the band.  A lane whose registers are ALL within the band and that dropped
-          // candidates during the sweep cannot tell (a city of a thousand co-located workers just beyond the row
-          // does this to every lane): then the list is swept a second time — by the whole workgroup, through the
-          // same LDS tiles, not lane by lane through L2 — looking only for an unlisted in-band candidate of
-          // another site.
-          bool unknown = false;
-          uint32_t in_regs = 0;
-#pragma unroll
-          for (int i = 0; i < PM_TOPN; ++i) {
-            const uint64_t k = q.r[i];
-            if (k == ~0ull) continue;
-            ++in_regs;
-            const uint64_t kb2 = (k >> SB) << SB;
-            if (kb2 == noloc_kb) continue;
-            const double a = __longlong_as_double((long long)kb2);
-            if (a - a_last <= band2) {
-              if (G(p.cc_site)[(uint32_t)(k & ((1ull << SB) - 1ull))] != site_last) tail_bad = 1;
-              if (i == PM_TOPN - 1) unknown = true;
-            }
+          // The unlisted candidates closest to the last entry are lanes K .. 63 of the sorted register; whatever
+          // else came near the row during the sweep is summarised in the tracker (see NearRow): of those, only
+          // the nearest one that does NOT sit at the last entry's site can break the certificate.
+          if (lane >= K && lane < n_tot) {
+            const uint64_t kb2 = (q.key >> SB) << SB;
+            if (kb2 != noloc_kb && __longlong_as_double((long long)kb2) - a_last <= band2 &&
+                G(p.cc_site)[(uint32_t)(q.key & ((1ull << SB) - 1ull))] != site_last)
+              tail_bad = 1;
           }
-          unknown = unknown && (n_mine - popped > in_regs);
-          need_pass2 = __ballot(unknown) != 0ull && __ballot(tail_bad) == 0ull;
-          if (!need_pass2) tail_ok = __ballot(tail_bad) == 0ull;
+          const uint64_t other = q.s1 != site_last ? q.m1 : q.m2;
+          const uint64_t kb_o = (other >> SB) << SB;
+          if (other != ~0ull && kb_o != noloc_kb && __longlong_as_double((long long)kb_o) - a_last <= band2) tail_bad = 1;
+          tail_ok = __ballot(tail_bad) == 0ull;
         }
       }
-    }
-    if (__syncthreads_or(need_pass2)) {  // uniform in the workgroup: every wave helps to stage the tiles
-      TileRegs tr;
-      tile_fetch(p, alive, loc, lw, n_list, 0u, tid, tr);
-      tile_store(tiles[0], tid, tr);
-      __syncthreads();
-      for (uint32_t t = 0; t < n_tiles; ++t) {
-        const bool more = t + 1u < n_tiles;
-        if (more) tile_fetch(p, alive, loc, lw, n_list, t + 1u, tid, tr);
-        if (need_pass2) {
-          const TileBuf& tb = tiles[t & 1u];
-#pragma unroll
-          for (uint32_t u = 0; u < PROP_TILE / 64u; ++u) {
-            const uint32_t o = u * 64u + lane, tt = t * PROP_TILE + o;
-            if (!((tb.alive[u] >> lane) & 1ull) || tt == s || !((tb.loc[u] >> lane) & 1ull)) continue;
-            const uint32_t st_site = tb.site[o];
-            if (st_site == site_last || (shared && st_site == ssite)) continue;  // (same-site candidates never enter the row)
-            const uint64_t k = pack_key((uint64_t)__double_as_longlong(prox_a(sg, tb.x[o], tb.y[o], tb.z[o], G(p.cc_lat),
-                                                                               G(p.cc_lon), G(p.cc_cos), tt)), tt, SB);
-            if (k <= e_last) continue;  // listed
-            const double a = __longlong_as_double((long long)((k >> SB) << SB));
-            if (a - a_last <= band2) tail_bad = 1;
-          }
-        }
-        if (more) tile_store(tiles[(t + 1u) & 1u], tid, tr);
-        __syncthreads();
-      }
-      if (need_pass2) tail_ok = __ballot(tail_bad) == 0ull;
     }
     if (!valid) continue;  // (the workgroup's last seeds may be fewer than four)
     PP_MARK(pt_flags);
 #ifdef PM_CARVE_PROF
     {
-      const uint64_t any_re = __ballot(n_resweep != 0);
       if (lane == 0) {
         unsigned long long* pr = (unsigned long long*)p.status->prof;
 #ifndef PM_CARVE_PROF_FINE  // (the fine build uses these slots for the validator's round phases)
@@ -2367,7 +2363,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         atomicMax(&pr[23], (unsigned long long)(pt_same + pt_sweep + pt_pop + pt_flags));
 #endif
         atomicAdd(&pr[24], 1ull);
-        atomicAdd(&pr[25], (any_re || need_pass2) ? 1ull : 0ull);
+        atomicAdd(&pr[25], (q.m1 != ~0ull) ? 1ull : 0ull);
       }
     }
 #endif

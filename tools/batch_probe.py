@@ -8,6 +8,12 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("PM_EXP_DEFINES"):  # experiment builds: a variant library with extra -D flags
+    from protocol_amd import build as B
+    alt = os.path.join(os.path.dirname(B.LIB_PATH), "libpm_engine_exp.so")
+    B.build(force=True, defines=os.environ["PM_EXP_DEFINES"].split(","), out=alt)
+    B.LIB_PATH = alt
+    B.needs_build = lambda: False
 from protocol_amd import engine as E, host
 from protocol_amd.swarm import baseline_config
 
