@@ -823,7 +823,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
   const lds_u64* const ROWS = (const lds_u64*)l_rows;
   const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
   const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
-  const lds_u32* const WID3 = (const lds_u32*)l_wid;
+  (void)l_wid;
   const lds_u32* const SITE3 = (const lds_u32*)l_site;
   const lds_u16* const NEXT3 = (const lds_u16*)l_next16;
   auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
@@ -831,7 +831,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto site_of = [SITE3, l_site](uint32_t sl) -> uint32_t { return BIG ? l_site[sl] : SITE3[sl]; };
-  auto wid_of = [WID3](uint32_t sl) -> uint32_t { return BIG ? sl : WID3[sl]; };
+  auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
   // next located slot at the same site: LDS u16 for small lists, HBM u32 for big ones
   auto next_of = [NEXT3, l_next32, n_list_v](uint32_t sl) -> uint32_t {
     if (!BIG) {
@@ -1097,7 +1097,7 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   const lds_u64* const ROWS = (const lds_u64*)l_rows;
   const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
   const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
-  const lds_u32* const WID3 = (const lds_u32*)l_wid;    // dereferenced only when !BIG
+  (void)l_wid;  // (members are recorded as slots; the worker ids are looked up after the run)
   const lds_u32* const SITE3 = (const lds_u32*)l_site;  // idem
   const lds_u16* const NEXT3 = (const lds_u16*)l_next16;
   lds_u32* const CLAIM = (lds_u32*)l_claim;             // [CARVE_WAVES * 64] claimed slots of the round
@@ -1106,7 +1106,7 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   auto kill = [A](uint32_t i) {
     __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  auto wid_of = [WID3](uint32_t sl) -> uint32_t { return BIG ? sl : WID3[sl]; };
+  auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
   auto site_of = [SITE3, l_site](uint32_t sl) -> uint32_t { return BIG ? l_site[sl] : SITE3[sl]; };
   auto next_of = [NEXT3, l_next32, n_list_v](uint32_t sl) -> uint32_t {
     if (!BIG) {
@@ -1424,7 +1424,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
   constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
   const uint32_t lw = (c.n_list + 63u) >> 6;
   const bool have_props = c.mode == CARVE_MODE_FORM && c.use_props;
-  auto wid_of = [l_wid](uint32_t sl) -> uint32_t { return BIG ? sl : l_wid[sl]; };  // big lists: translated after the run
+  auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
   bool cache_valid = false;
   for (;;) {
     if (have_props) {
@@ -2104,43 +2104,47 @@ __device__ __forceinline__ void near_row_offer(NearRow& r, uint64_t k, uint32_t 
 // workgroup: the sweep of a seed is then a chain of LDS reads (~64 cycles) instead of L2 round trips (~500), the
 // next tile's global loads are in flight while the current one is consumed (two buffers), and every candidate
 // row is fetched once per workgroup instead of once per seed.
-#define PROP_TILE 512u
+#ifndef PROP_TILE
+#define PROP_TILE 512u  // (256 / 512 / 1024 measure the same at 10 k and 100 k candidates)
+#endif
+#define PROP_TILE_PER_THREAD (PROP_TILE / 256u)
+#define PROP_TILE_WORDS (PROP_TILE / 64u)
 struct TileBuf {
   double x[PROP_TILE], y[PROP_TILE], z[PROP_TILE];  // unit vectors
   uint32_t site[PROP_TILE];
-  uint64_t alive[PROP_TILE / 64u], loc[PROP_TILE / 64u];
+  uint64_t alive[PROP_TILE_WORDS], loc[PROP_TILE_WORDS];
 };
-struct TileRegs {  // one thread's share of a tile on its way from HBM/L2 to LDS: slots tid and tid + 256
-  double x[2], y[2], z[2];
-  uint32_t site[2];
+struct TileRegs {  // one thread's share of a tile on its way from HBM/L2 to LDS: slots tid, tid + 256, ...
+  double x[PROP_TILE_PER_THREAD], y[PROP_TILE_PER_THREAD], z[PROP_TILE_PER_THREAD];
+  uint32_t site[PROP_TILE_PER_THREAD];
   uint64_t bm;
 };
 template <typename BP>
 __device__ __forceinline__ void tile_fetch(const CarveArgs& p, BP alive, BP loc, uint32_t lw, uint32_t n_list,
                                            uint32_t tile, uint32_t tid, TileRegs& r) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t t = tile * PROP_TILE + (uint32_t)h * 256u + tid;
+  for (uint32_t h = 0; h < PROP_TILE_PER_THREAD; ++h) {
+    const uint32_t t = tile * PROP_TILE + h * 256u + tid;
     const uint32_t tc = t < n_list ? t : n_list - 1u;  // unconditional loads; the bitmaps are zero beyond the list
     r.x[h] = G(p.cc_ux)[tc];
     r.y[h] = G(p.cc_uy)[tc];
     r.z[h] = G(p.cc_uz)[tc];
     r.site[h] = G(p.cc_site)[tc];
   }
-  const uint32_t j = tile * (PROP_TILE / 64u) + (tid & 7u);
-  r.bm = (tid < 16u && j < lw) ? (tid < 8u ? alive[j] : loc[j]) : 0ull;
+  const uint32_t j = tile * PROP_TILE_WORDS + (tid % PROP_TILE_WORDS);
+  r.bm = (tid < 2u * PROP_TILE_WORDS && j < lw) ? (tid < PROP_TILE_WORDS ? alive[j] : loc[j]) : 0ull;
 }
 __device__ __forceinline__ void tile_store(TileBuf& tb, uint32_t tid, const TileRegs& r) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t o = (uint32_t)h * 256u + tid;
+  for (uint32_t h = 0; h < PROP_TILE_PER_THREAD; ++h) {
+    const uint32_t o = h * 256u + tid;
     tb.x[o] = r.x[h];
     tb.y[o] = r.y[h];
     tb.z[o] = r.z[h];
     tb.site[o] = r.site[h];
   }
-  if (tid < 8u) tb.alive[tid] = r.bm;
-  else if (tid < 16u) tb.loc[tid - 8u] = r.bm;
+  if (tid < PROP_TILE_WORDS) tb.alive[tid] = r.bm;
+  else if (tid < 2u * PROP_TILE_WORDS) tb.loc[tid - PROP_TILE_WORDS] = r.bm;
 }
 // keys of one seed against a staged tile: lane l owns the slots t = l (mod 64), as everywhere in this kernel.
 // Straight-line code: every LDS read of four strides is issued up front, the chord key is computed for every lane,
@@ -2149,7 +2153,7 @@ __device__ __forceinline__ void tile_store(TileBuf& tb, uint32_t tid, const Tile
 __device__ __forceinline__ void tile_keys(const CarveArgs& p, const TileBuf& tb, uint32_t tile, uint32_t lane, uint32_t s,
                                           bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps,
                                           NearRow& q, uint32_t& n_mine) {
-#pragma unroll
+#pragma unroll 1
   for (uint32_t h = 0; h < PROP_TILE / 256u; ++h) {
     double x[4], y[4], z[4];
     uint32_t si[4];
@@ -2809,7 +2813,6 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     }
     if (in_lds) {
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) {
-        lds_wid[sl] = G(p.slot_wid)[sl];
         lds_site[sl] = G(p.cc_site)[sl];
         const uint32_t nx = (c.use_props && c.prop_k) ? G(p.same_next)[sl] : PM_NONE;
         lds_next[sl] = nx < c.n_list ? (uint16_t)nx : (uint16_t)0xFFFFu;
@@ -2821,7 +2824,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     const uint32_t mem_before_run = c.mem_off;
     int rc;
     if (in_lds) {
-      rc = carve_run_lds<false>(p, red, c, lds_wid, lds_site, lds_next, nullptr, lds_key, lds_key, r_alive, r_loc,
+      rc = carve_run_lds<false>(p, red, c, p.slot_wid, lds_site, lds_next, nullptr, lds_key, lds_key, r_alive, r_loc,
                                 part, sel_out, steps_before);
     } else if (big) {
       rc = carve_run_lds<true>(p, red, c, p.slot_wid, p.cc_site, nullptr, p.same_next, p.keys, lds_key, r_alive, r_loc,
@@ -2834,17 +2837,22 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     (void)slow0;
     (void)slow_before_cfg;
     __syncthreads();
-    if (big) {  // slots -> worker ids for everything this run appended
-      for (uint32_t k = mem_before_run + tid; k < c.mem_off; k += CARVE_THREADS) G(p.members)[k] = G(p.slot_wid)[G(p.members)[k]];
-      __syncthreads();
-    }
     PROF_MARK(13);
-    // dead slots -> position bitmap, so the next compaction / configuration sees the removals
-    {
+    if (in_lds || big) {
+      // Everything this run took is a member it appended (recorded as a SLOT): clear its position in the eligible
+      // bitmap, so the next compaction / configuration sees the removal, and replace the slot by the worker id.
+      // (Proportional to the groups formed, not to the length of the list.)
+      for (uint32_t k = mem_before_run + tid; k < c.mem_off; k += CARVE_THREADS) {
+        const uint32_t sl = G(p.members)[k];
+        const uint32_t i = G(p.slot_pos)[sl] & 0x7FFFFFFFu;  // bit 31: the slot has a location
+        atomicAnd((unsigned long long*)&G(p.alive_g)[i >> 6], ~(1ull << (i & 63u)));
+        G(p.members)[k] = G(p.slot_wid)[sl];
+      }
+    } else {  // lists in HBM: carve_step_mem records worker ids; dead slots -> position bitmap
       const uint64_t* alive = r_alive;
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS)
         if (!bit_at(alive, sl)) {
-          const uint32_t i = G(p.slot_pos)[sl] & 0x7FFFFFFFu;  // bit 31: the slot has a location
+          const uint32_t i = G(p.slot_pos)[sl] & 0x7FFFFFFFu;
           atomicAnd((unsigned long long*)&G(p.alive_g)[i >> 6], ~(1ull << (i & 63u)));
         }
     }
