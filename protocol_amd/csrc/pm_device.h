@@ -104,7 +104,7 @@ struct CarveStatus {
   uint32_t n_props;      // neighbour lists computed by this rank's proposer
   uint32_t need_prep;    // (external preparation) the next candidate list has not been prepared yet
   uint32_t g_lo, g_hi;   // groups appended by the last validation launch (their group_of is written by the prep kernels)
-  uint32_t _pad_prep;
+  uint32_t n_batches;    // validation launches that had a prepared list to run (the host sizes its next queue by it)
   unsigned long long prop_keys;  // keys (Haversine terms) those sweeps evaluated
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };

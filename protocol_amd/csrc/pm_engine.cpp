@@ -211,6 +211,7 @@ struct pm_engine {
 
   // ---- carve scratch
   DevBuf<uint32_t> d_order;
+  uint32_t form_rounds_hint = 0;  // validation rounds the last proposal-driven carve needed (0 = unknown)
   DevBuf<double> d_c_lat, d_c_lon, d_c_cos, d_cc_lat, d_cc_lon, d_cc_cos, d_c_u[3], d_cc_u[3];
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
   DevBuf<uint32_t> d_slot_pos, d_slot_wid;
@@ -807,7 +808,10 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   int32_t rc = form_begin(e, &r);
   if (rc) return rc;
   if (!r.nothing) {
-    uint32_t batch = r.a.n_avail + 3u;
+    // (propose, validate, prepare) rounds are queued blindly and the ones behind a finished carve return at once —
+    // at ~5 us per empty launch.  The first queue is sized by what the previous carve of this engine needed (a
+    // periodic match changes little from tick to tick); one configuration = at least one round otherwise.
+    uint32_t batch = e->form_rounds_hint ? e->form_rounds_hint + 1u : r.a.n_avail + 3u;
     for (uint32_t spins = 0;; ++spins) {
       // every poll either ends the carve or follows launches that formed at least one group or moved on to the
       // next configuration: far fewer rounds than this, or the device side is stuck — fail instead of hanging
@@ -822,9 +826,10 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
       host_mark("form: status back");
       if (r.st.state == CARVE_STATE_DONE) break;
       if (r.st.state != CARVE_STATE_RUNNING || !r.use_props) return set_error(PM_ENODEV, "carve kernel did not complete");
-      batch = 16u;  // more re-proposal rounds than were queued, or re-armed after a host-resolved step
+      batch = 8u;  // more re-proposal rounds than were queued, or re-armed after a host-resolved step
     }
   }
+  if (!r.nothing && r.use_props) e->form_rounds_hint = r.st.n_batches;
   return form_finish(e, &r, n_formed, defer_absorb);
 }
 

@@ -2404,7 +2404,6 @@ __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_l
   const auto g_lc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
   const auto seed_map = G(p.seed_map);
   const auto seed_prefix = G(p.seed_prefix);
-  const auto seed_slots = G(p.seed_slots);
   const uint32_t lwp = (n_list + 63u) >> 6;
   uint32_t acc = 0, limit = n_list;
   for (uint32_t j0 = 0; j0 < lwp; j0 += 64u) {
@@ -2422,8 +2421,6 @@ __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_l
     if (j < lwp && lane <= last) {
       seed_map[j] = m;
       seed_prefix[j] = acc + incl - cnt;
-      uint32_t o = acc + incl - cnt;  // seed number -> slot (the proposer takes its seeds from this list)
-      for (uint64_t mm = m; mm; mm &= mm - 1ull) seed_slots[o++] = j * 64u + (uint32_t)__builtin_ctzll(mm);
     }
     acc += __shfl(incl, (int)last, 64);
     if (over) {
@@ -2433,6 +2430,19 @@ __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_l
   }
   *limit_out = limit < n_list ? limit : n_list;
   *n_seeds_out = acc;
+}
+
+// seed number -> slot (the proposer takes its seeds from this dense list): every thread of the workgroup expands
+// the bitmap words it owns, after prop_limit_scan (and a barrier) have produced seed_map / seed_prefix
+__device__ __forceinline__ void prop_seed_slots(const CarveArgs& p, uint32_t limit, uint32_t tid, uint32_t n_threads) {
+  const auto seed_map = G((const uint64_t*)p.seed_map);
+  const auto seed_prefix = G((const uint32_t*)p.seed_prefix);
+  const auto seed_slots = G(p.seed_slots);
+  const uint32_t words = (limit + 63u) >> 6;
+  for (uint32_t j = tid; j < words; j += n_threads) {
+    uint32_t o = seed_prefix[j];
+    for (uint64_t mm = seed_map[j]; mm; mm &= mm - 1ull) seed_slots[o++] = j * 64u + (uint32_t)__builtin_ctzll(mm);
+  }
 }
 
 __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& red, uint32_t n_list, uint32_t* n_seeds) {
@@ -2448,6 +2458,7 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
   __syncthreads();
   const uint32_t r = red.b[0];
   *n_seeds = red.b[1];
+  prop_seed_slots(p, r, threadIdx.x, CARVE_THREADS);
   __syncthreads();
   return r;
 }
@@ -2604,7 +2615,17 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   if (p.proximity && n_list <= PM_CARVE_BIG_SLOTS && max_s - 1u < PM_PROP_META) {
     const uint32_t k = max_s - 1u + PM_PROP_RESERVE;
     prop_k = k < PM_PROP_META ? k : PM_PROP_META;
-    if (wave == 0) prop_limit_scan(p, n_list, lane, &limit, &n_seeds);
+    if (wave == 0) {
+      prop_limit_scan(p, n_list, lane, &limit, &n_seeds);
+      if (lane == 0) {
+        s_red[1] = limit;
+        s_red[2] = n_seeds;
+      }
+    }
+    __syncthreads();  // (uniform: prop_k depends on the configuration only)
+    limit = s_red[1];
+    n_seeds = s_red[2];
+    prop_seed_slots(p, limit, tid, 256u);
   }
   if (tid == 0) {
     st->cur_ci = ci;
@@ -2906,6 +2927,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     }
     st->fast_steps += c.fast_steps;
     st->slow_steps += c.steps - c.fast_steps;
+    if (!(flags_in & CARVE_F_INIT)) st->n_batches += 1;
   }
 }
 
