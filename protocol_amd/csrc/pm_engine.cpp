@@ -640,9 +640,10 @@ struct FormRun {
 static int32_t form_queue_init(pm_engine* e, FormRun* r) {
   HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
   if (r->use_props) {
-    HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_PROPS | CARVE_F_EXTPREP, r->start_ci, r->lds, e->stream));
-    launch_carve_prep(e->d_carve_args.p, e->W, e->stream);  // the first candidate list
-    e->tick_carve_launches += 2;
+    launch_carve_elig(e->d_carve_args.p, e->W, r->start_ci, e->stream);  // the ordered eligible list
+    launch_carve_prep(e->d_carve_args.p, e->W, e->stream);               // the first candidate list
+    HIPCHK(hipGetLastError());
+    e->tick_carve_launches += 3;
   } else
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, r->start_ci, r->lds, e->stream));
   e->tick_carve_launches++;

@@ -2638,6 +2638,115 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Full-chip construction of the ordered eligible list at the start of a proposal-driven FORM carve (the INIT launch
+// of the validator did this on one CU: 0.5 ms at 100 k rows, and a tenth of an incremental tick that adds a few
+// hundred workers to a standing swarm).  Same two-step shape as the list preparation above:
+//   carve_elig_count_kernel   eligible rows (Healthy & p2p & unassigned, mod.rs:492-497) per block; clears loc_g
+//   carve_elig_place_kernel   stable placement (position order = row order), the position-indexed columns, the
+//                             loc bitmap; the block that finishes last writes the alive bitmap and the status
+// One 64-row word per wave, four waves per block.
+
+__device__ __forceinline__ bool row_eligible(const CarveArgs& p, uint32_t w) {
+  if (w >= p.W) return false;
+  const uint32_t f = G(p.wflags)[w];
+  return (f & PM_W_HEALTHY) && (f & PM_W_HAS_P2P) && G(p.group_of)[w] < 0;
+}
+
+__global__ __launch_bounds__(256) void carve_elig_count_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;
+  if (G(p.status)->state != CARVE_STATE_RUNNING) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  __shared__ uint32_t s_c[PREP_WAVES];
+  const uint32_t j = blockIdx.x * PREP_WAVES + wave;
+  const uint64_t bal = __ballot(row_eligible(p, j * 64u + lane));
+  if (lane == 0) {
+    s_c[wave] = (uint32_t)__popcll(bal);
+    if (j < ((p.W + 63u) >> 6)) G(p.loc_g)[j] = 0ull;  // (the positions are a subset of the rows)
+  }
+  if (blockIdx.x == 0 && tid <= PM_MAX_CONFIGS + 1u) p.prep_counts[tid] = 0u;  // totals and both tickets
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < PREP_WAVES; ++w) sum += s_c[w];
+    G(p.prep_block_counts)[(size_t)blockIdx.x * PM_MAX_CONFIGS] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void carve_elig_place_kernel(const CarveArgs* __restrict__ pa, uint32_t start_ci) {
+  const CarveArgs& p = *pa;
+  const auto st = G(p.status);
+  if (st->state != CARVE_STATE_RUNNING) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  __shared__ uint32_t s_red[2 * PREP_WAVES + 2];
+  __shared__ uint32_t s_bits[PREP_WAVES][64];
+  // ---- this block's first position: eligible rows of the blocks in front of it
+  uint32_t part = 0;
+  for (uint32_t b = tid; b < blockIdx.x; b += 256u) part += G((const uint32_t*)p.prep_block_counts)[(size_t)b * PM_MAX_CONFIGS];
+  part = wave_sum(part);
+  if (lane == 0) s_red[wave] = part;
+  const uint32_t w = (blockIdx.x * PREP_WAVES + wave) * 64u + lane;
+  const bool e = row_eligible(p, w);
+  const uint64_t bal = __ballot(e);
+  const uint32_t cnt = (uint32_t)__popcll(bal);
+  if (lane == 0) s_red[PREP_WAVES + wave] = cnt;
+  __syncthreads();
+  uint32_t off = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PREP_WAVES; ++k) off += s_red[k];
+  for (uint32_t k = 0; k < wave; ++k) off += s_red[PREP_WAVES + k];
+  const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+  if (e) {
+    const uint32_t i = off + rank;
+    const uint32_t has_loc = (G(p.wflags)[w] & PM_W_HAS_LOC) ? 1u : 0u;
+    G(p.order)[i] = w;
+    G(p.c_lat)[i] = G(p.lat)[w];
+    G(p.c_lon)[i] = G(p.lon)[w];
+    G(p.c_cos)[i] = G(p.coslat)[w];
+    G(p.c_ux)[i] = G(p.ux)[w];
+    G(p.c_uy)[i] = G(p.uy)[w];
+    G(p.c_uz)[i] = G(p.uz)[w];
+    G(p.c_site)[i] = G(p.site)[w];
+    G(p.c_compat)[i] = G(p.compat)[w];
+    s_bits[wave][rank] = has_loc;
+  }
+  // the located bits of this wave's positions [off, off + cnt): compacted by rank, ORed into loc_g (at most two words)
+  __syncthreads();
+  const uint64_t locm = __ballot(lane < cnt && s_bits[wave][lane] != 0u);
+  if (lane == 0 && locm) {
+    const auto loc = (unsigned long long*)p.loc_g;
+    const uint32_t sh = off & 63u;
+    atomicOr(&loc[off >> 6], (unsigned long long)(locm << sh));
+    if (sh && (locm >> (64u - sh))) atomicOr(&loc[(off >> 6) + 1u], (unsigned long long)(locm >> (64u - sh)));
+  }
+  // ---- the block that finishes last completes the list and publishes it
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_red[0] = atomicAdd(&p.prep_counts[PM_MAX_CONFIGS + 1u], 1u);
+  __syncthreads();
+  if (s_red[0] != gridDim.x - 1u) return;
+  __threadfence();
+  uint32_t total = 0;
+  for (uint32_t b = tid; b < gridDim.x; b += 256u) total += G((const uint32_t*)p.prep_block_counts)[(size_t)b * PM_MAX_CONFIGS];
+  total = wave_sum(total);
+  __syncthreads();
+  if (lane == 0) s_red[1u + wave] = total;
+  __syncthreads();
+  const uint32_t n = s_red[1] + s_red[2] + s_red[3] + s_red[4];
+  const uint32_t n_words = (n + 63u) >> 6;
+  for (uint32_t j = tid; j < n_words; j += 256u)
+    G(p.alive_g)[j] = (j + 1u < n_words || (n & 63u) == 0u) ? ~0ull : ((1ull << (n & 63u)) - 1ull);
+  if (tid <= PM_MAX_CONFIGS + 1u) p.prep_counts[tid] = 0u;  // totals + tickets of the first list preparation
+  if (tid == 0) {
+    st->n_eligible = n;
+    st->total_available = n;  // mod.rs:503
+    st->cur_ci = start_ci;
+    st->need_prep = 1u;
+    st->g_lo = st->g_hi = st->n_groups;
+  }
+}
+
 __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* __restrict__ pa, uint32_t flags_in,
                                                               uint32_t start_ci) {
   const CarveArgs& p = *pa;  // argument block in device memory (a by-value struct this large would be
@@ -3100,6 +3209,13 @@ void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(carve_prep_count_kernel, dim3(blocks), dim3(256), 0, s, d_args);
   hipLaunchKernelGGL(carve_prep_place_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+}
+// the ordered eligible list of a proposal-driven FORM carve (instead of the validator's INIT launch)
+void launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t start_ci, hipStream_t s) {
+  uint32_t blocks = ((W + 63u) / 64u + PREP_WAVES - 1u) / PREP_WAVES;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(carve_elig_count_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+  hipLaunchKernelGGL(carve_elig_place_kernel, dim3(blocks), dim3(256), 0, s, d_args, start_ci);
 }
 // group_of for the groups of the last validation launch (the count kernel's first half), e.g. after the carve ended
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
