@@ -216,6 +216,11 @@ int32_t pm_tasks_delete(pm_engine*, const uint64_t* uids, uint32_t n, uint32_t* 
 /* StatusUpdatePlugin::handle_status_change (status_update_impl.rs:8-39): dead != 0 means the new
  * status is Dead or LowBalance => dissolve the worker's whole group. */
 int32_t pm_on_worker_status(pm_engine*, uint32_t worker, uint32_t flags_new, uint32_t dead);
+/* The same for n workers in one call, applied in array order (the status updater's sweep marks many nodes in one
+ * pass, status_update/mod.rs; a tombstoning node sync does too).  dead may be NULL (= none of them).  An index out
+ * of range fails the call before anything is applied. */
+int32_t pm_on_worker_status_many(pm_engine*, const uint32_t* workers, const uint32_t* flags_new, const uint32_t* dead,
+                                 uint32_t n);
 /* dissolve_group (mod.rs:1423-1487) by group slot. */
 int32_t pm_dissolve_group(pm_engine*, uint32_t group_slot);
 /* Drop all groups (bench: cold start of a full-swarm match). */

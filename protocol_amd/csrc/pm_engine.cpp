@@ -635,13 +635,14 @@ struct FormRun {
   size_t lds = 0;
   bool use_props = false;
   bool nothing = false;  // no configuration / no worker: nothing to carve
+  uint32_t n_bound = 0;  // rows outside any group when the carve starts (>= the eligible list): sizes the prep grids
 };
 
 static int32_t form_queue_init(pm_engine* e, FormRun* r) {
   HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
   if (r->use_props) {
     launch_carve_elig(e->d_carve_args.p, e->W, r->start_ci, e->stream);  // the ordered eligible list
-    launch_carve_prep(e->d_carve_args.p, e->W, e->stream);               // the first candidate list
+    launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);         // the first candidate list
     HIPCHK(hipGetLastError());
     e->tick_carve_launches += 3;
   } else
@@ -663,6 +664,12 @@ static int32_t form_begin(pm_engine* e, FormRun* r) {
   r->start_ci = 0;
   r->nothing = r->avail.empty() || e->W == 0;
   if (r->nothing) return PM_OK;
+  // the eligible list is a subset of the rows no group holds (host mirror, current after absorb_groups): the
+  // per-round preparation kernels are sized by that, not by the table (an incremental tick on a standing swarm
+  // prepares lists of a few thousand positions out of a hundred thousand rows)
+  r->n_bound = uint32_t(std::count_if(e->h_group_of.begin(), e->h_group_of.end(), [](int32_t g) { return g < 0; }));
+  if (e->h_group_of.size() != e->W) r->n_bound = e->W;
+  if (r->n_bound == 0) r->n_bound = 1;
   CarveArgs& a = r->a;
   rc = fill_carve_args(e, &a, CARVE_MODE_FORM, 0);
   if (rc) return rc;
@@ -691,9 +698,9 @@ static int32_t form_begin(pm_engine* e, FormRun* r) {
 }
 
 // the proposer launch, bracketed by its own hipEvents when pm_engine_config.time_proposer asks for the split
-static int32_t launch_propose_timed(pm_engine* e) {
+static int32_t launch_propose_timed(pm_engine* e, uint32_t n_bound) {
   if (!e->cfg.time_proposer) {
-    launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+    launch_carve_propose(e->d_carve_args.p, n_bound, e->stream);
     return PM_OK;
   }
   while (e->prop_ev.size() < e->prop_ev_used + 2) {
@@ -702,7 +709,7 @@ static int32_t launch_propose_timed(pm_engine* e) {
     e->prop_ev.push_back(x);
   }
   HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used], e->stream));
-  launch_carve_propose(e->d_carve_args.p, e->W, e->stream);
+  launch_carve_propose(e->d_carve_args.p, n_bound, e->stream);
   HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used + 1], e->stream));
   e->prop_ev_used += 2;
   return PM_OK;
@@ -712,10 +719,10 @@ static int32_t launch_propose_timed(pm_engine* e) {
 // finished carve return immediately
 static int32_t form_queue_pairs(pm_engine* e, FormRun* r, uint32_t count) {
   for (uint32_t k = 0; k < count; ++k) {
-    int32_t rc = launch_propose_timed(e);
+    int32_t rc = launch_propose_timed(e, r->n_bound);
     if (rc) return rc;
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, r->lds, e->stream));
-    launch_carve_prep(e->d_carve_args.p, e->W, e->stream);  // group_of of the new groups + the next candidate list
+    launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);  // group_of of the new groups + the next candidate list
     e->tick_carve_launches += 4;
   }
   return PM_OK;
@@ -1980,6 +1987,26 @@ int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, u
   return PM_OK;
 }
 
+int32_t pm_on_worker_status_many(pm_engine* e, const uint32_t* workers, const uint32_t* flags_new, const uint32_t* dead,
+                                 uint32_t n) {
+  if (!e || (n && (!workers || !flags_new))) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->have_workers) return set_error(PM_ERANGE, "worker index out of range");
+  for (uint32_t k = 0; k < n; ++k)
+    if (workers[k] >= e->W) return set_error(PM_ERANGE, "worker index out of range");
+  if (!n) return PM_OK;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  ABSORB_PENDING(e);
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t w = workers[k];
+    e->h_flags[w] = flags_new[k];
+    if (dead && dead[k] && e->h_group_of[w] >= 0) dissolve_locked(e, uint32_t(e->h_group_of[w]));  // status_update_impl.rs:17-29
+  }
+  e->flags_dirty = true;
+  e->compat_dirty = true;
+  return PM_OK;
+}
+
 int32_t pm_dissolve_group(pm_engine* e, uint32_t slot) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
@@ -2382,7 +2409,7 @@ int32_t pm_dist_carve_next(pm_engine* e, pm_dist_xfer* x, uint32_t* more) {
     }
     if (r->st.state == CARVE_STATE_RUNNING && r->use_props) {
       // a candidate list is prepared: this rank's share of the batch's neighbour lists
-      int32_t rcp = launch_propose_timed(e);
+      int32_t rcp = launch_propose_timed(e, e->form->n_bound);
       if (rcp) {
         dist_abort(e);
         return rcp;
@@ -2410,7 +2437,7 @@ int32_t pm_dist_carve_validate(pm_engine* e) {
   HIPCHK(hipSetDevice(e->cfg.device));
   if (e->dist_phase != 1 || !e->form || e->form->nothing) return set_error(PM_ESTATE, "no proposal batch pending");
   HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, e->form->lds, e->stream));
-  launch_carve_prep(e->d_carve_args.p, e->W, e->stream);
+  launch_carve_prep(e->d_carve_args.p, e->form->n_bound, e->stream);
   e->tick_carve_launches += 3;
   return PM_OK;
 }

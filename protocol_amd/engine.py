@@ -87,7 +87,7 @@ class Assignment(C.Structure):
 EXPORTS = [
     "pm_engine_config_default", "pm_engine_create", "pm_engine_destroy", "pm_last_error", "pm_set_configs",
     "pm_set_model_table", "pm_set_enabled_mask", "pm_upload_workers", "pm_update_workers", "pm_upload_tasks",
-    "pm_on_worker_status", "pm_dissolve_group", "pm_reset_groups", "pm_compat_masks", "pm_form_groups",
+    "pm_on_worker_status", "pm_on_worker_status_many", "pm_dissolve_group", "pm_reset_groups", "pm_compat_masks", "pm_form_groups",
     "pm_merge_solo_groups", "pm_get_groups", "pm_match", "pm_match_per_task", "pm_newest_task", "pm_tick",
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
         L.pm_update_workers.argtypes = [vp, vp, C.POINTER(WorkerSoa)]
         L.pm_upload_tasks.argtypes = [vp, C.POINTER(TaskSoa)]
         L.pm_on_worker_status.argtypes = [vp, u32, u32, u32]
+        L.pm_on_worker_status_many.argtypes = [vp, vp, vp, vp, u32]
         L.pm_dissolve_group.argtypes = [vp, u32]
         L.pm_reset_groups.argtypes = [vp]
         L.pm_compat_masks.argtypes = [vp, vp]
@@ -310,6 +311,15 @@ class Engine:
     # ---- events
     def on_worker_status(self, worker: int, flags_new: int, dead: bool):
         check(lib().pm_on_worker_status(self._h, worker, flags_new, int(dead)))
+
+    def on_worker_status_many(self, workers, flags_new, dead=None):
+        """pm_on_worker_status for a batch, in array order; `dead`: per-entry flags (None = nobody)."""
+        w, f = _arr(workers, np.uint32), _arr(flags_new, np.uint32)
+        assert len(w) == len(f)
+        d = _arr(dead, np.uint32) if dead is not None else None
+        assert d is None or len(d) == len(w)
+        check(lib().pm_on_worker_status_many(self._h, w.ctypes.data if len(w) else None, f.ctypes.data if len(f) else None,
+                                             d.ctypes.data if d is not None and len(d) else None, len(w)))
 
     def dissolve_group(self, slot: int):
         check(lib().pm_dissolve_group(self._h, slot))

@@ -155,6 +155,7 @@ extern "C" {
     fn pm_tasks_insert_front(e: *mut c_void, rows: *const pm_task_soa) -> i32;
     fn pm_tasks_delete(e: *mut c_void, uids: *const u64, n: u32, n_deleted: *mut u32) -> i32;
     fn pm_on_worker_status(e: *mut c_void, worker: u32, flags_new: u32, dead: u32) -> i32;
+    fn pm_on_worker_status_many(e: *mut c_void, workers: *const u32, flags_new: *const u32, dead: *const u32, n: u32) -> i32;
     fn pm_tick(e: *mut c_void, stats: *mut pm_stats) -> i32;
     fn pm_lookup_task_for_worker(e: *mut c_void, worker: u32, out: *mut pm_assignment) -> i32;
     fn pm_host_group_vars(input: *const c_char, v: *const pm_group_vars, out: *mut c_char, cap: usize, needed: *mut usize) -> i32;
@@ -395,12 +396,18 @@ impl GpuMatchPlugin {
         }
         if new_model { self.push_model_table(&t); }
         // nodes that left the store: tombstone (their group dissolves, like a death; status_update_impl.rs:17-29)
+        let (mut gone, mut gone_flags) = (Vec::<u32>::new(), Vec::<u32>::new());
         for i in 0..seen.len() {
             if !seen[i] && t.present[i] {
                 t.present[i] = false;
                 t.rows[i].flags &= !W_HEALTHY;
-                check(unsafe { pm_on_worker_status(self.engine, i as u32, t.rows[i].flags, 1) })?;
+                gone.push(i as u32);
+                gone_flags.push(t.rows[i].flags);
             }
+        }
+        if !gone.is_empty() {
+            let dead = vec![1u32; gone.len()];
+            check(unsafe { pm_on_worker_status_many(self.engine, gone.as_ptr(), gone_flags.as_ptr(), dead.as_ptr(), gone.len() as u32) })?;
         }
         if !upd_idx.is_empty() {
             // keep the ranks the engine already has for rewritten rows

@@ -145,3 +145,43 @@ def test_appended_and_rewritten_rows_track_the_oracle():
         s = check(f"tick {k}")
         assert s["n_formed"] > 0
     eng.close()
+
+
+def test_status_changes_in_one_call_equal_the_single_calls():
+    """pm_on_worker_status_many == the same events through pm_on_worker_status, one by one (status_update_impl.rs:8-39:
+    a death dissolves the whole group; the survivors re-group on the next tick)."""
+    sw = make_swarm(11, 400, 1500)
+    packed = host.pack_workers(sw)
+    flags = packed["flags"].astype(np.int64)
+    engines = []
+    for _ in range(2):
+        eng = E.Engine()
+        host.load_swarm(eng, sw)
+        eng.tick()
+        engines.append(eng)
+    a, b = engines
+    assert engine_groups(a) == engine_groups(b)
+    rng = np.random.default_rng(3)
+    healthy = np.nonzero(sw.status == 2)[0]
+    for tick in range(3):
+        victims = rng.choice(healthy, size=40, replace=False)
+        back = victims[:10]                                    # ten of them report healthy again in the same sweep
+        ws = np.concatenate([victims, back])
+        fl = np.concatenate([flags[victims] & ~E.W_HEALTHY, flags[back]])
+        dead = np.concatenate([np.ones(len(victims)), np.zeros(len(back))]).astype(np.uint32)
+        for w, f, d in zip(ws, fl, dead):
+            a.on_worker_status(int(w), int(f), bool(d))
+        b.on_worker_status_many(ws, fl, dead)
+        assert engine_groups(a) == engine_groups(b)            # the dissolutions, before any tick
+        a.tick()
+        b.tick()
+        assert engine_groups(a) == engine_groups(b)
+        assert _tasks_of(a, sw.W) == _tasks_of(b, sw.W)
+        for w in victims[10:]:                                 # the rest come back for the next round
+            a.on_worker_status(int(w), int(flags[w]), False)
+        b.on_worker_status_many(victims[10:], flags[victims[10:]])
+    with pytest.raises(E.EngineError):
+        b.on_worker_status_many([0, sw.W], [0, 0])             # out of range: nothing applied
+    assert engine_groups(a) == engine_groups(b)
+    a.close()
+    b.close()
