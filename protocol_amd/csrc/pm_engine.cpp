@@ -224,7 +224,7 @@ struct pm_engine {
   DevBuf<uint32_t> d_first, d_count, d_rank, d_chosen, d_perm;
   DevBuf<pm_assignment> d_table;
   DevBuf<uint32_t> d_task_col;
-  pm_assignment* h_table_pinned = nullptr;
+  const pm_assignment* h_table = nullptr;  // the snapshot published last (host side of the lock-free look-up)
   // pinned staging for the group records a carve appended (absorbed into the host list by absorb_groups)
   uint32_t* h_gstage = nullptr;
   size_t h_gstage_cap = 0;
@@ -233,7 +233,6 @@ struct pm_engine {
   uint32_t ab_g0 = 0, ab_g1 = 0, ab_m0 = 0, ab_m1 = 0, ab_solo = 0;
   uint32_t* h_gtask_pinned = nullptr;
   size_t h_gtask_cap = 0;
-  size_t h_table_cap = 0;
   DevBuf<uint32_t> d_nb_idx;
   DevBuf<long long> d_nb_val;
 
@@ -989,16 +988,11 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   return PM_OK;
 }
 
-// D2H of the assignment table + the group task words, then swap in the new published snapshot.
+// D2H of the assignment table + the group task words; the table lands directly in the snapshot buffer that is
+// not current (pinned host memory, written by the copy engine between the odd and the even mark of its sequence
+// counter — see PubTable), which then becomes the published one.
 static int32_t publish(pm_engine* e) {
   const size_t G = e->groups.size();
-  if (e->h_table_cap < e->W) {
-    if (e->h_table_pinned) (void)hipHostFree(e->h_table_pinned);
-    e->h_table_pinned = nullptr;
-    e->h_table_cap = 0;
-    HIPCHK(hipHostMalloc((void**)&e->h_table_pinned, sizeof(pm_assignment) * std::max<uint32_t>(e->W, 1)));
-    e->h_table_cap = e->W;
-  }
   if (e->h_gtask_cap < G) {
     if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
     e->h_gtask_pinned = nullptr;
@@ -1008,41 +1002,47 @@ static int32_t publish(pm_engine* e) {
     e->h_gtask_cap = cap;
   }
   const uint32_t* g_task = e->h_gtask_pinned;
-  if (e->W)
-    HIPCHK(hipMemcpyAsync(e->h_table_pinned, e->d_table.p, sizeof(pm_assignment) * e->W, hipMemcpyDeviceToHost,
-                          e->stream));
-  if (G) HIPCHK(hipMemcpyAsync(e->h_gtask_pinned, e->d_g_task_next.p, G * 4, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  const int cur = e->pub_cur.load(std::memory_order_relaxed);
+  const int nx = cur < 0 ? 0 : (cur ^ 1);
+  PubTable& t = e->pub[nx];
+  uint64_t* words = t.words.load(std::memory_order_relaxed);
+  if (t.cap_rows < e->W || !words) {  // buffers only grow; a replaced one is retired, not freed (a reader may hold it)
+    const size_t cap = std::max<size_t>(size_t(e->W) + e->W / 8 + 64, 64);
+    uint64_t* nw = nullptr;
+    if (hipHostMalloc((void**)&nw, cap * 32) != hipSuccess || !nw)
+      return set_error(PM_ENOMEM, "out of pinned host memory for the published table");
+    std::memset(nw, 0, cap * 32);
+    const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+    t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd while the pointer changes
+    std::atomic_thread_fence(std::memory_order_release);
+    if (words) e->pub_retired.push_back(words);
+    words = nw;
+    t.cap_rows = cap;
+    t.words.store(nw, std::memory_order_relaxed);
+    t.seq.store(s0 + 2, std::memory_order_release);
+  }
+  const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+  t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
+  std::atomic_thread_fence(std::memory_order_release);
+  hipError_t herr = hipSuccess;
+  if (e->W) herr = hipMemcpyAsync(words, e->d_table.p, sizeof(pm_assignment) * e->W, hipMemcpyDeviceToHost, e->stream);
+  if (herr == hipSuccess && G)
+    herr = hipMemcpyAsync(e->h_gtask_pinned, e->d_g_task_next.p, G * 4, hipMemcpyDeviceToHost, e->stream);
+  if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
+  if (herr != hipSuccess) {
+    t.n.store(0, std::memory_order_relaxed);          // contents undefined: nothing to look up in this buffer
+    t.seq.store(s0 + 2, std::memory_order_release);
+    HIPCHK(herr);
+  }
+  t.n.store(e->W, std::memory_order_relaxed);
+  t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
+  e->pub_cur.store(nx, std::memory_order_release);
+  e->h_table = reinterpret_cast<const pm_assignment*>(words);
   for (size_t g = 0; g < G; ++g) {
     e->groups[g].task = g_task[g];
     e->groups[g].task_uid = g_task[g] == PM_NONE ? 0 : (e->tasks_have_uid ? e->h_tuid[g_task[g]] : task_position(e, g_task[g]));
   }
   std::swap(e->d_g_task, e->d_g_task_next);
-  // swap in the new snapshot (see PubTable)
-  const int cur = e->pub_cur.load(std::memory_order_relaxed);
-  const int nx = cur < 0 ? 0 : (cur ^ 1);
-  PubTable& t = e->pub[nx];
-  const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
-  t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
-  std::atomic_thread_fence(std::memory_order_release);
-  uint64_t* words = t.words.load(std::memory_order_relaxed);
-  if (t.cap_rows < e->W || !words) {
-    const size_t cap = std::max<size_t>(size_t(e->W) + e->W / 8 + 64, 64);
-    uint64_t* nw = static_cast<uint64_t*>(std::malloc(cap * 32));
-    if (!nw) {
-      t.seq.store(s0 + 2, std::memory_order_release);
-      return set_error(PM_ENOMEM, "out of host memory for the published table");
-    }
-    if (words) e->pub_retired.push_back(words);
-    words = nw;
-    t.cap_rows = cap;
-    t.words.store(nw, std::memory_order_relaxed);
-  }
-  const uint64_t* src = reinterpret_cast<const uint64_t*>(e->h_table_pinned);
-  for (size_t i = 0; i < size_t(e->W) * 4; ++i) __atomic_store_n(&words[i], src[i], __ATOMIC_RELAXED);
-  t.n.store(e->W, std::memory_order_relaxed);
-  t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
-  e->pub_cur.store(nx, std::memory_order_release);
   return PM_OK;
 }
 
@@ -1326,9 +1326,9 @@ void pm_engine_destroy(pm_engine* e) {
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
   if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
   if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
-  if (e->h_table_pinned) (void)hipHostFree(e->h_table_pinned);
-  for (PubTable& t : e->pub) std::free(t.words.load());
-  for (uint64_t* q : e->pub_retired) std::free(q);
+  for (PubTable& t : e->pub)
+    if (t.words.load()) (void)hipHostFree(t.words.load());
+  for (uint64_t* q : e->pub_retired) (void)hipHostFree(q);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->kev)
@@ -2110,7 +2110,7 @@ int32_t pm_match(pm_engine* e, uint32_t* task_of_worker, uint32_t* applicable_co
   rc = publish(e);
   if (rc) return rc;
   if (task_of_worker)
-    for (uint32_t w = 0; w < e->W; ++w) task_of_worker[w] = e->h_table_pinned[w].task;
+    for (uint32_t w = 0; w < e->W; ++w) task_of_worker[w] = e->h_table[w].task;
   if (applicable_count) std::copy(cnt.begin(), cnt.end(), applicable_count);
   return PM_OK;
 }
