@@ -38,7 +38,7 @@ print(f"  inside run: rounds={out[0]} ({pct(out[0])}; {out[1]} rounds, {out[2]} 
       f"sequential path={out[11]} ({pct(out[11])}) staging={out[20]} ({pct(out[20])}; {out[21]} refills) exact steps={out[22]} ({pct(out[22])})")
 print(f"  prepare: count passes={out[26]} ({out[30]} calls) placement={out[27]} proposal limit={out[28]} other={out[29]}")
 print(f"  exact-sweep reasons: no proposal={out[16]} debug hook={out[17]} row exhausted={out[18]} certificate={out[19]}")
-print(f"  proposer waves: {out[24]} proposals ({out[25]} with a lane re-sweep); ticks summed over waves: same-site links={out[5]} (slowest wave {out[31]}) sweep={out[6]} pop={out[7]} flags={out[8]}; slowest wave={out[23]}")
-if out[5]:
+print(f"  proposer waves: {out[24]} proposals ({out[25]} with near misses in the tracker); ticks summed over waves: same-site links={out[5]} (slowest wave {out[31]}) sweep={out[6]} read-out={out[7]} flags={out[8]}; slowest wave={out[23]}")
+if os.environ.get("PM_PROF_FINE"):
     print(f"  fine: wave0 spec={out[5]}; wave1 wait={out[6]} commit={out[7]} sync={out[8]} chk={out[16]} b2wait={out[17]}; wave7 chk={out[18]} spec={out[19]}")
 print(f"  total ticks {tot}; ticks per ms = {tot / s['ms_carve_kernel']:.0f}")

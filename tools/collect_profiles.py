@@ -66,7 +66,7 @@ def main():
         except Exception as ex:  # noqa: BLE001
             print("pmc pass failed:", counter, ex)
             sums[counter] = {}
-    groups = {"carve": ("carve_kernel", "carve_propose_kernel"),
+    groups = {"carve": ("carve_",),  # validator, proposer, eligible-list and list-preparation kernels
               "pair_sweep": ("pair_sweep", "pair_init", "build_planes"),
               "compat_kernel": ("compat_kernel",)}
     traffic = {}
