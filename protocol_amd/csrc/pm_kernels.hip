@@ -1317,6 +1317,14 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
       dbg_at = commits_done + (r ? dbg_every - r : 0u);
     }
     uint32_t cmask = 0, stop_code = ROUND_OK, stop_wave = 0, commits = commits_done, open = 1u;
+    // the usual round: nobody claims anybody else's slots or seed, nobody needs the exact sweep, and neither the
+    // output arrays nor the debug hook end the round early — every wave of the round commits
+    const bool all_clear = __ballot(cw != 0u) == 0ull && commits_done + n_round <= max_commits &&
+                           !(dbg_at - commits_done < n_round);
+    if (all_clear) {
+      cmask = (1u << n_round) - 1u;
+      commits = commits_done + n_round;
+    } else
 #pragma unroll
     for (uint32_t v = 0; v < CARVE_WAVES; ++v) {
       const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)v);

@@ -132,6 +132,43 @@ def test_near_mirror_sites_with_a_lone_survivor():
     _check(sw, expect_host_resolved=True)
 
 
+def test_lone_node_of_another_site_behind_a_crowd_beyond_the_row():
+    """The tail certificate of a proposal row: a crowd of co-located nodes fills the row and continues far beyond
+    it (all at the row's last entry's site — harmless), and ONE node of another site, nearly mirrored about the
+    seed's meridian and therefore inside the band, comes last in input order: its key ties with the crowd's, the
+    slot order puts it behind all of them, so it is not in the row — yet the reference, whose distances differ
+    there, ranks it FIRST.  The proposer has to notice it among the candidates it rejected at the threshold (the
+    tracker keeps the nearest rejected key at a site other than the first one's) and withhold `tail_ok`; the step
+    then goes to the exact sweep and on to the host.  Several clusters, both orientations, lists longer than one
+    64-slot stride so that the lone node is rejected, not pushed out."""
+    from oracle import oracle_ffi as orc
+    n_cluster, crowd = 6, 150
+    per = crowd + 2
+    sw = _set_configs(make_swarm(38, 50, n_cluster * per), [("eight", 8, 8, None), ("pairs", 2, 2, None)])
+    sw.status[:] = 2
+    sw.has_p2p[:] = True
+    sw.has_loc[:] = True
+    k = np.arange(sw.W) % per               # slot 0 of a cluster: the seed; 1 .. crowd: the crowd; last: the lone node
+    c = np.arange(sw.W) // per
+    sw.lat[:] = 10.0 + 3.0 * c
+    lone_west = (c % 2) == 0                # west is the truly nearer side (see the previous test)
+    east, west = 32.2, 31.8
+    sw.lon[:] = np.where(k == 0, 32.0, np.where(k == per - 1, np.where(lone_west, west, east),
+                                                np.where(lone_west, east, west)))
+    d_e = orc.calculate_distance(10.0, 32.0, 10.0, east)
+    d_w = orc.calculate_distance(10.0, 32.0, 10.0, west)
+    assert d_e > d_w and d_e - d_w < 1e-12 * d_e
+    _check(sw, expect_host_resolved=True)
+    # what is being protected: in the clusters whose lone node is on the nearer side the reference's first group
+    # holds it, although seven of the crowd come first in input order
+    st = oracle_state_for(sw, reference_shaped=True)
+    st.try_form_new_groups()
+    first_groups = {min(m): m for (_s, _id, _c, m, _t) in st.groups()}
+    for cl in range(n_cluster):
+        seed, lone = cl * per, cl * per + per - 1
+        assert (lone in first_groups[seed]) == bool(lone_west[seed])
+
+
 def test_antipodal_points_are_outside_the_reference_domain():
     """Two clusters at exact antipodes.  For such pairs the reference's Haversine term rounds to a > 1 about half
     of the time, its distance is NaN, and `partial_cmp(..).unwrap_or(Equal)` (mod.rs:239-253) stops being an
