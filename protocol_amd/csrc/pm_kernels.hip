@@ -612,6 +612,16 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 #define CARVE_WAVES 8
 // a value that is the same in every lane, moved to an SGPR
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// an LDS address as an opaque SGPR value (wave-uniform by construction): the compiler can neither re-derive it nor
+// treat it as a vector value
+template <typename LP, typename GP>
+__device__ __forceinline__ LP lds_pin(GP* g) {
+  LP p = (LP)g;
+  uint32_t a = (uint32_t)(uintptr_t)p;
+  a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+  asm volatile("" : "+s"(a));
+  return (LP)(uintptr_t)a;
+}
 // The carve kernels take their argument block through a pointer (see carve_kernel), so the compiler cannot
 // see that the pointers inside it are global memory and would emit FLAT accesses — which count against the
 // LDS counter as well and serialise every LDS wait behind the outstanding HBM traffic.  G() restores the
@@ -1093,14 +1103,16 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   typedef __attribute__((address_space(3))) unsigned long long lds_u64;
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   typedef __attribute__((address_space(3))) uint16_t lds_u16;
-  lds_u64* const A = (lds_u64*)l_alive;
-  const lds_u64* const ROWS = (const lds_u64*)l_rows;
-  const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
-  const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
+  // (lds_pin: the addresses are made opaque and held in SGPRs — left alone, the compiler re-derives every one of
+  // them from the dynamic-LDS offset table with a scalar load and an lgkmcnt(0) wait, several times per round)
+  lds_u64* const A = lds_pin<lds_u64*>(l_alive);
+  const lds_u64* const ROWS = lds_pin<const lds_u64*>(l_rows);
+  const lds_u32* const C_SLOT = lds_pin<const lds_u32*>(red.cache_slot);
+  const lds_u32* const C_NEXT = lds_pin<const lds_u32*>(red.cache_next);
   (void)l_wid;  // (members are recorded as slots; the worker ids are looked up after the run)
-  const lds_u32* const SITE3 = (const lds_u32*)l_site;  // idem
-  const lds_u16* const NEXT3 = (const lds_u16*)l_next16;
-  lds_u32* const CLAIM = (lds_u32*)l_claim;             // [CARVE_WAVES * 64] claimed slots of the round
+  const lds_u32* const SITE3 = BIG ? nullptr : lds_pin<const lds_u32*>(l_site);  // dereferenced only when !BIG
+  const lds_u16* const NEXT3 = BIG ? nullptr : lds_pin<const lds_u16*>(l_next16);
+  lds_u32* const CLAIM = lds_pin<lds_u32*>(l_claim);    // [CARVE_WAVES * 64] claimed slots of the round
   lds_u32* const CONF = CLAIM + CARVE_WAVES * 64u;      // [CARVE_WAVES] conflict words
   auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
   auto kill = [A](uint32_t i) {
@@ -1129,6 +1141,7 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   const uint32_t room_g = cap_g > base_groups ? cap_g - base_groups : 0u;
   const uint32_t room_m = cap_m > base_mem ? (cap_m - base_mem) / group_n : 0u;
   const uint32_t max_commits = UNI(room_g < room_m ? room_g : room_m);
+  const uint32_t fit_total = UNI(base_cand / group_n);  // full groups the live candidates allow (commits_done never exceeds it)
   int action = FAST_SEQ;
   uint32_t next_row = 0, commits_done = 0;
 #ifdef PM_CARVE_PROF
@@ -1150,9 +1163,8 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     // front of it (mod.rs:545-551) — that also keeps the loop guards true (max_s >= min_s): the round is as
     // wide as the candidates allow, and the last partial group of a configuration goes to carve_fast_steps.
     const uint32_t n_cand_now = base_cand - commits_done * group_n;
-    uint32_t n_fit = 0;
-#pragma unroll
-    for (uint32_t k = 1; k <= CARVE_WAVES; ++k) n_fit += (k * group_n <= n_cand_now) ? 1u : 0u;
+    const uint32_t fit_left = fit_total - commits_done;  // = n_cand_now / group_n
+    const uint32_t n_fit = fit_left < CARVE_WAVES ? fit_left : CARVE_WAVES;
     if (n_fit == 0u) {
       action = FAST_SEQ;
       break;
