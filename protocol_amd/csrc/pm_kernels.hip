@@ -2404,6 +2404,12 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   }
 }
 
+#ifndef PM_PROP_CAP_DIV_BIG
+#define PM_PROP_CAP_DIV_BIG 10u
+#endif
+#ifndef PM_PROP_CAP_DIV
+#define PM_PROP_CAP_DIV 5u
+#endif
 // One proposal per located slot, at most PM_PROP_MAX_SEEDS per batch.  Returns the slot after the word in which
 // the cap-th located slot falls (a later batch covers the rest), or n_list; *n_seeds = the located live slots
 // below it (the batch's seeds).  Also records, per bitmap word below the limit, the seed bitmap and the number of
@@ -2415,9 +2421,9 @@ __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_l
   // The configuration is re-prepared (and re-proposed) once half of its list is dead; by then the seed
   // pointer has advanced through roughly the first eighth of the slots (each group removes max_s slots
   // spread over the whole list), so later slots never consume this round's proposals: cap the batch.
-  // (big lists: a tenth — their proposal sweeps are what a match of 100 k workers spends its time on; measured
-  // at 1M x 100k: 1/5 38 ms, 1/7 35 ms, 1/10 33 ms, 1/16 35 ms)
-  uint32_t cap = n_list > PM_CARVE_SLOTS ? n_list / 10u : n_list / 5u;
+  // (big lists: a tenth; measured again with the sorted-lane proposer at 1M x 100k, carve through the stepwise
+  // tick: 1/6 26.3 ms, 1/8 22.5, 1/10 22.0, 1/14 22.7; small lists 1/3 .. 1/7 all within 1 %)
+  uint32_t cap = n_list > PM_CARVE_SLOTS ? n_list / PM_PROP_CAP_DIV_BIG : n_list / PM_PROP_CAP_DIV;
   if (cap < 512u) cap = 512u;
   if (cap > PM_PROP_MAX_SEEDS) cap = PM_PROP_MAX_SEEDS;
   const auto g_al = G((const uint64_t*)p.bits_scratch);
