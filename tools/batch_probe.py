@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-batch timing of the carve through the stepwise tick (one rank): seeds of the batch, proposer time, validation
-(+ preparation of the next list) time.  usage: python tools/batch_probe.py [config index] """
+(+ preparation of the next list) time.  usage: python tools/batch_probe.py [config index]
+PM_EXP_DEFINES=A=1,B builds and uses a variant library with those -D flags (e.g. PROP_TILE=1024u,
+PM_PROP_CAP_DIV_BIG=8u) — how the tile sizes and batch caps quoted in DESIGN.md were compared."""
 import os
 import sys
 import time
