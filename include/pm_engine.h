@@ -221,6 +221,32 @@ int32_t pm_on_worker_status(pm_engine*, uint32_t worker, uint32_t flags_new, uin
  * of range fails the call before anything is applied. */
 int32_t pm_on_worker_status_many(pm_engine*, const uint32_t* workers, const uint32_t* flags_new, const uint32_t* dead,
                                  uint32_t n);
+/* Group life-cycle feed for the webhook / metrics emission that follows every creation and dissolution in the
+ * reference (send_group_created after try_form_new_groups, mod.rs:612-625; send_group_destroyed per dissolved solo
+ * group then send_group_created for the merged one, mod.rs:974-1000; send_group_destroyed in dissolve_group,
+ * mod.rs:1469-1481).  Off by default; once enabled the engine logs one event per creation / dissolution, in the
+ * order the reference would emit them, until the caller drains the log:
+ *   pm_form_groups / pm_tick      created, in formation order
+ *   pm_merge_solo_groups / tick   per merge: destroyed for each solo group of the batch (batch order), then created
+ *   pm_on_worker_status(dead), pm_dissolve_group, pm_tasks_delete, pm_upload_tasks (claimed task gone)   destroyed
+ *     (several groups hit by one pm_tasks_delete: the reference walks a Redis SCAN there — order unpinned; the engine
+ *     goes through its group list in creation order)
+ * pm_reset_groups and a pm_upload_workers that drops the groups log nothing (no counterpart in the reference).
+ * Members are worker indices in BTreeSet<String> order (address rank), as in pm_get_groups. */
+enum { PM_GROUP_CREATED = 1, PM_GROUP_DESTROYED = 2 };
+typedef struct pm_group_event {
+  uint64_t group_id;     /* generate_group_id value */
+  uint32_t kind;         /* PM_GROUP_CREATED / PM_GROUP_DESTROYED */
+  uint32_t config;       /* index of the configuration (row of pm_set_configs) */
+  uint32_t member_begin; /* into the members array handed to pm_drain_group_events */
+  uint32_t n_members;
+} pm_group_event;
+int32_t pm_enable_group_events(pm_engine*, uint32_t on); /* switching off also clears the log */
+/* Copies the logged events (oldest first) and their members out and clears the log.  n_events / n_members always
+ * report what the log holds; with a buffer that is too small (or NULL) the call returns PM_ERANGE and drains
+ * nothing, so `pm_drain_group_events(e, NULL, 0, NULL, 0, &ne, &nm)` is the size query. */
+int32_t pm_drain_group_events(pm_engine*, pm_group_event* events, uint32_t cap_events, uint32_t* members,
+                              uint32_t cap_members, uint32_t* n_events, uint32_t* n_members);
 /* dissolve_group (mod.rs:1423-1487) by group slot. */
 int32_t pm_dissolve_group(pm_engine*, uint32_t group_slot);
 /* Drop all groups (bench: cold start of a full-swarm match). */

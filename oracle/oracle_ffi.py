@@ -110,6 +110,10 @@ def lib() -> C.CDLL:
                                      C.POINTER(C.c_int64)]
         L.orc_group_info.restype = C.c_int
         L.orc_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_events.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_events.restype = C.c_size_t
+        L.orc_events_clear.argtypes = [vp]
+        L.orc_events_clear.restype = None
         L.orc_group_vars.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
         L.orc_group_vars.restype = C.c_void_p
         L.orc_volume_vars.argtypes = [C.c_char_p, C.c_char_p]
@@ -128,6 +132,10 @@ def lib() -> C.CDLL:
         L.orc_pair_sweep_per_worker_mt.restype = C.c_int
         _lib = L
     return _lib
+
+
+GROUP_EVENT = np.dtype([("group_id", np.uint64), ("kind", np.uint32), ("config", np.uint32),
+                        ("member_begin", np.uint32), ("n_members", np.uint32)])
 
 
 def _p(a: np.ndarray) -> int:
@@ -348,6 +356,18 @@ class State:
                                     C.byref(task)):
                 out.append((s, gid.value, cfg.value, buf[:n.value].tolist(), task.value))
         return out
+
+    def drain_events(self):
+        """[(kind, group id, config idx, members in BTreeSet order)] since the last drain: what the webhook plugins
+        would have been called with, in call order (kind 1 = created, 2 = destroyed)"""
+        nm = C.c_size_t(0)
+        ne = lib().orc_events(self._h, None, 0, None, 0, C.byref(nm))
+        ev = np.zeros(max(ne, 1), dtype=GROUP_EVENT)
+        mem = np.zeros(max(nm.value, 1), dtype=np.uint32)
+        lib().orc_events(self._h, _p(ev), ne, _p(mem), nm.value, C.byref(nm))
+        lib().orc_events_clear(self._h)
+        return [(int(e["kind"]), int(e["group_id"]), int(e["config"]),
+                 mem[int(e["member_begin"]):int(e["member_begin"]) + int(e["n_members"])].tolist()) for e in ev[:ne]]
 
     def counters(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -467,7 +467,41 @@ struct orc_state {
   size_t n_slots, cap_slots, n_live;
   uint64_t id_rng;
   uint64_t n_hav, n_meets;
+  /* webhook feed: what send_group_created / send_group_destroyed would have been called with, in call order
+   * (mod.rs:612-625, 974-1000, 1469-1481) */
+  orc_group_event* ev;
+  size_t n_ev, cap_ev;
+  uint32_t* ev_mem;
+  size_t n_evm, cap_evm;
 };
+
+static void log_event(orc_state* st, uint32_t kind, const grp* g) {
+  if (st->n_ev == st->cap_ev) {
+    st->cap_ev = st->cap_ev ? st->cap_ev * 2 : 256;
+    st->ev = realloc(st->ev, st->cap_ev * sizeof(*st->ev));
+  }
+  while (st->n_evm + g->n > st->cap_evm) {
+    st->cap_evm = st->cap_evm ? st->cap_evm * 2 : 1024;
+    st->ev_mem = realloc(st->ev_mem, st->cap_evm * sizeof(uint32_t));
+  }
+  orc_group_event* e = &st->ev[st->n_ev++];
+  e->group_id = g->id;
+  e->kind = kind;
+  e->config = g->cfg;
+  e->member_begin = (uint32_t)st->n_evm;
+  e->n_members = g->n;
+  memcpy(st->ev_mem + st->n_evm, g->members, sizeof(uint32_t) * g->n); /* group.nodes.iter(): BTreeSet order */
+  st->n_evm += g->n;
+}
+
+size_t orc_events(const orc_state* st, orc_group_event* out, size_t cap, uint32_t* members, size_t cap_members,
+                  size_t* n_members) {
+  if (n_members) *n_members = st->n_evm;
+  if (out && cap >= st->n_ev) memcpy(out, st->ev, st->n_ev * sizeof(*out));
+  if (members && cap_members >= st->n_evm) memcpy(members, st->ev_mem, st->n_evm * sizeof(uint32_t));
+  return st->n_ev;
+}
+void orc_events_clear(orc_state* st) { st->n_ev = st->n_evm = 0; }
 
 orc_state* orc_state_new(const orc_node* nodes, size_t n_nodes, const orc_config* cfgs, size_t n_cfgs,
                          const orc_policy* policy) {
@@ -493,6 +527,8 @@ orc_state* orc_state_new(const orc_node* nodes, size_t n_nodes, const orc_config
 void orc_state_free(orc_state* st) {
   if (!st) return;
   for (size_t i = 0; i < st->n_slots; ++i) free(st->groups[i].members);
+  free(st->ev);
+  free(st->ev_mem);
   free(st->groups);
   free(st->node_group);
   free(st->enabled);
@@ -536,12 +572,14 @@ static uint32_t new_group(orc_state* st, uint32_t cfg, const uint32_t* members, 
   }
   for (uint32_t i = 0; i < n; ++i) st->node_group[members[i]] = (int32_t)st->n_slots;
   st->n_live++;
+  log_event(st, ORC_GROUP_CREATED, g);
   return (uint32_t)st->n_slots++;
 }
 
 void orc_dissolve_group(orc_state* st, uint32_t slot) { /* mod.rs:1423-1487 */
   if (slot >= st->n_slots || !st->groups[slot].alive) return;
   grp* g = &st->groups[slot];
+  log_event(st, ORC_GROUP_DESTROYED, g); /* :1469-1481 */
   for (uint32_t i = 0; i < g->n; ++i)
     if (st->node_group[g->members[i]] == (int32_t)slot) st->node_group[g->members[i]] = -1;
   g->alive = 0;

@@ -245,6 +245,20 @@ int orc_group_info(const orc_state*, uint32_t slot, uint64_t* id, uint32_t* conf
 /* last orc_try_form_new_groups: number of Haversine evaluations and `meets` evaluations done */
 void orc_counters(const orc_state*, uint64_t* n_haversine, uint64_t* n_meets);
 
+/* What the webhook plugins would have been called with, in call order: send_group_created for every group of
+ * try_form_new_groups (mod.rs:612-625); per merge send_group_destroyed for each dissolved solo group, then
+ * send_group_created for the merged one (mod.rs:974-1000); send_group_destroyed in dissolve_group
+ * (mod.rs:1469-1481).  Members in group.nodes (BTreeSet<String>) order.  orc_events returns the number of logged
+ * events and copies them out when the buffers are large enough. */
+enum { ORC_GROUP_CREATED = 1, ORC_GROUP_DESTROYED = 2 };
+typedef struct orc_group_event {
+  uint64_t group_id;
+  uint32_t kind, config, member_begin, n_members;
+} orc_group_event;
+size_t orc_events(const orc_state*, orc_group_event* out, size_t cap, uint32_t* members, size_t cap_members,
+                  size_t* n_members);
+void orc_events_clear(orc_state*);
+
 /* splitmix64 — the one PRNG used by the generator, the chooser and the group-id stream. */
 uint64_t orc_splitmix64(uint64_t* state);
 

@@ -212,6 +212,10 @@ struct pm_engine {
   // ---- carve scratch
   DevBuf<uint32_t> d_order;
   uint32_t form_rounds_hint = 0;  // validation rounds the last proposal-driven carve needed (0 = unknown)
+  // group life-cycle feed (pm_enable_group_events / pm_drain_group_events)
+  bool events_on = false;
+  std::vector<pm_group_event> ev_log;
+  std::vector<uint32_t> ev_members;
   DevBuf<double> d_c_lat, d_c_lon, d_c_cos, d_cc_lat, d_cc_lon, d_cc_cos, d_c_u[3], d_cc_u[3];
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
   DevBuf<uint32_t> d_slot_pos, d_slot_wid;
@@ -286,8 +290,24 @@ static void reset_groups_locked(pm_engine* e) {
 // the list right away would renumber every later slot (O(groups + workers) per call).  The entry is only
 // marked here — the members are free at once — and compact_groups() removes all marked entries in one pass,
 // in list order, before anything looks at slot numbers again.
+// one entry of the group life-cycle feed; members in BTreeSet<String> order (address rank), like pm_get_groups
+static void log_group_event(pm_engine* e, uint32_t kind, const Group& gr) {
+  if (!e->events_on) return;
+  pm_group_event ev{};
+  ev.group_id = gr.id;
+  ev.kind = kind;
+  ev.config = gr.cfg;
+  ev.member_begin = uint32_t(e->ev_members.size());
+  ev.n_members = uint32_t(gr.members.size());
+  e->ev_members.insert(e->ev_members.end(), gr.members.begin(), gr.members.end());
+  std::sort(e->ev_members.end() - ptrdiff_t(gr.members.size()), e->ev_members.end(),
+            [&](uint32_t a, uint32_t b) { return e->h_addr_rank[a] < e->h_addr_rank[b]; });
+  e->ev_log.push_back(ev);
+}
+
 static void dissolve_locked(pm_engine* e, uint32_t slot) {
   if (slot >= e->groups.size() || e->groups[slot].dead) return;
+  log_group_event(e, PM_GROUP_DESTROYED, e->groups[slot]);  // mod.rs:1469-1481
   for (uint32_t w : e->groups[slot].members) e->h_group_of[w] = -1;
   e->groups[slot].dead = true;
   e->n_dead_groups++;
@@ -600,6 +620,7 @@ static int32_t absorb_groups(pm_engine* e) {
     gr.task_uid = 0;
     gr.members.assign(members + (g_off[k] - m0), members + (g_off[k] - m0) + g_n[k]);
     for (uint32_t w : gr.members) e->h_group_of[w] = int32_t(g0 + k);
+    log_group_event(e, PM_GROUP_CREATED, gr);  // mod.rs:612-625
     e->groups.push_back(std::move(gr));
   }
   e->absorb_pending = false;
@@ -1225,6 +1246,8 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
       if (gr.task != PM_NONE) gr.task_uid = e->tasks_have_uid ? e->h_tuid[gr.task] : task_position(e, gr.task);
       std::vector<uint32_t> old_slots;
       for (uint32_t w : b) old_slots.push_back(uint32_t(e->h_group_of[w]));
+      for (uint32_t s : old_slots) log_group_event(e, PM_GROUP_DESTROYED, e->groups[s]);  // send_merge_webhooks,
+      log_group_event(e, PM_GROUP_CREATED, gr);                                            // mod.rs:974-1000
       std::sort(old_slots.rbegin(), old_slots.rend());
       for (uint32_t s : old_slots) e->groups.erase(e->groups.begin() + s);  // mod.rs:903-921
       e->groups.push_back(std::move(gr));                                    // mod.rs:924-942
@@ -1822,7 +1845,7 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
         if (keys[h] == k && vals[h] == PM_NONE) vals[h] = i;  // first occurrence, like a map's emplace
       }
     }
-    for (size_t g = e->groups.size(); g-- > 0;) {
+    for (size_t g = 0; g < e->groups.size(); ++g) {  // (creation order: dissolutions are logged in it)
       Group& gr = e->groups[g];
       if (gr.dead || gr.task == PM_NONE) continue;
       uint32_t ni = PM_NONE;  // position in the new list
@@ -1947,7 +1970,7 @@ int32_t pm_tasks_delete(pm_engine* e, const uint64_t* uids, uint32_t n, uint32_t
   if (slots.empty()) return PM_OK;
   std::vector<uint32_t> sorted = slots;
   std::sort(sorted.begin(), sorted.end());
-  for (size_t g = e->groups.size(); g-- > 0;) {
+  for (size_t g = 0; g < e->groups.size(); ++g) {  // (creation order: dissolutions are logged in it)
     const Group& gr = e->groups[g];
     if (!gr.dead && gr.task != PM_NONE && std::binary_search(sorted.begin(), sorted.end(), gr.task))
       dissolve_locked(e, uint32_t(g));
@@ -2004,6 +2027,35 @@ int32_t pm_on_worker_status_many(pm_engine* e, const uint32_t* workers, const ui
   }
   e->flags_dirty = true;
   e->compat_dirty = true;
+  return PM_OK;
+}
+
+int32_t pm_enable_group_events(pm_engine* e, uint32_t on) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  ABSORB_PENDING(e);  // creations of a carve that has not been absorbed yet belong to the old setting
+  e->events_on = on != 0;
+  if (!e->events_on) {
+    e->ev_log.clear();
+    e->ev_members.clear();
+  }
+  return PM_OK;
+}
+
+int32_t pm_drain_group_events(pm_engine* e, pm_group_event* events, uint32_t cap_events, uint32_t* members,
+                              uint32_t cap_members, uint32_t* n_events, uint32_t* n_members) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  ABSORB_PENDING(e);
+  const uint32_t ne = uint32_t(e->ev_log.size()), nm = uint32_t(e->ev_members.size());
+  if (n_events) *n_events = ne;
+  if (n_members) *n_members = nm;
+  if ((ne && (!events || cap_events < ne)) || (nm && (!members || cap_members < nm)))
+    return set_error(PM_ERANGE, "event buffers too small");
+  std::copy(e->ev_log.begin(), e->ev_log.end(), events);
+  std::copy(e->ev_members.begin(), e->ev_members.end(), members);
+  e->ev_log.clear();
+  e->ev_members.clear();
   return PM_OK;
 }
 

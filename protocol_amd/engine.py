@@ -32,6 +32,9 @@ alt_row_dt = np.dtype([("flags", "<u4"), ("count", "<u4"), ("memory_mb", "<u4"),
                        ("model_row", "<u4")], align=True)
 group_dt = np.dtype([("id", "<u8"), ("config", "<u4"), ("n_members", "<u4"), ("member_begin", "<u4"),
                      ("task", "<u4")], align=True)
+GROUP_EVENT = np.dtype([("group_id", "<u8"), ("kind", "<u4"), ("config", "<u4"), ("member_begin", "<u4"),
+                        ("n_members", "<u4")])   # pm_group_event
+GROUP_CREATED, GROUP_DESTROYED = 1, 2
 assignment_dt = np.dtype([("task", "<u4"), ("group_slot", "<u4"), ("group_index", "<u4"), ("group_size", "<u4"),
                           ("next_worker", "<u4"), ("group_id", "<u8")], align=True)
 assert config_row_dt.itemsize == 32 and alt_row_dt.itemsize == 32 and assignment_dt.itemsize == 32
@@ -87,7 +90,8 @@ class Assignment(C.Structure):
 EXPORTS = [
     "pm_engine_config_default", "pm_engine_create", "pm_engine_destroy", "pm_last_error", "pm_set_configs",
     "pm_set_model_table", "pm_set_enabled_mask", "pm_upload_workers", "pm_update_workers", "pm_upload_tasks",
-    "pm_on_worker_status", "pm_on_worker_status_many", "pm_dissolve_group", "pm_reset_groups", "pm_compat_masks", "pm_form_groups",
+    "pm_on_worker_status", "pm_on_worker_status_many", "pm_enable_group_events", "pm_drain_group_events",
+    "pm_dissolve_group", "pm_reset_groups", "pm_compat_masks", "pm_form_groups",
     "pm_merge_solo_groups", "pm_get_groups", "pm_match", "pm_match_per_task", "pm_newest_task", "pm_tick",
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
@@ -130,6 +134,8 @@ def lib() -> C.CDLL:
         L.pm_upload_tasks.argtypes = [vp, C.POINTER(TaskSoa)]
         L.pm_on_worker_status.argtypes = [vp, u32, u32, u32]
         L.pm_on_worker_status_many.argtypes = [vp, vp, vp, vp, u32]
+        L.pm_enable_group_events.argtypes = [vp, u32]
+        L.pm_drain_group_events.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]
         L.pm_dissolve_group.argtypes = [vp, u32]
         L.pm_reset_groups.argtypes = [vp]
         L.pm_compat_masks.argtypes = [vp, vp]
@@ -320,6 +326,23 @@ class Engine:
         assert d is None or len(d) == len(w)
         check(lib().pm_on_worker_status_many(self._h, w.ctypes.data if len(w) else None, f.ctypes.data if len(f) else None,
                                              d.ctypes.data if d is not None and len(d) else None, len(w)))
+
+    def enable_group_events(self, on: bool = True):
+        check(lib().pm_enable_group_events(self._h, int(on)))
+
+    def drain_group_events(self):
+        """[(kind, group id, config, members in BTreeSet order)] since the last drain (kind 1 = created, 2 = destroyed):
+        the webhook feed, in the order the reference emits it"""
+        ne, nm = C.c_uint32(0), C.c_uint32(0)
+        rc = lib().pm_drain_group_events(self._h, None, 0, None, 0, C.byref(ne), C.byref(nm))
+        if rc == 0:
+            return []                                          # the log is empty
+        ev = np.zeros(max(ne.value, 1), dtype=GROUP_EVENT)
+        mem = np.zeros(max(nm.value, 1), dtype=np.uint32)
+        check(lib().pm_drain_group_events(self._h, ev.ctypes.data, len(ev), mem.ctypes.data, len(mem), C.byref(ne),
+                                          C.byref(nm)))
+        return [(int(e["kind"]), int(e["group_id"]), int(e["config"]),
+                 mem[int(e["member_begin"]):int(e["member_begin"]) + int(e["n_members"])].tolist()) for e in ev[:ne.value]]
 
     def dissolve_group(self, slot: int):
         check(lib().pm_dissolve_group(self._h, slot))

@@ -28,6 +28,7 @@ use shared::models::task::Task;
 
 use crate::models::node::{NodeStatus, OrchestratorNode};
 use crate::plugins::node_groups::NodeGroupConfiguration;
+use crate::plugins::webhook::WebhookPlugin;
 
 pub const PM_NONE: u32 = 0xFFFF_FFFF;
 pub const PM_ABI_VERSION: u32 = 2;
@@ -99,6 +100,17 @@ pub struct pm_task_soa {
     pub uid: *const u64,
 }
 
+/// include/pm_engine.h: one entry of the group life-cycle feed (kind 1 = created, 2 = destroyed)
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct pm_group_event {
+    pub group_id: u64,
+    pub kind: u32,
+    pub config: u32,
+    pub member_begin: u32,
+    pub n_members: u32,
+}
+
 #[repr(C)]
 #[derive(Default)]
 pub struct pm_assignment {
@@ -156,6 +168,9 @@ extern "C" {
     fn pm_tasks_delete(e: *mut c_void, uids: *const u64, n: u32, n_deleted: *mut u32) -> i32;
     fn pm_on_worker_status(e: *mut c_void, worker: u32, flags_new: u32, dead: u32) -> i32;
     fn pm_on_worker_status_many(e: *mut c_void, workers: *const u32, flags_new: *const u32, dead: *const u32, n: u32) -> i32;
+    fn pm_enable_group_events(e: *mut c_void, on: u32) -> i32;
+    fn pm_drain_group_events(e: *mut c_void, events: *mut pm_group_event, cap_events: u32, members: *mut u32,
+                             cap_members: u32, n_events: *mut u32, n_members: *mut u32) -> i32;
     fn pm_tick(e: *mut c_void, stats: *mut pm_stats) -> i32;
     fn pm_lookup_task_for_worker(e: *mut c_void, worker: u32, out: *mut pm_assignment) -> i32;
     fn pm_host_group_vars(input: *const c_char, v: *const pm_group_vars, out: *mut c_char, cap: usize, needed: *mut usize) -> i32;
@@ -265,6 +280,7 @@ impl GpuMatchPlugin {
         // an empty worker / task table, so that the delta calls have something to extend
         let empty = RowColumns::default();
         check(unsafe { pm_upload_workers(this.engine, &empty.soa(), 0) }).expect("pm_upload_workers");
+        check(unsafe { pm_enable_group_events(this.engine, 1) }).expect("pm_enable_group_events");   // webhook feed
         let t = pm_task_soa { n: 0, topo_mask: std::ptr::null(), created_at: std::ptr::null(), uid: [0u64; 0].as_ptr() };
         check(unsafe { pm_upload_tasks(this.engine, &t) }).expect("pm_upload_tasks");
         this
@@ -482,11 +498,39 @@ impl GpuMatchPlugin {
         self.push_enabled(&tasks)
     }
 
-    /// One body of run_group_management_loop (mod.rs:180-203) + every worker's filter_tasks.
-    pub fn tick(&self) -> Result<pm_stats> {
+    /// One body of run_group_management_loop (mod.rs:180-203) + every worker's filter_tasks, then the webhooks the
+    /// reference sends from inside try_form_new_groups / execute_group_merge (mod.rs:612-625, 974-1000).
+    pub fn tick(&self, webhooks: Option<&[WebhookPlugin]>) -> Result<pm_stats> {
         let mut s = pm_stats::default();
         check(unsafe { pm_tick(self.engine, &mut s) })?;
+        self.emit_group_webhooks(webhooks)?;
         Ok(s)
+    }
+
+    /// Drains the engine's group life-cycle feed into send_group_created / send_group_destroyed, in the order the
+    /// reference emits them.  Call it after anything that can create or dissolve groups: tick, handle_status_change,
+    /// on_task_deleted, sync_nodes (tombstones), dissolve_group.  (pm_enable_group_events(1) in `new`.)
+    pub fn emit_group_webhooks(&self, webhooks: Option<&[WebhookPlugin]>) -> Result<()> {
+        let (mut ne, mut nm) = (0u32, 0u32);
+        let rc = unsafe { pm_drain_group_events(self.engine, std::ptr::null_mut(), 0, std::ptr::null_mut(), 0, &mut ne, &mut nm) };
+        if rc == 0 { return Ok(()); }                       // empty log
+        let mut events = vec![pm_group_event::default(); ne as usize];
+        let mut members = vec![0u32; nm as usize];
+        check(unsafe { pm_drain_group_events(self.engine, events.as_mut_ptr(), ne, members.as_mut_ptr(), nm, &mut ne, &mut nm) })?;
+        let Some(plugins) = webhooks else { return Ok(()) };
+        let t = self.nodes.read();
+        for ev in &events[..ne as usize] {
+            let id = format!("{:x}", ev.group_id);                                   // generate_group_id, mod.rs:1489-1493
+            let name = self.config_names[ev.config as usize].clone();
+            let nodes: Vec<String> = members[ev.member_begin as usize..(ev.member_begin + ev.n_members) as usize]
+                .iter().map(|&w| t.address_strings[w as usize].clone()).collect();  // group.nodes order
+            for p in plugins {
+                let r = if ev.kind == 1 { p.send_group_created(id.clone(), name.clone(), nodes.clone()) }
+                        else { p.send_group_destroyed(id.clone(), name.clone(), nodes.clone()) };
+                if let Err(e) = r { log::error!("Failed to send group webhook: {e}"); }   // as in the reference: logged, not fatal
+            }
+        }
+        Ok(())
     }
 
     fn render(f: impl Fn(*mut c_char, usize, *mut usize) -> i32) -> Result<String> {

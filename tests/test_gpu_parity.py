@@ -226,8 +226,18 @@ def test_merge_solo_groups_bit_exact(seed):
     sw, st, eng = _solo_scenario(seed)
     assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
     assert sum(len(g[2]) == 1 for g in engine_groups(eng)) > 10
-    assert st.try_merge_solo_groups() == eng.merge_solo_groups() > 0
+    # the webhook feed of the merge pass (send_merge_webhooks, mod.rs:974-1000): per merge, destroyed for every solo
+    # group of the batch in batch order, then created for the merged group
+    eng.enable_group_events()
+    st.drain_events()
+    n_merged = eng.merge_solo_groups()
+    assert st.try_merge_solo_groups() == n_merged > 0
     assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    ev = eng.drain_group_events()
+    assert ev == st.drain_events()
+    assert sum(k == E.GROUP_CREATED for k, *_ in ev) == n_merged
+    assert sum(k == E.GROUP_DESTROYED for k, *_ in ev) == sum(len(m) for k, _i, _c, m in ev if k == E.GROUP_CREATED)
+    assert eng.drain_group_events() == []                                  # drained
     eng.close()
 
 
@@ -451,6 +461,35 @@ def test_engine_argument_errors():
     eng.close()
 
 
+def test_group_event_feed_semantics():
+    """off by default; a drain with buffers that are too small reports the sizes and drains nothing; switching the
+    feed off clears it; pm_reset_groups logs nothing"""
+    import ctypes as C
+    sw = baseline_config(0, seed=3)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    eng.tick()
+    assert eng.drain_group_events() == []                          # not enabled: nothing was logged
+    eng.reset_groups()
+    eng.enable_group_events()
+    eng.form_groups()
+    groups = engine_groups(eng)
+    ne, nm = C.c_uint32(0), C.c_uint32(0)
+    one = np.zeros(1, dtype=E.GROUP_EVENT)
+    rc = E.lib().pm_drain_group_events(eng._h, one.ctypes.data, 1, None, 0, C.byref(ne), C.byref(nm))
+    assert rc == E.PM_ERANGE and ne.value == len(groups) and nm.value == sum(len(g[2]) for g in groups)
+    ev = eng.drain_group_events()                                  # still all there
+    assert [(i, c, m) for k, i, c, m in ev] == [(i, c, m) for i, c, m, _t in groups]
+    assert all(k == E.GROUP_CREATED for k, *_ in ev)
+    eng.reset_groups()                                             # (bench helper: no counterpart, no events)
+    assert eng.drain_group_events() == []
+    eng.tick()
+    eng.enable_group_events(False)
+    eng.enable_group_events(True)
+    assert eng.drain_group_events() == []                          # switching off cleared the log
+    eng.close()
+
+
 @pytest.mark.parametrize("deltas", [False, True])
 def test_streaming_churn_parity(deltas):
     """(deltas: the task table is maintained with pm_tasks_insert_front / pm_tasks_delete instead of re-uploading
@@ -467,10 +506,12 @@ def test_streaming_churn_parity(deltas):
     st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False)
     eng = E.Engine()
     host.load_swarm(eng, sw)
+    eng.enable_group_events()
     flags = host.worker_flags(sw).astype(np.int64)
     masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
     joiners = list(np.nonzero(late & (status0 == 2))[0])
     next_uid = 1 << 40
+    n_events = [0, 0]
     for tick in range(6):
         # ---- task churn: 40 new tasks (newest => front of get_all_tasks), one claimed task deleted from tick 2 on
         n_new = 40
@@ -519,6 +560,13 @@ def test_streaming_churn_parity(deltas):
         assert got == want, f"tick {tick}"
         assert sorted(oracle_groups(st)) == sorted(engine_groups(eng)), f"tick {tick}"
         assert s["host_resolved_steps"] == 0
+        # the webhook feed of the tick, in the reference's emission order: dissolutions by the deleted task and by
+        # the deaths, then the creations of try_form_new_groups, then the merges (mod.rs:612-625, 974-1000, 1469-1481)
+        ev = eng.drain_group_events()
+        assert ev == st.drain_events(), f"tick {tick}"
+        n_events[0] += sum(k == E.GROUP_CREATED for k, *_ in ev)
+        n_events[1] += sum(k == E.GROUP_DESTROYED for k, *_ in ev)
+    assert n_events[0] > 100 and n_events[1] > 20
     eng.close()
 
 

@@ -282,3 +282,28 @@ def test_threaded_pair_sweep_equals_the_sequential_one():
     for threads in (2, 5, 64):
         b = orc.pair_sweep_per_worker(tasks, cfgs, cfg_of_node, threads=threads)
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
+def test_webhook_feed_follows_the_emission_sites():
+    """send_group_created for every formed group in formation order (mod.rs:612-625); a death dissolves the group:
+    send_group_destroyed with its members (mod.rs:1469-1481); a merge sends destroyed for each solo group of the
+    batch, then created for the merged group (mod.rs:974-1000).  Members always in group.nodes (BTreeSet) order."""
+    nodes = nodes_of(*[mk_node(a) for a in A[:5]])
+    cfgs = cfgs_of(orc.make_config("pair", 2, 2, None), orc.make_config("solo", 1, 1, None))
+    st = orc.State(nodes, cfgs, tasks=orc.make_task(0, ["pair", "solo"]))
+    assert st.try_form_new_groups() == 3                     # two pairs and a solo group
+    ev = st.drain_events()
+    groups = st.groups()
+    assert ev == [(1, gid, cfg, mem) for _s, gid, cfg, mem, _t in groups]
+    assert [len(m) for _k, _i, _c, m in ev] == [2, 2, 1]
+    assert st.drain_events() == []
+    st.set_node_status(0, orc.ST_DEAD)                       # its pair dissolves, the partner is free again
+    (k, gid, _cfg, mem), = st.drain_events()
+    assert (k, gid, mem) == (2, groups[0][1], groups[0][3])
+    assert st.try_form_new_groups() == 1                     # the partner becomes a solo group
+    (k, _gid, cfg, mem), = st.drain_events()
+    assert (k, cfg, len(mem)) == (1, 1, 1)
+    assert st.try_merge_solo_groups() == 1                   # the two solo groups merge into a pair
+    ev = st.drain_events()
+    assert [k for k, *_ in ev] == [2, 2, 1]
+    assert sorted(ev[0][3] + ev[1][3]) == ev[2][3] and ev[2][2] == 0
