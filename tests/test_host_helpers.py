@@ -32,6 +32,60 @@ def test_library_exports_every_declared_symbol():
     assert L.pm_abi_version() == 2
 
 
+def _c_prototypes(text):
+    """{name: number of parameters} of the `int32_t|void|... pm_*(...)` prototypes in a C header"""
+    out = {}
+    for m in re.finditer(r"\b(pm_[a-z_0-9]+)\s*\(([^;{}]*?)\)\s*;", re.sub(r"/\*.*?\*/", "", text, flags=re.S)):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_rust_shim_binds_the_header_as_declared():
+    """rust/gpu_match_plugin.rs cannot be compiled in this image (no cargo): at least every function of its
+    extern "C" block must exist in include/pm_engine.h with the same number of parameters, the repr(C) structs it
+    passes by pointer must have the fields of the C structs in the same order, and nothing it calls may be missing
+    from the block."""
+    hdr = open(os.path.join(ROOT, "include", "pm_engine.h")).read()
+    rs = open(os.path.join(ROOT, "rust", "gpu_match_plugin.rs")).read()
+    protos = _c_prototypes(hdr)
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    bound = {}
+    for m in re.finditer(r"fn (pm_[a-z_0-9]+)\s*\((.*?)\)\s*(?:->\s*[\w:*<> ]+)?;", block, flags=re.S):
+        args = m.group(2).strip()
+        bound[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    assert len(bound) >= 30
+    for name, n in bound.items():
+        assert name in protos, f"{name} is bound by the Rust shim but not declared in pm_engine.h"
+        assert protos[name] == n, f"{name}: {n} parameters in the Rust shim, {protos[name]} in pm_engine.h"
+    called = set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", rs[rs.index("\n}\n", rs.index('extern "C" {')):]))
+    called -= {"pm_engine_config", "pm_worker_soa", "pm_task_soa", "pm_stats", "pm_group_event", "pm_assignment"}
+    assert called <= set(bound), f"called but not bound: {sorted(called - set(bound))}"
+    # struct layouts: field names in order
+    def c_fields(name):
+        body = re.findall(r"typedef struct(?: \w+)?\s*\{([^{}]*)\}\s*" + name + r"\s*;", hdr, flags=re.S)[0]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            first = names[0].split()[-1]
+            fields.append(first.lstrip("*").split("[")[0])
+            fields += [n.strip().lstrip("*").split("[")[0] for n in names[1:]]
+        return fields
+
+    def rs_fields(name):
+        body = re.search(r"pub struct " + name + r"\s*\{(.*?)\n\}", rs, flags=re.S).group(1)
+        return re.findall(r"pub (\w+)\s*:", body)
+
+    for name in ("pm_engine_config", "pm_worker_soa", "pm_task_soa", "pm_config_row", "pm_gpu_alt_row", "pm_assignment",
+                 "pm_group_event", "pm_stats"):
+        assert rs_fields(name) == c_fields(name), name
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="this check is for boxes without a GPU")
 def test_engine_fails_loudly_without_gpu():
     with pytest.raises(E.EngineError) as ei:
