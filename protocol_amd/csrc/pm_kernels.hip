@@ -608,8 +608,13 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 // kernel's (key, position) order), the selected SET is the reference's.  Otherwise the step is
 // reported as UNCERTAIN and the engine settles exactly that step on the host with glibc.
 
-#define CARVE_THREADS 512
+// (16 waves = 16 seeds per round compiles — the whole kernel then has to fit 128 VGPRs: 103 spilled — and was measured:
+// carve 3.57 ms instead of 2.47 at 100k x 10k, 24.3 instead of 19.2 ms at 1M x 100k; four waves per SIMD share the
+// scalar issue the rounds are bound by)
+#ifndef CARVE_WAVES
 #define CARVE_WAVES 8
+#endif
+#define CARVE_THREADS (CARVE_WAVES * 64)
 // a value that is the same in every lane, moved to an SGPR
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 // an LDS address as an opaque SGPR value (wave-uniform by construction): the compiler can neither re-derive it nor
@@ -1072,7 +1077,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 // are still alive when its turn comes (dead entries ahead of them stay dead, and fewer live neighbours can
 // only remove certificate obligations).  The turns are not taken one after the other: every wave posts the
 // slots it would take, compares them against the claims of the waves ahead of it (one LDS read + a readlane
-// loop), posts an 8-bit conflict word, and then all waves replay the round in seed order from those words
+// loop), posts a conflict word (one bit per wave ahead), and then all waves replay the round in seed order from those words
 // alone — a handful of scalar operations — and the winners commit concurrently.  The first wave that cannot
 // commit (a slot taken: redo from its row; exact sweep needed) ends the round.  Used while the configuration
 // has enough live candidates that the loop guards and `want` cannot change within a round; the tail goes
@@ -1113,7 +1118,10 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
   const lds_u32* const SITE3 = BIG ? nullptr : lds_pin<const lds_u32*>(l_site);  // dereferenced only when !BIG
   const lds_u16* const NEXT3 = BIG ? nullptr : lds_pin<const lds_u16*>(l_next16);
   lds_u32* const CLAIM = lds_pin<lds_u32*>(l_claim);    // [CARVE_WAVES * 64] claimed slots of the round
-  lds_u32* const CONF = CLAIM + CARVE_WAVES * 64u;      // [CARVE_WAVES] conflict words
+  lds_u32* const CONF = CLAIM + CARVE_WAVES * 64u;      // [CARVE_WAVES] conflict words: who claims my slots | my seed << 16
+  lds_u32* const RES = CONF + CARVE_WAVES;              // [CARVE_WAVES] ROUND_OK / ROUND_SLOW of each wave's selection
+  constexpr uint32_t WMASK = (1u << CARVE_WAVES) - 1u;
+  static_assert(CARVE_WAVES <= 16, "a conflict word holds two masks of CARVE_WAVES bits");
   auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
   auto kill = [A](uint32_t i) {
     __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1311,7 +1319,10 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
         }
       }
     }
-    if (have && lane == 0) CONF[wave] = conf | (seed_hit << 8) | (res << 16);
+    if (have && lane == 0) {
+      CONF[wave] = conf | (seed_hit << 16);
+      RES[wave] = res;
+    }
 #ifdef PM_CARVE_PROF_FINE
     { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_chk += tb - ta; ta = tb; }
 #endif
@@ -1323,6 +1334,7 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     // seed was taken is no step at all; the first wave that cannot commit (exact sweep needed, a slot taken,
     // arrays full) ends the round.  Straight-line scalar code: taken branches are what this loop would pay for.
     const uint32_t cw = lane < n_round ? CONF[lane] : 0u;
+    const uint32_t rw = lane < n_round ? RES[lane] : 0u;
     uint32_t dbg_at = 0xFFFFFFFFu;  // commit count at which the debug hook forces the exact sweep
     if (dbg_every) {
       const uint32_t r = (steps_before + base_steps + commits_done + 1u) % dbg_every;
@@ -1331,7 +1343,7 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
     uint32_t cmask = 0, stop_code = ROUND_OK, stop_wave = 0, commits = commits_done, open = 1u;
     // the usual round: nobody claims anybody else's slots or seed, nobody needs the exact sweep, and neither the
     // output arrays nor the debug hook end the round early — every wave of the round commits
-    const bool all_clear = __ballot(cw != 0u) == 0ull && commits_done + n_round <= max_commits &&
+    const bool all_clear = __ballot((cw | rw) != 0u) == 0ull && commits_done + n_round <= max_commits &&
                            !(dbg_at - commits_done < n_round);
     if (all_clear) {
       cmask = (1u << n_round) - 1u;
@@ -1340,10 +1352,10 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
 #pragma unroll
     for (uint32_t v = 0; v < CARVE_WAVES; ++v) {
       const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)v);
-      const uint32_t seed_taken = ((word >> 8) & cmask & 0xFFu) ? 1u : 0u;
-      uint32_t verdict = word >> 16;
+      const uint32_t seed_taken = ((word >> 16) & cmask & WMASK) ? 1u : 0u;
+      uint32_t verdict = (uint32_t)__builtin_amdgcn_readlane((int)rw, (int)v);
       verdict = commits == dbg_at ? (uint32_t)ROUND_SLOW : verdict;
-      const uint32_t v_ok = (word & cmask & 0xFFu) ? (uint32_t)ROUND_RETRY : (uint32_t)ROUND_OK;
+      const uint32_t v_ok = (word & cmask & WMASK) ? (uint32_t)ROUND_RETRY : (uint32_t)ROUND_OK;
       const uint32_t v_ok2 = commits >= max_commits ? (uint32_t)ROUND_OVERFLOW : v_ok;
       verdict = verdict == ROUND_OK ? v_ok2 : verdict;
       const uint32_t consider = (v < n_round ? 1u : 0u) & open & (seed_taken ^ 1u);
