@@ -715,7 +715,7 @@ __device__ __forceinline__ double hav_a(double lat1, double lon1, double cos1, d
 // relative error of ~7e-16 / sqrt(a): under 1e-12 — a fifteenth of the certificate band (2^-36) — for a >=
 // PM_A_CHORD_MIN (about 10 km), and that is where it is used; nearer candidates (rare: a handful per seed) take the
 // sine form, whose error is independent of the distance.  Every path of the proposer goes through this one
-// function, so a candidate's key is the same bit pattern whenever it is recomputed (re-sweeps compare keys).
+// function, so a candidate's key is the same bit pattern wherever it is computed.
 struct SeedGeo {
   double lat, lon, cos, ux, uy, uz;
 };
@@ -2795,7 +2795,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   uint64_t* part = reinterpret_cast<uint64_t*>(s_raw);                       // [16 * PART]
   uint64_t* lds_alive = part + CARVE_WAVES * PM_CARVE_PART;                  // [SLOTS / 64]
   uint64_t* lds_loc = lds_alive + PM_CARVE_SLOTS / 64;                       // [SLOTS / 64]
-  uint32_t* lds_wid = reinterpret_cast<uint32_t*>(lds_loc + PM_CARVE_SLOTS / 64);  // [SLOTS]
+  uint32_t* lds_wid = reinterpret_cast<uint32_t*>(lds_loc + PM_CARVE_SLOTS / 64);  // [SLOTS] big lists: the alive bitmap (small lists: unused)
   uint32_t* lds_site = lds_wid + PM_CARVE_SLOTS;                             // [SLOTS]
   uint64_t* lds_key = reinterpret_cast<uint64_t*>(lds_site + PM_CARVE_SLOTS);  // [SLOTS]
   uint32_t* sel_out = reinterpret_cast<uint32_t*>(lds_key + PM_CARVE_SLOTS);  // [SEL_CAP]
