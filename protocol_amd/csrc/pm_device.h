@@ -30,7 +30,8 @@ static constexpr double PM_TIE_BAND_MEM = 1.0 / 268435456.0;    // 2^-28
 static constexpr uint32_t PM_CARVE_CACHE_ROWS = 128;   // proposal rows staged in LDS (128 * 64 * 8 B = the key array)
 static constexpr uint32_t PM_PROP_ROW = 64;            // proposal row stride (entries)
 static constexpr uint32_t PM_PROP_META = 63;           // entry of a row that carries its flags word (so K <= 63)
-static constexpr uint32_t PM_PROP_RESERVE = 48;        // entries beyond max_group_size - 1 (24 -> 48: exact steps 1.3 % -> 0.4 %)
+static constexpr uint32_t PM_PROP_RESERVE = 64;        // entries beyond max_group_size - 1: the proposer's register holds 64 sorted
+                                                       // keys whatever K is, so every row is as long as a row can be (K = 63)
 static constexpr uint32_t PM_PROP_MAX_SEEDS = 16384;   // located slots that get a proposal per configuration
 static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
                                              size_t(PM_CARVE_SLOTS) * 18 + size_t(PM_CARVE_SEL_CAP) * 4 + 2560;
