@@ -252,6 +252,8 @@ pub struct GpuMatchPlugin {
     tasks: parking_lot::RwLock<Vec<Task>>,   // get_all_tasks order: the engine reports positions in this Vec
     /// `upload:<node>:<group>:*` key count (scheduler_impl.rs:130-153): stays with the Redis store
     upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>,
+    /// as in NodeGroupsPlugin (mod.rs:107, 124): the plugins told about every group created / destroyed
+    webhook_plugins: Option<Vec<WebhookPlugin>>,
 }
 
 unsafe impl Send for GpuMatchPlugin {}
@@ -263,7 +265,8 @@ impl GpuMatchPlugin {
     /// Same contract as NodeGroupsPlugin::new (node_groups/mod.rs:113-175): duplicate names or max < min panic,
     /// exactly like the reference constructor (the engine answers PM_EINVAL for the latter).
     pub fn new(templates: Vec<NodeGroupConfiguration>, device: i32,
-               upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>) -> Self {
+               upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>,
+               webhook_plugins: Option<Vec<WebhookPlugin>>) -> Self {
         let mut cfg: pm_engine_config = unsafe { std::mem::zeroed() };
         unsafe { pm_engine_config_default(&mut cfg) };
         cfg.device = device;
@@ -275,7 +278,7 @@ impl GpuMatchPlugin {
         }
         let mut this = Self { engine, config_names: templates.iter().map(|t| t.name.clone()).collect(),
                               req_models: Vec::new(), nodes: Default::default(), tasks: Default::default(),
-                              upload_counter };
+                              upload_counter, webhook_plugins };
         this.set_configs(&templates);
         // an empty worker / task table, so that the delta calls have something to extend
         let empty = RowColumns::default();
@@ -439,7 +442,8 @@ impl GpuMatchPlugin {
             let ranks = Self::address_ranks(&t.address_strings);
             check(unsafe { pm_set_addr_ranks(self.engine, ranks.as_ptr(), ranks.len() as u32) })?;
         }
-        Ok(())
+        drop(t);
+        self.emit_group_webhooks()      // tombstoned nodes dissolved their groups
     }
 
     /// rank of address.to_string() in byte order (BTreeSet<String>, mod.rs:424-434)
@@ -495,29 +499,31 @@ impl GpuMatchPlugin {
         check(unsafe { pm_tasks_delete(self.engine, &uid, 1, &mut n) })?;
         let mut tasks = self.tasks.write();
         tasks.retain(|t| t.id != task.id);
-        self.push_enabled(&tasks)
+        self.push_enabled(&tasks)?;
+        drop(tasks);
+        self.emit_group_webhooks()      // dissolve_group's send_group_destroyed, mod.rs:1469-1481
     }
 
     /// One body of run_group_management_loop (mod.rs:180-203) + every worker's filter_tasks, then the webhooks the
     /// reference sends from inside try_form_new_groups / execute_group_merge (mod.rs:612-625, 974-1000).
-    pub fn tick(&self, webhooks: Option<&[WebhookPlugin]>) -> Result<pm_stats> {
+    pub fn tick(&self) -> Result<pm_stats> {
         let mut s = pm_stats::default();
         check(unsafe { pm_tick(self.engine, &mut s) })?;
-        self.emit_group_webhooks(webhooks)?;
+        self.emit_group_webhooks()?;
         Ok(s)
     }
 
     /// Drains the engine's group life-cycle feed into send_group_created / send_group_destroyed, in the order the
-    /// reference emits them.  Call it after anything that can create or dissolve groups: tick, handle_status_change,
-    /// on_task_deleted, sync_nodes (tombstones), dissolve_group.  (pm_enable_group_events(1) in `new`.)
-    pub fn emit_group_webhooks(&self, webhooks: Option<&[WebhookPlugin]>) -> Result<()> {
+    /// reference emits them.  Runs after everything that can create or dissolve groups: tick, handle_status_change,
+    /// on_task_deleted, sync_nodes (tombstones).  (pm_enable_group_events(1) in `new`.)
+    fn emit_group_webhooks(&self) -> Result<()> {
         let (mut ne, mut nm) = (0u32, 0u32);
         let rc = unsafe { pm_drain_group_events(self.engine, std::ptr::null_mut(), 0, std::ptr::null_mut(), 0, &mut ne, &mut nm) };
         if rc == 0 { return Ok(()); }                       // empty log
         let mut events = vec![pm_group_event::default(); ne as usize];
         let mut members = vec![0u32; nm as usize];
         check(unsafe { pm_drain_group_events(self.engine, events.as_mut_ptr(), ne, members.as_mut_ptr(), nm, &mut ne, &mut nm) })?;
-        let Some(plugins) = webhooks else { return Ok(()) };
+        let Some(plugins) = &self.webhook_plugins else { return Ok(()) };
         let t = self.nodes.read();
         for ev in &events[..ne as usize] {
             let id = format!("{:x}", ev.group_id);                                   // generate_group_id, mod.rs:1489-1493
@@ -585,7 +591,10 @@ impl GpuMatchPlugin {
         if node.status == NodeStatus::Healthy { flags |= W_HEALTHY; }
         t.rows[w as usize].flags = flags;
         let dead = matches!(node.status, NodeStatus::Dead | NodeStatus::LowBalance) as u32;
-        check(unsafe { pm_on_worker_status(self.engine, w, flags, dead) })
+        check(unsafe { pm_on_worker_status(self.engine, w, flags, dead) })?;
+        drop(t);
+        if dead != 0 { self.emit_group_webhooks()?; }      // the whole group was dissolved (status_update_impl.rs:17-29)
+        Ok(())
     }
 }
 
