@@ -461,6 +461,48 @@ def test_engine_argument_errors():
     eng.close()
 
 
+def test_task_observer_flow():
+    """tests.rs:679-731 and 1467-1628 through the engine: while no task lists a configuration nothing is enabled and
+    nothing forms; tasks arrive (on_task_created enables their topologies) and the groups form; deleting the task a
+    group works on dissolves it at once (on_task_deleted).  The enabled set is the shim's job
+    (rust/gpu_match_plugin.rs push_enabled = protocol_amd.swarm.Swarm.enabled_mask): here it is set by hand."""
+    sw = make_swarm(12, 60, 400)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    none = np.zeros(len(cfgs), dtype=np.uint8)
+    st = orc.State(nodes, cfgs, enabled=none, tasks=tasks[:0], reference_shaped=False)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+    eng.upload_tasks(masks[:0], created[:0], uid[:0])
+    eng.set_enabled_mask(0)
+    s = eng.tick()
+    assert s["n_groups"] == 0 == st.try_form_new_groups()
+    assert all(eng.lookup(w).task == NONE for w in range(0, sw.W, 7))
+    # the tasks arrive (in front of an empty list), their topologies get enabled
+    eng.tasks_insert_front(masks, created, uid)
+    eng.set_enabled_mask(sw.enabled_mask())
+    st.set_tasks(tasks)
+    st.set_enabled(enabled)
+    eng.tick()
+    assert st.try_form_new_groups() > 20
+    st.try_merge_solo_groups()
+    want = [st.get_task_for_node(w) for w in range(sw.W)]
+    got = [(-1 if eng.lookup(w).task == NONE else eng.lookup(w).task) for w in range(sw.W)]
+    assert got == want
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    # delete the task most groups work on
+    claimed = [g[4] for g in st.groups() if g[4] >= 0]
+    victim = max(set(claimed), key=claimed.count)
+    keep = np.ones(len(tasks), dtype=bool)
+    keep[victim] = False
+    assert eng.tasks_delete(uid[victim:victim + 1]) == 1
+    st.set_tasks(tasks[keep])
+    st.remap_tasks(np.where(keep, np.cumsum(keep) - 1, -1))
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))          # dissolved at once, before any tick
+    assert len(engine_groups(eng)) < len(claimed)
+    eng.close()
+
+
 def test_group_event_feed_semantics():
     """off by default; a drain with buffers that are too small reports the sizes and drains nothing; switching the
     feed off clears it; pm_reset_groups logs nothing"""

@@ -307,3 +307,59 @@ def test_webhook_feed_follows_the_emission_sites():
     ev = st.drain_events()
     assert [k for k, *_ in ev] == [2, 2, 1]
     assert sorted(ev[0][3] + ev[1][3]) == ev[2][3] and ev[2][2] == 0
+
+
+def _enabled_by_tasks(cfgs, tasks):
+    """available_node_group_configs as the task observers leave it: on_task_created enables every topology a task
+    lists (mod.rs:1224-1243), on_task_deleted disables one when no remaining task lists it (mod.rs:1293-1318) — i.e.
+    the union of the current tasks' allowed_topologies (an unrestricted task enables nothing)"""
+    names = [bytes(n).rstrip(b"\0").decode() for n in cfgs["name"]]
+    on = np.zeros(len(cfgs), dtype=np.uint8)
+    for t in tasks:
+        if t["restricted"]:
+            for k in range(int(t["n_topologies"])):
+                name = bytes(t["topologies"][k]).rstrip(b"\0").decode()
+                if name in names:
+                    on[names.index(name)] = 1
+    return on
+
+
+def test_group_scheduling_without_tasks():
+    # tests.rs:679-731: no task ever enabled the configuration, so nothing forms and nobody gets anything
+    nodes = nodes_of(mk_node(A[0]), mk_node(A[1]))
+    cfgs = cfgs_of(orc.make_config("test-config", 2, 5, None))
+    tasks = tasks_of()
+    st = orc.State(nodes, cfgs, enabled=_enabled_by_tasks(cfgs, tasks), tasks=tasks)
+    assert st.get_task_for_node(0) == -1
+    assert st.try_form_new_groups() == 0 and st.n_groups == 0
+    assert st.get_task_for_node(0) == -1 and st.get_task_for_node(1) == -1
+
+
+def test_task_observer():
+    # tests.rs:1467-1628: configurations follow the tasks; deleting a task dissolves the group that works on it
+    nodes = nodes_of(mk_node(A[0]), mk_node(A[1]), mk_node(A[2], orc.ST_DISCOVERED))
+    cfgs = cfgs_of(orc.make_config("test-config", 1, 1, None), orc.make_config("test-config2", 1, 1, None))
+    tasks = tasks_of()
+    st = orc.State(nodes, cfgs, enabled=_enabled_by_tasks(cfgs, tasks), tasks=tasks)
+    assert st.try_form_new_groups() == 0 and st.node_to_group[0] < 0          # :1513-1520 no task, no group
+    task, task2 = orc.make_task(1, ["test-config"]), orc.make_task(2, ["test-config2"])
+    tasks = tasks_of(task2, task)                                              # get_all_tasks: newest first
+    st.set_tasks(tasks)
+    st.set_enabled(_enabled_by_tasks(cfgs, tasks))
+    assert list(st.enabled) == [1, 1]                                          # :1566-1569 both available, in order
+    assert st.try_form_new_groups() == 2
+    n2g = st.node_to_group
+    assert n2g[0] >= 0 and n2g[1] >= 0 and n2g[0] != n2g[1]                    # :1571-1583
+    st.set_node_status(2, orc.ST_HEALTHY)                                      # node 3 appears
+    assert st.try_form_new_groups() == 1 and st.node_to_group[2] >= 0          # :1585-1600
+    # the third group works on `task` (assign_task_to_group, :1612-1616): it is a test-config group (first
+    # available configuration), whose only applicable task that is
+    assert st.get_task_for_node(2) == 1
+    working_on_task = [g for g in st.groups() if g[4] == 1]
+    # delete `task`: every group working on it dissolves immediately (:1618-1636); test-config is no longer listed
+    tasks = tasks_of(task2)
+    st.set_tasks(tasks)
+    st.remap_tasks([0, -1])
+    st.set_enabled(_enabled_by_tasks(cfgs, tasks))
+    assert st.node_to_group[2] < 0 and list(st.enabled) == [0, 1]
+    assert all(st.node_to_group[m] < 0 for g in working_on_task for m in g[3])
