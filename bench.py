@@ -432,6 +432,24 @@ def main() -> int:
         out["ranks_seen"] = ranks_seen
         out["dist"] = {"workers_owned_by_rank0": own, "exchanges_per_tick": sharded.exchanges / (args.steps + args.warmup),
                        "backend": backend, "identical_groups_on_all_ranks": True}
+        if rank == 0:
+            # the SAME swarm on one GPU, unsharded (a second engine on rank 0's device, after the timed region): the
+            # N = 1 line of the default command is a different workload (configs[1]), so the honest one-GPU
+            # reference for this line's strong scaling is measured here
+            solo = E.Engine(device=local_rank, group_id_seed=args.seed)
+            host.load_swarm(solo, sw)
+            ts = []
+            for k in range(4):
+                solo.reset_groups()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                solo.tick()
+                ts.append(time.perf_counter() - t1)
+            solo.close()
+            one = statistics.median(ts[1:])
+            out["dist"]["one_gpu_same_workload"] = {"ms_per_step": 1e3 * one, "value": float(T) * float(W) / one,
+                                                    "note": "rank 0, unsharded engine, p50 of 3 cold matches"}
+            out["dist"]["speedup_vs_one_gpu"] = one / (elapsed / args.steps)
     single = rank == 0 and world == 1
     if single and not args.no_extras:
         try:
@@ -485,6 +503,7 @@ def main() -> int:
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # (rank 0 may still be measuring its one-GPU reference)
         dist.destroy_process_group()
     return 0
 
