@@ -27,14 +27,22 @@ static constexpr uint32_t PM_CARVE_SLOT_BITS_MEM = 21; // same for lists kept in
 static constexpr double PM_TIE_BAND = 1.0 / 68719476736.0;      // 2^-36
 static constexpr double PM_TIE_BAND_BIG = 1.0 / 2147483648.0;   // 2^-31
 static constexpr double PM_TIE_BAND_MEM = 1.0 / 268435456.0;    // 2^-28
-static constexpr uint32_t PM_CARVE_CACHE_ROWS = 128;   // proposal rows staged in LDS (128 * 64 * 8 B = the key array)
-static constexpr uint32_t PM_PROP_ROW = 64;            // proposal row stride (entries)
-static constexpr uint32_t PM_PROP_META = 63;           // entry of a row that carries its flags word (so K <= 63)
+static constexpr uint32_t PM_PROP_ROW = 96;            // proposal row stride (u64 words): word 0 = flags, words 1..63 = keys,
+static constexpr uint32_t PM_PROP_SLOTS = 64;          // then from this word on 64 x u32: flags, the slots of entries 0..62
+static constexpr uint32_t PM_PROP_KMAX = 63;           // neighbours a row can list (word 0 carries the flags)
+// flags word of a proposal row (low 32 bits of word 0): bits 0..7 entries, bits 8..15 first entry that lies within
+// the certificate band of the LAST entry (a selection that ends in front of it never touches the row's tail)
+static constexpr uint32_t PM_ROW_SAFE = 1u << 27;        // no listed Haversine term beyond PM_A_MAX_SAFE
+static constexpr uint32_t PM_ROW_TAIL_CLEAR = 1u << 28;  // the first unlisted candidate is beyond the band of the last entry
+static constexpr uint32_t PM_ROW_CLEAN = 1u << 29;       // no two entries within the band of each other at different sites
+static constexpr uint32_t PM_ROW_TAIL_OK = 1u << 30;     // everything unlisted within the band of the last entry sits at its site
+static constexpr uint32_t PM_ROW_COMPLETE = 1u << 31;    // the row lists every live candidate
 static constexpr uint32_t PM_PROP_RESERVE = 64;        // entries beyond max_group_size - 1: the proposer's register holds 64 sorted
                                                        // keys whatever K is, so every row is as long as a row can be (K = 63)
 static constexpr uint32_t PM_PROP_MAX_SEEDS = 16384;   // located slots that get a proposal per configuration
+// part | alive, loc bitmaps | wid | site | key | sel_out | BlockRed + s_n
 static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
-                                             size_t(PM_CARVE_SLOTS) * 18 + size_t(PM_CARVE_SEL_CAP) * 4 + 2560;
+                                             size_t(PM_CARVE_SLOTS) * 16 + size_t(PM_CARVE_SEL_CAP) * 4 + 1024;
 
 struct CompatArgs {
   uint32_t W, n_cfgs, model_words;
@@ -145,9 +153,8 @@ struct CarveArgs {
   uint64_t* keys;          // packed keys when the candidate list does not fit in LDS
   uint32_t bits_stride;
   uint32_t _pad0;
-  // proposals (carve_propose_kernel): one row of PM_PROP_ROW u64 per seed of the batch — packed keys sorted
-  // ascending, the flags word in entry PM_PROP_META (low byte: entries; bit 31: the row holds every live
-  // candidate; bits 30..28: tail_ok, clean, tail_clear).  Seed i of a batch (rank among the live located slots
+  // proposals (carve_propose_kernel): one row of PM_PROP_ROW u64 per seed of the batch — the flags word (PM_ROW_*)
+  // in word 0, then the packed keys sorted ascending.  Seed i of a batch (rank among the live located slots
   // below prop_limit) belongs to rank i % world and is row i / world of that rank's segment; `prop` holds all
   // segments back to back ([world][rows_pr] rows — what the all-gather delivers), `prop_send` is this rank's
   // segment (the same memory as `prop` when world == 1).
@@ -160,7 +167,6 @@ struct CarveArgs {
   uint32_t count_keys, _pad_ck;  // proposer: count the keys it sweeps (bench bookkeeping)
   uint32_t* prep_block_counts;   // [blocks][PM_MAX_CONFIGS] live compatible positions per block and configuration
   uint32_t* prep_counts;         // [PM_MAX_CONFIGS] totals, [PM_MAX_CONFIGS] = finished-blocks ticket
-  uint32_t* same_next;     // next located slot at the same site (identical coordinates), PM_NONE = none
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];

@@ -149,7 +149,7 @@ struct pm_engine {
       h_addr_rank;
   std::vector<double> h_lat, h_lon;
   std::vector<uint32_t> h_site;  // equal (lat, lon) bit patterns <=> equal site id
-  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_same_next, d_seed_prefix, d_seed_slots, d_prep_block_counts, d_prep_counts;
+  DevBuf<uint32_t> d_site, d_c_site, d_cc_site, d_seed_prefix, d_seed_slots, d_prep_block_counts, d_prep_counts;
   DevBuf<uint64_t> d_prop, d_prop_send, d_seed_map;
   uint32_t tick_fast_steps = 0;
   DevBuf<uint32_t> d_flags, d_gpu_count, d_gpu_mem, d_gpu_cls, d_cpu_cores, d_ram, d_storage, d_addr_rank;
@@ -471,7 +471,6 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_slot_wid.ensure(cap));
   HIPCHK(e->d_c_site.ensure(cap));
   HIPCHK(e->d_cc_site.ensure(cap));
-  HIPCHK(e->d_same_next.ensure(cap));
   {  // proposal rows: at most PM_PROP_MAX_SEEDS + 63 seeds per batch, dealt round-robin over the ranks
     const size_t world = e->dist_world;
     const size_t rows_pr = (size_t(PM_PROP_MAX_SEEDS) + 64 + world - 1) / world;
@@ -535,7 +534,6 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->count_keys = e->cfg.time_proposer ? 1u : 0u;
   a->prep_block_counts = e->d_prep_block_counts.p;
   a->prep_counts = e->d_prep_counts.p;
-  a->same_next = e->d_same_next.p;
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
   a->bits_stride = stride;
   a->status = e->d_status.p;
@@ -1339,7 +1337,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_rank_in_group.release(); e->d_g_id.release();
   e->d_order.release(); e->d_c_lat.release(); e->d_c_lon.release(); e->d_c_cos.release();
   e->d_cc_lat.release(); e->d_cc_lon.release(); e->d_cc_cos.release(); e->d_slot_pos.release(); e->d_slot_wid.release();
-  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_seed_slots.release(); e->d_prep_block_counts.release(); e->d_prep_counts.release(); e->d_same_next.release();
+  e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_seed_slots.release(); e->d_prep_block_counts.release(); e->d_prep_counts.release();
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();

@@ -661,6 +661,11 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
   return ((uint64_t)mh << 32) | ml;
 }
 
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+}
+
 // barrier for exchanges that go through LDS only (no global-memory drain)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -674,12 +679,6 @@ struct BlockRed {
   unsigned long long f_cand_sum;
   unsigned long long _spare0;
   uint32_t _spare1, _spare2;
-  // proposal rows staged in LDS (they alias the slow path's key array): slot and row number (in the proposal
-  // buffer) per staged row; the row's flags word travels in its last entry (PM_PROP_META)
-  uint32_t cache_n, cache_pad;
-  uint32_t cache_slot[PM_CARVE_CACHE_ROWS];
-  uint32_t cache_row[PM_CARVE_CACHE_ROWS];
-  uint32_t cache_next[PM_CARVE_CACHE_ROWS];  // same_next of the staged slot
 };
 
 // sin on [-pi/2, pi/2] as an odd Taylor polynomial to x^19 (|rel err| < 1e-15 there); larger arguments
@@ -777,41 +776,40 @@ __device__ __forceinline__ void ctx_set_geometry(StepCtx& c) {
   c.band = c.big ? PM_TIE_BAND_BIG : PM_TIE_BAND;
 }
 
-enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_REFILL = 3, FAST_REPROPOSE = 4, FAST_SEQ = 5 };
-enum { ROUND_OK = 0, ROUND_SLOW = 1, ROUND_RETRY = 2, ROUND_OVERFLOW = 3 };
+enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_AGAIN = 3, FAST_REPROPOSE = 4, FAST_SEQ = 5, FAST_WIDEN = 6 };
+#define LANE_E_MAX 23u  // most row entries a lane of carve_lane_rounds looks at
 
-// Fast steps, executed by wave 0 alone while the other waves are parked at a barrier: the expensive
-// part of a step (keys for every live candidate + top-k) was done for every possible seed by
-// carve_propose_kernel against the live set at the start of the configuration.  Because candidates are
-// only ever REMOVED, the reference's sorted remaining list is the proposal list minus the dead entries,
-// as long as the proposal still holds enough live entries and the boundary can be certified; otherwise
-// the step is handed to the exact full sweep (FAST_SLOW).
 #ifdef PM_CARVE_PROF_FINE
 #define PROF_COUNT(slot) do { if (lane == 0) G(p.status)->prof[slot] += 1; } while (0)
 #else
 #define PROF_COUNT(slot)
 #endif
-#ifdef PM_CARVE_PROF_FINE
-#define FP_DECL uint64_t fp_t = __builtin_amdgcn_s_memtime(), fp_acc[6] = {0, 0, 0, 0, 0, 0}
-#define FP_MARK(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); fp_acc[i] += t_ - fp_t; fp_t = t_; } while (0)
-#define FP_FLUSH() do { if (lane == 0) { G(p.status)->prof[23] += fp_acc[0] + fp_acc[5]; } } while (0)
-#else
-#define FP_DECL
-#define FP_MARK(i)
-#define FP_FLUSH()
-#endif
-#define FAST_RETURN(code) do { FP_FLUSH(); c_ref = c; return (code); } while (0)
-#ifdef PM_CARVE_PROF  // why a step went to the exact sweep: 16 no proposal, 17 debug hook, 18 row exhausted, 19 certificate
+#define FAST_RETURN(code) do { c_ref = c; seed_cur = cur; return (code); } while (0)
+#ifdef PM_CARVE_PROF  // why a step went to the exact sweep: 20 no proposal, 21 debug hook, 25 row exhausted, 31 certificate
 #define SLOW_RETURN(why) do { if (lane == 0) G(p.status)->prof[why] += 1; FAST_RETURN(FAST_SLOW); } while (0)
 #else
 #define SLOW_RETURN(why) FAST_RETURN(FAST_SLOW)
 #endif
 
+// The proposals of a batch as the validating wave sees them: seed number i (rank among the live located slots below
+// prop_limit at preparation time, ascending slot order) -> its slot (seed_slots, dense) and its row.
+__device__ __forceinline__ uint32_t prop_row_of(uint32_t i, uint32_t world, uint32_t rows_pr) {
+  return world > 1u ? (i % world) * rows_pr + i / world : i;
+}
+
+// Fast steps one at a time, executed by wave 0 alone while the other waves are parked at a barrier: the expensive
+// part of a step (keys for every live candidate + top-k) was done for every possible seed by
+// carve_propose_kernel against the live set at the start of the batch.  Because candidates are
+// only ever REMOVED, the reference's sorted remaining list is the proposal row minus the dead entries,
+// as long as the row still holds enough live entries and the boundary can be certified; otherwise
+// the step is handed to the exact full sweep (FAST_SLOW).  The whole wave looks at one row (lane = entry), so this
+// path sees all 63 entries and re-derives the certificate from the keys; it takes what the lane-per-seed rounds
+// (carve_lane_rounds) hand over — rows that are not certified wholesale, thinned-out rows, wide groups, the last
+// partial group of a configuration — and the first-come tail.  At most max_steps steps (FAST_AGAIN when reached).
 template <bool BIG>
-__device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed& red, StepCtx& c_ref,
-                                             const uint32_t* l_wid, const uint32_t* l_site, const uint16_t* l_next16,
-                                             const uint32_t* l_next32, const uint64_t* l_rows, uint64_t* l_alive,
-                                             const uint64_t* l_loc, uint32_t steps_before) {
+__device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref, const uint32_t* l_site,
+                                             uint64_t* l_alive, const uint64_t* l_loc, uint32_t steps_before,
+                                             uint32_t& seed_cur, uint32_t max_steps) {
   StepCtx c = c_ref;  // registers for the whole run (the reference lives in the caller's scratch frame)
   const uint32_t lane = threadIdx.x & 63u;
   // argument-block fields used per step, loaded once: the stores below go through flat pointers the compiler
@@ -820,70 +818,52 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
   const auto g_cfg = G(p.g_cfg);
   const auto g_n = G(p.g_n);
   const auto g_off = G(p.g_off);
+  const auto prop = G((const uint64_t*)p.prop);
+  const auto seed_slots = G((const uint32_t*)p.seed_slots);
   const uint32_t cap_groups = p.cap_groups, cap_members = p.cap_members;
   const uint32_t dbg_every = p.debug_uncertain_every;
+  const uint32_t world = UNI(p.dist_world), rows_pr = UNI(c.rows_pr), n_seeds = UNI(c.n_seeds);
   constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   constexpr uint64_t SLOT_MASK = (1ull << SB) - 1ull;
   constexpr uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
   constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
-  // big lists: members are recorded as SLOTS and translated to worker ids by one parallel pass after the run
-  // (a dependent HBM load per member would stall the single validating wave)
-  // (lambdas capture plain values: a by-reference capture of `c` would pin the whole context in scratch)
-  const uint32_t n_list_v = c.n_list;
   typedef __attribute__((address_space(3))) unsigned long long lds_u64;
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
-  typedef __attribute__((address_space(3))) uint16_t lds_u16;
   lds_u64* const A = (lds_u64*)l_alive;
   const lds_u64* const LOC = (const lds_u64*)l_loc;
-  const lds_u64* const ROWS = (const lds_u64*)l_rows;
-  const lds_u32* const C_SLOT = (const lds_u32*)red.cache_slot;
-  const lds_u32* const C_NEXT = (const lds_u32*)red.cache_next;
-  (void)l_wid;
   const lds_u32* const SITE3 = (const lds_u32*)l_site;
-  const lds_u16* const NEXT3 = (const lds_u16*)l_next16;
   auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
   auto kill = [A](uint32_t i) {
     __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
+  // (members are recorded as SLOTS and translated to worker ids by one parallel pass after the run)
   auto site_of = [SITE3, l_site](uint32_t sl) -> uint32_t { return BIG ? l_site[sl] : SITE3[sl]; };
-  auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
-  // next located slot at the same site: LDS u16 for small lists, HBM u32 for big ones
-  auto next_of = [NEXT3, l_next32, n_list_v](uint32_t sl) -> uint32_t {
-    if (!BIG) {
-      const uint32_t v = NEXT3[sl];
-      return v == 0xFFFFu ? PM_NONE : v;
-    }
-    const uint32_t v = l_next32[sl];
-    return v < n_list_v ? v : PM_NONE;
-  };
   const uint32_t lw = (c.n_list + 63u) >> 6;
-  uint32_t row_ptr = 0;  // staged rows are in ascending slot order, and so are the seeds
-  uint32_t fc_j = 0;     // first bitmap word that may still hold a live slot (first-come steps)
-  const uint32_t cache_n = red.cache_n;
-  FP_DECL;
+  uint32_t cur = UNI(seed_cur);  // seeds in front of it are dead for good (they are consumed in ascending order)
+  uint32_t fc_j = 0;             // first bitmap word that may still hold a live slot (first-come steps)
+  uint32_t done = 0;
   PROF_COUNT(20);  // calls
   for (;;) {
-    FP_MARK(5);
+    if (done >= max_steps) FAST_RETURN(FAST_AGAIN);
     if (!(c.total_available >= c.min_s && c.n_cand >= c.min_s && c.n_cand > 0)) FAST_RETURN(FAST_DONE);
-    // ---- seed (mod.rs:526-530): the first live located slot.  The staged rows are exactly the live located
-    // slots in ascending order, so it is the first staged row whose slot is still alive.
+    // ---- seed (mod.rs:526-530): the first live located slot = the first live entry of the batch's seed list
     uint32_t f_loc = PM_NONE;
     if (c.proximity) {
       if (c.prop_k) {
-        while (row_ptr < cache_n) {
-          const uint32_t r = row_ptr + lane;
-          const uint32_t sl = r < cache_n ? C_SLOT[r] : PM_NONE;
-          const bool al = sl != PM_NONE && alive_at(sl);
+        while (cur < n_seeds) {
+          const uint32_t i = cur + lane;
+          const uint32_t sl = seed_slots[i < n_seeds ? i : n_seeds - 1u];
+          const bool al = i < n_seeds && alive_at(sl);
           const uint64_t m = __ballot(al);
           if (m) {
             const int l = __builtin_ctzll(m);
-            row_ptr += (uint32_t)l;
+            cur += (uint32_t)l;
             f_loc = (uint32_t)__builtin_amdgcn_readlane((int)sl, l);
             break;
           }
-          row_ptr += 64u;
+          cur += 64u;
         }
-        if (f_loc == PM_NONE && cache_n == PM_CARVE_CACHE_ROWS) FAST_RETURN(FAST_REFILL);  // more may follow
+        if (cur > n_seeds) cur = n_seeds;
         if (f_loc == PM_NONE && c.prop_limit < c.n_list) {
           // every proposed slot is used up; located candidates beyond the proposal batch need a new round
           bool more = false;
@@ -910,7 +890,6 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         }
       }
     }
-    FP_MARK(0);
     const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // mod.rs:545-551
     if (c.n_groups >= cap_groups || c.mem_off + want + 1u > cap_members) FAST_RETURN(FAST_OVERFLOW);
 
@@ -942,7 +921,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
           const uint32_t rk = __builtin_amdgcn_mbcnt_hi(w_hi, __builtin_amdgcn_mbcnt_lo(w_lo, 0u));
           const bool mine = ((w >> lane) & 1ull) && rk < need - cnt;
           const uint64_t take = __ballot(mine);
-          if (mine) members[mem_off + cnt + rk] = wid_of(j * 64u + lane);
+          if (mine) members[mem_off + cnt + rk] = j * 64u + lane;
           if (lane == 0) A[j] = w & ~take;
           cnt += __popcll(take);
         }
@@ -971,46 +950,30 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
 
     PROF_COUNT(22);  // located sequential steps (attempts)
     const uint32_t seed = f_loc;
-    if (c.prop_k == 0 || seed >= c.prop_limit) {  SLOW_RETURN(16); }
-    if (dbg_every && ((steps_before + c.steps + 1u) % dbg_every) == 0u) SLOW_RETURN(17);
+    if (c.prop_k == 0 || seed >= c.prop_limit) {  SLOW_RETURN(20); }
+    if (dbg_every && ((steps_before + c.steps + 1u) % dbg_every) == 0u) SLOW_RETURN(21);
 
-    // ---- candidates with the seed's exact coordinates are at distance 0 — ahead of everybody else, in input
-    // (slot) order — and the proposal rows of shared sites leave them out: the same_next chain lists them
-    // (all of them lie behind the seed: a live one in front of it would have been the seed).  The group is
-    // the first live ones of the chain, topped up from the row.
-    const uint32_t first_same = want > 0 ? C_NEXT[row_ptr] : PM_NONE;  // staged with the row
-    uint32_t cnt = 0, mine_slot = PM_NONE;
-    if (first_same != PM_NONE) {
-      uint32_t t = first_same;
-      while (t != PM_NONE && cnt < want) {
-        if (alive_at(t)) {
-          if (lane == cnt) mine_slot = t;
-          ++cnt;
-        }
-        t = next_of(t);
-      }
-    }
-    const uint32_t need = want - cnt;  // still to come from the row
-
-    FP_MARK(1);
-    // ---- the seed's neighbour list (staged in LDS, row_ptr points at it): one packed key per lane, ascending
-    const uint32_t nk_word = (uint32_t)ROWS[row_ptr * PM_PROP_ROW + PM_PROP_META];  // the row's flags word
+    // ---- the seed's neighbour row: one packed key per lane, ascending.  Candidates with the seed's exact
+    // coordinates are at distance 0 and head the row in slot order (only those behind the seed are listed: a live one
+    // in front of it would have been the seed).
+    const size_t rbase = (size_t)prop_row_of(cur, world, rows_pr) * PM_PROP_ROW;
+    const uint32_t nk_word = UNI((uint32_t)prop[rbase]);  // the row's flags word
     const uint32_t n_k = nk_word & 0xFFu;
-    const bool complete = (nk_word >> 31) != 0u;
-    const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
-    const bool row_clean = ((nk_word >> 29) & 1u) != 0u;
-    const bool tail_clear = ((nk_word >> 28) & 1u) != 0u;
-    const uint64_t e = lane < n_k ? ROWS[row_ptr * PM_PROP_ROW + lane] : ~0ull;
+    const bool complete = (nk_word & PM_ROW_COMPLETE) != 0u;
+    const bool tail_ok = (nk_word & PM_ROW_TAIL_OK) != 0u;
+    const bool row_clean = (nk_word & PM_ROW_CLEAN) != 0u;
+    const bool tail_clear = (nk_word & PM_ROW_TAIL_CLEAR) != 0u;
+    const bool row_safe = (nk_word & PM_ROW_SAFE) != 0u;
+    const uint64_t e = lane < n_k ? prop[rbase + 1u + lane] : ~0ull;
     const uint32_t slot = (uint32_t)(e & SLOT_MASK);
     const bool alive = lane < n_k && alive_at(slot);
     const uint64_t am = __ballot(alive);
     const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
-    if ((uint32_t)__popcll(am) < need) {  SLOW_RETURN(18); }  // list exhausted by earlier groups
-    const bool sel = alive && rank < need;
-    FP_MARK(2);
-    // the proposer certified the whole row (clean) and its tail (complete / tail_clear): nothing left to prove
-    if (need > 0 && !(row_clean && (complete || tail_clear))) {
-      const uint64_t lm = __ballot(sel && rank == need - 1u);
+    if ((uint32_t)__popcll(am) < want) {  SLOW_RETURN(25); }  // row exhausted by earlier groups
+    const bool sel = alive && rank < want;
+    // the proposer certified the whole row (clean, safe) and its tail (complete / tail_clear): nothing left to prove
+    if (want > 0 && !(row_clean && row_safe && (complete || tail_clear))) {
+      const uint64_t lm = __ballot(sel && rank == want - 1u);
       const int lane_m = __builtin_ctzll(lm);
       const uint64_t e_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), lane_m) << 32) |
                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, lane_m);
@@ -1022,11 +985,11 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
         // an unselected one of the boundary's site just above it may be ordered either way by the reference.
         const double a_m = __longlong_as_double((long long)kb_m);
         const double band = a_m * band_rel + 1e-300;
-        if (a_m > PM_A_MAX_SAFE) SLOW_RETURN(19);
+        if (a_m > PM_A_MAX_SAFE) SLOW_RETURN(31);
         const uint32_t site_m = site_of((uint32_t)(e_m & SLOT_MASK));
         const uint64_t kb = (e >> SB) << SB;
         const bool near = alive && kb != noloc_key && fabs(__longlong_as_double((long long)kb) - a_m) <= band;
-        if (__ballot(near && site_of(slot) != site_m)) {  SLOW_RETURN(19); }
+        if (__ballot(near && site_of(slot) != site_m)) {  SLOW_RETURN(31); }
         if (!complete) {
           // candidates beyond the list are >= its last entry: either that entry clears the band, or it sits
           // at e_m's site and the proposer verified (tail_ok) that everything unlisted within the band of
@@ -1036,25 +999,20 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, last_l);
           const uint64_t kb_l = (e_l >> SB) << SB;
           if (kb_l != noloc_key && (__longlong_as_double((long long)kb_l) - a_m) <= band) {
-            if (!(tail_ok && site_of((uint32_t)(e_l & SLOT_MASK)) == site_m)) SLOW_RETURN(19);
+            if (!(tail_ok && site_of((uint32_t)(e_l & SLOT_MASK)) == site_m)) SLOW_RETURN(31);
           }
         }
       }
     }
-    FP_MARK(3);
-    // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): same-site members
-    // first (distance 0, slot order), then the row's in key order
-    if (lane < cnt) {
-      kill(mine_slot);
-      members[c.mem_off + 1u + lane] = wid_of(mine_slot);
-    }
+    // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): the seed, then the row's
+    // first `want` live entries in key order
     if (sel) {
       kill(slot);
-      members[c.mem_off + 1u + cnt + rank] = wid_of(slot);
+      members[c.mem_off + 1u + rank] = slot;
     }
     if (lane == 0) {
       kill(seed);
-      members[c.mem_off] = wid_of(seed);
+      members[c.mem_off] = seed;
       g_cfg[c.n_groups] = c.cfg;
       g_n[c.n_groups] = want + 1u;
       g_off[c.n_groups] = c.mem_off;
@@ -1066,376 +1024,320 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, const BlockRed&
     c.total_available -= want + 1u;
     c.steps += 1;
     c.fast_steps += 1;
-    FP_MARK(4);
+    cur += 1u;  // this seed is dead now
+    ++done;
   }
 }
 
-// Speculative rounds (all waves).  A fast step is bound by the issue latency of one wave, so the waves
-// work side by side: at the start of a round every wave takes one of the next live staged rows (= upcoming
-// seeds in input order) and pre-computes its selection against the current bitmap.  Because slots only ever
-// die, a pre-computed selection is still exactly the step's result iff its seed and all its selected slots
-// are still alive when its turn comes (dead entries ahead of them stay dead, and fewer live neighbours can
-// only remove certificate obligations).  The turns are not taken one after the other: every wave posts the
-// slots it would take, compares them against the claims of the waves ahead of it (one LDS read + a readlane
-// loop), posts a conflict word (one bit per wave ahead), and then all waves replay the round in seed order from those words
-// alone — a handful of scalar operations — and the winners commit concurrently.  The first wave that cannot
-// commit (a slot taken: redo from its row; exact sweep needed) ends the round.  Used while the configuration
-// has enough live candidates that the loop guards and `want` cannot change within a round; the tail goes
-// through carve_fast_steps.
+// The chain of located steps of a proposal batch, one seed after the other, by wave 0 alone — no speculation: what
+// makes a step cheap is that nothing but the step's own dependency is on its critical path.  A step depends on its
+// predecessors through the alive bitmap only (row -> live bits -> kill: one LDS read, one ballot, one LDS atomic), and
+// LDS operations of one wave execute in order, so the next seed's read is issued right behind this seed's kill without
+// waiting for it.  Everything else is off the chain, and the loop over the steps touches LDS only (a global store in
+// it would put a wait for the memory pipeline into every step, as would a load consumed in it):
+//  * the proposal rows (lane = row entry, lane 0 = the seed itself; 256 coalesced bytes per row) are requested a
+//    block of CHAIN_BLOCK seeds ahead and parked in a small LDS ring when they have arrived; a step reads its row
+//    from the ring one step early;
+//  * the seeds of a block are picked from a 64-entry chunk of the seed list with one ballot (a seed that dies before
+//    its turn shows up as bit 0 of its own row's live mask);
+//  * the members are collected in LDS (the key array is idle while the chain runs) and written out, with the group
+//    records, when the chain ends or the buffer is full; the certificate is read off the row's flags word.
+// Because candidates are only ever REMOVED, the reference's sorted remaining list (mod.rs:234-255) is the proposal
+// row minus its dead entries; the group is the seed plus the row's first `want` live entries (mod.rs:545-561).
+// Full groups only (want = max_s - 1).  Everything else is handed to carve_fast_steps, which looks at the seed
+// at seed_cur with the row's keys: rows whose flags do not settle the certificate, exhausted rows (-> exact sweep),
+// the debug hook (FAST_SLOW: exactly one step), the last partial group, the first-come tail, the end of the
+// batch (FAST_SEQ).
+#ifndef CHAIN_BLOCK
+#define CHAIN_BLOCK 8u
+#endif
+#define CHAIN_RING (2u * CHAIN_BLOCK)                  // rows parked in LDS (a power of two, >= 2 blocks)
+#define CHAIN_RING_WORDS (3u * CHAIN_RING * 64u)       // per row and lane: bitmap word address, bit, slot
+#define CHAIN_STAGE_WORDS (PM_CARVE_SLOTS * 2u - CHAIN_RING_WORDS)  // member slots collected in LDS (the key array)
 template <bool BIG>
-__device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red, StepCtx& c_ref, const uint32_t* l_wid,
-                                              const uint32_t* l_site, const uint16_t* l_next16,
-                                              const uint32_t* l_next32, const uint64_t* l_rows, uint64_t* l_alive,
-                                              uint32_t* l_claim, uint32_t steps_before) {
+__device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint64_t* l_alive, uint32_t* l_buf,
+                                        uint32_t steps_before, uint32_t& seed_cur) {
   StepCtx c = c_ref;
-  // Everything below that is the same in all lanes is pinned into SGPRs (UNI): values that arrive through
-  // memory or as arguments of a non-inlined function are VGPRs to the compiler, and every branch on them
-  // becomes an exec-mask sequence, every add a VALU instruction — this loop is bound by instruction issue.
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = UNI(tid >> 6);
-  steps_before = UNI(steps_before);
-  constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
-  constexpr uint64_t SLOT_MASK = (1ull << SB) - 1ull;
-  constexpr uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
-  constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
+  constexpr uint32_t NB = CHAIN_BLOCK, R = CHAIN_RING;
+  static_assert(R >= 2u * NB && (R & (R - 1u)) == 0u && R <= 64u, "ring geometry");
+  const uint32_t lane = threadIdx.x & 63u;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  lds_u32* const A = lds_pin<lds_u32*>(l_alive);  // the alive bitmap as 32-bit words
+  // ring entry r: for every lane the LDS address of its slot's bitmap word (RA), its bit (RB; 0 = no entry) and the
+  // slot (RE); lane 0 stands for the seed, lane e + 1 for row entry e
+  lds_u32* const RA = lds_pin<lds_u32*>(l_buf);
+  lds_u32* const RB = RA + R * 64u;
+  lds_u32* const RE = RB + R * 64u;
+  lds_u32* const STAGE = RE + R * 64u;
+  const uint32_t a_base = (uint32_t)(uintptr_t)A;
   const auto members = G(p.members);
   const auto g_cfg = G(p.g_cfg);
   const auto g_n = G(p.g_n);
   const auto g_off = G(p.g_off);
+  const auto rows32 = G((const uint32_t*)p.prop);  // row r: 2 * PM_PROP_ROW words; its compact slot list (flags word,
+                                                   // slot of entry 0, 1, ...) starts at word 2 * PM_PROP_SLOTS
+  const auto seed_slots = G((const uint32_t*)p.seed_slots);
   const uint32_t dbg_every = UNI(p.debug_uncertain_every);
+  const uint32_t world = UNI(p.dist_world), rows_pr = UNI(c.rows_pr), n_seeds = UNI(c.n_seeds);
   const uint32_t n_list_v = UNI(c.n_list);
-  // LDS views with an explicit address space: one conversion here instead of a generic-pointer null check and
-  // aperture add in front of every ds_read / ds_write
-  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-  typedef __attribute__((address_space(3))) uint32_t lds_u32;
-  typedef __attribute__((address_space(3))) uint16_t lds_u16;
-  // (lds_pin: the addresses are made opaque and held in SGPRs — left alone, the compiler re-derives every one of
-  // them from the dynamic-LDS offset table with a scalar load and an lgkmcnt(0) wait, several times per round)
-  lds_u64* const A = lds_pin<lds_u64*>(l_alive);
-  const lds_u64* const ROWS = lds_pin<const lds_u64*>(l_rows);
-  const lds_u32* const C_SLOT = lds_pin<const lds_u32*>(red.cache_slot);
-  const lds_u32* const C_NEXT = lds_pin<const lds_u32*>(red.cache_next);
-  (void)l_wid;  // (members are recorded as slots; the worker ids are looked up after the run)
-  const lds_u32* const SITE3 = BIG ? nullptr : lds_pin<const lds_u32*>(l_site);  // dereferenced only when !BIG
-  const lds_u16* const NEXT3 = BIG ? nullptr : lds_pin<const lds_u16*>(l_next16);
-  lds_u32* const CLAIM = lds_pin<lds_u32*>(l_claim);    // [CARVE_WAVES * 64] claimed slots of the round
-  lds_u32* const CONF = CLAIM + CARVE_WAVES * 64u;      // [CARVE_WAVES] conflict words: who claims my slots | my seed << 16
-  lds_u32* const RES = CONF + CARVE_WAVES;              // [CARVE_WAVES] ROUND_OK / ROUND_SLOW of each wave's selection
-  constexpr uint32_t WMASK = (1u << CARVE_WAVES) - 1u;
-  static_assert(CARVE_WAVES <= 16, "a conflict word holds two masks of CARVE_WAVES bits");
-  auto alive_at = [A](uint32_t i) -> bool { return (A[i >> 6] >> (i & 63u)) & 1ull; };
-  auto kill = [A](uint32_t i) {
-    __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
-  auto site_of = [SITE3, l_site](uint32_t sl) -> uint32_t { return BIG ? l_site[sl] : SITE3[sl]; };
-  auto next_of = [NEXT3, l_next32, n_list_v](uint32_t sl) -> uint32_t {
-    if (!BIG) {
-      const uint32_t v = NEXT3[sl];
-      return v == 0xFFFFu ? PM_NONE : v;
-    }
-    const uint32_t v = l_next32[sl];
-    return v < n_list_v ? v : PM_NONE;
-  };
-  const uint32_t group_n = UNI(c.max_s);
-  const uint32_t want = group_n - 1u;
-  const uint32_t cache_n = UNI(red.cache_n);
+  const uint32_t group_n = UNI(c.max_s), want = group_n - 1u;
   const uint32_t cfg = UNI(c.cfg);
-  // Every group committed here has exactly max_s members, so all running counters are functions of the
-  // number of commits, which every wave tracks identically (commits_done).
-  const uint32_t base_groups = UNI(c.n_groups), base_mem = UNI(c.mem_off), base_cand = UNI(c.n_cand),
-                 base_steps = UNI(c.steps);
-  // room left in the output arrays, in commits
   const uint32_t cap_g = UNI(p.cap_groups), cap_m = UNI(p.cap_members);
-  const uint32_t room_g = cap_g > base_groups ? cap_g - base_groups : 0u;
-  const uint32_t room_m = cap_m > base_mem ? (cap_m - base_mem) / group_n : 0u;
-  const uint32_t max_commits = UNI(room_g < room_m ? room_g : room_m);
-  const uint32_t fit_total = UNI(base_cand / group_n);  // full groups the live candidates allow (commits_done never exceeds it)
+  const uint32_t step0 = UNI(steps_before) + UNI(c.steps);
+  const uint32_t base_cand = UNI(c.n_cand);
+  uint32_t n_groups = UNI(c.n_groups), mem_off = UNI(c.mem_off);  // as of the last write-out
+  uint32_t n_cand = base_cand, commits = 0, staged = 0;            // staged: groups collected in LDS
   int action = FAST_SEQ;
-  uint32_t next_row = 0, commits_done = 0;
-#ifdef PM_CARVE_PROF
-  const uint64_t rt0 = __builtin_amdgcn_s_memtime();
-  uint32_t n_rounds_prof = 0;
-#endif
-#ifdef PM_CARVE_PROF_FINE
-  uint64_t t_spec = 0, t_wait = 0, t_commit = 0, t_sync = 0, t_chk = 0, t_b2 = 0;
-#endif
-  for (;;) {
-#ifdef PM_CARVE_PROF
-    ++n_rounds_prof;
-#endif
-#ifdef PM_CARVE_PROF_FINE
-    uint64_t ta = __builtin_amdgcn_s_memtime();
-#endif
-    const uint32_t row_ptr = next_row;
-    // Every commit of a round takes a full group (want = max_s - 1), which needs max_s live candidates in
-    // front of it (mod.rs:545-551) — that also keeps the loop guards true (max_s >= min_s): the round is as
-    // wide as the candidates allow, and the last partial group of a configuration goes to carve_fast_steps.
-    const uint32_t n_cand_now = base_cand - commits_done * group_n;
-    const uint32_t fit_left = fit_total - commits_done;  // = n_cand_now / group_n
-    const uint32_t n_fit = fit_left < CARVE_WAVES ? fit_left : CARVE_WAVES;
-    if (n_fit == 0u) {
-      action = FAST_SEQ;
-      break;
-    }
-    // More than half of the list is dead: the neighbour lists are thinning out.  Re-prepare (compact) and
-    // re-propose now, before rows start running out of live entries and every step needs the exact sweep.
-    if (n_cand_now * 2u < n_list_v && n_list_v > 256u && commits_done > 0u) {
-      action = FAST_REPROPOSE;
-      break;
-    }
-    // ---- the live staged rows of this 64-row window, in order; wave w takes the w-th
-    const uint32_t rr = row_ptr + lane;
-    const uint32_t sl_l = rr < cache_n ? C_SLOT[rr] : PM_NONE;
-    const bool al_l = sl_l != PM_NONE && alive_at(sl_l);
-    const uint64_t m = __ballot(al_l);
-    if (m == 0ull) {
-      if (row_ptr + 64u >= cache_n) {
-        action = cache_n == PM_CARVE_CACHE_ROWS ? FAST_REFILL : FAST_SEQ;  // SEQ: no located rows left here
-        break;
-      }
-      next_row = row_ptr + 64u;
-      continue;
-    }
-    const uint32_t n_live = __popcll(m);
-    const uint32_t n_round = n_live < n_fit ? n_live : n_fit;
-    // the lane holding the k-th live row, without a loop: rank of each live lane, one ballot per question
-    const uint32_t rank_l = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    const bool have = wave < n_round;
-    const uint64_t mine_b = __ballot(al_l && rank_l == wave);
-    const uint32_t my_l = have ? (uint32_t)__builtin_ctzll(mine_b) : 0u;
-    const uint32_t last_l = (uint32_t)__builtin_ctzll(__ballot(al_l && rank_l == n_round - 1u));
+  uint32_t exit_cur = n_seeds;  // where carve_fast_steps resumes its search for the first live seed
 
-    // ---- speculative selection for my row (against the bitmap as of now).  The slots the step would take
-    // go straight into this wave's claim list in LDS: members in selection order, then the seed.
-    uint32_t res = ROUND_OK;  // ROUND_SLOW: needs the exact sweep
-    uint32_t my_wid = 0, seed = PM_NONE, seed_wid = 0;
-    const uint32_t my_row = row_ptr + my_l;
-    const uint32_t stride = want + 1u;
-    const uint32_t cbase = wave * stride;
-    if (have) {
-      seed = (uint32_t)__builtin_amdgcn_readlane((int)sl_l, (int)my_l);
-      // every LDS read of the row is issued up front (they return in order, one latency for all)
-      const uint64_t e = ROWS[my_row * PM_PROP_ROW + lane];
-      const uint32_t fs_raw = C_NEXT[my_row];
-      seed_wid = wid_of(seed);
-      const uint32_t slot = (uint32_t)(e & SLOT_MASK);
-      const uint32_t nk_word = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, (int)PM_PROP_META);  // flags word
-      const uint32_t n_k = nk_word & 0xFFu;
-      const bool alive = lane < n_k && alive_at(slot);
-      const uint32_t first_same = want > 0 ? UNI(fs_raw) : PM_NONE;
-      // Candidates at the seed's own site are at distance 0 — ahead of everybody else, in slot order — and
-      // the proposal rows of shared sites leave them out: the same_next chain lists them (all of them lie
-      // behind the seed: a live one in front of it would have been the seed).  The group is the first live
-      // ones of the chain, topped up from the row.
-      uint32_t cnt = 0, ms = PM_NONE;
-      if (first_same != PM_NONE) {
-        uint32_t t = first_same;
-        while (t != PM_NONE && cnt < want) {
-          const uint32_t tn = UNI(next_of(t));  // issued together with the bitmap word
-          if (UNI((uint32_t)alive_at(t))) {
-            if (lane == cnt) ms = t;
-            ++cnt;
-          }
-          t = tn;
-        }
-      }
-      if (lane < cnt) CLAIM[cbase + lane] = ms;
-      if (cnt < want) {
-        const uint32_t need = want - cnt;  // still to come from the row
-        const bool complete = (nk_word >> 31) != 0u;
-        const bool tail_ok = ((nk_word >> 30) & 1u) != 0u;
-        const bool row_clean = ((nk_word >> 29) & 1u) != 0u;
-        const bool tail_clear = ((nk_word >> 28) & 1u) != 0u;
-        const uint64_t am = __ballot(alive);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-        if ((uint32_t)__popcll(am) < need) {
-          res = ROUND_SLOW;
-        } else {
-          const bool sel = alive && rank < need;
-          if (!(row_clean && (complete || tail_clear))) {
-            const uint64_t lm = __ballot(sel && rank == need - 1u);
-            const int lane_m = __builtin_ctzll(lm);
-            const uint64_t e_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), lane_m) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, lane_m);
-            const uint64_t kb_m = (e_m >> SB) << SB;
-            if (kb_m != noloc_key) {
-              const double a_m = __longlong_as_double((long long)kb_m);
-              const double band = a_m * band_rel + 1e-300;
-              if (a_m > PM_A_MAX_SAFE) res = ROUND_SLOW;
-              const uint32_t site_m = site_of((uint32_t)(e_m & SLOT_MASK));
-              const uint64_t kb = (e >> SB) << SB;
-              // symmetric band around the last selected entry, selected entries included (see carve_fast_steps)
-              const bool near = alive && kb != noloc_key && fabs(__longlong_as_double((long long)kb) - a_m) <= band;
-              if (__ballot(near && site_of(slot) != site_m)) res = ROUND_SLOW;
-              if (!complete) {
-                const int last_e = (int)n_k - 1;
-                const uint64_t e_l = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), last_e) << 32) |
-                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, last_e);
-                const uint64_t kb_l = (e_l >> SB) << SB;
-                if (kb_l != noloc_key && (__longlong_as_double((long long)kb_l) - a_m) <= band)
-                  if (!(tail_ok && site_of((uint32_t)(e_l & SLOT_MASK)) == site_m)) res = ROUND_SLOW;
-              }
-            }
-          }
-          if (sel) CLAIM[cbase + cnt + rank] = slot;  // the scatter is the compaction: rank = position in the group
-        }
-      }
-      if (res != ROUND_OK && lane < want) CLAIM[cbase + lane] = 0xFFFFFFFEu;  // no claim
-      if (lane == want) CLAIM[cbase + want] = seed;
+  // groups collected in LDS -> group records + members (all of them full groups, back to back)
+  auto write_out = [&]() {
+    for (uint32_t g = lane; g < staged; g += 64u) {
+      g_cfg[n_groups + g] = cfg;
+      g_n[n_groups + g] = group_n;
+      g_off[n_groups + g] = mem_off + g * group_n;
     }
-    // my claims as the other waves will see them (lane k = member k, lane want = the seed)
-    const uint32_t mine_l = (have && lane <= want) ? CLAIM[cbase + lane] : PM_NONE;
-    if (have && res == ROUND_OK && lane < want) my_wid = wid_of(mine_l);
-#ifdef PM_CARVE_PROF_FINE
-    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_spec += tb - ta; ta = tb; }
-#endif
-    lds_barrier();
-#ifdef PM_CARVE_PROF_FINE
-    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; ta = tb; }
-#endif
-    // ---- which earlier waves of this round claim one of my slots (conf) / my seed (seed_hit)?  Slots only
-    // ever die, so my pre-computed selection is exactly the step's result iff none of its slots is taken by
-    // a group committed before it.
-    uint32_t conf = 0, seed_hit = 0;
-    if (have && wave > 0) {
-      const uint32_t n_foreign = cbase;  // the claim lists of waves 0 .. wave-1 are contiguous
-      for (uint32_t base = 0; base < n_foreign; base += 64u) {
-        const uint32_t idx = base + lane;
-        const uint32_t f = idx < n_foreign ? CLAIM[idx] : 0xFFFFFFFEu;
-        const bool hit_seed = f == seed;
-        bool hit = hit_seed;
-        // lanes beyond `want` of mine_l hold PM_NONE, which no claim equals: no bound check in the loop
-        for (uint32_t e0 = 0; e0 < want; e0 += 8u) {
-#pragma unroll
-          for (uint32_t u = 0; u < 8u; ++u)
-            hit |= f == (uint32_t)__builtin_amdgcn_readlane((int)mine_l, (int)((e0 + u) & 63u));
-        }
-        if (__ballot(hit)) {
-          for (uint32_t v = 0; v < wave; ++v) {
-            const bool in_v = idx >= v * stride && idx < (v + 1u) * stride;
-            if (__ballot(hit && in_v)) conf |= 1u << v;
-            if (__ballot(hit_seed && in_v)) seed_hit |= 1u << v;
-          }
-        }
-      }
+    const uint32_t nm = staged * group_n;
+    for (uint32_t k = lane; k < nm; k += 64u) members[mem_off + k] = STAGE[k];
+    n_groups += staged;
+    mem_off += nm;
+    staged = 0u;
+  };
+  // Commits that can follow one another before any of the conditions that end the chain can come true (they are
+  // looked at again when the budget is used up): candidates for full groups, room in the output arrays and in the
+  // LDS buffer, the re-proposal threshold, the debug hook.  >= 1 whenever none of those conditions holds.
+  auto budget_now = [&]() -> uint32_t {
+    uint32_t b = n_cand / group_n;
+    const uint32_t room_g = cap_g - (n_groups + staged), room_m = (cap_m - mem_off) / group_n - staged;
+    b = b < room_g ? b : room_g;
+    b = b < room_m ? b : room_m;
+    const uint32_t room_s = CHAIN_STAGE_WORDS / group_n - staged;
+    b = b < room_s ? b : room_s;
+    if (n_list_v > 256u) {
+      const uint32_t t = n_cand * 2u >= n_list_v ? (n_cand * 2u - n_list_v) / (2u * group_n) + 1u : 1u;
+      b = b < t ? b : t;
     }
-    if (have && lane == 0) {
-      CONF[wave] = conf | (seed_hit << 16);
-      RES[wave] = res;
-    }
-#ifdef PM_CARVE_PROF_FINE
-    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_chk += tb - ta; ta = tb; }
-#endif
-    lds_barrier();
-#ifdef PM_CARVE_PROF_FINE
-    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_b2 += tb - ta; ta = tb; }
-#endif
-    // ---- every wave replays the round identically, in seed order, from the conflict words: a wave whose
-    // seed was taken is no step at all; the first wave that cannot commit (exact sweep needed, a slot taken,
-    // arrays full) ends the round.  Straight-line scalar code: taken branches are what this loop would pay for.
-    const uint32_t cw = lane < n_round ? CONF[lane] : 0u;
-    const uint32_t rw = lane < n_round ? RES[lane] : 0u;
-    uint32_t dbg_at = 0xFFFFFFFFu;  // commit count at which the debug hook forces the exact sweep
     if (dbg_every) {
-      const uint32_t r = (steps_before + base_steps + commits_done + 1u) % dbg_every;
-      dbg_at = commits_done + (r ? dbg_every - r : 0u);
+      const uint32_t r = (step0 + commits + 1u) % dbg_every;
+      b = b < dbg_every - r ? b : dbg_every - r;
     }
-    uint32_t cmask = 0, stop_code = ROUND_OK, stop_wave = 0, commits = commits_done, open = 1u;
-    // the usual round: nobody claims anybody else's slots or seed, nobody needs the exact sweep, and neither the
-    // output arrays nor the debug hook end the round early — every wave of the round commits
-    const bool all_clear = __ballot((cw | rw) != 0u) == 0ull && commits_done + n_round <= max_commits &&
-                           !(dbg_at - commits_done < n_round);
-    if (all_clear) {
-      cmask = (1u << n_round) - 1u;
-      commits = commits_done + n_round;
-    } else
+    return b;
+  };
+
+  // ---- the seed list, 64 entries at a time (q: slots of entries cbase .. cbase + 63; qn: the next 64, on their way)
+  uint32_t cbase = UNI(seed_cur) & ~63u, cpos = UNI(seed_cur);  // cpos: first entry not yet handed to a block
+  auto load_chunk = [&](uint32_t b) -> uint32_t {
+    const uint32_t i = b + lane;
+    return seed_slots[i < n_seeds ? i : (n_seeds ? n_seeds - 1u : 0u)];
+  };
+  uint32_t q = load_chunk(cbase), qn = load_chunk(cbase + 64u);
+  // ring entry r: seed number and what the step needs of the row's flags word in lane r of ridx_v / rmeta_v
+  // (bit 0: clean and safe, bit 1: the tail is settled, bits 8..15: first entry within the band of the last one);
+  // entries [tail, head)
+  uint32_t ridx_v = 0u, rmeta_v = 0u, head = 0u, tail = 0u;
+  // the block on its way: rows in prow[], seed number / slot in lanes 0 .. pend_n - 1 of pidx_v / ppos_v
+  uint32_t prow[NB], pidx_v = 0u, ppos_v = 0u, pend_n = 0u;
 #pragma unroll
-    for (uint32_t v = 0; v < CARVE_WAVES; ++v) {
-      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)v);
-      const uint32_t seed_taken = ((word >> 16) & cmask & WMASK) ? 1u : 0u;
-      uint32_t verdict = (uint32_t)__builtin_amdgcn_readlane((int)rw, (int)v);
-      verdict = commits == dbg_at ? (uint32_t)ROUND_SLOW : verdict;
-      const uint32_t v_ok = (word & cmask & WMASK) ? (uint32_t)ROUND_RETRY : (uint32_t)ROUND_OK;
-      const uint32_t v_ok2 = commits >= max_commits ? (uint32_t)ROUND_OVERFLOW : v_ok;
-      verdict = verdict == ROUND_OK ? v_ok2 : verdict;
-      const uint32_t consider = (v < n_round ? 1u : 0u) & open & (seed_taken ^ 1u);
-      const uint32_t ok = consider & (verdict == ROUND_OK ? 1u : 0u);
-      const uint32_t stop_now = consider & (ok ^ 1u);
-      cmask |= ok << v;
-      commits += ok;
-      stop_code = stop_now ? verdict : stop_code;
-      stop_wave = stop_now ? v : stop_wave;
-      open &= stop_now ^ 1u;
-    }
-    if (have && ((cmask >> wave) & 1u)) {
-      const uint32_t ci = commits_done + (uint32_t)__popc(cmask & ((1u << wave) - 1u));
-      const uint32_t n_groups = base_groups + ci, mem_off = base_mem + ci * group_n;
-      if (lane < want) {
-        kill(mine_l);
-        members[mem_off + 1u + lane] = my_wid;
-      }
-      if (lane == 0) {
-        kill(seed);
-        members[mem_off] = seed_wid;
-        g_cfg[n_groups] = cfg;
-        g_n[n_groups] = group_n;
-        g_off[n_groups] = mem_off;
-      }
-    }
-    commits_done = commits;
-#ifdef PM_CARVE_PROF_FINE
-    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_commit += tb - ta; ta = tb; }
-#endif
-    lds_barrier();  // the round's bitmap updates are in place
-#ifdef PM_CARVE_PROF_FINE
-    { const uint64_t tb = __builtin_amdgcn_s_memtime(); t_sync += tb - ta; ta = tb; }
-#endif
-    next_row = row_ptr + last_l + 1u;
-    if (stop_code != ROUND_OK) {
+  for (uint32_t k = 0; k < NB; ++k) prow[k] = 0u;
+  uint32_t budget = 0u;
 #ifdef PM_CARVE_PROF
-      if (tid == 0) G(p.status)->prof[stop_code == ROUND_RETRY ? 3 : 4] += 1;
+  uint64_t ct = __builtin_amdgcn_s_memtime(), ct_park = 0, ct_fetch = 0, ct_steps = 0;
+  uint32_t cn_outer = 0, cn_dead = 0, cn_wait = 0;
+#define CH_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - ct; ct = t_; } while (0)
+#define CH_COUNT(var) (++var)
+#else
+#define CH_MARK(var)
+#define CH_COUNT(var)
 #endif
-      if (stop_code == ROUND_SLOW) {
-        action = FAST_SLOW;
-        break;
+
+  if (n_seeds > 0u) {
+    for (;;) {
+      CH_COUNT(cn_outer);
+      head = UNI(head);
+      tail = UNI(tail);
+      pend_n = UNI(pend_n);
+      cpos = UNI(cpos);
+      cbase = UNI(cbase);
+      // ---- (a) the block requested a round of steps ago has arrived: park it in the ring, digested
+      if (pend_n && head - tail + pend_n <= R) {
+        uint32_t pmeta_v = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < NB; ++k) {
+          if (k < pend_n) {
+            const uint32_t meta = UNI(prow[k]);
+            const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)ppos_v, (int)k);
+            const uint32_t e = lane == 0u ? sp : prow[k];
+            const uint32_t o = ((head + k) & (R - 1u)) * 64u + lane;
+            RA[o] = a_base + ((e >> 5) << 2);
+            RB[o] = lane <= (meta & 0xFFu) ? 1u << (e & 31u) : 0u;
+            RE[o] = e;
+            const uint32_t m2 = (((meta & PM_ROW_CLEAN) && (meta & PM_ROW_SAFE)) ? 1u : 0u) |
+                                ((meta & (PM_ROW_COMPLETE | PM_ROW_TAIL_CLEAR | PM_ROW_TAIL_OK)) ? 2u : 0u) | (meta & 0xFF00u);
+            pmeta_v = lane == k ? m2 : pmeta_v;
+          }
+        }
+        // lane r of the ring registers <- lane (r - head) mod R of the block registers
+        const uint32_t src = (lane - head) & (R - 1u);
+        const uint32_t vi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)pidx_v);
+        const uint32_t vm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)pmeta_v);
+        const bool mine = lane < R && src < pend_n;
+        ridx_v = mine ? vi : ridx_v;
+        rmeta_v = mine ? vm : rmeta_v;
+        head += pend_n;
+        pend_n = 0u;
       }
-      if (stop_code == ROUND_OVERFLOW) {
-        action = FAST_OVERFLOW;
-        break;
+      CH_MARK(ct_park);
+      // ---- (b) request the rows of the next (up to) NB seeds of the list that are alive right now
+      while (pend_n == 0u && cpos < n_seeds) {
+        const uint32_t i = cbase + lane;
+        const uint32_t w = A[q >> 5];
+        uint64_t m = __ballot(i >= cpos && i < n_seeds && ((w >> (q & 31u)) & 1u) != 0u);
+        const uint32_t n_m = (uint32_t)__popcll(m);
+        pend_n = n_m < NB ? n_m : NB;
+#pragma unroll
+        for (uint32_t k = 0; k < NB; ++k) {
+          if (k < pend_n) {  // the k-th live entry of the chunk -> lane k of the block registers
+            const uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t si = cbase + l;
+            const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)l);
+            pidx_v = lane == k ? si : pidx_v;
+            ppos_v = lane == k ? sp : ppos_v;
+            prow[k] = rows32[(size_t)prop_row_of(si, world, rows_pr) * (2u * PM_PROP_ROW) + 2u * PM_PROP_SLOTS + lane];
+            cpos = si + 1u;
+          }
+        }
+        if (m == 0ull) cpos = cbase + 64u;  // nothing alive behind them in this chunk
+        if (cpos >= cbase + 64u) {          // the chunk is used up: on to the next one
+          cbase += 64u;
+          q = qn;
+          qn = load_chunk(cbase + 64u);
+        }
       }
-      // ROUND_RETRY: an earlier commit of this round took one of that wave's slots; redo from its row
-      uint64_t t = m;
-      for (uint32_t k = 0; k < stop_wave; ++k) t &= t - 1ull;
-      next_row = row_ptr + (uint32_t)__builtin_ctzll(t);
+      CH_MARK(ct_fetch);
+      // ---- (c) steps
+      if (tail == head) {
+        if (pend_n == 0u) {  // the list is used up
+          action = FAST_SEQ;
+          exit_cur = n_seeds;
+          break;
+        }
+        CH_COUNT(cn_wait);
+        continue;  // (the first block, or a block of seeds that had all died: wait for the rows under way)
+      }
+      uint32_t n_steps = head - tail;
+      n_steps = n_steps < NB ? n_steps : NB;
+      bool stop = false;
+      uint32_t o_next = (tail & (R - 1u)) * 64u + lane;
+      uint32_t ra_n = RA[o_next], rb_n = RB[o_next], re_n = RE[o_next];
+      for (uint32_t s = 0; s < n_steps; ++s) {
+        // (loop-carried counters pinned as wave-uniform: otherwise every branch on them is an exec-mask sequence)
+        tail = UNI(tail);
+        budget = UNI(budget);
+        staged = UNI(staged);
+        n_cand = UNI(n_cand);
+        commits = UNI(commits);
+        const uint32_t r = tail & (R - 1u);
+        const uint32_t ra = ra_n, rb = rb_n, re = re_n;
+        const uint32_t w = *(lds_u32*)(uintptr_t)ra;
+        o_next = ((tail + 1u) & (R - 1u)) * 64u + lane;  // (the next step's row, one step early)
+        ra_n = RA[o_next];
+        rb_n = RB[o_next];
+        re_n = RE[o_next];
+        const uint64_t a = __ballot((w & rb) != 0u);
+        ++tail;
+        if (!(a & 1ull)) {  // absorbed by a group since its row was requested: no step
+          CH_COUNT(cn_dead);
+          continue;
+        }
+        if (budget == 0u) {
+          exit_cur = (uint32_t)__builtin_amdgcn_readlane((int)ridx_v, (int)r);
+          // `while total_available >= min` with `compatible < min => break` (mod.rs:507,517-519) hold while full
+          // groups fit (max_s >= min_s); the last, partial group is carve_fast_steps' business
+          if (n_cand < group_n) {
+            action = FAST_SEQ;
+            stop = true;
+            break;
+          }
+          if (n_groups + staged >= cap_g || mem_off + (staged + 1u) * group_n > cap_m) {
+            action = FAST_OVERFLOW;
+            stop = true;
+            break;
+          }
+          // More than half of the list is dead: the neighbour rows are thinning out.  Re-prepare (compact) and
+          // re-propose now, before rows start running out of live entries.
+          if (n_cand * 2u < n_list_v && n_list_v > 256u && commits > 0u) {
+            action = FAST_REPROPOSE;
+            stop = true;
+            break;
+          }
+          if (dbg_every && ((step0 + commits + 1u) % dbg_every) == 0u) {
+            action = FAST_SLOW;
+            stop = true;
+            break;
+          }
+          if ((staged + 1u) * group_n > CHAIN_STAGE_WORDS) write_out();
+          budget = budget_now();
+        }
+        // my rank among the live lanes: 0 for the seed, e + 1 for the e-th live entry
+        const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a, 0u));
+        const uint64_t selm = a & __ballot(rk <= want);  // the seed and its `want` nearest live neighbours
+        const uint32_t n_live = (uint32_t)__popcll(a) - 1u;
+        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)rmeta_v, (int)r);
+        // the row's flags settle the certificate: no two entries near each other at different sites, nothing near
+        // the antipode, and a tail that is complete / clear / at one site — or a selection that ends in front of
+        // the tail's band
+        bool ok = n_live >= want;
+        if (want != 0u) {
+          ok = ok && (m2 & 1u);
+          if (!(m2 & 2u)) ok = ok && 62u - (uint32_t)__builtin_clzll(selm | 2ull) < ((m2 >> 8) & 0xFFu);
+        }
+        if (!ok) {
+          exit_cur = (uint32_t)__builtin_amdgcn_readlane((int)ridx_v, (int)r);
+          action = FAST_SLOW;
+          stop = true;
+          break;
+        }
+        // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
+        if ((selm >> lane) & 1ull) {
+          __hip_atomic_fetch_and((lds_u32*)(uintptr_t)ra, ~rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          STAGE[staged * group_n + rk] = re;  // slots (translated to worker ids after the run); rk = 0: the seed
+        }
+        staged += 1u;
+        n_cand -= group_n;
+        commits += 1u;
+        budget -= 1u;
+      }
+      CH_MARK(ct_steps);
+      if (stop) break;
     }
   }
-  lds_barrier();
-  {
-    const uint32_t commits = commits_done;
+  write_out();
+  c.n_groups = n_groups;
+  c.mem_off = mem_off;
+  c.n_cand = n_cand;
+  c.total_available -= commits * group_n;
+  c.steps += commits;
+  c.fast_steps += commits;
+  // sum over the commits of the live candidates before each: base, base - g, base - 2g, ...
+  c.cand_sum += (unsigned long long)commits * base_cand -
+                (unsigned long long)group_n * ((unsigned long long)commits * (commits ? commits - 1u : 0u) / 2ull);
 #ifdef PM_CARVE_PROF
-    if (tid == 0) {
-      G(p.status)->prof[0] += __builtin_amdgcn_s_memtime() - rt0;
-      G(p.status)->prof[1] += n_rounds_prof;
-      G(p.status)->prof[2] += commits;
-    }
-#endif
-#ifdef PM_CARVE_PROF_FINE
-    if (tid == 0) G(p.status)->prof[5] += t_spec;
-    if (tid == 64) { G(p.status)->prof[6] += t_wait; G(p.status)->prof[7] += t_commit; G(p.status)->prof[8] += t_sync; G(p.status)->prof[16] += t_chk; G(p.status)->prof[17] += t_b2; }
-    if (tid == 448) { G(p.status)->prof[18] += t_chk; G(p.status)->prof[19] += t_spec; }
-#endif
-    c.n_groups = base_groups + commits;
-    c.mem_off = base_mem + commits * group_n;
-    c.n_cand = base_cand - commits * group_n;
-    c.total_available -= commits * group_n;
-    c.steps += commits;
-    c.fast_steps += commits;
-    // sum over the commits of the live candidates before each: base, base - g, base - 2g, ...
-    c.cand_sum += (unsigned long long)commits * base_cand -
-                  (unsigned long long)group_n * ((unsigned long long)commits * (commits ? commits - 1u : 0u) / 2ull);
+  if (lane == 0u) {
+    unsigned long long* pr = (unsigned long long*)p.status->prof;
+    pr[1] += 1u;        // calls
+    pr[2] += commits;
+    pr[4] += action == FAST_SLOW ? 1u : 0u;
+    pr[16] += ct_park;
+    pr[17] += ct_fetch;
+    pr[18] += ct_steps;
+    pr[19] += cn_outer;
+    pr[23] += cn_dead;
+    pr[24] += cn_wait;
   }
-  lds_barrier();
+#endif
   c_ref = c;
+  seed_cur = exit_cur;
   return action;
 }
 
@@ -1447,104 +1349,35 @@ __device__ __noinline__ int carve_fast_rounds(const CarveArgs& p, BlockRed& red,
 // cannot be certified.
 template <bool BIG>
 __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, StepCtx& c, const uint32_t* l_wid,
-                                          const uint32_t* l_site, const uint16_t* l_next, const uint32_t* l_next32,
-                                          uint64_t* l_key, uint64_t* l_rows, uint64_t* l_alive,
+                                          const uint32_t* l_site, uint64_t* l_key, uint64_t* l_alive,
                                           const uint64_t* l_loc, uint64_t* part, uint32_t* sel_out,
-                                          uint32_t steps_before) {
+                                          uint32_t* l_stage, uint32_t steps_before) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
   const uint32_t lw = (c.n_list + 63u) >> 6;
   const bool have_props = c.mode == CARVE_MODE_FORM && c.use_props;
   auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
-  bool cache_valid = false;
+  uint32_t seed_cur = 0;  // wave 0: how far into the batch's seed list the carve has come
   for (;;) {
     if (have_props) {
-      if (!cache_valid && c.prop_k) {
-        PROF_DECL;
-        // ---- stage the proposal rows of the next PM_CARVE_CACHE_ROWS live located slots in LDS (they
-        // alias l_key, which only the slow sweep uses): wave 0 lists the slots, all waves copy the rows
-        if (wave == 0) {
-          // 64 bitmap words per pass, one word per lane; the non-empty ones are then visited in order with
-          // the whole wave looking at one word (lane = bit): rank within the word + running base = row.
-          // The row a slot's proposal sits in is its rank among the batch's seeds (seed_map / seed_prefix:
-          // the live located slots below prop_limit at preparation time), dealt round-robin over the ranks.
-          const uint32_t world = p.dist_world, rows_pr = c.rows_pr;
-          const auto seed_map = G((const uint64_t*)p.seed_map);
-          const auto seed_prefix = G((const uint32_t*)p.seed_prefix);
-          uint32_t base = 0;
-          for (uint32_t j0 = 0; j0 < lw && base < PM_CARVE_CACHE_ROWS; j0 += 64u) {
-            const uint32_t j = j0 + lane;
-            uint64_t w = j < lw ? (l_alive[j] & l_loc[j]) : 0ull;
-            // proposals exist for slots below prop_limit only
-            if (j * 64u + 64u > c.prop_limit)
-              w = (j * 64u >= c.prop_limit) ? 0ull : (w & ((1ull << (c.prop_limit & 63u)) - 1ull));
-            const uint32_t jc = j < lw ? j : lw - 1u;  // unconditional loads (clamped), used only where w != 0
-            const uint64_t pm = seed_map[jc];
-            const uint32_t pf = seed_prefix[jc];
-            uint64_t nz = __ballot(w != 0ull);
-            while (nz && base < PM_CARVE_CACHE_ROWS) {
-              const int src = __builtin_ctzll(nz);
-              nz &= nz - 1ull;
-              const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, src);
-              const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), src);
-              const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pm, src);
-              const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pm >> 32), src);
-              const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)pf, src);
-              const uint32_t bit = ((lane < 32u ? w_lo >> lane : w_hi >> (lane - 32u)) & 1u);
-              const uint32_t r = base + __builtin_amdgcn_mbcnt_hi(w_hi, __builtin_amdgcn_mbcnt_lo(w_lo, 0u));
-              if (bit && r < PM_CARVE_CACHE_ROWS) {
-                const uint32_t i = f0 + __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));  // seed number
-                red.cache_slot[r] = (j0 + (uint32_t)src) * 64u + lane;
-                red.cache_row[r] = world > 1u ? (i % world) * rows_pr + i / world : i;
-              }
-              base += (uint32_t)__popc(w_lo) + (uint32_t)__popc(w_hi);
-            }
-          }
-          if (lane == 0) red.cache_n = base < PM_CARVE_CACHE_ROWS ? base : PM_CARVE_CACHE_ROWS;
-        }
-        lds_barrier();
-        const uint32_t rows = red.cache_n;
-        {  // all loads of a wave are issued before the first LDS store (rows: one u64 per lane; directory
-           // words: one staged row per thread)
-          uint64_t rowv[PM_CARVE_CACHE_ROWS / CARVE_WAVES];
-#pragma unroll
-          for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
-            const uint32_t r = wave + k * CARVE_WAVES;
-            rowv[k] = r < rows ? G(p.prop)[(size_t)red.cache_row[r] * PM_PROP_ROW + lane] : ~0ull;
-          }
-          uint32_t nx = PM_NONE;
-          if (tid < rows) nx = G(p.same_next)[red.cache_slot[tid]];
-#pragma unroll
-          for (uint32_t k = 0; k < PM_CARVE_CACHE_ROWS / CARVE_WAVES; ++k) {
-            const uint32_t r = wave + k * CARVE_WAVES;
-            if (r < rows) l_rows[r * PM_PROP_ROW + lane] = rowv[k];
-          }
-          if (tid < rows) red.cache_next[tid] = nx < c.n_list ? nx : PM_NONE;
-        }
-        lds_barrier();
-        cache_valid = true;
-        PROF_MARK(20);  // staging
-#ifdef PM_CARVE_PROF
-        if (tid == 0) G(p.status)->prof[21] += 1;
-#endif
-      }
-      if (c.prop_k && c.proximity && p.rounds_enabled) {
-        const int ract = carve_fast_rounds<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive,
-                                                reinterpret_cast<uint32_t*>(part), steps_before);
-        if (ract == FAST_OVERFLOW) return STEP_OVERFLOW;
-        if (ract == FAST_REPROPOSE) return STEP_CONTINUE;  // re-prepare + next proposal round
-        if (ract == FAST_REFILL) {
-          cache_valid = false;
-          continue;
-        }
-        // FAST_SEQ / FAST_SLOW: the sequential fast path below decides (it re-derives the seed)
-      }
-      // whatever the rounds left over (tails, first-come groups, the step that needs the exact sweep): wave 0
-      // commits as many steps as the proposals allow; everyone else waits at the barrier
+      // Everything the proposals can serve is done by wave 0 alone (everyone else waits at the barrier): the chain
+      // of located steps (carve_chain), and — with the row's keys at hand — whatever it hands over: rows whose
+      // flags do not settle the certificate, exhausted rows, the last partial group, the first-come tail.
       if (wave == 0) {
         PROF_DECL;
-        const int act = carve_fast_steps<BIG>(p, red, c, l_wid, l_site, l_next, l_next32, l_rows, l_alive, l_loc, steps_before);
+        const bool chain = c.prop_k && c.proximity && p.rounds_enabled && c.max_s - 1u < PM_PROP_KMAX;
+        int act = FAST_SEQ;
+        for (;;) {
+          if (chain) {
+            act = carve_chain<BIG>(p, c, l_alive, l_stage, steps_before, seed_cur);
+            PROF_MARK(0);
+            if (act == FAST_OVERFLOW || act == FAST_REPROPOSE) break;
+          }
+          act = carve_fast_steps<BIG>(p, c, l_site, l_alive, l_loc, steps_before, seed_cur,
+                                      (chain && act == FAST_SLOW) ? 1u : 0xFFFFFFFFu);
+          if (act != FAST_AGAIN) break;
+        }
         if (lane == 0) {
           red.f_action = (uint32_t)act;
           red.f_n_cand = c.n_cand;
@@ -1569,12 +1402,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
       lds_barrier();  // the mailbox is rewritten after the next slow step
       if (act == FAST_DONE) return STEP_BREAK;
       if (act == FAST_OVERFLOW) return STEP_OVERFLOW;
-      if (act == FAST_REFILL) {
-        cache_valid = false;
-        continue;
-      }
       if (act == FAST_REPROPOSE) return STEP_CONTINUE;  // re-prepare: next proposal batch
-      if (l_rows == l_key) cache_valid = false;  // the slow sweep below overwrites the staged rows
     }
     // FORM: `while total_available >= min` (mod.rs:507) with `compatible < min => break` (:517-519).
     // MERGE: `while remaining_groups.len() >= min` (mod.rs:695).
@@ -2074,10 +1902,6 @@ __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {  // lane i <- la
   const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
-  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) |
-         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
-}
 // Upper end of the window behind the threshold.  The row's last entry (the K-th nearest, K <= 63) never lies
 // beyond lane 63, and lane 63 only ever moves inwards, so a candidate that finishes within the band
 // (a <= a_last (1 + 4 band) + 1e-300) of the last entry is, whenever it is looked at, fewer than 4 band 2^53 ulps
@@ -2204,9 +2028,10 @@ __device__ __forceinline__ void tile_keys(const CarveArgs& p, const TileBuf& tb,
     for (uint32_t v = 0; v < 4u; ++v) {
       const uint32_t u = h * 4u + v, t = tile * PROP_TILE + u * 64u + lane;
       const bool located = (lwd[v] >> lane) & 1ull;
-      // candidates at the seed's own (shared) site are not listed: the validator takes them from the
-      // same_next chain, ahead of everything in the row
-      const bool counts = ((aw[v] >> lane) & 1ull) && t != s && !(shared && located && si[v] == ssite);
+      // candidates at the seed's own (shared) site are at distance 0 (key = their slot): the ones behind the seed
+      // head its row in slot order; the ones in front of it are dead by the time it is a seed (a live located slot
+      // in front of it would be the seed instead) and would only fill the row
+      const bool counts = ((aw[v] >> lane) & 1ull) && t != s && !(shared && located && si[v] == ssite && t < s);
       const double dx = x[v] - sg.ux, dy = y[v] - sg.uy, dz = z[v] - sg.uz;
       double a = 0.25 * fma(dx, dx, fma(dy, dy, dz * dz));
       const bool near = counts && located && a < PM_A_CHORD_MIN;  // (see prox_a: the sine form below ~10 km)
@@ -2233,59 +2058,12 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   const double TIE_BAND = n_list > PM_CARVE_SLOTS ? PM_TIE_BAND_BIG : PM_TIE_BAND;
   const uint64_t WINDOW_ULPS = n_list > PM_CARVE_SLOTS ? (1ull << 25) : (1ull << 20);  // 8 band 2^53 (see near_window)
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave_g = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
   const auto alive = G((const uint64_t*)p.bits_scratch);
   const auto loc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
   const uint32_t lw = (n_list + 63u) >> 6;
-#ifdef PM_CARVE_PROF
-  const uint64_t prof_k0 = __builtin_amdgcn_s_memtime();
-#endif
-  // ---- phase 1: same-site links for every located live slot (the validator's same-site shortcut walks them);
-  // only sites shared by several workers (bit 31 of the interned id) can have one.  One wave per slot.
-  for (uint32_t s = wave_g; s < n_list; s += n_waves) {
-    if (!(bit_at(alive, s) && bit_at(loc, s))) continue;  // wave-uniform
-    const uint32_t ssite = G(p.cc_site)[s];
-    uint32_t same = PM_NONE;
-    if (ssite & 0x80000000u) {
-      // sixteen strides per step, every load unconditional and independent: the last member of a site scans to
-      // the end of the list, and a load per step would make that wave the launch's tail
-      for (uint32_t j0 = s >> 6; j0 < lw && same == PM_NONE; j0 += 16u) {
-        uint32_t si[16];
-        uint64_t m[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const uint32_t j = j0 + (uint32_t)u;
-          const uint32_t jc = j < lw ? j : lw - 1u;
-          const uint32_t t = j * 64u + lane;
-          si[u] = G(p.cc_site)[t < n_list ? t : n_list - 1u];
-          m[u] = alive[jc] & loc[jc];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const uint32_t j = j0 + (uint32_t)u;
-          const uint32_t t = j * 64u + lane;
-          const bool hit = j < lw && t > s && t < n_list && ((m[u] >> lane) & 1ull) && si[u] == ssite;
-          const uint64_t hm = __ballot(hit);
-          if (hm && same == PM_NONE) same = j * 64u + (uint32_t)__builtin_ctzll(hm);
-        }
-      }
-    }
-    if (lane == 0) G(p.same_next)[s] = same;
-  }
-#ifdef PM_CARVE_PROF
-#ifndef PM_CARVE_PROF_FINE
-  {
-    const uint64_t dt1 = __builtin_amdgcn_s_memtime() - prof_k0;
-    if (lane == 0) {
-      atomicAdd(&((unsigned long long*)p.status->prof)[5], (unsigned long long)dt1);
-      atomicMax(&((unsigned long long*)p.status->prof)[31], (unsigned long long)dt1);
-    }
-  }
-#endif
-#endif
-  // ---- phase 2: the neighbour rows.  Four seeds per workgroup (one per wave) sweep the candidate list together,
+  // ---- the neighbour rows.  Four seeds per workgroup (one per wave) sweep the candidate list together,
   // tile by tile through LDS.  The seeds of the batch are dealt round-robin over the ranks: this rank computes
-  // seed numbers my_rank, my_rank + world, ... (every rank linked same_next for the whole list above).
+  // seed numbers my_rank, my_rank + world, ...
   __shared__ TileBuf tiles[2];
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
   const uint32_t n_seeds = st->n_seeds;
@@ -2297,7 +2075,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     const bool valid = out_row < n_my;
     const uint32_t s = valid ? seed_slots[world > 1u ? my_rank + world * out_row : out_row] : 0u;
     const uint32_t ssite = G(p.cc_site)[s];
-#ifdef PM_CARVE_PROF
+#ifdef PM_PROP_PROF
     uint64_t pt = __builtin_amdgcn_s_memtime(), pt_same = 0, pt_sweep = 0, pt_pop = 0, pt_flags = 0;
     (void)pt_same; (void)pt_sweep; (void)pt_pop; (void)pt_flags;
 #define PP_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - pt; pt = t_; } while (0)
@@ -2387,7 +2165,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     }
     if (!valid) continue;  // (the workgroup's last seeds may be fewer than four)
     PP_MARK(pt_flags);
-#ifdef PM_CARVE_PROF
+#ifdef PM_PROP_PROF
     {
       if (lane == 0) {
         unsigned long long* pr = (unsigned long long*)p.status->prof;
@@ -2410,9 +2188,32 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         atomicAdd(&p.status->n_props, 1u);
       }
     }
-    // the row: K sorted entries, and the flags word in the last entry (PM_PROP_META)
-    const uint32_t meta = n_k | ((n_k < K) ? 0x80000000u : 0u) | (tail_ok << 30) | (clean << 29) | (tail_clear << 28);
-    prop_out[(size_t)out_row * PM_PROP_ROW + lane] = lane == PM_PROP_META ? (uint64_t)meta : mine;
+    // what the lane-per-seed rounds need to settle a step from the flags alone: is any listed term near the antipode,
+    // and from which entry on does the row lie within the certificate band of its LAST entry (a selection that ends
+    // in front of that entry has nothing to do with the row's tail) — the validator's own band expression
+    uint32_t safe, j_tail = n_k;
+    {
+      const uint64_t kb = (mine >> SB) << SB;
+      const bool located = lane < n_k && kb != noloc_kb;
+      const double a_l = __longlong_as_double((long long)kb);
+      safe = __ballot(located && a_l > PM_A_MAX_SAFE) == 0ull;
+      if (n_k > 0u) {
+        const uint64_t kb_le = (readlane_u64(mine, n_k - 1u) >> SB) << SB;
+        if (kb_le != noloc_kb) {
+          const double a_le = __longlong_as_double((long long)kb_le);
+          const uint64_t within = __ballot(located && (a_le - a_l) <= a_l * TIE_BAND + 1e-300);
+          j_tail = within ? (uint32_t)__builtin_ctzll(within) : n_k;
+        }
+      }
+    }
+    // the row: the flags word, then the K sorted entries
+    const uint32_t meta = n_k | (j_tail << 8) | (safe ? PM_ROW_SAFE : 0u) | ((n_k < K) ? PM_ROW_COMPLETE : 0u) |
+                          (tail_ok ? PM_ROW_TAIL_OK : 0u) | (clean ? PM_ROW_CLEAN : 0u) | (tail_clear ? PM_ROW_TAIL_CLEAR : 0u);
+    prop_out[(size_t)out_row * PM_PROP_ROW + ((lane + 1u) & 63u)] = lane == 63u ? (uint64_t)meta : mine;
+    // ... and the same once more as 32-bit words (flags, slot of entry 0, slot of entry 1, ...): what a lane of
+    // carve_lane_rounds reads — the head of this list, one or two cache lines
+    reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(prop_out + (size_t)out_row * PM_PROP_ROW + PM_PROP_SLOTS)[(lane + 1u) & 63u] =
+        lane == 63u ? meta : (uint32_t)(mine & ((1ull << SB) - 1ull));
   }
 }
 
@@ -2650,9 +2451,9 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   __syncthreads();
   uint32_t prop_k = 0, limit = 0, n_seeds = 0;
   const uint32_t max_s = p.max_size[ci];
-  if (p.proximity && n_list <= PM_CARVE_BIG_SLOTS && max_s - 1u < PM_PROP_META) {
+  if (p.proximity && n_list <= PM_CARVE_BIG_SLOTS && max_s - 1u < PM_PROP_KMAX) {
     const uint32_t k = max_s - 1u + PM_PROP_RESERVE;
-    prop_k = k < PM_PROP_META ? k : PM_PROP_META;
+    prop_k = k < PM_PROP_KMAX ? k : PM_PROP_KMAX;
     if (wave == 0) {
       prop_limit_scan(p, n_list, lane, &limit, &n_seeds);
       if (lane == 0) {
@@ -2799,8 +2600,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   uint32_t* lds_site = lds_wid + PM_CARVE_SLOTS;                             // [SLOTS]
   uint64_t* lds_key = reinterpret_cast<uint64_t*>(lds_site + PM_CARVE_SLOTS);  // [SLOTS]
   uint32_t* sel_out = reinterpret_cast<uint32_t*>(lds_key + PM_CARVE_SLOTS);  // [SEL_CAP]
-  uint16_t* lds_next = reinterpret_cast<uint16_t*>(sel_out + PM_CARVE_SEL_CAP);  // [SLOTS]
-  BlockRed& red = *reinterpret_cast<BlockRed*>(lds_next + PM_CARVE_SLOTS);
+  BlockRed& red = *reinterpret_cast<BlockRed*>(sel_out + PM_CARVE_SEL_CAP);
   uint32_t& s_n = *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&red) + sizeof(BlockRed));
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -2935,9 +2735,9 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         break;
       }
       // proposals: one neighbour list per located slot, K = (max - 1) + reserve entries
-      if ((flags & CARVE_F_PROPS) && p.proximity && c.n_list <= PM_CARVE_BIG_SLOTS && c.max_s - 1u < PM_PROP_META) {
+      if ((flags & CARVE_F_PROPS) && p.proximity && c.n_list <= PM_CARVE_BIG_SLOTS && c.max_s - 1u < PM_PROP_KMAX) {
         const uint32_t k = c.max_s - 1u + PM_PROP_RESERVE;
-        c.prop_k = k < PM_PROP_META ? k : PM_PROP_META;  // the last entry of a row carries its flags word
+        c.prop_k = k < PM_PROP_KMAX ? k : PM_PROP_KMAX;  // the last entry of a row carries its flags word
         // one proposal per located slot, at most PM_PROP_MAX_SEEDS per round: prop_limit = the slot after the
         // PM_PROP_MAX_SEEDS-th located one (a later round covers the rest)
         uint32_t n_seeds = 0;
@@ -2979,24 +2779,19 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
         r_loc[j] = g_loc[j];
       }
     }
-    if (in_lds) {
-      for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) {
-        lds_site[sl] = G(p.cc_site)[sl];
-        const uint32_t nx = (c.use_props && c.prop_k) ? G(p.same_next)[sl] : PM_NONE;
-        lds_next[sl] = nx < c.n_list ? (uint16_t)nx : (uint16_t)0xFFFFu;
-      }
-    }
+    if (in_lds)
+      for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) lds_site[sl] = G(p.cc_site)[sl];
     __syncthreads();
     PROF_MARK(10);
     const uint32_t slow0 = c.steps - c.fast_steps;
     const uint32_t mem_before_run = c.mem_off;
     int rc;
     if (in_lds) {
-      rc = carve_run_lds<false>(p, red, c, p.slot_wid, lds_site, lds_next, nullptr, lds_key, lds_key, r_alive, r_loc,
-                                part, sel_out, steps_before);
+      rc = carve_run_lds<false>(p, red, c, p.slot_wid, lds_site, lds_key, r_alive, r_loc, part, sel_out,
+                                reinterpret_cast<uint32_t*>(lds_key), steps_before);
     } else if (big) {
-      rc = carve_run_lds<true>(p, red, c, p.slot_wid, p.cc_site, nullptr, p.same_next, p.keys, lds_key, r_alive, r_loc,
-                               part, sel_out, steps_before);
+      rc = carve_run_lds<true>(p, red, c, p.slot_wid, p.cc_site, p.keys, r_alive, r_loc, part, sel_out,
+                               reinterpret_cast<uint32_t*>(lds_key), steps_before);
     } else {
       do {
         rc = carve_step_mem(p, red, c, part, p.keys, p.slot_wid, g_alive, g_loc, steps_before);
