@@ -1029,165 +1029,119 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
   }
 }
 
-// The chain of located steps of a proposal batch, one seed after the other, by wave 0 alone — no speculation: what
-// makes a step cheap is that nothing but the step's own dependency is on its critical path.  A step depends on its
-// predecessors through the alive bitmap only (row -> live bits -> kill: one LDS read, one ballot, one LDS atomic), and
-// LDS operations of one wave execute in order, so the next seed's read is issued right behind this seed's kill without
-// waiting for it.  Everything else is off the chain, and the loop over the steps touches LDS only (a global store in
-// it would put a wait for the memory pipeline into every step, as would a load consumed in it):
-//  * the proposal rows (lane = row entry, lane 0 = the seed itself; 256 coalesced bytes per row) are requested a
-//    block of CHAIN_BLOCK seeds ahead and parked in a small LDS ring when they have arrived; a step reads its row
-//    from the ring one step early;
-//  * the seeds of a block are picked from a 64-entry chunk of the seed list with one ballot (a seed that dies before
-//    its turn shows up as bit 0 of its own row's live mask);
-//  * the members are collected in LDS (the key array is idle while the chain runs) and written out, with the group
-//    records, when the chain ends or the buffer is full; the certificate is read off the row's flags word.
+// The chain of located steps of a proposal batch, one seed after the other — no speculation: what makes a step cheap
+// is that nothing but the step's own dependency is on its critical path.  A step depends on its predecessors through
+// the alive bitmap only (row -> live bits -> kill: one LDS read, one ballot, one LDS atomic), and LDS operations of
+// one wave execute in order, so the next seed's read is issued right behind this seed's kill without waiting for
+// it.  A lone wave issues an instruction every eight or nine cycles, so the step is cut down to that dependency and
+// everything else is done by two other waves of the workgroup, a pipeline through LDS rings (no barrier; the waves
+// poll a few control words):
+//   wave 1, the producer:  walks the batch's seed list, takes the entries whose seed is alive at that moment,
+//                          requests their proposal rows (lane = row entry, lane 0 = the seed itself; 256 coalesced
+//                          bytes per row, two blocks of CHAIN_BLOCK rows in flight) and parks them, digested — per
+//                          lane the LDS address of the slot's bitmap word and its bit — in a ring;
+//   wave 0, the chain:     per ring entry: the live lanes of the row (one read, one ballot); a dead seed (absorbed by
+//                          a group since its row was requested) is no step; otherwise the seed and its first `want`
+//                          live entries are killed (one atomic) and the live mask is passed on;
+//   wave 2, the collector: re-derives the selection from the live mask, collects the members in LDS (the key array is
+//                          idle while the chain runs) and writes them out with the group records, then hands the ring
+//                          entry back to the producer.
 // Because candidates are only ever REMOVED, the reference's sorted remaining list (mod.rs:234-255) is the proposal
 // row minus its dead entries; the group is the seed plus the row's first `want` live entries (mod.rs:545-561).
-// Full groups only (want = max_s - 1).  Everything else is handed to carve_fast_steps, which looks at the seed
-// at seed_cur with the row's keys: rows whose flags do not settle the certificate, exhausted rows (-> exact sweep),
-// the debug hook (FAST_SLOW: exactly one step), the last partial group, the first-come tail, the end of the
-// batch (FAST_SEQ).
+// Full groups only (want = max_s - 1), and only rows whose flags word settles the certificate wholesale.  Everything
+// else is handed to carve_fast_steps, which looks at the seed at seed_cur with the row's keys: other rows, exhausted
+// rows (-> exact sweep), the debug hook (FAST_SLOW: exactly one step), the last partial group, the first-come tail,
+// the end of the batch (FAST_SEQ).
 #ifndef CHAIN_BLOCK
 #define CHAIN_BLOCK 8u
 #endif
-#define CHAIN_RING (2u * CHAIN_BLOCK)                  // rows parked in LDS (a power of two, >= 2 blocks)
-#define CHAIN_RING_WORDS (3u * CHAIN_RING * 64u)       // per row and lane: bitmap word address, bit, slot
-#define CHAIN_STAGE_WORDS (PM_CARVE_SLOTS * 2u - CHAIN_RING_WORDS)  // member slots collected in LDS (the key array)
+#ifndef CHAIN_RING
+#define CHAIN_RING 32u                                 // rows parked in LDS (a power of two, >= 2 blocks)
+#endif
+// LDS layout of the chain inside the (idle) key array, in 32-bit words: per ring entry and lane (bitmap word address,
+// bit) as one 64-bit word and the slot; per ring entry the seed number, the digested flags and the live mask; the
+// control block; then the member buffer
+#define CHAIN_RING_WORDS (3u * CHAIN_RING * 64u + 4u * CHAIN_RING + 16u)
+#define CHAIN_STAGE_WORDS (PM_CARVE_SLOTS * 2u - CHAIN_RING_WORDS)
+// control words (u32 index into the control block)
+enum { CC_HEAD = 0, CC_CRIT = 1, CC_TAIL = 2, CC_CMD = 3, CC_ACK1 = 4, CC_ACK2 = 5, CC_START = 6, CC_DONE = 7,
+       CC_ABORT = 8, CC_G0 = 9, CC_M0 = 10 };
+enum { CH_RUN = 1u, CH_STOP = 2u, CH_QUIT = 3u };  // low two bits of a command word (the rest: sequence number)
+#define CHAIN_SPIN_LIMIT (1u << 22)  // polls before a wait gives up (a lost hand-shake must never hang the GPU)
+typedef __attribute__((address_space(3))) uint32_t chain_lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long chain_lds_u64;
+__device__ __forceinline__ uint32_t cc_ld(chain_lds_u32* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void cc_st(chain_lds_u32* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+struct ChainLds {
+  chain_lds_u64 *RAB, *Q;
+  chain_lds_u32 *RE, *RI, *RM, *CC, *STAGE;
+};
+__device__ __forceinline__ ChainLds chain_lds(uint32_t* l_buf) {
+  ChainLds L;
+  L.RAB = lds_pin<chain_lds_u64*>(l_buf);
+  L.Q = L.RAB + CHAIN_RING * 64u;
+  L.RE = (chain_lds_u32*)(L.Q + CHAIN_RING);
+  L.RI = L.RE + CHAIN_RING * 64u;
+  L.RM = L.RI + CHAIN_RING;
+  L.CC = L.RM + CHAIN_RING;
+  L.STAGE = L.CC + 16u;
+  return L;
+}
+// wait for a command word other than `seen`; 0 = gave up (abort)
+__device__ __forceinline__ uint32_t chain_wait_cmd(const ChainLds& L, uint32_t seen) {
+  uint32_t cmd, spins = 0u;
+  while ((cmd = cc_ld(&L.CC[CC_CMD])) == seen) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > CHAIN_SPIN_LIMIT || cc_ld(&L.CC[CC_ABORT])) {
+      cc_st(&L.CC[CC_ABORT], 1u);
+      return 0u;
+    }
+  }
+  return cmd;
+}
+
+// ---- producer (wave 1): serves RUN commands until QUIT
 template <bool BIG>
-__device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint64_t* l_alive, uint32_t* l_buf,
-                                        uint32_t steps_before, uint32_t& seed_cur) {
-  StepCtx c = c_ref;
+__device__ __noinline__ void carve_chain_produce(const CarveArgs& p, const StepCtx& c, uint64_t* l_alive, uint32_t* l_buf) {
   constexpr uint32_t NB = CHAIN_BLOCK, R = CHAIN_RING;
-  static_assert(R >= 2u * NB && (R & (R - 1u)) == 0u && R <= 64u, "ring geometry");
+  static_assert(R >= 2u * NB && (R & (R - 1u)) == 0u, "ring geometry");
   const uint32_t lane = threadIdx.x & 63u;
-  typedef __attribute__((address_space(3))) uint32_t lds_u32;
-  lds_u32* const A = lds_pin<lds_u32*>(l_alive);  // the alive bitmap as 32-bit words
-  // ring entry r: for every lane the LDS address of its slot's bitmap word (RA), its bit (RB; 0 = no entry) and the
-  // slot (RE); lane 0 stands for the seed, lane e + 1 for row entry e
-  lds_u32* const RA = lds_pin<lds_u32*>(l_buf);
-  lds_u32* const RB = RA + R * 64u;
-  lds_u32* const RE = RB + R * 64u;
-  lds_u32* const STAGE = RE + R * 64u;
+  chain_lds_u32* const A = lds_pin<chain_lds_u32*>(l_alive);
+  const ChainLds L = chain_lds(l_buf);
   const uint32_t a_base = (uint32_t)(uintptr_t)A;
-  const auto members = G(p.members);
-  const auto g_cfg = G(p.g_cfg);
-  const auto g_n = G(p.g_n);
-  const auto g_off = G(p.g_off);
   const auto rows32 = G((const uint32_t*)p.prop);  // row r: 2 * PM_PROP_ROW words; its compact slot list (flags word,
                                                    // slot of entry 0, 1, ...) starts at word 2 * PM_PROP_SLOTS
   const auto seed_slots = G((const uint32_t*)p.seed_slots);
-  const uint32_t dbg_every = UNI(p.debug_uncertain_every);
   const uint32_t world = UNI(p.dist_world), rows_pr = UNI(c.rows_pr), n_seeds = UNI(c.n_seeds);
-  const uint32_t n_list_v = UNI(c.n_list);
-  const uint32_t group_n = UNI(c.max_s), want = group_n - 1u;
-  const uint32_t cfg = UNI(c.cfg);
-  const uint32_t cap_g = UNI(p.cap_groups), cap_m = UNI(p.cap_members);
-  const uint32_t step0 = UNI(steps_before) + UNI(c.steps);
-  const uint32_t base_cand = UNI(c.n_cand);
-  uint32_t n_groups = UNI(c.n_groups), mem_off = UNI(c.mem_off);  // as of the last write-out
-  uint32_t n_cand = base_cand, commits = 0, staged = 0;            // staged: groups collected in LDS
-  int action = FAST_SEQ;
-  uint32_t exit_cur = n_seeds;  // where carve_fast_steps resumes its search for the first live seed
-
-  // groups collected in LDS -> group records + members (all of them full groups, back to back)
-  auto write_out = [&]() {
-    for (uint32_t g = lane; g < staged; g += 64u) {
-      g_cfg[n_groups + g] = cfg;
-      g_n[n_groups + g] = group_n;
-      g_off[n_groups + g] = mem_off + g * group_n;
+  uint32_t seen = 0u;  // last command word acted on
+  for (;;) {
+    uint32_t cmd = chain_wait_cmd(L, seen);
+    if (cmd == 0u) return;
+    seen = cmd;
+    if ((cmd & 3u) == CH_QUIT) return;
+    if ((cmd & 3u) != CH_RUN) {  // (a STOP without a RUN in between)
+      cc_st(&L.CC[CC_ACK1], cmd);
+      continue;
     }
-    const uint32_t nm = staged * group_n;
-    for (uint32_t k = lane; k < nm; k += 64u) members[mem_off + k] = STAGE[k];
-    n_groups += staged;
-    mem_off += nm;
-    staged = 0u;
-  };
-  // Commits that can follow one another before any of the conditions that end the chain can come true (they are
-  // looked at again when the budget is used up): candidates for full groups, room in the output arrays and in the
-  // LDS buffer, the re-proposal threshold, the debug hook.  >= 1 whenever none of those conditions holds.
-  auto budget_now = [&]() -> uint32_t {
-    uint32_t b = n_cand / group_n;
-    const uint32_t room_g = cap_g - (n_groups + staged), room_m = (cap_m - mem_off) / group_n - staged;
-    b = b < room_g ? b : room_g;
-    b = b < room_m ? b : room_m;
-    const uint32_t room_s = CHAIN_STAGE_WORDS / group_n - staged;
-    b = b < room_s ? b : room_s;
-    if (n_list_v > 256u) {
-      const uint32_t t = n_cand * 2u >= n_list_v ? (n_cand * 2u - n_list_v) / (2u * group_n) + 1u : 1u;
-      b = b < t ? b : t;
-    }
-    if (dbg_every) {
-      const uint32_t r = (step0 + commits + 1u) % dbg_every;
-      b = b < dbg_every - r ? b : dbg_every - r;
-    }
-    return b;
-  };
-
-  // ---- the seed list, 64 entries at a time (q: slots of entries cbase .. cbase + 63; qn: the next 64, on their way)
-  uint32_t cbase = UNI(seed_cur) & ~63u, cpos = UNI(seed_cur);  // cpos: first entry not yet handed to a block
-  auto load_chunk = [&](uint32_t b) -> uint32_t {
-    const uint32_t i = b + lane;
-    return seed_slots[i < n_seeds ? i : (n_seeds ? n_seeds - 1u : 0u)];
-  };
-  uint32_t q = load_chunk(cbase), qn = load_chunk(cbase + 64u);
-  // ring entry r: seed number and what the step needs of the row's flags word in lane r of ridx_v / rmeta_v
-  // (bit 0: clean and safe, bit 1: the tail is settled, bits 8..15: first entry within the band of the last one);
-  // entries [tail, head)
-  uint32_t ridx_v = 0u, rmeta_v = 0u, head = 0u, tail = 0u;
-  // the block on its way: rows in prow[], seed number / slot in lanes 0 .. pend_n - 1 of pidx_v / ppos_v
-  uint32_t prow[NB], pidx_v = 0u, ppos_v = 0u, pend_n = 0u;
+    // ---- RUN: the seed list from CC_START on, 64 entries at a time (q: slots of entries cbase .. cbase + 63; qn: the
+    // next 64, on their way)
+    const uint32_t start = UNI(cc_ld(&L.CC[CC_START]));
+    uint32_t cbase = start & ~63u, cpos = start, head = 0u;  // cpos: first entry not yet handed to a block
+    auto load_chunk = [&](uint32_t b) -> uint32_t {
+      const uint32_t i = b + lane;
+      return seed_slots[i < n_seeds ? i : (n_seeds ? n_seeds - 1u : 0u)];
+    };
+    uint32_t q = load_chunk(cbase), qn = load_chunk(cbase + 64u);
+    uint32_t rowA[NB], rowB[NB], idxA = 0u, idxB = 0u, posA = 0u, posB = 0u, nA = 0u, nB = 0u;
 #pragma unroll
-  for (uint32_t k = 0; k < NB; ++k) prow[k] = 0u;
-  uint32_t budget = 0u;
-#ifdef PM_CARVE_PROF
-  uint64_t ct = __builtin_amdgcn_s_memtime(), ct_park = 0, ct_fetch = 0, ct_steps = 0;
-  uint32_t cn_outer = 0, cn_dead = 0, cn_wait = 0;
-#define CH_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - ct; ct = t_; } while (0)
-#define CH_COUNT(var) (++var)
-#else
-#define CH_MARK(var)
-#define CH_COUNT(var)
-#endif
-
-  if (n_seeds > 0u) {
-    for (;;) {
-      CH_COUNT(cn_outer);
-      head = UNI(head);
-      tail = UNI(tail);
-      pend_n = UNI(pend_n);
-      cpos = UNI(cpos);
-      cbase = UNI(cbase);
-      // ---- (a) the block requested a round of steps ago has arrived: park it in the ring, digested
-      if (pend_n && head - tail + pend_n <= R) {
-        uint32_t pmeta_v = 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < NB; ++k) {
-          if (k < pend_n) {
-            const uint32_t meta = UNI(prow[k]);
-            const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)ppos_v, (int)k);
-            const uint32_t e = lane == 0u ? sp : prow[k];
-            const uint32_t o = ((head + k) & (R - 1u)) * 64u + lane;
-            RA[o] = a_base + ((e >> 5) << 2);
-            RB[o] = lane <= (meta & 0xFFu) ? 1u << (e & 31u) : 0u;
-            RE[o] = e;
-            const uint32_t m2 = (((meta & PM_ROW_CLEAN) && (meta & PM_ROW_SAFE)) ? 1u : 0u) |
-                                ((meta & (PM_ROW_COMPLETE | PM_ROW_TAIL_CLEAR | PM_ROW_TAIL_OK)) ? 2u : 0u) | (meta & 0xFF00u);
-            pmeta_v = lane == k ? m2 : pmeta_v;
-          }
-        }
-        // lane r of the ring registers <- lane (r - head) mod R of the block registers
-        const uint32_t src = (lane - head) & (R - 1u);
-        const uint32_t vi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)pidx_v);
-        const uint32_t vm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)pmeta_v);
-        const bool mine = lane < R && src < pend_n;
-        ridx_v = mine ? vi : ridx_v;
-        rmeta_v = mine ? vm : rmeta_v;
-        head += pend_n;
-        pend_n = 0u;
-      }
-      CH_MARK(ct_park);
-      // ---- (b) request the rows of the next (up to) NB seeds of the list that are alive right now
+    for (uint32_t k = 0; k < NB; ++k) rowA[k] = rowB[k] = 0u;
+    // request the rows of the next (up to) NB seeds of the list that are alive right now
+    auto request = [&](uint32_t (&prow)[NB], uint32_t& pidx_v, uint32_t& ppos_v, uint32_t& pend_n) {
+      pend_n = 0u;
       while (pend_n == 0u && cpos < n_seeds) {
         const uint32_t i = cbase + lane;
         const uint32_t w = A[q >> 5];
@@ -1214,44 +1168,288 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
           qn = load_chunk(cbase + 64u);
         }
       }
-      CH_MARK(ct_fetch);
-      // ---- (c) steps
-      if (tail == head) {
-        if (pend_n == 0u) {  // the list is used up
+    };
+    // park a block that has arrived: wait for room, write the digested rows, publish the new head.
+    // Returns false when a new command came in while waiting.
+    auto park = [&](uint32_t (&prow)[NB], uint32_t pidx_v, uint32_t ppos_v, uint32_t& pend_n) -> bool {
+      if (pend_n == 0u) return true;
+      uint32_t sp_n = 0u;
+      while (head - cc_ld(&L.CC[CC_TAIL]) + pend_n > R) {
+        __builtin_amdgcn_s_sleep(1);
+        if (cc_ld(&L.CC[CC_CMD]) != seen) return false;
+        if (++sp_n > CHAIN_SPIN_LIMIT) {
+          cc_st(&L.CC[CC_ABORT], 1u);
+          return false;
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < NB; ++k) {
+        if (k < pend_n) {
+          const uint32_t meta = UNI(prow[k]);
+          const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)ppos_v, (int)k);
+          const uint32_t si = (uint32_t)__builtin_amdgcn_readlane((int)pidx_v, (int)k);
+          const uint32_t e = lane == 0u ? sp : prow[k];
+          const uint32_t r = (head + k) & (R - 1u);
+          const uint32_t o = r * 64u + lane;
+          const uint32_t bit = lane <= (meta & 0xFFu) ? 1u << (e & 31u) : 0u;
+          L.RAB[o] = ((unsigned long long)bit << 32) | (a_base + ((e >> 5) << 2));
+          L.RE[o] = e;
+          // what a step needs of the flags word: bit 0 clean and safe, bit 1 the tail is settled, bits 8..15 the
+          // first entry within the band of the last one
+          const uint32_t m2 = (((meta & PM_ROW_CLEAN) && (meta & PM_ROW_SAFE)) ? 1u : 0u) |
+                              ((meta & (PM_ROW_COMPLETE | PM_ROW_TAIL_CLEAR | PM_ROW_TAIL_OK)) ? 2u : 0u) | (meta & 0xFF00u);
+          if (lane == 0u) {
+            L.RI[r] = si;
+            L.RM[r] = m2;
+          }
+        }
+      }
+      head += pend_n;
+      pend_n = 0u;
+      cc_st(&L.CC[CC_HEAD], head);  // (LDS operations of a wave execute in order: the rows are there before the head)
+      return true;
+    };
+    bool running = true;
+    request(rowA, idxA, posA, nA);
+    while (running) {
+      request(rowB, idxB, posB, nB);
+      if (!park(rowA, idxA, posA, nA)) break;
+      if (nB == 0u) running = false;
+      if (running) {
+        request(rowA, idxA, posA, nA);
+        if (!park(rowB, idxB, posB, nB)) break;
+        if (nA == 0u) running = false;
+      }
+      if (cc_ld(&L.CC[CC_CMD]) != seen) break;
+    }
+    if (!running) cc_st(&L.CC[CC_DONE], 1u);  // the list is used up: CC_HEAD is final
+    cmd = chain_wait_cmd(L, seen);
+    if (cmd == 0u) return;
+    seen = cmd;
+    if ((cmd & 3u) == CH_QUIT) return;
+    cc_st(&L.CC[CC_ACK1], cmd);  // STOP
+  }
+}
+
+// ---- collector (wave 2): serves RUN commands until QUIT
+template <bool BIG>
+__device__ __noinline__ void carve_chain_collect(const CarveArgs& p, const StepCtx& c, uint32_t* l_buf) {
+  constexpr uint32_t R = CHAIN_RING;
+  const uint32_t lane = threadIdx.x & 63u;
+  const ChainLds L = chain_lds(l_buf);
+  const auto members = G(p.members);
+  const auto g_cfg = G(p.g_cfg);
+  const auto g_n = G(p.g_n);
+  const auto g_off = G(p.g_off);
+  const uint32_t group_n = UNI(c.max_s), want = group_n - 1u, cfg = UNI(c.cfg);
+  uint32_t seen = 0u;
+  for (;;) {
+    uint32_t cmd = chain_wait_cmd(L, seen);
+    if (cmd == 0u) return;
+    seen = cmd;
+    if ((cmd & 3u) == CH_QUIT) return;
+    if ((cmd & 3u) != CH_RUN) {
+      cc_st(&L.CC[CC_ACK2], cmd);
+      continue;
+    }
+    uint32_t n_groups = UNI(cc_ld(&L.CC[CC_G0])), mem_off = UNI(cc_ld(&L.CC[CC_M0]));  // as of the last write-out
+    uint32_t staged = 0u, t2 = 0u;
+    // groups collected in LDS -> group records + members (all of them full groups, back to back)
+    auto write_out = [&]() {
+      for (uint32_t g = lane; g < staged; g += 64u) {
+        g_cfg[n_groups + g] = cfg;
+        g_n[n_groups + g] = group_n;
+        g_off[n_groups + g] = mem_off + g * group_n;
+      }
+      const uint32_t nm = staged * group_n;
+      for (uint32_t k = lane; k < nm; k += 64u) members[mem_off + k] = L.STAGE[k];
+      n_groups += staged;
+      mem_off += nm;
+      staged = 0u;
+    };
+    uint32_t idle = 0u;
+    bool stopping = false;
+    for (;;) {
+      const uint32_t crit = UNI(cc_ld(&L.CC[CC_CRIT]));
+      if (t2 != crit) {
+        idle = 0u;
+        while (t2 != crit) {
+          t2 = UNI(t2);
+          staged = UNI(staged);
+          const uint32_t r = t2 & (R - 1u);
+          const unsigned long long av = L.Q[r];
+          const uint64_t a = ((uint64_t)UNI((uint32_t)(av >> 32)) << 32) | UNI((uint32_t)av);
+          if (a) {  // a committed step: the seed and its `want` nearest live neighbours, in key order
+            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a, 0u));
+            if (((a >> lane) & 1ull) && rk <= want)
+              L.STAGE[staged * group_n + rk] = L.RE[r * 64u + lane];  // slots (translated to worker ids after the run)
+            staged += 1u;
+            if ((staged + 1u) * group_n > CHAIN_STAGE_WORDS) write_out();
+          }
+          ++t2;
+        }
+        cc_st(&L.CC[CC_TAIL], t2);  // room for the producer
+        continue;
+      }
+      if (stopping) break;  // (CC_CRIT was final when the STOP was seen, and everything up to it is collected)
+      if (cc_ld(&L.CC[CC_CMD]) != seen) {
+        stopping = true;  // one more look at CC_CRIT: the chain publishes its last entries before the STOP
+        continue;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      if (++idle > CHAIN_SPIN_LIMIT || cc_ld(&L.CC[CC_ABORT])) {
+        cc_st(&L.CC[CC_ABORT], 1u);
+        return;
+      }
+    }
+    write_out();
+    cmd = chain_wait_cmd(L, seen);
+    if (cmd == 0u) return;
+    seen = cmd;
+    if ((cmd & 3u) == CH_QUIT) return;
+    cc_st(&L.CC[CC_ACK2], cmd);  // STOP: the members are written
+  }
+}
+
+// ---- the chain itself (wave 0)
+template <bool BIG>
+__device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint32_t* l_buf, uint32_t steps_before,
+                                        uint32_t& seed_cur, uint32_t& cmd_seq) {
+  StepCtx c = c_ref;
+  constexpr uint32_t R = CHAIN_RING;
+  const uint32_t lane = threadIdx.x & 63u;
+  typedef chain_lds_u32 lds_u32;
+  const ChainLds L = chain_lds(l_buf);
+  const uint32_t dbg_every = UNI(p.debug_uncertain_every);
+  const uint32_t n_seeds = UNI(c.n_seeds);
+  const uint32_t n_list_v = UNI(c.n_list);
+  const uint32_t group_n = UNI(c.max_s), want = group_n - 1u;
+  const uint32_t cap_g = UNI(p.cap_groups), cap_m = UNI(p.cap_members);
+  const uint32_t step0 = UNI(steps_before) + UNI(c.steps);
+  const uint32_t base_cand = UNI(c.n_cand), base_groups = UNI(c.n_groups), base_mem = UNI(c.mem_off);
+  uint32_t n_cand = base_cand, commits = 0;
+  int action = FAST_SEQ;
+  uint32_t exit_cur = n_seeds;  // where carve_fast_steps resumes its search for the first live seed
+  // Commits that can follow one another before any of the conditions that end the chain can come true (they are
+  // looked at again when the budget is used up): candidates for full groups, room in the output arrays, the
+  // re-proposal threshold, the debug hook.  >= 1 whenever none of those conditions holds.
+  auto budget_now = [&]() -> uint32_t {
+    uint32_t b = n_cand / group_n;
+    const uint32_t room_g = cap_g - (base_groups + commits), room_m = (cap_m - base_mem) / group_n - commits;
+    b = b < room_g ? b : room_g;
+    b = b < room_m ? b : room_m;
+    if (n_list_v > 256u) {
+      const uint32_t t = n_cand * 2u >= n_list_v ? (n_cand * 2u - n_list_v) / (2u * group_n) + 1u : 1u;
+      b = b < t ? b : t;
+    }
+    if (dbg_every) {
+      const uint32_t r = (step0 + commits + 1u) % dbg_every;
+      b = b < dbg_every - r ? b : dbg_every - r;
+    }
+    return b;
+  };
+#ifdef PM_CARVE_PROF
+  uint64_t ct = __builtin_amdgcn_s_memtime(), ct_wait = 0, ct_steps = 0, ct_stop = 0;
+  uint32_t cn_outer = 0, cn_dead = 0, cn_wait = 0;
+#define CH_MARK(var) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); var += t_ - ct; ct = t_; } while (0)
+#define CH_COUNT(var) (++var)
+#else
+#define CH_MARK(var)
+#define CH_COUNT(var)
+#endif
+
+  // ---- start the producer and the collector
+  if (lane == 0u) {
+    cc_st(&L.CC[CC_HEAD], 0u);
+    cc_st(&L.CC[CC_CRIT], 0u);
+    cc_st(&L.CC[CC_TAIL], 0u);
+    cc_st(&L.CC[CC_DONE], 0u);
+    cc_st(&L.CC[CC_START], UNI(seed_cur));
+    cc_st(&L.CC[CC_G0], base_groups);
+    cc_st(&L.CC[CC_M0], base_mem);
+  }
+  cmd_seq += 4u;
+  if (lane == 0u) cc_st(&L.CC[CC_CMD], cmd_seq | CH_RUN);
+  uint32_t tail = 0u, budget = 0u;
+  bool aborted = false;
+  if (n_seeds > 0u) {
+    for (;;) {
+      CH_COUNT(cn_outer);
+      tail = UNI(tail);
+      // ---- rows parked and not yet looked at
+      uint32_t head = UNI(cc_ld(&L.CC[CC_HEAD]));
+      if (head == tail) {
+        uint32_t sp_n = 0u;
+        bool used_up = false;
+        for (;;) {
+          const uint32_t done = UNI(cc_ld(&L.CC[CC_DONE]));
+          head = UNI(cc_ld(&L.CC[CC_HEAD]));  // (read behind the flag: a set flag means this head is final)
+          if (head != tail) break;
+          if (done) {
+            used_up = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          if (++sp_n > CHAIN_SPIN_LIMIT || UNI(cc_ld(&L.CC[CC_ABORT]))) {
+            aborted = true;
+            break;
+          }
+        }
+        CH_COUNT(cn_wait);
+        if (aborted) break;
+        if (used_up) {  // the list is used up
           action = FAST_SEQ;
           exit_cur = n_seeds;
           break;
         }
-        CH_COUNT(cn_wait);
-        continue;  // (the first block, or a block of seeds that had all died: wait for the rows under way)
       }
+      CH_MARK(ct_wait);
       uint32_t n_steps = head - tail;
-      n_steps = n_steps < NB ? n_steps : NB;
+      n_steps = n_steps < 16u ? n_steps : 16u;
       bool stop = false;
-      uint32_t o_next = (tail & (R - 1u)) * 64u + lane;
-      uint32_t ra_n = RA[o_next], rb_n = RB[o_next], re_n = RE[o_next];
-      for (uint32_t s = 0; s < n_steps; ++s) {
-        // (loop-carried counters pinned as wave-uniform: otherwise every branch on them is an exec-mask sequence)
-        tail = UNI(tail);
-        budget = UNI(budget);
-        staged = UNI(staged);
-        n_cand = UNI(n_cand);
-        commits = UNI(commits);
-        const uint32_t r = tail & (R - 1u);
-        const uint32_t ra = ra_n, rb = rb_n, re = re_n;
-        const uint32_t w = *(lds_u32*)(uintptr_t)ra;
-        o_next = ((tail + 1u) & (R - 1u)) * 64u + lane;  // (the next step's row, one step early)
-        ra_n = RA[o_next];
-        rb_n = RB[o_next];
-        re_n = RE[o_next];
-        const uint64_t a = __ballot((w & rb) != 0u);
-        ++tail;
-        if (!(a & 1ull)) {  // absorbed by a group since its row was requested: no step
-          CH_COUNT(cn_dead);
-          continue;
-        }
+      unsigned long long rab_n = L.RAB[(tail & (R - 1u)) * 64u + lane];
+      uint32_t rm_n = L.RM[tail & (R - 1u)];
+      const uint32_t flags_needed = want != 0u ? 3u : 0u;
+      uint32_t s = 0u;
+      while (s < n_steps) {
+        // ---- the steps that need no second look, as straight-line code with ONE way out: a dead seed (absorbed by a
+        // group since its row was requested) is a step that selects nothing
+        bool good = true;
+        uint64_t a = 0ull;
+        uint32_t r = 0u, ra = 0u, rb = 0u, m2 = 0u;
+        do {
+          r = tail & (R - 1u);
+          ra = (uint32_t)rab_n;
+          rb = (uint32_t)(rab_n >> 32);
+          m2 = UNI(rm_n);
+          const uint32_t w = *(lds_u32*)(uintptr_t)ra;
+          rab_n = L.RAB[((tail + 1u) & (R - 1u)) * 64u + lane];  // (the next step's row, one step early)
+          rm_n = L.RM[(tail + 1u) & (R - 1u)];
+          a = __ballot((w & rb) != 0u);
+          const bool live = (a & 1ull) != 0ull;
+          // my rank among the live lanes: 0 for the seed, e + 1 for the e-th live entry
+          const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a, 0u));
+          const uint64_t selm = live ? a & __ballot(rk <= want) : 0ull;  // the seed and its `want` nearest live neighbours
+          // enough live entries, a row whose flags settle the certificate wholesale, and no end of the chain in sight
+          good = !live || ((uint32_t)__popcll(selm) == group_n && (m2 & flags_needed) == flags_needed && budget != 0u);
+          if (__builtin_expect(!good, 0)) break;
+          // commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
+          if ((selm >> lane) & 1ull)
+            __hip_atomic_fetch_and((lds_u32*)(uintptr_t)ra, ~rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          L.Q[r] = live ? a : 0ull;  // (every lane the same word: the collector re-derives the selection from it)
+          ++tail;
+          ++s;
+          n_cand -= live ? group_n : 0u;
+          commits += live ? 1u : 0u;
+          budget -= live ? 1u : 0u;
+#ifdef PM_CARVE_PROF
+          cn_dead += live ? 0u : 1u;
+#endif
+        } while (s < n_steps);
+        if (good) break;
+        // ---- a live seed that needs a second look (its row is loaded: ra, rb, m2, a)
         if (budget == 0u) {
-          exit_cur = (uint32_t)__builtin_amdgcn_readlane((int)ridx_v, (int)r);
+          exit_cur = UNI(L.RI[r]);
           // `while total_available >= min` with `compatible < min => break` (mod.rs:507,517-519) hold while full
           // groups fit (max_s >= min_s); the last, partial group is carve_fast_steps' business
           if (n_cand < group_n) {
@@ -1259,7 +1457,7 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
             stop = true;
             break;
           }
-          if (n_groups + staged >= cap_g || mem_off + (staged + 1u) * group_n > cap_m) {
+          if (base_groups + commits >= cap_g || base_mem + (commits + 1u) * group_n > cap_m) {
             action = FAST_OVERFLOW;
             stop = true;
             break;
@@ -1276,45 +1474,58 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
             stop = true;
             break;
           }
-          if ((staged + 1u) * group_n > CHAIN_STAGE_WORDS) write_out();
           budget = budget_now();
         }
-        // my rank among the live lanes: 0 for the seed, e + 1 for the e-th live entry
-        const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a, 0u));
-        const uint64_t selm = a & __ballot(rk <= want);  // the seed and its `want` nearest live neighbours
-        const uint32_t n_live = (uint32_t)__popcll(a) - 1u;
-        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)rmeta_v, (int)r);
-        // the row's flags settle the certificate: no two entries near each other at different sites, nothing near
-        // the antipode, and a tail that is complete / clear / at one site — or a selection that ends in front of
-        // the tail's band
-        bool ok = n_live >= want;
-        if (want != 0u) {
-          ok = ok && (m2 & 1u);
-          if (!(m2 & 2u)) ok = ok && 62u - (uint32_t)__builtin_clzll(selm | 2ull) < ((m2 >> 8) & 0xFFu);
+        {
+          const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a, 0u));
+          const uint64_t selm = a & __ballot(rk <= want);
+          // enough live entries, and a row whose flags settle the certificate: no two entries near each other at
+          // different sites, nothing near the antipode, and a tail that is complete / clear / at one site — or a
+          // selection that ends in front of the tail's band
+          bool ok = (uint32_t)__popcll(selm) == group_n;
+          if (want != 0u && (m2 & 3u) != 3u)
+            ok = ok && (m2 & 1u) && 62u - (uint32_t)__builtin_clzll(selm | 2ull) < ((m2 >> 8) & 0xFFu);
+          if (!ok) {
+            exit_cur = UNI(L.RI[r]);
+            action = FAST_SLOW;
+            stop = true;
+            break;
+          }
+          if ((selm >> lane) & 1ull)
+            __hip_atomic_fetch_and((lds_u32*)(uintptr_t)ra, ~rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          L.Q[r] = a;
+          ++tail;
+          ++s;
+          n_cand -= group_n;
+          commits += 1u;
+          budget -= 1u;
         }
-        if (!ok) {
-          exit_cur = (uint32_t)__builtin_amdgcn_readlane((int)ridx_v, (int)r);
-          action = FAST_SLOW;
-          stop = true;
-          break;
-        }
-        // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585)
-        if ((selm >> lane) & 1ull) {
-          __hip_atomic_fetch_and((lds_u32*)(uintptr_t)ra, ~rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          STAGE[staged * group_n + rk] = re;  // slots (translated to worker ids after the run); rk = 0: the seed
-        }
-        staged += 1u;
-        n_cand -= group_n;
-        commits += 1u;
-        budget -= 1u;
       }
+      if (lane == 0u) cc_st(&L.CC[CC_CRIT], tail);  // for the collector
       CH_MARK(ct_steps);
       if (stop) break;
     }
   }
-  write_out();
-  c.n_groups = n_groups;
-  c.mem_off = mem_off;
+  // ---- stop the other two (they must be off the key array before it is used again; the collector writes out first)
+  cmd_seq += 4u;
+  if (lane == 0u) cc_st(&L.CC[CC_CMD], cmd_seq | CH_STOP);
+  {
+    uint32_t sp_n = 0u;
+    while (UNI(cc_ld(&L.CC[CC_ACK1])) != (cmd_seq | CH_STOP) || UNI(cc_ld(&L.CC[CC_ACK2])) != (cmd_seq | CH_STOP)) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++sp_n > CHAIN_SPIN_LIMIT || UNI(cc_ld(&L.CC[CC_ABORT]))) {
+        aborted = true;
+        break;
+      }
+    }
+  }
+  CH_MARK(ct_stop);
+  if (aborted) {
+    if (lane == 0u) cc_st(&L.CC[CC_ABORT], 1u);
+    action = FAST_OVERFLOW;  // (reported as an error; never seen)
+  }
+  c.n_groups = base_groups + commits;
+  c.mem_off = base_mem + commits * group_n;
   c.n_cand = n_cand;
   c.total_available -= commits * group_n;
   c.steps += commits;
@@ -1328,8 +1539,8 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
     pr[1] += 1u;        // calls
     pr[2] += commits;
     pr[4] += action == FAST_SLOW ? 1u : 0u;
-    pr[16] += ct_park;
-    pr[17] += ct_fetch;
+    pr[16] += ct_wait;
+    pr[17] += ct_stop;
     pr[18] += ct_steps;
     pr[19] += cn_outer;
     pr[23] += cn_dead;
@@ -1359,18 +1570,24 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
   const bool have_props = c.mode == CARVE_MODE_FORM && c.use_props;
   auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
   uint32_t seed_cur = 0;  // wave 0: how far into the batch's seed list the carve has come
+  const ChainLds CL = chain_lds(l_stage);
   for (;;) {
     if (have_props) {
       // Everything the proposals can serve is done by wave 0 alone (everyone else waits at the barrier): the chain
       // of located steps (carve_chain), and — with the row's keys at hand — whatever it hands over: rows whose
       // flags do not settle the certificate, exhausted rows, the last partial group, the first-come tail.
+      const bool chain = c.prop_k && c.proximity && p.rounds_enabled && c.max_s - 1u < PM_PROP_KMAX;
+      if (chain) {  // the control block of the chain (an exact step in between has used the key array it lives in)
+        if (tid < 16u) cc_st(&CL.CC[tid], 0u);
+        lds_barrier();
+      }
       if (wave == 0) {
         PROF_DECL;
-        const bool chain = c.prop_k && c.proximity && p.rounds_enabled && c.max_s - 1u < PM_PROP_KMAX;
         int act = FAST_SEQ;
+        uint32_t cmd_seq = 0u;  // commands to the producer are numbered
         for (;;) {
           if (chain) {
-            act = carve_chain<BIG>(p, c, l_alive, l_stage, steps_before, seed_cur);
+            act = carve_chain<BIG>(p, c, l_stage, steps_before, seed_cur, cmd_seq);
             PROF_MARK(0);
             if (act == FAST_OVERFLOW || act == FAST_REPROPOSE) break;
           }
@@ -1378,6 +1595,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
                                       (chain && act == FAST_SLOW) ? 1u : 0xFFFFFFFFu);
           if (act != FAST_AGAIN) break;
         }
+        if (chain && lane == 0) cc_st(&CL.CC[CC_CMD], (cmd_seq + 4u) | CH_QUIT);  // waves 1 and 2 come to the barrier
         if (lane == 0) {
           red.f_action = (uint32_t)act;
           red.f_n_cand = c.n_cand;
@@ -1389,6 +1607,10 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
           red.f_cand_sum = c.cand_sum;
         }
         PROF_MARK(11);
+      } else if (wave == 1 && chain) {
+        carve_chain_produce<BIG>(p, c, l_alive, l_stage);
+      } else if (wave == 2 && chain) {
+        carve_chain_collect<BIG>(p, c, l_stage);
       }
       lds_barrier();
       const uint32_t act = red.f_action;

@@ -38,7 +38,7 @@ print(f"  launch anatomy (ticks): init/status={out[15]} ({pct(out[15])}) prepare
       f"group_of+exit={out[14]} ({pct(out[14])})")
 print(f"  inside run: chain of located steps={out[0]} ({pct(out[0])}; {out[1]} calls, {out[2]} commits = {out[0] / max(out[2], 1):.0f} ticks each, "
       f"{out[4]} hand-overs) wave 0 in total={out[11]} ({pct(out[11])}) exact steps={out[22]} ({pct(out[22])})")
-print(f"  chain anatomy (ticks): park rows={out[16]} request rows={out[17]} steps={out[18]}; {out[19]} blocks, {out[24]} of them waited for rows, {out[23]} seeds dead at their turn")
+print(f"  chain anatomy (ticks): waiting for rows={out[16]} steps={out[18]} stopping the other waves={out[17]}; {out[19]} batches of steps, {out[24]} of them waited, {out[23]} seeds dead at their turn")
 print(f"  prepare: count passes={out[26]} ({out[30]} calls) placement={out[27]} proposal limit={out[28]} other={out[29]}")
 print(f"  exact-sweep reasons: no proposal={out[20]} debug hook={out[21]} row exhausted={out[25]} certificate={out[31]}")
 print(f"  total ticks {tot}; ticks per ms = {tot / s['ms_carve_kernel']:.0f}")
