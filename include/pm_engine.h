@@ -151,10 +151,15 @@ typedef struct {
   uint32_t debug_uncertain_every; /* test hook: treat every n-th carve step as a near-tie so the
                                      exact host resolve path runs (0 = off) */
   uint32_t sweep_variant;        /* pair-sweep kernel: 0 = default (best), 1 = scalar reference kernel */
-  uint32_t carve_variant;        /* group formation: 0 = default (full-chip neighbour-list proposals + speculative
-                                    in-order validation rounds),
+  uint32_t carve_variant;        /* group formation: 0 = default (full-chip neighbour-list proposals validated by the
+                                    in-order chain, one batch at a time),
                                     1 = single-workgroup sequential exact sweep only (the straightforward kernel),
-                                    2 = proposals with single-wave sequential validation (no speculative rounds) */
+                                    2 = proposals with single-wave validation that re-derives every certificate from
+                                        the row's keys,
+                                    4 = as 0, but the next batch is prepared and proposed (from a snapshot, on a
+                                        second stream) beside the validation of the batch in front of it; measured
+                                        slower than 0 on the BASELINE swarms — the batch behind is stale by what the
+                                        one in front consumes — and kept as a tested alternative */
   uint32_t time_proposer;        /* bench: hipEvents around every proposer launch (pm_stats.ms_propose_kernel) */
 } pm_engine_config;
 

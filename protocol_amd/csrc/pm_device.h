@@ -114,8 +114,27 @@ struct CarveStatus {
   uint32_t need_prep;    // (external preparation) the next candidate list has not been prepared yet
   uint32_t g_lo, g_hi;   // groups appended by the last validation launch (their group_of is written by the prep kernels)
   uint32_t n_batches;    // validation launches that had a prepared list to run (the host sizes its next queue by it)
+  uint32_t n_void;       // validation launches whose batch had been prepared for another configuration, or for nothing
+  // how validation launches ended: 0 chain: list thinned out, 1 seeds of the batch used up, 2 exact step: thinned out,
+  // 3 configuration exhausted, 4 batch prepared for another configuration, 5 batch too stale, 6 configuration not entered
+  uint32_t why[8];
   unsigned long long prop_keys;  // keys (Haversine terms) those sweeps evaluated
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
+};
+
+// A proposal batch as its preparation describes it (carve_plan_kernel + carve_prep_*_kernel write it, the proposer
+// and the validator read it).  A batch may be prepared while the batch in front of it is still being validated —
+// from a snapshot of the position bitmap, for the configuration the carve is expected to be at — so the validator
+// accepts it only if it started from the configuration the carve really is at (ci0), and treats what has been
+// removed since the snapshot as dead slots.
+struct BatchDesc {
+  uint32_t planned;          // the plan ran (the carve was RUNNING)
+  uint32_t ci0;              // configuration (position in the carve order) the preparation started from
+  uint32_t total_available;  // as of the plan (an upper bound of what the validator will find)
+  uint32_t valid;            // a candidate list was prepared: configuration `ci`, the first from ci0 on that can be entered
+  uint32_t none;             // no configuration from ci0 on can be entered any more
+  uint32_t ci, n_list, prop_k, prop_limit, rows_pr, n_seeds;
+  uint32_t _pad;
 };
 
 struct CarveArgs {
@@ -167,6 +186,10 @@ struct CarveArgs {
   uint32_t count_keys, _pad_ck;  // proposer: count the keys it sweeps (bench bookkeeping)
   uint32_t* prep_block_counts;   // [blocks][PM_MAX_CONFIGS] live compatible positions per block and configuration
   uint32_t* prep_counts;         // [PM_MAX_CONFIGS] totals, [PM_MAX_CONFIGS] = finished-blocks ticket
+  BatchDesc* desc;               // this argument block's batch (the per-batch scratch above belongs to it)
+  const BatchDesc* desc_prev;    // the batch in front of it (the other argument block's; itself when there is one block)
+  uint64_t* alive_snap;          // the position bitmap as the preparation saw it (bits_stride words)
+  uint32_t speculative, _pad_sp; // the preparation may run beside the validation of the batch in front
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];
@@ -215,7 +238,7 @@ void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_b
                    uint32_t* idx_by_block, long long* val_by_block, uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
-void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s);
+void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s);  // plan + count + place
 void launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t start_ci, hipStream_t s);
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);

@@ -129,6 +129,7 @@ struct pm_engine {
   bool k_sweep_recorded = false, k_compat_recorded = false;
   uint64_t tick_cand_sum = 0;
   unsigned long long carve_prof[32]{};
+  unsigned long long carve_why[10]{};  // CarveStatus::why of the last carve, its batches and its void launches
   std::mutex mu;
 
   // ---- configuration tables
@@ -220,7 +221,25 @@ struct pm_engine {
   DevBuf<uint64_t> d_c_compat, d_keys, d_bits;
   DevBuf<uint32_t> d_slot_pos, d_slot_wid;
   DevBuf<CarveStatus> d_status;
-  DevBuf<CarveArgs> d_carve_args;
+  DevBuf<CarveArgs> d_carve_args;   // [2]: one argument block per proposal batch in flight (the second one only
+                                    // differs in the per-batch scratch, see CarveSet)
+  DevBuf<BatchDesc> d_desc;         // [2]
+  DevBuf<uint64_t> d_snap;          // [2][stride] position-bitmap snapshots of the preparations
+  // per-batch scratch of the SECOND argument block (the first uses the d_cc_* / d_slot_* / d_prop ... members):
+  // with two sets the next batch is prepared and proposed on stream_p while the batch in front is validated
+  struct CarveSet {
+    DevBuf<double> cc_lat, cc_lon, cc_cos, cc_u[3];
+    DevBuf<uint32_t> cc_site, slot_pos, slot_wid, seed_prefix, seed_slots, prep_block_counts, prep_counts;
+    DevBuf<uint64_t> prop, seed_map, bits;
+    void release() {
+      cc_lat.release(); cc_lon.release(); cc_cos.release();
+      for (auto& u : cc_u) u.release();
+      cc_site.release(); slot_pos.release(); slot_wid.release(); seed_prefix.release(); seed_slots.release();
+      prep_block_counts.release(); prep_counts.release(); prop.release(); seed_map.release(); bits.release();
+    }
+  } set2;
+  hipStream_t stream_p = nullptr;   // preparation + proposals of the batch behind the one being validated
+  std::vector<hipEvent_t> pipe_ev;  // [2k] batch k proposed, [2k + 1] batch k validated
   DevBuf<uint32_t> d_m_cfg, d_m_n, d_m_off, d_m_members;  // MERGE batches
 
   // ---- sweep scratch
@@ -483,15 +502,17 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     HIPCHK(e->d_prep_counts.ensure(PM_MAX_CONFIGS + 8));
   }
   HIPCHK(e->d_status.ensure(1));
-  HIPCHK(e->d_carve_args.ensure(1));
+  HIPCHK(e->d_carve_args.ensure(2));
+  HIPCHK(e->d_desc.ensure(2));
   const uint32_t stride = uint32_t((cap + 63) / 64);
   HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
+  HIPCHK(e->d_snap.ensure(size_t(stride) * 2));
   std::memset(a, 0, sizeof(*a));
   a->mode = mode;
   a->W = e->W;
   a->proximity = e->cfg.proximity_enabled;
   a->debug_uncertain_every = e->cfg.debug_uncertain_every;
-  a->rounds_enabled = e->cfg.carve_variant == 0 ? 1u : 0u;
+  a->rounds_enabled = (e->cfg.carve_variant == 0 || e->cfg.carve_variant == 4) ? 1u : 0u;
   a->wflags = e->d_flags.p;
   a->lat = e->d_lat.p;
   a->lon = e->d_lon.p;
@@ -537,6 +558,52 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->bits_scratch = e->d_bits.p + size_t(stride) * 2;
   a->bits_stride = stride;
   a->status = e->d_status.p;
+  a->desc = e->d_desc.p;
+  a->desc_prev = e->d_desc.p;  // (one argument block: no batch in front)
+  a->alive_snap = e->d_snap.p;
+  a->speculative = 0;
+  return PM_OK;
+}
+
+// The second argument block: the same carve, its own per-batch scratch.
+static int32_t fill_carve_args2(pm_engine* e, const CarveArgs& a, CarveArgs* b) {
+  const size_t cap = std::max<size_t>(e->W, 1);
+  auto& s2 = e->set2;
+  HIPCHK(s2.cc_lat.ensure(cap));
+  HIPCHK(s2.cc_lon.ensure(cap));
+  HIPCHK(s2.cc_cos.ensure(cap));
+  for (auto& u : s2.cc_u) HIPCHK(u.ensure(cap));
+  HIPCHK(s2.cc_site.ensure(cap));
+  HIPCHK(s2.slot_pos.ensure(cap));
+  HIPCHK(s2.slot_wid.ensure(cap));
+  HIPCHK(s2.prop.ensure((size_t(PM_PROP_MAX_SEEDS) + 64) * PM_PROP_ROW));
+  HIPCHK(s2.seed_map.ensure((cap + 63) / 64 + 64));
+  HIPCHK(s2.seed_prefix.ensure((cap + 63) / 64 + 64));
+  HIPCHK(s2.seed_slots.ensure(size_t(PM_PROP_MAX_SEEDS) + 128));
+  HIPCHK(s2.prep_block_counts.ensure(((cap + 255) / 256 + 1) * PM_MAX_CONFIGS));
+  HIPCHK(s2.prep_counts.ensure(PM_MAX_CONFIGS + 8));
+  HIPCHK(s2.bits.ensure(size_t(a.bits_stride) * 2));
+  *b = a;
+  b->cc_lat = s2.cc_lat.p;
+  b->cc_lon = s2.cc_lon.p;
+  b->cc_cos = s2.cc_cos.p;
+  b->cc_ux = s2.cc_u[0].p;
+  b->cc_uy = s2.cc_u[1].p;
+  b->cc_uz = s2.cc_u[2].p;
+  b->cc_site = s2.cc_site.p;
+  b->slot_pos = s2.slot_pos.p;
+  b->slot_wid = s2.slot_wid.p;
+  b->prop = s2.prop.p;
+  b->prop_send = s2.prop.p;
+  b->seed_map = s2.seed_map.p;
+  b->seed_prefix = s2.seed_prefix.p;
+  b->seed_slots = s2.seed_slots.p;
+  b->prep_block_counts = s2.prep_block_counts.p;
+  b->prep_counts = s2.prep_counts.p;
+  b->bits_scratch = s2.bits.p;
+  b->desc = e->d_desc.p + 1;
+  b->desc_prev = e->d_desc.p;
+  b->alive_snap = e->d_snap.p + a.bits_stride;
   return PM_OK;
 }
 
@@ -647,6 +714,10 @@ static void host_mark(const char* what) {
 // (one status read per proposal batch, the all-gather of the batch's rows issued by the caller in between).
 struct FormRun {
   CarveArgs a;
+  CarveArgs b;              // the second argument block (pipelined carve)
+  BatchDesc desc[2] = {};   // the batch descriptors as of the last poll
+  bool pipelined = false;   // two batches in flight: batch k + 1 prepared and proposed beside the validation of batch k
+  uint32_t kP = 0, kV = 0;  // batches whose preparation / validation has been queued
   CarveStatus st;
   std::vector<uint32_t> avail;
   uint32_t g0 = 0, m0 = 0, start_ci = 0;
@@ -656,20 +727,84 @@ struct FormRun {
   uint32_t n_bound = 0;  // rows outside any group when the carve starts (>= the eligible list): sizes the prep grids
 };
 
+static int32_t launch_propose_timed(pm_engine* e, const CarveArgs* d_args, uint32_t n_bound, hipStream_t s);
+
+static int32_t pipe_event(pm_engine* e, size_t i, hipEvent_t* ev) {
+  while (e->pipe_ev.size() <= i) {
+    hipEvent_t x = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    e->pipe_ev.push_back(x);
+  }
+  *ev = e->pipe_ev[i];
+  return PM_OK;
+}
+
+// Pipelined carve: batch k lives in argument block k & 1.  Its preparation and its proposals go to stream_p —
+// behind the validation of batch k - 2, which used the same block — its validation to the engine's stream, behind
+// its proposals.  So the validation of batch k and the preparation of batch k + 1 run side by side.
+static int32_t pipe_queue_prepare(pm_engine* e, FormRun* r) {
+  const uint32_t k = r->kP;
+  const CarveArgs* blk = e->d_carve_args.p + (k & 1u);
+  hipEvent_t ev = nullptr;
+  if (k >= 2u) {
+    int32_t rc = pipe_event(e, size_t(2) * (k - 2u) + 1u, &ev);
+    if (rc) return rc;
+    HIPCHK(hipStreamWaitEvent(e->stream_p, ev, 0));
+  }
+  launch_carve_prep(blk, r->n_bound, e->stream_p);
+  int32_t rc = launch_propose_timed(e, blk, r->n_bound, e->stream_p);
+  if (rc) return rc;
+  rc = pipe_event(e, size_t(2) * k, &ev);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ev, e->stream_p));
+  e->tick_carve_launches += 4;
+  r->kP = k + 1u;
+  return PM_OK;
+}
+static int32_t pipe_queue_validate(pm_engine* e, FormRun* r) {
+  const uint32_t k = r->kV;
+  const CarveArgs* blk = e->d_carve_args.p + (k & 1u);
+  hipEvent_t ev = nullptr;
+  int32_t rc = pipe_event(e, size_t(2) * k, &ev);
+  if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(e->stream, ev, 0));
+  HIPCHK(launch_carve(blk, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, r->lds, e->stream));
+  rc = pipe_event(e, size_t(2) * k + 1u, &ev);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ev, e->stream));
+  e->tick_carve_launches += 1;
+  r->kV = k + 1u;
+  return PM_OK;
+}
+
 static int32_t form_queue_init(pm_engine* e, FormRun* r) {
   HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
   if (r->use_props) {
+    HIPCHK(hipMemsetAsync(e->d_desc.p, 0, 2 * sizeof(BatchDesc), e->stream));
     launch_carve_elig(e->d_carve_args.p, e->W, r->start_ci, e->stream);  // the ordered eligible list
-    launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);         // the first candidate list
+    e->tick_carve_launches += 2;
+    if (r->pipelined) {
+      // (both streams are idle here: the first call of a carve, or a poll has just drained them)
+      hipEvent_t ev = nullptr;
+      int32_t rc = pipe_event(e, 0, &ev);  // (re-recorded by the first preparation below)
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(ev, e->stream));
+      HIPCHK(hipStreamWaitEvent(e->stream_p, ev, 0));  // the eligible list first
+      r->kP = r->kV = 0;
+      rc = pipe_queue_prepare(e, r);
+      if (rc) return rc;
+    } else {
+      launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);         // the first candidate list
+      e->tick_carve_launches += 3;
+    }
     HIPCHK(hipGetLastError());
-    e->tick_carve_launches += 3;
   } else
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, r->start_ci, r->lds, e->stream));
   e->tick_carve_launches++;
   return PM_OK;
 }
 
-static int32_t form_begin(pm_engine* e, FormRun* r) {
+static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
   int32_t rc = absorb_groups(e);  // a match that failed half-way may have left the last carve unabsorbed
   if (rc) return rc;
   rc = ensure_compat(e);
@@ -710,15 +845,25 @@ static int32_t form_begin(pm_engine* e, FormRun* r) {
   r->st.n_groups = r->g0;
   r->st.n_members = r->m0;
   r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
+  // Two batches in flight on one GPU (the stepwise multi-GPU tick exchanges the rows of every batch through its
+  // caller, one batch at a time)
+  r->pipelined = allow_pipeline && r->use_props && e->dist_world == 1 && e->stream_p != nullptr && e->cfg.carve_variant == 4;
+  if (r->pipelined) {
+    a.speculative = 1;
+    a.desc_prev = e->d_desc.p + 1;
+    rc = fill_carve_args2(e, a, &r->b);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_carve_args.p + 1, &r->b, sizeof(r->b), hipMemcpyHostToDevice, e->stream));
+  }
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipEventRecord(e->kev[2], e->stream));
   return form_queue_init(e, r);  // prepares the first candidate list (all of it when there are no proposals)
 }
 
 // the proposer launch, bracketed by its own hipEvents when pm_engine_config.time_proposer asks for the split
-static int32_t launch_propose_timed(pm_engine* e, uint32_t n_bound) {
+static int32_t launch_propose_timed(pm_engine* e, const CarveArgs* d_args, uint32_t n_bound, hipStream_t s) {
   if (!e->cfg.time_proposer) {
-    launch_carve_propose(e->d_carve_args.p, n_bound, e->stream);
+    launch_carve_propose(d_args, n_bound, s);
     return PM_OK;
   }
   while (e->prop_ev.size() < e->prop_ev_used + 2) {
@@ -726,9 +871,9 @@ static int32_t launch_propose_timed(pm_engine* e, uint32_t n_bound) {
     HIPCHK(hipEventCreate(&x));
     e->prop_ev.push_back(x);
   }
-  HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used], e->stream));
-  launch_carve_propose(e->d_carve_args.p, n_bound, e->stream);
-  HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used + 1], e->stream));
+  HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used], s));
+  launch_carve_propose(d_args, n_bound, s);
+  HIPCHK(hipEventRecord(e->prop_ev[e->prop_ev_used + 1], s));
   e->prop_ev_used += 2;
   return PM_OK;
 }
@@ -736,8 +881,17 @@ static int32_t launch_propose_timed(pm_engine* e, uint32_t n_bound) {
 // (propose, validate) pairs: one per configuration plus one per re-proposal round; launches queued behind a
 // finished carve return immediately
 static int32_t form_queue_pairs(pm_engine* e, FormRun* r, uint32_t count) {
+  if (r->pipelined) {
+    for (uint32_t k = 0; k < count; ++k) {
+      int32_t rc = pipe_queue_prepare(e, r);  // the batch behind ...
+      if (rc) return rc;
+      rc = pipe_queue_validate(e, r);         // ... beside the validation of this one
+      if (rc) return rc;
+    }
+    return PM_OK;
+  }
   for (uint32_t k = 0; k < count; ++k) {
-    int32_t rc = launch_propose_timed(e, r->n_bound);
+    int32_t rc = launch_propose_timed(e, e->d_carve_args.p, r->n_bound, e->stream);
     if (rc) return rc;
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, r->lds, e->stream));
     launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);  // group_of of the new groups + the next candidate list
@@ -753,6 +907,8 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
     HIPCHK(hipEventRecord(e->kev[3], e->stream));
     HIPCHK(hipMemcpyAsync(&r->st, e->d_status.p, sizeof(r->st), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (r->pipelined) HIPCHK(hipStreamSynchronize(e->stream_p));  // (a preparation queued behind the last validation)
+    if (r->use_props) HIPCHK(hipMemcpy(r->desc, e->d_desc.p, sizeof(r->desc), hipMemcpyDeviceToHost));
     {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
@@ -788,6 +944,9 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   e->tick_props += st.n_props;
   e->tick_prop_keys += st.prop_keys;
   std::memcpy(e->carve_prof, st.prof, sizeof(st.prof));
+  for (int k = 0; k < 8; ++k) e->carve_why[k] = st.why[k];
+  e->carve_why[8] = st.n_batches;
+  e->carve_why[9] = st.n_void;
 
   // The new group records stay in HBM for the match; their ids (generate_group_id stream) and empty task
   // words are filled in on the device, and a copy travels to pinned host memory for absorb_groups().
@@ -831,7 +990,7 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
 
 static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = false) {
   FormRun r;
-  int32_t rc = form_begin(e, &r);
+  int32_t rc = form_begin(e, &r, /*allow_pipeline=*/true);
   if (rc) return rc;
   if (!r.nothing) {
     // (propose, validate, prepare) rounds are queued blindly and the ones behind a finished carve return at once —
@@ -855,7 +1014,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
       batch = 8u;  // more re-proposal rounds than were queued, or re-armed after a host-resolved step
     }
   }
-  if (!r.nothing && r.use_props) e->form_rounds_hint = r.st.n_batches;
+  if (!r.nothing && r.use_props) e->form_rounds_hint = r.st.n_batches + r.st.n_void;
   return form_finish(e, &r, n_formed, defer_absorb);
 }
 
@@ -1297,6 +1456,7 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
   if (!e) return set_error(PM_ENOMEM, "out of host memory");
   e->cfg = *cfg;
   e->id_rng = cfg->group_id_seed;
+  (void)hipStreamCreateWithFlags(&e->stream_p, hipStreamNonBlocking);  // (without it the carve is not pipelined)
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     delete e;
     return set_error(PM_ENODEV, "hipStreamCreate failed");
@@ -1356,6 +1516,9 @@ void pm_engine_destroy(pm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t x : e->prop_ev) (void)hipEventDestroy(x);
   if (e->stream_owned) (void)hipStreamDestroy(e->stream_owned);
+  if (e->stream_p) (void)hipStreamDestroy(e->stream_p);
+  for (hipEvent_t x : e->pipe_ev) (void)hipEventDestroy(x);
+  e->set2.release(); e->d_desc.release(); e->d_snap.release();
   delete e->form;
   delete e;
 }
@@ -2434,7 +2597,7 @@ int32_t pm_dist_tick_begin(pm_engine* e) {
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   e->form = new (std::nothrow) FormRun();
   if (!e->form) return set_error(PM_ENOMEM, "out of host memory");
-  rc = form_begin(e, e->form);
+  rc = form_begin(e, e->form, /*allow_pipeline=*/false);
   if (rc) {
     dist_abort(e);
     return rc;
@@ -2459,7 +2622,7 @@ int32_t pm_dist_carve_next(pm_engine* e, pm_dist_xfer* x, uint32_t* more) {
     }
     if (r->st.state == CARVE_STATE_RUNNING && r->use_props) {
       // a candidate list is prepared: this rank's share of the batch's neighbour lists
-      int32_t rcp = launch_propose_timed(e, e->form->n_bound);
+      int32_t rcp = launch_propose_timed(e, e->d_carve_args.p, e->form->n_bound, e->stream);
       if (rcp) {
         dist_abort(e);
         return rcp;
@@ -2468,7 +2631,7 @@ int32_t pm_dist_carve_next(pm_engine* e, pm_dist_xfer* x, uint32_t* more) {
       HIPCHK(hipGetLastError());
       x->send_ptr = uint64_t(reinterpret_cast<uintptr_t>(r->a.prop_send));
       x->recv_ptr = uint64_t(reinterpret_cast<uintptr_t>(r->a.prop));
-      x->bytes_per_rank = r->st.prop_k ? uint64_t(r->st.rows_pr) * PM_PROP_ROW * 8u : 0u;
+      x->bytes_per_rank = (r->desc[0].valid && r->desc[0].prop_k) ? uint64_t(r->desc[0].rows_pr) * PM_PROP_ROW * 8u : 0u;
       *more = 1;
       return PM_OK;
     }
@@ -2579,6 +2742,7 @@ int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap)
   std::lock_guard<std::mutex> lk(e->mu);
   const uint32_t n = std::min<uint32_t>(cap, uint32_t(sizeof(e->carve_prof) / sizeof(e->carve_prof[0])));
   std::memcpy(out, e->carve_prof, size_t(n) * sizeof(unsigned long long));
+  for (uint32_t k = 32; k < cap && k < 42; ++k) out[k] = e->carve_why[k - 32];  // (how the validation launches ended)
   return PM_OK;
 }
 

@@ -755,6 +755,7 @@ struct StepCtx {
   uint32_t mode, proximity, min_s, max_s, cfg;
   uint32_t n_list;       // slots of the current list
   uint32_t n_cand;       // live slots
+  uint32_t n_start;      // live slots when the validation of this batch started
   uint32_t n_groups, mem_off;
   uint32_t total_available;
   uint32_t steps, fast_steps;
@@ -873,7 +874,10 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
             if (j == (c.prop_limit >> 6)) ll &= ~((1ull << (c.prop_limit & 63u)) - 1ull);
             more = __ballot(ll != 0ull) != 0ull;
           }
-          if (more) FAST_RETURN(FAST_REPROPOSE);
+          if (more) {
+            if (lane == 0) G(p.status)->why[1] += 1u;
+            FAST_RETURN(FAST_REPROPOSE);
+          }
         }
       } else {
         for (uint32_t j0 = 0; j0 < lw; j0 += 64u) {
@@ -1052,6 +1056,15 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
 // else is handed to carve_fast_steps, which looks at the seed at seed_cur with the row's keys: other rows, exhausted
 // rows (-> exact sweep), the debug hook (FAST_SLOW: exactly one step), the last partial group, the first-come tail,
 // the end of the batch (FAST_SEQ).
+// a proposal batch ends (the list is compacted and re-proposed) once fewer than 1 / PM_THIN_DIV of the slots that were
+// alive when its validation started are left; a batch prepared beside the one in front of it is not worth validating
+// when less than 1 / PM_STALE_DIV of its list is still alive (the next one is prepared from the state as it is then)
+#ifndef PM_THIN_DIV
+#define PM_THIN_DIV 2u
+#endif
+#ifndef PM_STALE_DIV
+#define PM_STALE_DIV 3u
+#endif
 #ifndef CHAIN_BLOCK
 #define CHAIN_BLOCK 8u
 #endif
@@ -1322,7 +1335,7 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
   const ChainLds L = chain_lds(l_buf);
   const uint32_t dbg_every = UNI(p.debug_uncertain_every);
   const uint32_t n_seeds = UNI(c.n_seeds);
-  const uint32_t n_list_v = UNI(c.n_list);
+  const uint32_t n_list_v = UNI(c.n_list), n_start = UNI(c.n_start);
   const uint32_t group_n = UNI(c.max_s), want = group_n - 1u;
   const uint32_t cap_g = UNI(p.cap_groups), cap_m = UNI(p.cap_members);
   const uint32_t step0 = UNI(steps_before) + UNI(c.steps);
@@ -1339,7 +1352,7 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
     b = b < room_g ? b : room_g;
     b = b < room_m ? b : room_m;
     if (n_list_v > 256u) {
-      const uint32_t t = n_cand * 2u >= n_list_v ? (n_cand * 2u - n_list_v) / (2u * group_n) + 1u : 1u;
+      const uint32_t t = n_cand * PM_THIN_DIV >= n_start ? (n_cand * PM_THIN_DIV - n_start) / (PM_THIN_DIV * group_n) + 1u : 1u;
       b = b < t ? b : t;
     }
     if (dbg_every) {
@@ -1462,9 +1475,10 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
             stop = true;
             break;
           }
-          // More than half of the list is dead: the neighbour rows are thinning out.  Re-prepare (compact) and
-          // re-propose now, before rows start running out of live entries.
-          if (n_cand * 2u < n_list_v && n_list_v > 256u && commits > 0u) {
+          // A good part of what was alive when the batch started is gone: the neighbour rows are thinning out.
+          // Re-prepare (compact) and re-propose now, before rows start running out of live entries.
+          if (n_cand * PM_THIN_DIV < n_start && n_list_v > 256u && commits > 0u) {
+            if (lane == 0u) p.status->why[0] += 1u;
             action = FAST_REPROPOSE;
             stop = true;
             break;
@@ -1843,7 +1857,10 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
     c.steps += 1;
     // drop dead slots once more than half of the list is gone.  With proposals this also ends the launch:
     // the list is re-prepared and the next propose / validate pair continues with fresh neighbour lists.
-    if (c.n_cand * 2u < c.n_list && c.n_list > (have_props ? 256u : CARVE_THREADS)) return STEP_CONTINUE;
+    if (c.n_cand * (have_props ? PM_THIN_DIV : 2u) < (have_props ? c.n_start : c.n_list) && c.n_list > (have_props ? 256u : CARVE_THREADS)) {
+      if (tid == 0) p.status->why[2] += 1u;
+      return STEP_CONTINUE;
+    }
   }
 }
 
@@ -2271,8 +2288,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   const CarveArgs& p = *pa;  // argument block in device memory: read through the scalar cache, never copied
   const auto st = G((const CarveStatus*)p.status);
   if (st->state != CARVE_STATE_RUNNING) return;
-  if (st->cur_ci >= p.n_avail) return;
-  const uint32_t K = st->prop_k, n_list = st->n_list;
+  const auto D = G((const BatchDesc*)p.desc);
+  if (!D->planned || !D->valid) return;
+  const uint32_t K = D->prop_k, n_list = D->n_list;
   const uint32_t world = p.dist_world, my_rank = p.dist_rank;
   const auto prop_out = G(p.prop_send);
   if (K == 0 || n_list > PM_CARVE_BIG_SLOTS) return;
@@ -2288,7 +2306,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   // seed numbers my_rank, my_rank + world, ...
   __shared__ TileBuf tiles[2];
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
-  const uint32_t n_seeds = st->n_seeds;
+  const uint32_t n_seeds = D->n_seeds;
   const uint32_t n_my = world > 1u ? (n_seeds > my_rank ? (n_seeds - my_rank + world - 1u) / world : 0u) : n_seeds;
   const uint32_t n_tiles = (n_list + PROP_TILE - 1u) / PROP_TILE;
   const auto seed_slots = G((const uint32_t*)p.seed_slots);
@@ -2538,29 +2556,54 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
 
 #define PREP_WAVES 4
 
+// The plan of a preparation, decided once (one thread) so that every block of the two kernels behind it works on the
+// same configuration: where the search for the next configuration starts.  Beside a validation in flight (speculative
+// mode) that is a guess: the batch in front works on configuration ci of a list of n_list slots; it ends with the
+// list thinned out — the same configuration again — unless the list is small enough to be finished in one go.
+__global__ __launch_bounds__(128) void carve_plan_kernel(const CarveArgs* __restrict__ pa) {
+  static_assert(PM_MAX_CONFIGS + 2u <= 128u, "one thread per counter");
+  const CarveArgs& p = *pa;
+  const auto st = G(p.status);
+  const uint32_t tid = threadIdx.x;
+  if (st->state != CARVE_STATE_RUNNING) {
+    if (tid == 0) p.desc->planned = 0u;
+    return;
+  }
+  if (tid <= PM_MAX_CONFIGS + 1u) p.prep_counts[tid] = 0u;  // totals + ticket of this preparation
+  if (tid == 0) {
+    const uint32_t cur = st->cur_ci;
+    uint32_t ci0 = cur;
+    const BatchDesc dp = *p.desc_prev;
+    if (p.speculative && p.desc_prev != p.desc && dp.planned && dp.valid && dp.ci0 == cur)
+      ci0 = dp.n_list > 256u ? dp.ci : dp.ci + 1u;
+    BatchDesc d = {};
+    d.planned = 1u;
+    d.ci0 = ci0;
+    d.total_available = st->total_available;
+    *p.desc = d;
+  }
+}
+
 __global__ __launch_bounds__(256) void carve_prep_count_kernel(const CarveArgs* __restrict__ pa) {
   const CarveArgs& p = *pa;
   const auto st = G(p.status);
+  const auto D = G((const BatchDesc*)p.desc);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t wave_g = blockIdx.x * PREP_WAVES + wave, n_waves = gridDim.x * PREP_WAVES;
-  // group_of for the groups the last validation launch appended (idempotent; also runs after the carve ended)
-  {
-    const uint32_t g_lo = st->g_lo, g_hi = st->g_hi;
-    for (uint32_t g = g_lo + wave_g; g < g_hi; g += n_waves) {
-      const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
-      for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
-    }
-  }
-  if (st->state != CARVE_STATE_RUNNING || !st->need_prep || st->cur_ci >= p.n_avail) return;
+  const uint32_t wave_g = blockIdx.x * PREP_WAVES + wave;
+  if (st->state != CARVE_STATE_RUNNING || !D->planned || D->ci0 >= p.n_avail) return;
   __shared__ uint32_t s_cnt[PREP_WAVES][PM_MAX_CONFIGS];
-  const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6, ci0 = st->cur_ci;
+  const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6, ci0 = D->ci0;
   const uint32_t j = wave_g;  // this wave's word of the position space
   uint64_t m = 0;
   if (j < n_words) {
     const uint32_t i = j * 64u + lane;
-    const bool alive = i < n && ((G(p.alive_g)[j] >> lane) & 1ull);
+    const uint64_t aw = G(p.alive_g)[j];  // (a validation in flight may be clearing bits: the snapshot is what counts)
+    const bool alive = i < n && ((aw >> lane) & 1ull);
     m = alive ? G((const uint64_t*)p.c_compat)[i] : 0ull;
-    if (lane == 0) G(p.bits_scratch)[p.bits_stride + j] = 0ull;  // slot loc bitmap: the placement ORs its bits in
+    if (lane == 0) {
+      G(p.alive_snap)[j] = aw;
+      G(p.bits_scratch)[p.bits_stride + j] = 0ull;  // slot loc bitmap: the placement ORs its bits in
+    }
   }
   for (uint32_t ci = ci0; ci < p.n_avail; ++ci) {
     const uint32_t cnt = (uint32_t)__popcll(__ballot((m >> p.avail_cfg[ci]) & 1ull));
@@ -2579,16 +2622,17 @@ __global__ __launch_bounds__(256) void carve_prep_count_kernel(const CarveArgs* 
 __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* __restrict__ pa) {
   const CarveArgs& p = *pa;
   const auto st = G(p.status);
-  // (a carve whose last configuration has just been exhausted arrives here with cur_ci == n_avail: the selection
-  // below finds nothing and the last block reports DONE)
-  if (st->state != CARVE_STATE_RUNNING || !st->need_prep) return;
+  const auto D = G((const BatchDesc*)p.desc);
+  if (st->state != CARVE_STATE_RUNNING || !D->planned) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   __shared__ uint32_t s_red[PREP_WAVES + 4];
   __shared__ uint32_t s_bits[PREP_WAVES][64];
   const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6;
-  const uint32_t total_available = st->total_available;
-  // ---- the next configuration whose loop would be entered (mod.rs:505-519), the same in every block
-  uint32_t ci = st->cur_ci, n_list = 0;
+  const uint32_t total_available = D->total_available;
+  // ---- the next configuration whose loop would be entered (mod.rs:505-519), the same in every block.  (Counts and
+  // total_available only ever shrink: a configuration that cannot be entered by these numbers cannot be entered by
+  // the validator's either, so skipping it is final.)
+  uint32_t ci = D->ci0, n_list = 0;
   for (; ci < p.n_avail; ++ci) {
     const uint32_t min_s = p.min_size[ci];
     if (total_available < min_s) continue;             // `while` never entered (:507)
@@ -2608,7 +2652,7 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     const uint32_t j = blockIdx.x * PREP_WAVES + wave;
     const uint32_t i = j * 64u + lane;
     const uint32_t ic = i < n ? i : (n ? n - 1u : 0u);
-    const uint64_t aw = j < n_words ? G(p.alive_g)[j] : 0ull;
+    const uint64_t aw = j < n_words ? G((const uint64_t*)p.alive_snap)[j] : 0ull;
     const uint64_t lg = j < n_words ? G(p.loc_g)[j] : 0ull;
     const uint64_t cm = n ? G((const uint64_t*)p.c_compat)[ic] : 0ull;
     const uint32_t ow = n ? G(p.order)[ic] : 0u;
@@ -2659,9 +2703,8 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   __threadfence();
   if (none) {
     if (tid == 0) {
-      st->state = CARVE_STATE_DONE;
-      st->cur_ci = p.n_avail;
-      st->need_prep = 0;
+      p.desc->ci = p.n_avail;
+      p.desc->none = 1u;
     }
     return;
   }
@@ -2689,13 +2732,14 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     prop_seed_slots(p, limit, tid, 256u);
   }
   if (tid == 0) {
-    st->cur_ci = ci;
-    st->n_list = n_list;
-    st->prop_k = prop_k;
-    st->prop_limit = limit;
-    st->rows_pr = (n_seeds + p.dist_world - 1u) / p.dist_world;
-    st->n_seeds = n_seeds;
-    st->need_prep = 0;
+    BatchDesc* d = p.desc;
+    d->ci = ci;
+    d->n_list = n_list;
+    d->prop_k = prop_k;
+    d->prop_limit = limit;
+    d->rows_pr = (n_seeds + p.dist_world - 1u) / p.dist_world;
+    d->n_seeds = n_seeds;
+    d->valid = 1u;
   }
 }
 
@@ -2912,11 +2956,29 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       return;
     }
   } else {
-    if ((flags & CARVE_F_EXTPREP) && st->need_prep) return;  // nothing prepared (no configuration left, or stopped)
     n = st->n_eligible;
     c.total_available = st->total_available;
     ci = st->cur_ci;
     prepared = true;
+    if (flags & CARVE_F_EXTPREP) {
+      // the batch the preparation kernels describe: acceptable if it started from the configuration the carve is at
+      const BatchDesc d = *p.desc;
+      if (!d.planned || d.ci0 != ci || !(d.valid || d.none)) {
+        if (tid == 0) {  // (prepared beside the batch in front, for the configuration it did not end at)
+          st->n_void += 1u;
+          st->why[4] += 1u;
+        }
+        return;
+      }
+      if (d.none) {  // no configuration left that can be entered
+        if (tid == 0) {
+          st->state = CARVE_STATE_DONE;
+          st->cur_ci = p.n_avail;
+        }
+        return;
+      }
+      ci = d.ci;  // (the ones in between cannot be entered)
+    }
     if (ci >= p.n_avail) return;
   }
   c.n_groups = st->n_groups;
@@ -2970,6 +3032,15 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       prepared = true;
       PROF_MARK(28);
       if (!(flags & CARVE_F_RUN)) break;  // prepare-only launch
+    } else if (flags & CARVE_F_EXTPREP) {
+      const BatchDesc d = *p.desc;
+      c.n_list = d.n_list;
+      c.prop_k = d.prop_k;
+      c.prop_limit = d.prop_limit;
+      c.rows_pr = d.rows_pr;
+      c.n_seeds = d.n_seeds;
+      c.min_s = p.min_size[ci];
+      c.max_s = p.max_size[ci];
     } else {
       c.n_list = st->n_list;
       c.prop_k = st->prop_k;
@@ -2981,6 +3052,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     }
     c.cfg = p.avail_cfg[ci];
     c.n_cand = c.n_list;
+    c.n_start = c.n_list;
 
     // ---- run the prepared configuration.  Three storage modes:
     //   small (<= PM_CARVE_SLOTS slots):  every per-slot array in LDS
@@ -3004,6 +3076,47 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     if (in_lds)
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) lds_site[sl] = G(p.cc_site)[sl];
     __syncthreads();
+    if ((flags_in & CARVE_F_EXTPREP) && p.mode == CARVE_MODE_FORM) {
+      // The list may have been prepared before the batch in front of it was validated: whatever has left the
+      // position bitmap since then is a dead slot.  (No-op for a list prepared from the current state.)
+      uint32_t live = 0;
+      for (uint32_t base = 0; base < lw * 64u; base += CARVE_THREADS) {  // (a whole number of words per pass)
+        const uint32_t sl = base + tid;
+        bool al = false;
+        if (sl < c.n_list) {
+          const uint32_t i = G(p.slot_pos)[sl] & 0x7FFFFFFFu;
+          al = (G(p.alive_g)[i >> 6] >> (i & 63u)) & 1ull;
+        }
+        const uint64_t bal = __ballot(al);
+        if (lane == 0 && (sl >> 6) < lw) r_alive[sl >> 6] = bal;
+        live += (uint32_t)__popcll(bal);
+      }
+      if (lane == 0) red.a[wave] = live;
+      __syncthreads();
+      uint32_t tot = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < CARVE_WAVES; ++k) tot += red.a[k];
+      c.n_cand = tot;
+      c.n_start = tot;
+      __syncthreads();
+      // the loop of this configuration is entered only if ... (mod.rs:507, 517-519) — by the numbers as they are now
+      if (c.total_available < c.min_s || c.n_cand < c.min_s || c.n_cand == 0u) {
+        ++ci;
+        c.n_list = 0;
+        if (tid == 0) st->why[6] += 1u;
+        break;
+      }
+      // too little of the list is left for its neighbour rows to be of use (it was prepared before the batch in front
+      // of it took its share): leave it; the batch behind it was prepared from the state as it is now
+      if (p.speculative && c.n_list > 256u && c.n_cand * PM_STALE_DIV < c.n_list) {
+        if (tid == 0) {
+          st->n_void += 1u;
+          st->why[5] += 1u;
+        }
+        c.n_list = 0;
+        break;
+      }
+    }
     PROF_MARK(10);
     const uint32_t slow0 = c.steps - c.fast_steps;
     const uint32_t mem_before_run = c.mem_off;
@@ -3049,7 +3162,10 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       break;
     }
     prepared = false;
-    if (rc == STEP_BREAK) ++ci;  // configuration exhausted; STEP_CONTINUE => re-prepare the same configuration
+    if (rc == STEP_BREAK) {  // configuration exhausted; STEP_CONTINUE => re-prepare the same configuration
+      ++ci;
+      if (tid == 0) st->why[3] += 1u;
+    }
     if (flags & CARVE_F_EXTPREP) break;  // the next list is prepared on the whole chip (carve_prep_*_kernel)
     if (!(flags & CARVE_F_ALL)) flags &= ~CARVE_F_RUN;  // per-configuration launch: prepare the next list, leave
   }
@@ -3061,12 +3177,10 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     __syncthreads();
     for (uint32_t g = groups_at_entry + wave; g < c.n_groups; g += CARVE_WAVES) {
       const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
-      if (!ext)
-        for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
+      for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
       if (gn == 1u && lane == 0) atomicAdd(&p.status->n_solo, 1u);  // rare
     }
   }
-  if (ext && tid <= PM_MAX_CONFIGS) p.prep_counts[tid] = 0u;  // totals + ticket of the next preparation
   __syncthreads();
   PROF_MARK(14);
   if (tid == 0) {
@@ -3262,6 +3376,7 @@ void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng
 void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
   uint32_t blocks = ((W + 63u) / 64u + PREP_WAVES - 1u) / PREP_WAVES;
   if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(carve_plan_kernel, dim3(1), dim3(128), 0, s, d_args);
   hipLaunchKernelGGL(carve_prep_count_kernel, dim3(blocks), dim3(256), 0, s, d_args);
   hipLaunchKernelGGL(carve_prep_place_kernel, dim3(blocks), dim3(256), 0, s, d_args);
 }

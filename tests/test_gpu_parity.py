@@ -111,7 +111,7 @@ def test_form_groups_cfg2_bit_exact(seed, carve_variant):
     assert oracle_groups(st) == engine_groups(eng)
     stats = eng.last_stats()
     assert stats["host_resolved_steps"] == 0
-    if carve_variant in (0, 2):      # most steps must come straight from the neighbour-list proposals
+    if carve_variant in (0, 2, 4):   # most steps must come straight from the neighbour-list proposals
         assert stats["carve_fast_steps"] > 0.5 * stats["carve_steps"]
     eng.close()
 
@@ -147,7 +147,7 @@ def test_form_groups_without_proximity_and_with_partial_enable():
         eng.close()
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 2])
+@pytest.mark.parametrize("carve_variant", [0, 1, 2, 4])
 def test_host_resolve_path_gives_identical_groups(carve_variant):
     """debug_uncertain_every forces the exact host path (glibc distances) on every 3rd step."""
     sw = make_swarm(4, 200, 1500)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 NONE = 0xFFFFFFFF
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 2])
+@pytest.mark.parametrize("carve_variant", [0, 1, 2, 4])
 def test_form_groups_big_lists_bit_exact(carve_variant):
     """30k workers: several configurations have > 8192 candidates (big-list mode, proposal batches of 16384)."""
     sw = make_swarm(2, 2000, 30000, zipf=True)
