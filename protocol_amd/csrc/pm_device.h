@@ -238,7 +238,7 @@ void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_b
                    uint32_t* idx_by_block, long long* val_by_block, uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
-void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s);  // plan + count + place
+uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, bool speculative, hipStream_t s);  // [plan +] count + place
 void launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t start_ci, hipStream_t s);
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);

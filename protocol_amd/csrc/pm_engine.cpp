@@ -751,13 +751,13 @@ static int32_t pipe_queue_prepare(pm_engine* e, FormRun* r) {
     if (rc) return rc;
     HIPCHK(hipStreamWaitEvent(e->stream_p, ev, 0));
   }
-  launch_carve_prep(blk, r->n_bound, e->stream_p);
+  e->tick_carve_launches += launch_carve_prep(blk, r->n_bound, true, e->stream_p);
   int32_t rc = launch_propose_timed(e, blk, r->n_bound, e->stream_p);
   if (rc) return rc;
   rc = pipe_event(e, size_t(2) * k, &ev);
   if (rc) return rc;
   HIPCHK(hipEventRecord(ev, e->stream_p));
-  e->tick_carve_launches += 4;
+  e->tick_carve_launches += 1;
   r->kP = k + 1u;
   return PM_OK;
 }
@@ -794,8 +794,7 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r) {
       rc = pipe_queue_prepare(e, r);
       if (rc) return rc;
     } else {
-      launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);         // the first candidate list
-      e->tick_carve_launches += 3;
+      e->tick_carve_launches += launch_carve_prep(e->d_carve_args.p, r->n_bound, false, e->stream);  // the first candidate list
     }
     HIPCHK(hipGetLastError());
   } else
@@ -894,8 +893,7 @@ static int32_t form_queue_pairs(pm_engine* e, FormRun* r, uint32_t count) {
     int32_t rc = launch_propose_timed(e, e->d_carve_args.p, r->n_bound, e->stream);
     if (rc) return rc;
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, r->lds, e->stream));
-    launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);  // group_of of the new groups + the next candidate list
-    e->tick_carve_launches += 4;
+    e->tick_carve_launches += 2u + launch_carve_prep(e->d_carve_args.p, r->n_bound, false, e->stream);  // the next candidate list
   }
   return PM_OK;
 }
@@ -2650,8 +2648,7 @@ int32_t pm_dist_carve_validate(pm_engine* e) {
   HIPCHK(hipSetDevice(e->cfg.device));
   if (e->dist_phase != 1 || !e->form || e->form->nothing) return set_error(PM_ESTATE, "no proposal batch pending");
   HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, e->form->lds, e->stream));
-  launch_carve_prep(e->d_carve_args.p, e->form->n_bound, e->stream);
-  e->tick_carve_launches += 3;
+  e->tick_carve_launches += 1u + launch_carve_prep(e->d_carve_args.p, e->form->n_bound, false, e->stream);
   return PM_OK;
 }
 

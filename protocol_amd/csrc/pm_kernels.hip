@@ -1060,7 +1060,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
 // alive when its validation started are left; a batch prepared beside the one in front of it is not worth validating
 // when less than 1 / PM_STALE_DIV of its list is still alive (the next one is prepared from the state as it is then)
 #ifndef PM_THIN_DIV
-#define PM_THIN_DIV 2u
+#define PM_THIN_DIV 3u
 #endif
 #ifndef PM_STALE_DIV
 #define PM_STALE_DIV 3u
@@ -1385,6 +1385,9 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
   if (lane == 0u) cc_st(&L.CC[CC_CMD], cmd_seq | CH_RUN);
   uint32_t tail = 0u, budget = 0u;
   bool aborted = false;
+#ifdef PM_CHAIN_PRIO
+  __builtin_amdgcn_s_setprio(3);  // (the chain is the critical path; the waves beside it only feed it)
+#endif
   if (n_seeds > 0u) {
     for (;;) {
       CH_COUNT(cn_outer);
@@ -1520,6 +1523,9 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
       if (stop) break;
     }
   }
+#ifdef PM_CHAIN_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // ---- stop the other two (they must be off the key array before it is used again; the collector writes out first)
   cmd_seq += 4u;
   if (lane == 0u) cc_st(&L.CC[CC_CMD], cmd_seq | CH_STOP);
@@ -2273,7 +2279,12 @@ __device__ __forceinline__ void tile_keys(const CarveArgs& p, const TileBuf& tb,
       const bool counts = ((aw[v] >> lane) & 1ull) && t != s && !(shared && located && si[v] == ssite && t < s);
       const double dx = x[v] - sg.ux, dy = y[v] - sg.uy, dz = z[v] - sg.uz;
       double a = 0.25 * fma(dx, dx, fma(dy, dy, dz * dz));
-      const bool near = counts && located && a < PM_A_CHORD_MIN;  // (see prox_a: the sine form below ~10 km)
+      // (see prox_a: the sine form below ~10 km.  A candidate at the seed's own site — identical coordinates — has the
+      // Haversine term 0 in either form, exactly: sin(0) = 0; a city of co-located workers would otherwise send
+      // nearly every stride of its seeds' sweeps through the sine polynomials)
+      const bool same_site = located && si[v] == ssite;
+      const bool near = counts && located && a < PM_A_CHORD_MIN && !same_site;
+      a = same_site ? 0.0 : a;
       if (__ballot(near)) {
         if (near) a = hav_a(sg.lat, sg.lon, sg.cos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t]);
       }
@@ -2560,6 +2571,18 @@ __device__ __noinline__ uint32_t carve_prop_limit(const CarveArgs& p, BlockRed& 
 // same configuration: where the search for the next configuration starts.  Beside a validation in flight (speculative
 // mode) that is a guess: the batch in front works on configuration ci of a list of n_list slots; it ends with the
 // list thinned out — the same configuration again — unless the list is small enough to be finished in one go.
+__device__ __forceinline__ void plan_batch(const CarveArgs& p) {  // (one thread)
+  const uint32_t cur = p.status->cur_ci;
+  uint32_t ci0 = cur;
+  const BatchDesc dp = *p.desc_prev;
+  if (p.speculative && p.desc_prev != p.desc && dp.planned && dp.valid && dp.ci0 == cur)
+    ci0 = dp.n_list > 256u ? dp.ci : dp.ci + 1u;
+  BatchDesc d = {};
+  d.planned = 1u;
+  d.ci0 = ci0;
+  d.total_available = p.status->total_available;
+  *p.desc = d;
+}
 __global__ __launch_bounds__(128) void carve_plan_kernel(const CarveArgs* __restrict__ pa) {
   static_assert(PM_MAX_CONFIGS + 2u <= 128u, "one thread per counter");
   const CarveArgs& p = *pa;
@@ -2570,18 +2593,7 @@ __global__ __launch_bounds__(128) void carve_plan_kernel(const CarveArgs* __rest
     return;
   }
   if (tid <= PM_MAX_CONFIGS + 1u) p.prep_counts[tid] = 0u;  // totals + ticket of this preparation
-  if (tid == 0) {
-    const uint32_t cur = st->cur_ci;
-    uint32_t ci0 = cur;
-    const BatchDesc dp = *p.desc_prev;
-    if (p.speculative && p.desc_prev != p.desc && dp.planned && dp.valid && dp.ci0 == cur)
-      ci0 = dp.n_list > 256u ? dp.ci : dp.ci + 1u;
-    BatchDesc d = {};
-    d.planned = 1u;
-    d.ci0 = ci0;
-    d.total_available = st->total_available;
-    *p.desc = d;
-  }
+  if (tid == 0) plan_batch(p);
 }
 
 __global__ __launch_bounds__(256) void carve_prep_count_kernel(const CarveArgs* __restrict__ pa) {
@@ -2590,9 +2602,21 @@ __global__ __launch_bounds__(256) void carve_prep_count_kernel(const CarveArgs* 
   const auto D = G((const BatchDesc*)p.desc);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t wave_g = blockIdx.x * PREP_WAVES + wave;
-  if (st->state != CARVE_STATE_RUNNING || !D->planned || D->ci0 >= p.n_avail) return;
+  if (st->state != CARVE_STATE_RUNNING) {
+    if (!p.speculative && blockIdx.x == 0 && tid == 0) p.desc->planned = 0u;
+    return;
+  }
+  uint32_t ci0;
+  if (!p.speculative) {  // one batch at a time: the plan is the carve's own state, the same in every block
+    ci0 = st->cur_ci;
+    if (blockIdx.x == 0 && tid == 0) plan_batch(p);
+  } else {
+    if (!D->planned) return;
+    ci0 = D->ci0;
+  }
+  if (ci0 >= p.n_avail) return;
   __shared__ uint32_t s_cnt[PREP_WAVES][PM_MAX_CONFIGS];
-  const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6, ci0 = D->ci0;
+  const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6;
   const uint32_t j = wave_g;  // this wave's word of the position space
   uint64_t m = 0;
   if (j < n_words) {
@@ -2873,6 +2897,9 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   const auto st = G(p.status);
   uint32_t flags = flags_in;
   if (!(flags & CARVE_F_INIT) && st->state != CARVE_STATE_RUNNING) return;  // queued behind a finished carve
+  // (one batch at a time: the totals + ticket of the preparation behind this launch; beside a validation in flight
+  // the plan kernel clears them)
+  if ((flags & CARVE_F_EXTPREP) && !p.speculative && threadIdx.x <= PM_MAX_CONFIGS) p.prep_counts[threadIdx.x] = 0u;
   PROF_DECL;
 
   uint32_t n;
@@ -3076,7 +3103,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     if (in_lds)
       for (uint32_t sl = tid; sl < c.n_list; sl += CARVE_THREADS) lds_site[sl] = G(p.cc_site)[sl];
     __syncthreads();
-    if ((flags_in & CARVE_F_EXTPREP) && p.mode == CARVE_MODE_FORM) {
+    if ((flags_in & CARVE_F_EXTPREP) && p.mode == CARVE_MODE_FORM && p.speculative) {
       // The list may have been prepared before the batch in front of it was validated: whatever has left the
       // position bitmap since then is a dead slot.  (No-op for a list prepared from the current state.)
       uint32_t live = 0;
@@ -3108,7 +3135,7 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
       }
       // too little of the list is left for its neighbour rows to be of use (it was prepared before the batch in front
       // of it took its share): leave it; the batch behind it was prepared from the state as it is now
-      if (p.speculative && c.n_list > 256u && c.n_cand * PM_STALE_DIV < c.n_list) {
+      if (c.n_list > 256u && c.n_cand * PM_STALE_DIV < c.n_list) {
         if (tid == 0) {
           st->n_void += 1u;
           st->why[5] += 1u;
@@ -3373,14 +3400,16 @@ void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng
 }
 
 // the two full-chip kernels that prepare the next candidate list: one 64-position word per wave
-void launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s) {
+uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, bool speculative, hipStream_t s) {  // returns the launches it made
   uint32_t blocks = ((W + 63u) / 64u + PREP_WAVES - 1u) / PREP_WAVES;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(carve_plan_kernel, dim3(1), dim3(128), 0, s, d_args);
+  // (beside a validation in flight the plan has to be decided once, ahead of the blocks that act on it; otherwise
+  // every block of the count kernel derives the same plan from a status nobody is writing)
+  if (speculative) hipLaunchKernelGGL(carve_plan_kernel, dim3(1), dim3(128), 0, s, d_args);
   hipLaunchKernelGGL(carve_prep_count_kernel, dim3(blocks), dim3(256), 0, s, d_args);
   hipLaunchKernelGGL(carve_prep_place_kernel, dim3(blocks), dim3(256), 0, s, d_args);
+  return speculative ? 3u : 2u;
 }
-// the ordered eligible list of a proposal-driven FORM carve (instead of the validator's INIT launch)
 void launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t start_ci, hipStream_t s) {
   uint32_t blocks = ((W + 63u) / 64u + PREP_WAVES - 1u) / PREP_WAVES;
   if (blocks == 0) blocks = 1;

@@ -101,7 +101,7 @@ def test_form_groups_cfg1_bit_exact(seed, carve_variant):
     eng.close()
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 2])
+@pytest.mark.parametrize("carve_variant", [0, 1, 2, 4])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_form_groups_cfg2_bit_exact(seed, carve_variant):
     sw = baseline_config(1, seed=seed)
