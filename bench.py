@@ -245,50 +245,38 @@ def run_extra_configs2(E, host, seed):
 
 def run_extra_churn(E, host, seed, ticks=6):
     """BASELINE configs[4] on one GPU (the 8-GPU form is `--gpus 8`): 100k workers; per tick 10k tasks arrive, 1 % of
-    the workers die and 1 % brand-new workers join; one incremental match on the standing groups."""
-    from protocol_amd.swarm import make_swarm
-    W0, n_churn, n_new = 100_000, 1000, 10_000
-    sw_all = make_swarm(seed + 4, 10_000, W0 + n_churn * (ticks + 2))
+    the workers die and 1 % brand-new workers join; one incremental match on the standing groups.  The stream is
+    protocol_amd/churn.py — the one tests/golden/churn_digests.json pins against the oracle."""
+    from protocol_amd.churn import ChurnStream
+    cs = ChurnStream(seed, ticks + 2)
+    sw_all = cs.sw_all
     packed = host.pack_workers(sw_all)
     rows = lambda idx: {k: np.ascontiguousarray(v[idx]) for k, v in packed.items()}
     eng = E.Engine()
     cfg_rows, alt_rows, req_models = host.pack_configs(sw_all.configs)
     eng.set_configs(cfg_rows, alt_rows)
     eng.set_model_table(host.build_model_table(req_models, sw_all.model_names), len(req_models), len(sw_all.model_names))
-    eng.upload_workers(rows(np.arange(W0)))
-    masks, created, uid = sw_all.task_masks(), sw_all.created_at.copy(), sw_all.task_uid.copy()
-    eng.upload_tasks(masks, created, uid)
+    eng.upload_workers(rows(np.arange(cs.W0)))
+    eng.upload_tasks(cs.masks, cs.created, cs.uid)
     eng.set_enabled_mask(sw_all.enabled_mask())
     s0 = eng.tick()
-    rng = np.random.default_rng(seed)
     flags = packed["flags"].astype(np.int64)
-    alive = set(np.nonzero((sw_all.status[:W0] == 2))[0].tolist())
-    W, next_uid, t_max = W0, 1 << 40, int(created.max())
     out_ticks = []
     for t in range(ticks + 2):
-        leave = rng.choice(np.fromiter(alive, dtype=np.int64), size=n_churn, replace=False)  # (harness, not timed)
+        leave, idx_new, new_tasks = cs.step()  # (harness, not timed)
         t0 = time.perf_counter()
         eng.on_worker_status_many(leave, flags[leave] & ~E.W_HEALTHY, np.ones(len(leave), dtype=np.uint32))
         t1 = time.perf_counter()
-        alive.difference_update(int(w) for w in leave)
-        idx_new = np.arange(W, W + n_churn)
         new_rows = rows(idx_new)
         t1b = time.perf_counter()
         eng.append_workers(new_rows)
         t2 = time.perf_counter()
-        alive.update(int(w) for w in idx_new if sw_all.status[w] == 2)
-        W += n_churn
-        pick = rng.integers(0, len(masks), n_new)
-        new_tasks = (masks[pick], t_max + 1 + np.arange(n_new)[::-1], np.arange(next_uid, next_uid + n_new, dtype=np.uint64))
-        t2b = time.perf_counter()
-        eng.tasks_insert_front(*new_tasks)
-        t_max += n_new
-        next_uid += n_new
+        eng.tasks_insert_front(*new_tasks[:3])
         t3 = time.perf_counter()
         s = eng.tick()
         t4 = time.perf_counter()
         if t >= 2:
-            out_ticks.append({"status_ms": 1e3 * (t1 - t0), "append_ms": 1e3 * (t2 - t1b), "tasks_ms": 1e3 * (t3 - t2b),
+            out_ticks.append({"status_ms": 1e3 * (t1 - t0), "append_ms": 1e3 * (t2 - t1b), "tasks_ms": 1e3 * (t3 - t2),
                               "match_ms": 1e3 * (t4 - t3), "carve_ms": s["ms_carve"], "sweep_ms": s["ms_sweep"],
                               "publish_ms": s["ms_publish"], "formed": s["n_formed"], "groups": s["n_groups"]})
     eng.close()
@@ -296,6 +284,7 @@ def run_extra_churn(E, host, seed, ticks=6):
     return {"workload": ("BASELINE configs[4] on one GPU: 100k workers, per tick +10k tasks (pm_tasks_insert_front), 1% "
                          "workers die (one pm_on_worker_status_many call), 1% brand-new workers (pm_append_workers), incremental "
                          "pm_tick on the standing groups"),
+            "pinned_by": "tests/golden/churn_digests.json (the first three ticks of this stream against the oracle)",
             "ticks": len(out_ticks), "cold_match_ms": s0["ms_total"],
             "ms_per_tick": m("status_ms") + m("append_ms") + m("tasks_ms") + m("match_ms"),
             "split_ms_p50": {k: m(k) for k in ("status_ms", "append_ms", "tasks_ms", "match_ms", "carve_ms", "sweep_ms",

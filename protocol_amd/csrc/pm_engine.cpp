@@ -248,6 +248,7 @@ struct pm_engine {
   DevBuf<pm_assignment> d_table;
   DevBuf<uint32_t> d_task_col;
   const pm_assignment* h_table = nullptr;  // the snapshot published last (host side of the lock-free look-up)
+  uint64_t groups_epoch = 0, pub_groups_epoch = ~0ull;  // slot numbering of e->groups / the one the published rows use
   // pinned staging for the group records a carve appended (absorbed into the host list by absorb_groups)
   uint32_t* h_gstage = nullptr;
   size_t h_gstage_cap = 0;
@@ -337,6 +338,7 @@ static void compact_groups(pm_engine* e) {
   if (!e->n_dead_groups) return;
   e->groups.erase(std::remove_if(e->groups.begin(), e->groups.end(), [](const Group& g) { return g.dead; }),
                   e->groups.end());
+  e->groups_epoch++;  // (published group slots no longer index this list)
   std::fill(e->h_group_of.begin(), e->h_group_of.end(), -1);
   for (size_t g = 0; g < e->groups.size(); ++g)
     for (uint32_t w : e->groups[g].members) e->h_group_of[w] = int32_t(g);
@@ -1164,6 +1166,90 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   return PM_OK;
 }
 
+// The rows of a snapshot buffer, grown if need be (buffers only grow; a replaced one is retired, not freed: a reader
+// may still hold it)
+static int32_t pub_buffer(pm_engine* e, PubTable& t, uint32_t rows, uint64_t** out) {
+  uint64_t* words = t.words.load(std::memory_order_relaxed);
+  if (t.cap_rows < rows || !words) {
+    const size_t cap = std::max<size_t>(size_t(rows) + rows / 8 + 64, 64);
+    uint64_t* nw = nullptr;
+    if (hipHostMalloc((void**)&nw, cap * 32) != hipSuccess || !nw)
+      return set_error(PM_ENOMEM, "out of pinned host memory for the published table");
+    std::memset(nw, 0, cap * 32);
+    const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+    t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd while the pointer changes
+    std::atomic_thread_fence(std::memory_order_release);
+    if (words) e->pub_retired.push_back(words);
+    words = nw;
+    t.cap_rows = cap;
+    t.words.store(nw, std::memory_order_relaxed);
+    t.seq.store(s0 + 2, std::memory_order_release);
+  }
+  *out = words;
+  return PM_OK;
+}
+
+// Between two ticks the published table says what the last tick computed, while a task delta changes the POSITION of
+// every task behind it in the caller's list and a deleted task or a dead worker takes a group with it
+// (mod.rs:1259-1288, status_update_impl.rs:17-29).  The reference binds a group to its task by id
+// (get_current_group_task, scheduler_impl.rs:33): a heartbeat between two management-loop runs sees the same task
+// under its new position, and nothing for a worker whose group has just been dissolved.  pub_patch applies exactly
+// that to the published rows, in place (the sequence counter of the buffer is odd meanwhile: readers retry), from the
+// host's group list: a row of a dissolved group becomes the row of a worker in no group, a row of a standing group gets
+// the current position of the task the group holds.  `only` = just these workers (a dissolved group's members);
+// nullptr = every row (a task delta).  No device work; the device-side task column waits for the next tick.
+static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
+  const int cur = e->pub_cur.load(std::memory_order_relaxed);
+  if (cur < 0) return;  // nothing published
+  // the published rows name their group by the slot it had then; if the list has been compacted since, by its id
+  const bool by_id = e->pub_groups_epoch != e->groups_epoch;
+  std::unordered_map<uint64_t, uint32_t> slot_of_id;
+  if (by_id) {
+    slot_of_id.reserve(e->groups.size() * 2);
+    for (size_t g = 0; g < e->groups.size(); ++g)
+      if (!e->groups[g].dead) slot_of_id.emplace(e->groups[g].id, uint32_t(g));
+  }
+  PubTable& t = e->pub[cur];
+  const uint32_t n = t.n.load(std::memory_order_relaxed);
+  pm_assignment* rows = reinterpret_cast<pm_assignment*>(t.words.load(std::memory_order_relaxed));
+  if (!rows || !n) return;
+  const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+  t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
+  std::atomic_thread_fence(std::memory_order_release);
+  auto patch = [&](uint32_t w) {
+    pm_assignment a = rows[w];
+    if (a.group_slot == PM_NONE) return;
+    uint32_t slot = a.group_slot;
+    if (by_id) {
+      const auto it = slot_of_id.find(a.group_id);
+      slot = it == slot_of_id.end() ? PM_NONE : it->second;
+    }
+    const bool gone = slot >= e->groups.size() || e->groups[slot].dead;
+    if (gone) {
+      a.task = PM_NONE;
+      a.group_slot = PM_NONE;
+      a.group_index = 0;
+      a.group_size = 0;
+      a.next_worker = PM_NONE;
+      a.group_id = 0;
+    } else {
+      const uint32_t h = e->groups[slot].task;
+      a.task = h == PM_NONE ? PM_NONE : task_position(e, h);
+    }
+    uint64_t v[4];
+    std::memcpy(v, &a, sizeof(a));
+    uint64_t* dst = reinterpret_cast<uint64_t*>(&rows[w]);
+    for (int k = 0; k < 4; ++k) __atomic_store_n(&dst[k], v[k], __ATOMIC_RELAXED);
+  };
+  if (only) {
+    for (uint32_t w : *only)
+      if (w < n) patch(w);
+  } else {
+    for (uint32_t w = 0; w < n; ++w) patch(w);
+  }
+  t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
+}
+
 // D2H of the assignment table + the group task words; the table lands directly in the snapshot buffer that is
 // not current (pinned host memory, written by the copy engine between the odd and the even mark of its sequence
 // counter — see PubTable), which then becomes the published one.
@@ -1181,21 +1267,10 @@ static int32_t publish(pm_engine* e) {
   const int cur = e->pub_cur.load(std::memory_order_relaxed);
   const int nx = cur < 0 ? 0 : (cur ^ 1);
   PubTable& t = e->pub[nx];
-  uint64_t* words = t.words.load(std::memory_order_relaxed);
-  if (t.cap_rows < e->W || !words) {  // buffers only grow; a replaced one is retired, not freed (a reader may hold it)
-    const size_t cap = std::max<size_t>(size_t(e->W) + e->W / 8 + 64, 64);
-    uint64_t* nw = nullptr;
-    if (hipHostMalloc((void**)&nw, cap * 32) != hipSuccess || !nw)
-      return set_error(PM_ENOMEM, "out of pinned host memory for the published table");
-    std::memset(nw, 0, cap * 32);
-    const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
-    t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd while the pointer changes
-    std::atomic_thread_fence(std::memory_order_release);
-    if (words) e->pub_retired.push_back(words);
-    words = nw;
-    t.cap_rows = cap;
-    t.words.store(nw, std::memory_order_relaxed);
-    t.seq.store(s0 + 2, std::memory_order_release);
+  uint64_t* words = nullptr;
+  {
+    int32_t rcb = pub_buffer(e, t, e->W, &words);
+    if (rcb) return rcb;
   }
   const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
   t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
@@ -1214,6 +1289,7 @@ static int32_t publish(pm_engine* e) {
   t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
   e->pub_cur.store(nx, std::memory_order_release);
   e->h_table = reinterpret_cast<const pm_assignment*>(words);
+  e->pub_groups_epoch = e->groups_epoch;
   for (size_t g = 0; g < G; ++g) {
     e->groups[g].task = g_task[g];
     e->groups[g].task_uid = g_task[g] == PM_NONE ? 0 : (e->tasks_have_uid ? e->h_tuid[g_task[g]] : task_position(e, g_task[g]));
@@ -1279,6 +1355,10 @@ static void host_merge_select(pm_engine* e, const std::vector<uint32_t>& rem, co
 
 static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
   if (n_merged) *n_merged = 0;
+  if (e->n_dead_groups) {  // (the records of a carve not yet absorbed are numbered behind the list as it is: take
+    int32_t rc0 = absorb_groups(e);  // them in before the list is compacted)
+    if (rc0) return rc0;
+  }
   compact_groups(e);
   if (!e->have_cfgs || !e->have_workers) return set_error(PM_ESTATE, "configs and workers must be uploaded first");
   size_t solo = e->absorb_pending ? e->ab_solo : 0;  // single-node groups of the carve not yet absorbed
@@ -1534,6 +1614,7 @@ int32_t pm_set_configs(pm_engine* e, const pm_config_row* cfgs, uint32_t n_cfgs,
       return set_error(PM_ERANGE, "alternative range outside the alt table");
   }
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   HIPCHK(hipSetDevice(e->cfg.device));
   e->cfgs.assign(cfgs, cfgs + n_cfgs);
   e->alts.assign(alts, alts + n_alts);
@@ -1567,6 +1648,7 @@ int32_t pm_set_model_table(pm_engine* e, const uint32_t* bits, uint32_t n_rows, 
 int32_t pm_set_enabled_mask(pm_engine* e, uint64_t enabled) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   e->enabled = enabled;
   return PM_OK;
 }
@@ -2021,6 +2103,7 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
       }
     }
   }
+  pub_patch(e, nullptr);  // the published positions follow the new list
   return PM_OK;
 }
 
@@ -2088,6 +2171,7 @@ int32_t pm_tasks_insert_front(pm_engine* e, const pm_task_soa* t) {
   e->T += n;
   e->tprefix_dirty = true;
   e->h_tprefix_valid = false;
+  pub_patch(e, nullptr);  // n new tasks in front of the list: every published position moves back by n
   return PM_OK;
 }
 
@@ -2109,7 +2193,7 @@ int32_t pm_tasks_delete(pm_engine* e, const uint64_t* uids, uint32_t n, uint32_t
       if ((e->h_tlive[u >> 6] >> (u & 63u)) & 1ull) e->uid_to_u[e->h_tuid[u]] = u;
     e->uid_map_valid = true;
   }
-  std::vector<uint32_t> slots;
+  std::vector<uint32_t> slots;  // handles of the deleted tasks
   for (uint32_t k = 0; k < n; ++k) {
     auto it = e->uid_to_u.find(uids[k]);
     if (it == e->uid_to_u.end()) continue;
@@ -2123,10 +2207,11 @@ int32_t pm_tasks_delete(pm_engine* e, const uint64_t* uids, uint32_t n, uint32_t
       }
     }
     e->h_tmask[u] = 0;
-    e->h_tlive[u >> 6] &= ~(1ull << (u & 63u));
     slots.push_back(u);
   }
   if (slots.empty()) return PM_OK;
+  for (uint32_t u : slots) e->h_tlive[u >> 6] &= ~(1ull << (u & 63u));
+  e->h_tprefix_valid = false;
   std::vector<uint32_t> sorted = slots;
   std::sort(sorted.begin(), sorted.end());
   for (size_t g = 0; g < e->groups.size(); ++g) {  // (creation order: dissolutions are logged in it)
@@ -2153,19 +2238,26 @@ int32_t pm_tasks_delete(pm_engine* e, const uint64_t* uids, uint32_t n, uint32_t
   e->tprefix_dirty = true;
   e->h_tprefix_valid = false;
   if (n_deleted) *n_deleted = uint32_t(slots.size());
+  pub_patch(e, nullptr);  // a deleted task (and the group that held it) is gone, the tasks behind it move up
   return PM_OK;
 }
 
 int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, uint32_t dead) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   if (!e->have_workers || worker >= e->W) return set_error(PM_ERANGE, "worker index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   ABSORB_PENDING(e);
   e->h_flags[worker] = flags_new;
   e->flags_dirty = true;   // uploaded once before the next kernel that reads the column (sync_flags)
   e->compat_dirty = true;  // HAS_SPECS etc. may have changed with the row
-  if (dead && e->h_group_of[worker] >= 0) dissolve_locked(e, uint32_t(e->h_group_of[worker]));  // status_update_impl.rs:17-29
+  if (dead && e->h_group_of[worker] >= 0) {  // status_update_impl.rs:17-29
+    const uint32_t slot = uint32_t(e->h_group_of[worker]);
+    const std::vector<uint32_t> members = e->groups[slot].members;
+    dissolve_locked(e, slot);
+    pub_patch(e, &members);  // its workers are in no group from now on, also for a look-up before the next tick
+  }
   return PM_OK;
 }
 
@@ -2173,19 +2265,26 @@ int32_t pm_on_worker_status_many(pm_engine* e, const uint32_t* workers, const ui
                                  uint32_t n) {
   if (!e || (n && (!workers || !flags_new))) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   if (!e->have_workers) return set_error(PM_ERANGE, "worker index out of range");
   for (uint32_t k = 0; k < n; ++k)
     if (workers[k] >= e->W) return set_error(PM_ERANGE, "worker index out of range");
   if (!n) return PM_OK;
   HIPCHK(hipSetDevice(e->cfg.device));
   ABSORB_PENDING(e);
+  std::vector<uint32_t> freed;  // members of the groups this sweep dissolves
   for (uint32_t k = 0; k < n; ++k) {
     const uint32_t w = workers[k];
     e->h_flags[w] = flags_new[k];
-    if (dead && dead[k] && e->h_group_of[w] >= 0) dissolve_locked(e, uint32_t(e->h_group_of[w]));  // status_update_impl.rs:17-29
+    if (dead && dead[k] && e->h_group_of[w] >= 0) {  // status_update_impl.rs:17-29
+      const uint32_t slot = uint32_t(e->h_group_of[w]);
+      freed.insert(freed.end(), e->groups[slot].members.begin(), e->groups[slot].members.end());
+      dissolve_locked(e, slot);
+    }
   }
   e->flags_dirty = true;
   e->compat_dirty = true;
+  if (!freed.empty()) pub_patch(e, &freed);
   return PM_OK;
 }
 
@@ -2221,10 +2320,13 @@ int32_t pm_drain_group_events(pm_engine* e, pm_group_event* events, uint32_t cap
 int32_t pm_dissolve_group(pm_engine* e, uint32_t slot) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   ABSORB_PENDING(e);
   compact_groups(e);  // `slot` is a number of the compacted list (what pm_get_groups reports)
   if (slot >= e->groups.size()) return set_error(PM_ERANGE, "group slot out of range");
+  const std::vector<uint32_t> members = e->groups[slot].members;
   dissolve_locked(e, slot);
+  pub_patch(e, &members);
   compact_groups(e);
   return PM_OK;
 }
@@ -2232,6 +2334,7 @@ int32_t pm_dissolve_group(pm_engine* e, uint32_t slot) {
 int32_t pm_reset_groups(pm_engine* e) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   reset_groups_locked(e);
   return PM_OK;
 }
@@ -2252,6 +2355,7 @@ int32_t pm_compat_masks(pm_engine* e, uint64_t* mask_out) {
 int32_t pm_form_groups(pm_engine* e, uint32_t* n_formed) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   HIPCHK(hipSetDevice(e->cfg.device));
   e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
   e->tick_fast_steps = 0;
@@ -2266,6 +2370,7 @@ int32_t pm_form_groups(pm_engine* e, uint32_t* n_formed) {
 int32_t pm_merge_solo_groups(pm_engine* e, uint32_t* n_merged) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   HIPCHK(hipSetDevice(e->cfg.device));
   e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
   int32_t rc = run_merge(e, n_merged);
@@ -2312,6 +2417,7 @@ int32_t pm_get_groups(pm_engine* e, int32_t* group_of_worker, pm_group* groups, 
 int32_t pm_match(pm_engine* e, uint32_t* task_of_worker, uint32_t* applicable_count) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   HIPCHK(hipSetDevice(e->cfg.device));
   if (e->dist_world > 1) return set_error(PM_ESTATE, "multi-GPU engine: use the stepwise tick (pm_dist_tick_begin ...)");
   ABSORB_PENDING(e);
@@ -2330,6 +2436,8 @@ int32_t pm_match(pm_engine* e, uint32_t* task_of_worker, uint32_t* applicable_co
 // leaves first / count per task in d_first / d_count (worker indices are global: every rank holds the whole table)
 static int32_t run_match_per_task(pm_engine* e) {
   if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first");
+  if (e->dist_world > 1 && e->h_shard.size() != e->W)
+    return set_error(PM_ESTATE, "the worker table changed size: call pm_dist_configure again");
   ABSORB_PENDING(e);
   int32_t rc = ensure_compat(e);
   if (rc) return rc;
@@ -2376,6 +2484,7 @@ static int32_t run_match_per_task(pm_engine* e) {
 int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candidate_count) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   HIPCHK(hipSetDevice(e->cfg.device));
   int32_t rc = run_match_per_task(e);
   if (rc) return rc;
@@ -2393,6 +2502,7 @@ int32_t pm_match_per_task(pm_engine* e, uint32_t* best_worker, uint32_t* candida
 int32_t pm_match_per_task_device(pm_engine* e, uint64_t* best_ptr, uint64_t* count_ptr, uint32_t* n) {
   if (!e || !best_ptr || !count_ptr || !n) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   HIPCHK(hipSetDevice(e->cfg.device));
   ensure_price_order(e);
   if (e->any_price) return set_error(PM_ESTATE, "device-side bids are index-ordered: not available with a price column");
@@ -2480,6 +2590,7 @@ static int32_t tick_stats(pm_engine* e, pm_stats* stats, uint32_t n_formed, uint
 int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   HIPCHK(hipSetDevice(e->cfg.device));
   if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
     return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");

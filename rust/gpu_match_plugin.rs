@@ -33,6 +33,7 @@ use crate::plugins::webhook::WebhookPlugin;
 pub const PM_NONE: u32 = 0xFFFF_FFFF;
 pub const PM_ABI_VERSION: u32 = 2;
 const PM_EINVAL: i32 = -1;
+const PM_ERANGE: i32 = -5;
 
 #[repr(C)]
 pub struct pm_engine_config {
@@ -240,6 +241,7 @@ struct NodeTable {
     p2p_ids: Vec<String>,           // node.p2p_id.unwrap_or_default() (scheduler_impl.rs:118-128)
     rows: Vec<Row>,
     present: Vec<bool>,             // still in the node store
+    by_address: Vec<u32>,           // rows in address-string order (kept sorted: a new node is one binary search)
     spec_models: Vec<String>,       // interned gpu.model strings; the index is gpu_model_class
     spec_model_index: HashMap<String, u32>,
 }
@@ -409,6 +411,9 @@ impl GpuMatchPlugin {
                     t.p2p_ids.push(node.p2p_id.clone().unwrap_or_default());
                     t.rows.push(row.clone());
                     t.present.push(true);
+                    let key = &t.address_strings[i as usize];
+                    let at = t.by_address.partition_point(|&j| t.address_strings[j as usize] < *key);
+                    t.by_address.insert(at, i);
                     appended.push(&row, i);
                 }
             }
@@ -429,8 +434,9 @@ impl GpuMatchPlugin {
             check(unsafe { pm_on_worker_status_many(self.engine, gone.as_ptr(), gone_flags.as_ptr(), dead.as_ptr(), gone.len() as u32) })?;
         }
         if !upd_idx.is_empty() {
-            // keep the ranks the engine already has for rewritten rows
-            let ranks = Self::address_ranks(&t.address_strings[..seen.len()]);
+            // keep the ranks the engine already has for rewritten rows (ranks among the rows it knows: the new
+            // ones of this snapshot are sent behind this call)
+            let ranks = Self::address_ranks(&t.by_address, seen.len());
             for (k, &i) in upd_idx.iter().enumerate() { updated.addr_rank[k] = ranks[i as usize]; }
             check(unsafe { pm_update_workers(self.engine, upd_idx.as_ptr(), &updated.soa()) })?;
         }
@@ -439,19 +445,21 @@ impl GpuMatchPlugin {
             check(unsafe { pm_append_workers(self.engine, &appended.soa(), &mut first) })?;
             debug_assert_eq!(first as usize, seen.len());
             // a new address shifts the global ranks of the others: GROUP_INDEX only needs the relative order
-            let ranks = Self::address_ranks(&t.address_strings);
+            let ranks = Self::address_ranks(&t.by_address, t.rows.len());
             check(unsafe { pm_set_addr_ranks(self.engine, ranks.as_ptr(), ranks.len() as u32) })?;
         }
         drop(t);
         self.emit_group_webhooks()      // tombstoned nodes dissolved their groups
     }
 
-    /// rank of address.to_string() in byte order (BTreeSet<String>, mod.rs:424-434)
-    fn address_ranks(strings: &[String]) -> Vec<u32> {
-        let mut order: Vec<usize> = (0..strings.len()).collect();
-        order.sort_by(|&a, &b| strings[a].cmp(&strings[b]));
-        let mut rank = vec![0u32; strings.len()];
-        for (r, &i) in order.iter().enumerate() { rank[i] = r as u32; }
+    /// rank of address.to_string() in byte order (BTreeSet<String>, mod.rs:424-434) among the first `known` rows:
+    /// one pass over the sorted row list (no string is compared here; the list is kept sorted as nodes arrive)
+    fn address_ranks(by_address: &[u32], known: usize) -> Vec<u32> {
+        let mut rank = vec![0u32; known];
+        let mut r = 0u32;
+        for &i in by_address {
+            if (i as usize) < known { rank[i as usize] = r; r += 1; }
+        }
         rank
     }
 
@@ -520,9 +528,18 @@ impl GpuMatchPlugin {
         let (mut ne, mut nm) = (0u32, 0u32);
         let rc = unsafe { pm_drain_group_events(self.engine, std::ptr::null_mut(), 0, std::ptr::null_mut(), 0, &mut ne, &mut nm) };
         if rc == 0 { return Ok(()); }                       // empty log
-        let mut events = vec![pm_group_event::default(); ne as usize];
-        let mut members = vec![0u32; nm as usize];
-        check(unsafe { pm_drain_group_events(self.engine, events.as_mut_ptr(), ne, members.as_mut_ptr(), nm, &mut ne, &mut nm) })?;
+        // (another thread may log events between the size query and the drain: grow and try again; a drain that
+        // still fails is logged and left for the next call — it is not the tick that failed)
+        let (mut events, mut members) = (Vec::new(), Vec::new());
+        for _ in 0..8 {
+            events.resize(ne as usize, pm_group_event::default());
+            members.resize(nm as usize, 0u32);
+            let (cap_e, cap_m) = (ne, nm);
+            let rc = unsafe { pm_drain_group_events(self.engine, events.as_mut_ptr(), cap_e, members.as_mut_ptr(), cap_m, &mut ne, &mut nm) };
+            if rc == 0 { break; }
+            if rc != PM_ERANGE { log::error!("pm_drain_group_events: {rc}"); return Ok(()); }
+        }
+        if events.len() < ne as usize { log::error!("group events kept for the next drain"); return Ok(()); }
         let Some(plugins) = &self.webhook_plugins else { return Ok(()) };
         let t = self.nodes.read();
         for ev in &events[..ne as usize] {
@@ -548,6 +565,9 @@ impl GpuMatchPlugin {
         Ok(String::from_utf8(buf)?)
     }
 
+    /// (The positions pm_lookup_task_for_worker reports index `tasks` as it is NOW: the engine re-derives the published
+    /// positions inside pm_tasks_insert_front / pm_tasks_delete / pm_upload_tasks, and clears the rows of a group that a
+    /// deleted task or a dead node dissolved — no tick needed in between.)
     /// SchedulerPlugin::filter_tasks (plugins/mod.rs:66-78): lock-free lookup + the `${...}` templating the
     /// reference does at scheduler_impl.rs:112-205 (GROUP_INDEX, GROUP_SIZE, NEXT_P2P_ADDRESS, GROUP_ID, upload count).
     pub(crate) fn filter_tasks(&self, _tasks: &[Task], node_address: &Address) -> Result<Vec<Task>> {

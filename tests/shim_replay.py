@@ -1,0 +1,196 @@
+"""The call sequence of rust/gpu_match_plugin.rs (GpuMatchPlugin) against the C ABI, statement for statement — the
+executable stand-in for the Rust binding, which cannot be compiled in this image.  Every method names the Rust
+function it replays; the engine calls are made in the same order with the same arguments (ctypes through
+protocol_amd.engine).  The "store" is a protocol_amd.swarm.Swarm; a node is a row id of it.
+
+  ShimReplay(sw)                         GpuMatchPlugin::new: pm_engine_create, pm_set_configs (+ model table with no
+                                         spec models yet), EMPTY pm_upload_workers, pm_enable_group_events(1), EMPTY
+                                         pm_upload_tasks
+  sync_nodes(snapshot)                   one get_nodes() snapshot, in ANY order: model table (new spec models),
+                                         tombstones (pm_on_worker_status_many), rewritten rows (pm_update_workers with
+                                         their current ranks), new rows (pm_append_workers + pm_set_addr_ranks), then
+                                         the two-call pm_drain_group_events
+  sync_tasks / on_task_created / on_task_deleted / handle_status_change / tick     as named
+"""
+from __future__ import annotations
+
+import bisect
+import ctypes as C
+
+import numpy as np
+
+from protocol_amd import engine as E
+from protocol_amd import host
+
+_ROW_FIELDS = ("flags", "gpu_count", "gpu_mem_mb", "gpu_model_class", "cpu_cores", "ram_mb", "storage_gb", "price",
+               "lat", "lon")
+
+
+class ShimReplay:
+    def __init__(self, sw, **engine_kw):
+        self.sw = sw
+        self.eng = E.Engine(**engine_kw)                       # pm_engine_config_default + pm_engine_create
+        cfg_rows, alt_rows, self.req_models = host.pack_configs(sw.configs)
+        self.eng.set_configs(cfg_rows, alt_rows)               # set_configs
+        self.spec_models: list = []                            # interned in first-seen order (project)
+        self.spec_index: dict = {}
+        self._push_model_table()                               # push_model_table(&NodeTable::default())
+        self.packed_all = host.pack_workers(sw)                # the projection of every store row (project)
+        self.flags_all = self.packed_all["flags"].copy()
+        # NodeTable: index (address -> row), rows, present
+        self.index: dict = {}
+        self.node_of_row: list = []                            # engine row -> store row
+        self.rows: list = []                                   # projected row (tuple) per engine row
+        self.present: list = []
+        self.sorted_rows: list = []                            # engine rows in address-string order (incremental ranks)
+        self.sorted_keys: list = []
+        self.events: list = []                                 # what send_group_created / _destroyed were called with
+        self.tasks: list = []                                  # the shim's Vec<Task>: uids in list order
+        empty = {f: np.zeros(0, dtype=self.packed_all[f].dtype) for f in _ROW_FIELDS}
+        empty["addr_rank"] = np.zeros(0, dtype=np.uint32)
+        self.eng.upload_workers(empty)                         # pm_upload_workers(&empty, 0)
+        self.eng.enable_group_events(True)                     # pm_enable_group_events(1)
+        self.eng.upload_tasks(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.uint64))
+
+    # ---- helpers of the shim
+    def _push_model_table(self):
+        bits = host.build_model_table(self.req_models, self.spec_models)
+        self.eng.set_model_table(bits, len(self.req_models), len(self.spec_models))
+
+    def _project(self, node: int, status_healthy: bool):
+        """project(): one OrchestratorNode -> Row; interns its GPU model in first-seen order"""
+        new_model = False
+        row = {f: self.packed_all[f][node] for f in _ROW_FIELDS}
+        flags = int(row["flags"]) & ~E.W_HEALTHY
+        if status_healthy:
+            flags |= E.W_HEALTHY
+        row["flags"] = np.uint32(flags)
+        if flags & E.W_GPU_MODEL:
+            name = self.sw.model_names[int(row["gpu_model_class"])]
+            if name not in self.spec_index:
+                self.spec_index[name] = len(self.spec_models)
+                self.spec_models.append(name)
+                new_model = True
+            row["gpu_model_class"] = np.uint32(self.spec_index[name])
+        return row, new_model
+
+    def _ranks(self) -> np.ndarray:
+        """address_ranks(): rank of address.to_string() among the known rows (kept sorted incrementally)"""
+        rank = np.zeros(len(self.rows), dtype=np.uint32)
+        rank[np.array(self.sorted_rows, dtype=np.int64)] = np.arange(len(self.sorted_rows), dtype=np.uint32)
+        return rank
+
+    @staticmethod
+    def _columns(rows: list, ranks) -> dict:
+        out = {f: np.array([r[f] for r in rows]) for f in _ROW_FIELDS}
+        out["addr_rank"] = np.asarray(ranks, dtype=np.uint32)
+        return out
+
+    def _emit_group_webhooks(self):
+        """emit_group_webhooks(): size query, then the drain (Engine.drain_group_events makes exactly these two calls)"""
+        self.events.extend(self.eng.drain_group_events())
+
+    # ---- the plugin surface
+    def sync_nodes(self, snapshot, healthy):
+        """snapshot: store rows present now, in the store's order of the day; healthy: set of store rows with
+        status Healthy"""
+        seen = [False] * len(self.rows)
+        new_model = False
+        appended, upd_idx, updated = [], [], []
+        for node in snapshot:
+            row, nm = self._project(int(node), int(node) in healthy)
+            new_model |= nm
+            i = self.index.get(int(node))
+            if i is not None:
+                seen[i] = True
+                if any(self.rows[i][f] != row[f] for f in _ROW_FIELDS) or not self.present[i]:
+                    self.rows[i] = row
+                    self.present[i] = True
+                    upd_idx.append(i)
+                    updated.append(row)
+            else:
+                i = len(self.rows)
+                self.index[int(node)] = i
+                self.node_of_row.append(int(node))
+                self.rows.append(row)
+                self.present.append(True)
+                key = int(self.sw.address[int(node)])          # (digit-only address strings of one length: the
+                k = bisect.bisect_left(self.sorted_keys, key)  # integer order is the byte order of the strings)
+                self.sorted_keys.insert(k, key)
+                self.sorted_rows.insert(k, i)
+                appended.append(row)
+        if new_model:
+            self._push_model_table()
+        gone, gone_flags = [], []
+        for i in range(len(seen)):
+            if not seen[i] and self.present[i]:
+                self.present[i] = False
+                self.rows[i]["flags"] = np.uint32(int(self.rows[i]["flags"]) & ~E.W_HEALTHY)
+                gone.append(i)
+                gone_flags.append(int(self.rows[i]["flags"]))
+        if gone:
+            self.eng.on_worker_status_many(np.array(gone), np.array(gone_flags, dtype=np.uint32),
+                                           np.ones(len(gone), dtype=np.uint32))
+        if upd_idx:
+            ranks_known = np.zeros(len(seen), dtype=np.uint32)     # ranks among the rows the engine already has
+            order = [i for i in self.sorted_rows if i < len(seen)]
+            ranks_known[np.array(order, dtype=np.int64)] = np.arange(len(order), dtype=np.uint32)
+            self.eng.update_workers(np.array(upd_idx), self._columns(updated, ranks_known[np.array(upd_idx)]))
+        if appended:
+            first = self.eng.append_workers(self._columns(appended, np.zeros(len(appended), dtype=np.uint32)))
+            assert first == len(seen)
+            self.eng.set_addr_ranks(self._ranks())
+        self._emit_group_webhooks()
+
+    def _push_enabled(self):
+        self.eng.set_enabled_mask(self._enabled)
+
+    def sync_tasks(self, masks, created, uid, enabled):
+        self.eng.upload_tasks(masks, created, uid)
+        self._enabled = enabled
+        self._push_enabled()
+        self.tasks = [int(u) for u in uid]
+
+    def on_task_created(self, mask, created, uid, enabled):
+        self.eng.tasks_insert_front(np.array([mask], dtype=np.uint64), np.array([created], dtype=np.int64),
+                                    np.array([uid], dtype=np.uint64))
+        self.tasks.insert(0, int(uid))
+        self._enabled = enabled
+        self._push_enabled()
+
+    def on_task_deleted(self, uid, enabled):
+        assert self.eng.tasks_delete(np.array([uid], dtype=np.uint64)) == 1
+        self.tasks.remove(int(uid))
+        self._enabled = enabled
+        self._push_enabled()
+        self._emit_group_webhooks()
+
+    def handle_status_change(self, node: int, healthy: bool, dead: bool):
+        w = self.index.get(int(node))
+        if w is None:
+            return
+        flags = int(self.rows[w]["flags"]) & ~E.W_HEALTHY
+        if healthy:
+            flags |= E.W_HEALTHY
+        self.rows[w]["flags"] = np.uint32(flags)
+        self.eng.on_worker_status(w, flags, dead)
+        if dead:
+            self._emit_group_webhooks()
+
+    def tick(self):
+        s = self.eng.tick()
+        self._emit_group_webhooks()
+        return s
+
+    def filter_tasks(self, node: int):
+        """-> uid of the task the node gets, or None (pm_lookup_task_for_worker + the shim's Vec<Task> by position)"""
+        w = self.index.get(int(node))
+        if w is None:
+            return None
+        a = self.eng.lookup(w)
+        if a.task == 0xFFFFFFFF or a.task >= len(self.tasks):
+            return None
+        return self.tasks[a.task]
+
+    def close(self):
+        self.eng.close()

@@ -180,16 +180,18 @@ def _free_port() -> int:
     return port
 
 
-def _proc_main(rank, world, port, out_dir):
+def _proc_main(rank, world, port, out_dir, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0           # nccl (= RCCL): one GPU per rank; gloo: the ranks share GPU 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         sw = make_swarm(25, 4000, 6000)
-        eng = E.Engine(device=0, group_id_seed=5)
+        eng = E.Engine(device=dev, group_id_seed=5)
         host.load_swarm(eng, sw)
-        se = ShardedEngine(EngineLocal(eng, torch.device("cuda", 0)), sw.address)   # TorchExchanger, gloo staging
+        se = ShardedEngine(EngineLocal(eng, torch.device("cuda", dev)), sw.address)  # TorchExchanger (gloo: host-staged)
         stats = se.tick()
         best, count = se.match_per_task()
         with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
@@ -199,10 +201,10 @@ def _proc_main(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_processes_over_torch_distributed_share_the_gpu(tmp_path):
+def _two_processes(tmp_path, backend):
     import torch.multiprocessing as mp
     world = 2
-    mp.spawn(_proc_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_proc_main, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
     sw = make_swarm(25, 4000, 6000)
     eng = E.Engine(group_id_seed=5)
     host.load_swarm(eng, sw)
@@ -216,3 +218,16 @@ def test_two_processes_over_torch_distributed_share_the_gpu(tmp_path):
         assert g == g1 and np.array_equal(t, t1), f"rank {r}"
         assert np.array_equal(best, best1) and np.array_equal(count, count1)
         assert n_x > 3
+
+
+def test_two_processes_over_torch_distributed_share_the_gpu(tmp_path):
+    _two_processes(tmp_path, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL leg needs two GPUs (one process per GPU)")
+def test_two_processes_over_rccl(tmp_path):
+    """the same protocol with backend "nccl" (= RCCL over xGMI): the all-gathers of the proposal rows and of the
+    published rows read and write HBM directly, on the stream the engine's kernels run on.  Every rank must end with
+    the single-GPU engine's groups, table and per-task bids.  (Skipped on a one-GPU box: the driver's 8-GPU node runs it.)"""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _two_processes(tmp_path, "nccl")

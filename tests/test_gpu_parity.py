@@ -394,9 +394,11 @@ def test_lookups_from_other_threads_during_ticks():
         t.join()
     n_reads = sum(len(s) for s in seen)
     assert n_reads > 10000
+    # (a death between two ticks republishes the rows of the dissolved group's members as rows of workers in no group)
+    no_group = (NONE, NONE, 0, 0, NONE, 0)
     for k in range(8):
         for w, r in seen[k]:
-            assert r in published[w], (w, r)
+            assert r in published[w] or r == no_group, (w, r)
     assert max(len(p) for p in published) > 1          # the tables really changed under the readers
     eng.close()
 
@@ -500,6 +502,69 @@ def test_task_observer_flow():
     st.remap_tasks(np.where(keep, np.cumsum(keep) - 1, -1))
     assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))          # dissolved at once, before any tick
     assert len(engine_groups(eng)) < len(claimed)
+    eng.close()
+
+
+def test_lookups_between_ticks_follow_task_deltas_and_deaths():
+    """A heartbeat between two ticks (scheduler/mod.rs:26-36 between two runs of the management loop): the reference
+    binds a group to its task by id (get_current_group_task, scheduler_impl.rs:33), so after new tasks arrived in
+    front of the list every grouped worker still gets ITS task (under its new position), after a claimed task was
+    deleted its groups are gone at once (mod.rs:1259-1288), after a worker died its whole group is
+    (status_update_impl.rs:17-29) — all without a tick in between.  pm_lookup_task_for_worker must say the same."""
+    sw = make_swarm(14, 300, 1200)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    eng.tick()
+    st.try_form_new_groups()
+    st.try_merge_solo_groups()
+
+    def check():
+        want = [st.get_task_for_node(w) for w in range(sw.W)]
+        got = [(-1 if eng.lookup(w).task == NONE else eng.lookup(w).task) for w in range(sw.W)]
+        assert got == want
+        in_group = st.node_to_group >= 0
+        assert [eng.lookup(w).group_slot != NONE for w in range(sw.W)] == list(in_group)
+
+    check()
+    assert sum(1 for w in range(sw.W) if eng.lookup(w).task != NONE) > 100
+    masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+    # ---- 25 new tasks in front of the list: positions shift, bindings stay
+    n_new = 25
+    new_masks = masks[:n_new].copy()
+    new_created = created.max() + np.arange(n_new, 0, -1).astype(created.dtype)
+    new_uid = (np.arange(n_new) + (1 << 41)).astype(uid.dtype)
+    eng.tasks_insert_front(new_masks, new_created, new_uid)
+    new_rows = tasks[:n_new].copy()
+    new_rows["created_at"] = new_created
+    old_n = len(tasks)
+    tasks = np.concatenate([new_rows, tasks])
+    st.set_tasks(tasks)
+    st.remap_tasks(np.arange(old_n) + n_new)
+    masks, created, uid = np.concatenate([new_masks, masks]), np.concatenate([new_created, created]), np.concatenate([new_uid, uid])
+    check()
+    # ---- the task most groups work on is deleted: those groups dissolve, the tasks behind it move up
+    claimed = [g[4] for g in st.groups() if g[4] >= 0]
+    victim = max(set(claimed), key=claimed.count)
+    keep = np.ones(len(tasks), dtype=bool)
+    keep[victim] = False
+    assert eng.tasks_delete(uid[victim:victim + 1]) == 1
+    st.set_tasks(tasks[keep])
+    st.remap_tasks(np.where(keep, np.cumsum(keep) - 1, -1))
+    tasks, masks, created, uid = tasks[keep], masks[keep], created[keep], uid[keep]
+    check()
+    # ---- a grouped worker dies: its group is gone for every member
+    flags = host.worker_flags(sw).astype(np.int64)
+    victim_w = int(np.nonzero(st.node_to_group >= 0)[0][5])
+    st.set_node_status(victim_w, orc.ST_DEAD)
+    eng.on_worker_status(victim_w, int(flags[victim_w]) & ~E.W_HEALTHY, True)
+    check()
+    # ---- and the next tick agrees with a fresh look at everything
+    eng.tick()
+    st.try_form_new_groups()
+    st.try_merge_solo_groups()
+    check()
     eng.close()
 
 
