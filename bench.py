@@ -200,8 +200,8 @@ def chain_model(steps, carve_ms, prop_ms):
     floor_us = 3.0 * LDS_ROUND_TRIP_CYC / (CLOCK_GHZ * 1e3)
     val_ms = max(carve_ms - prop_ms, 0.0)
     return {"model": ("group g+1's seed depends on what group g removed: a chain of dependent steps; floor per step = 3 "
-                      "dependent LDS round trips (row -> live bits -> kill) of ~50 cycles at 2.4 GHz; the proposer "
-                      "launches between the validation launches are on the chain too"),
+                      "dependent LDS round trips (row -> live bits -> kill) of ~50 cycles at 2.4 GHz; the preparation "
+                      "and proposer launches between the validation launches are on the chain too (one batch at a time)"),
             "steps": steps, "floor_us_per_step": floor_us, "achieved_us_per_step": 1e3 * carve_ms / max(steps, 1),
             "validate_only_us_per_step": 1e3 * val_ms / max(steps, 1),
             "frac": floor_us / (1e3 * carve_ms / max(steps, 1)) if carve_ms > 0 else None}
@@ -342,12 +342,16 @@ def main() -> int:
     workload = names.get(cfg_index, f"BASELINE configs[{cfg_index}]")
 
     eng = E.Engine(device=local_rank, sweep_variant=args.sweep_variant, carve_variant=args.carve_variant,
-                   group_id_seed=args.seed)
+                   group_id_seed=args.seed, time_proposer=world > 1)  # (N > 1: the stepwise tick waits for every batch
+                                                                       # anyway, so timing its proposer costs nothing)
     host.load_swarm(eng, sw)
     sharded = None
     if world > 1:
         from protocol_amd.dist import EngineLocal, ShardedEngine
         sharded = ShardedEngine(EngineLocal(eng, dev), sw.address)
+
+    if sharded is not None:
+        sharded.time_exchanges = True
 
     def step():
         eng.reset_groups()
@@ -406,9 +410,13 @@ def main() -> int:
         "match_latency_ms": {"min": min(ms), "p50": statistics.median(ms), "max": max(ms)},
         "phase_ms_p50": {k: med(stats, k) for k in ("ms_compat", "ms_carve", "ms_merge", "ms_sweep", "ms_publish")},
         "groups": int(stats[-1]["n_groups"]), "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
-        "roofline": {"bound": "hbm", "kernel": "carve (carve_propose_kernel + carve_kernel launch sequence)",
+        "roofline": {"bound": "latency-chain",
+                     "kernel": "carve (preparation + carve_propose_kernel + carve_kernel launch sequence)",
                      "achieved": carve["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (carve["GB/s"] or 0.0) / HBM_PEAK_GBS,
+                     "bound_note": ("achieved / peak / frac are the contract's HBM accounting (algorithmic bytes over the "
+                                    "launch sequence's duration) and are NOT what binds the sequence: it is a chain of "
+                                    "dependent steps, priced in `chain` (floor per step vs achieved)"),
                      "traffic": traffic, "traffic_source": (f"profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                             f"of this command, a committed constant — not measured in this run")
                      if traffic_src else None,
@@ -419,8 +427,20 @@ def main() -> int:
     }
     if world > 1:
         out["ranks_seen"] = ranks_seen
-        out["dist"] = {"workers_owned_by_rank0": own, "exchanges_per_tick": sharded.exchanges / (args.steps + args.warmup),
-                       "backend": backend, "identical_groups_on_all_ranks": True}
+        n_ticks = args.steps + args.warmup
+        exch_ms = sharded.exchange_ms / n_ticks
+        # what the N GPUs share out (proposal sweeps: the summed proposer launches of this rank; pair sweep: owned rows)
+        # against what every rank repeats (validation chain + list preparation) — the Amdahl split of this design
+        prop_ms = med(stats, "ms_propose_kernel")
+        sharded_ms = prop_ms + med(stats, "ms_sweep")
+        out["dist"] = {"workers_owned_by_rank0": own, "exchanges_per_tick": sharded.exchanges / n_ticks,
+                       "backend": backend, "identical_groups_on_all_ranks": True,
+                       "exchange_ms": exch_ms, "sharded_ms": sharded_ms,
+                       "replicated_ms": max(1e3 * elapsed / args.steps - sharded_ms - exch_ms, 0.0),
+                       "split_note": ("per tick on rank 0: exchange = device time inside the all-gathers (events around "
+                                      "each); sharded = this rank's proposer launches (timed individually) + its pair "
+                                      "sweep; replicated = the rest of the tick (validation chain, list preparation, "
+                                      "publish) — the part N GPUs do not divide")}
         if rank == 0:
             # the SAME swarm on one GPU, unsharded (a second engine on rank 0's device, after the timed region): the
             # N = 1 line of the default command is a different workload (configs[1]), so the honest one-GPU

@@ -214,7 +214,9 @@ int32_t pm_upload_tasks(pm_engine*, const pm_task_soa* tasks);
  *                          the list, groups that had claimed one of them are dissolved; unknown ids are ignored.
  * Task indices reported by the engine (pm_assignment.task, pm_group.task, pm_match*, pm_newest_task) are always
  * positions in the caller's CURRENT list: after an insertion of n rows every older task's index is n higher,
- * after a deletion the later ones move up — exactly as in the caller's own Vec<Task>. */
+ * after a deletion the later ones move up — exactly as in the caller's own Vec<Task>.  That includes the table
+ * pm_lookup_task_for_worker reads: both calls (and pm_upload_tasks) re-derive the published positions on the host
+ * before they return, and clear the rows of the groups a deleted task took with it — no tick needed in between. */
 int32_t pm_tasks_insert_front(pm_engine*, const pm_task_soa* rows);
 int32_t pm_tasks_delete(pm_engine*, const uint64_t* uids, uint32_t n, uint32_t* n_deleted);
 

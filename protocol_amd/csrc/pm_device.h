@@ -189,7 +189,8 @@ struct CarveArgs {
   BatchDesc* desc;               // this argument block's batch (the per-batch scratch above belongs to it)
   const BatchDesc* desc_prev;    // the batch in front of it (the other argument block's; itself when there is one block)
   uint64_t* alive_snap;          // the position bitmap as the preparation saw it (bits_stride words)
-  uint32_t speculative, _pad_sp; // the preparation may run beside the validation of the batch in front
+  uint32_t speculative;          // the preparation may run beside the validation of the batch in front
+  uint32_t debug_mem_above;      // test hook: candidate lists longer than this take the all-in-HBM path (0 = off)
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];
@@ -231,6 +232,13 @@ void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const 
 void launch_task_prefix(const uint64_t* live, uint32_t w_begin, uint32_t w_end, uint32_t* prefix, hipStream_t s);
 void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, uint64_t* live, uint64_t* planes,
                         uint32_t stride, uint32_t n_planes, hipStream_t s);
+void launch_task_intern(const uint64_t* tmask, const uint64_t* live, uint32_t u_begin, uint32_t u_end, uint64_t valid,
+                        uint64_t* keys, uint32_t n_slots, uint32_t* vals, uint32_t* counter_and_overflow, uint64_t* umask,
+                        uint32_t cap_u, hipStream_t s);
+void launch_task_compact_class(const uint32_t* first_c, const uint32_t* count_c, const uint64_t* tmask, uint64_t valid,
+                               const uint64_t* keys, const uint32_t* vals, uint32_t n_slots, uint32_t u_begin,
+                               uint32_t u_end, const uint64_t* live, const uint32_t* prefix, uint32_t* first_out,
+                               uint32_t* count_out, hipStream_t s);
 void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint32_t u_begin, uint32_t u_end,
                          const uint64_t* live, const uint32_t* prefix, uint32_t* first_out, uint32_t* count_out,
                          hipStream_t s);

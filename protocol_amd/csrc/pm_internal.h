@@ -42,6 +42,8 @@ inline uint64_t splitmix64_mix(uint64_t x) {
 
 // debug export (PM_CARVE_PROF builds): copies min(cap, 32) phase counters of the last carve
 extern "C" int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap);
+// test hook: candidate lists longer than n slots go through the all-in-HBM carve path (0 = off)
+extern "C" int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n);
 // stream triad (a = b + 3c, f64) on the engine's stream: the measured HBM rate bench.py cites
 extern "C" int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s);
 #endif

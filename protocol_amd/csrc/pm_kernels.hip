@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void build_planes_kernel(const uint64_t* __res
 
 // grid = (ceil(R / 256), n_split): workgroup (x, y) sweeps its 256 rows over the plane words
 // [y * words_per_split, (y + 1) * words_per_split), staged through LDS in pieces of words_per_piece.
+template <uint32_t RPT>
 __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
                                                                 const uint64_t* __restrict__ planes,
                                                                 uint32_t stride, uint32_t w_begin, uint32_t w_end,
@@ -273,57 +274,76 @@ __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* 
   // The lanes of a wave read DIFFERENT planes at the same word j: with a plane stride that is a multiple of the 64
   // LDS banks (x 4 B) all of those reads would land in one bank.  An odd stride (in 8-byte words) spreads them.
   const uint32_t lds_stride = words_per_piece | 1u;
-  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  // RPT rows per thread (rows r0, r0 + 256, ...): a workgroup stages every plane of its word range into LDS once, so
+  // with a million rows (the per-task orientation) four rows per thread quarter that traffic — 1.2 GB of L2 reads
+  // at 1M x 100k otherwise
+  const uint32_t r0 = blockIdx.x * (256u * RPT) + threadIdx.x;
   const uint32_t w0 = w_begin + blockIdx.y * words_per_split;
   const uint32_t w1 = min(w_end, w0 + words_per_split);
   const uint64_t valid = n_planes >= 64u ? ~0ull : ((1ull << n_planes) - 1ull);
-  uint64_t sel = r < R ? (row_sel[r] & valid) : 0ull;
-  if (sel == valid && n_planes > 1u && n_planes < 64u) sel = 1ull << n_planes;  // every plane selected: read their OR
-  uint32_t first = PM_NONE, cnt = 0;
-  // wave-uniform: does any row of this wave select more than one plane?
-  const bool single = __ballot((sel & (sel - 1ull)) != 0ull) == 0ull;
-  const uint32_t my_plane = sel ? (uint32_t)__builtin_ctzll(sel) : 0u;
-  const uint64_t keep = sel ? ~0ull : 0ull;  // rows without a selector (workers outside groups) hit nothing
+  uint64_t sel[RPT], keep[RPT];
+  uint32_t first[RPT], cnt[RPT], my_plane[RPT];
+  bool single[RPT];
+#pragma unroll
+  for (uint32_t k = 0; k < RPT; ++k) {
+    const uint32_t r = r0 + k * 256u;
+    sel[k] = r < R ? (row_sel[r] & valid) : 0ull;
+    if (sel[k] == valid && n_planes > 1u && n_planes < 64u) sel[k] = 1ull << n_planes;  // every plane selected: read their OR
+    first[k] = PM_NONE;
+    cnt[k] = 0;
+    // wave-uniform: does any row of this wave select more than one plane?
+    single[k] = __ballot((sel[k] & (sel[k] - 1ull)) != 0ull) == 0ull;
+    my_plane[k] = sel[k] ? (uint32_t)__builtin_ctzll(sel[k]) : 0u;
+    keep[k] = sel[k] ? ~0ull : 0ull;  // rows without a selector (workers outside groups) hit nothing
+  }
   for (uint32_t j0 = w0; j0 < w1; j0 += words_per_piece) {
     const uint32_t nj = min(words_per_piece, w1 - j0);
     __syncthreads();  // the previous piece has been consumed
     for (uint32_t b = 0; b <= n_planes; ++b)
       for (uint32_t j = threadIdx.x; j < nj; j += 256u) s_pl[b * lds_stride + j] = planes[(size_t)b * stride + j0 + j];
     __syncthreads();
-    if (single) {
-      // every row of this wave selects at most one plane (the reference orientation: a group's configuration
-      // bit): one LDS read per word, no selector loop; four words per step keep the reads in flight
-      const uint64_t* pl = s_pl + my_plane * lds_stride;
-      uint32_t j = 0;
-      for (; j + 4u <= nj; j += 4u) {
-        const uint64_t h0 = pl[j] & keep, h1 = pl[j + 1u] & keep, h2 = pl[j + 2u] & keep, h3 = pl[j + 3u] & keep;
-        cnt += __popcll(h0) + __popcll(h1) + __popcll(h2) + __popcll(h3);
-        if (first == PM_NONE && (h0 | h1 | h2 | h3)) {
-          const uint32_t u = h0 ? 0u : (h1 ? 1u : (h2 ? 2u : 3u));
-          const uint64_t h = h0 ? h0 : (h1 ? h1 : (h2 ? h2 : h3));
-          first = (j0 + j + u) * 64u + __builtin_ctzll(h);
+#pragma unroll
+    for (uint32_t k = 0; k < RPT; ++k) {
+      if (single[k]) {
+        // every row of this wave selects at most one plane (the reference orientation: a group's configuration
+        // bit; a task of one topology, or of all of them): one LDS read per word, no selector loop; four words per
+        // step keep the reads in flight
+        const uint64_t* pl = s_pl + my_plane[k] * lds_stride;
+        uint32_t j = 0;
+        for (; j + 4u <= nj; j += 4u) {
+          const uint64_t h0 = pl[j] & keep[k], h1 = pl[j + 1u] & keep[k], h2 = pl[j + 2u] & keep[k], h3 = pl[j + 3u] & keep[k];
+          cnt[k] += __popcll(h0) + __popcll(h1) + __popcll(h2) + __popcll(h3);
+          if (first[k] == PM_NONE && (h0 | h1 | h2 | h3)) {
+            const uint32_t u = h0 ? 0u : (h1 ? 1u : (h2 ? 2u : 3u));
+            const uint64_t h = h0 ? h0 : (h1 ? h1 : (h2 ? h2 : h3));
+            first[k] = (j0 + j + u) * 64u + __builtin_ctzll(h);
+          }
         }
-      }
-      for (; j < nj; ++j) {
-        const uint64_t h = pl[j] & keep;
-        cnt += __popcll(h);
-        if (h && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(h);
-      }
-    } else {
-      for (uint32_t j = 0; j < nj; ++j) {
-        uint64_t hits = 0;
-        uint64_t s = sel;
-        while (s) {  // OR the planes this row selects
-          const uint32_t b = __builtin_ctzll(s);
-          s &= s - 1;
-          hits |= s_pl[b * lds_stride + j];
+        for (; j < nj; ++j) {
+          const uint64_t h = pl[j] & keep[k];
+          cnt[k] += __popcll(h);
+          if (h && first[k] == PM_NONE) first[k] = (j0 + j) * 64u + __builtin_ctzll(h);
         }
-        cnt += __popcll(hits);
-        if (hits && first == PM_NONE) first = (j0 + j) * 64u + __builtin_ctzll(hits);
+      } else {
+        for (uint32_t j = 0; j < nj; ++j) {
+          uint64_t hits = 0;
+          uint64_t s = sel[k];
+          while (s) {  // OR the planes this row selects
+            const uint32_t b = __builtin_ctzll(s);
+            s &= s - 1;
+            hits |= s_pl[b * lds_stride + j];
+          }
+          cnt[k] += __popcll(hits);
+          if (hits && first[k] == PM_NONE) first[k] = (j0 + j) * 64u + __builtin_ctzll(hits);
+        }
       }
     }
   }
-  if (r < R) pair_fold(first_out, count_out, r, first, cnt, atomic != 0u);
+#pragma unroll
+  for (uint32_t k = 0; k < RPT; ++k) {
+    const uint32_t r = r0 + k * 256u;
+    if (r < R) pair_fold(first_out, count_out, r, first[k], cnt[k], atomic != 0u);
+  }
 }
 
 __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t* __restrict__ row_sel, uint32_t R,
@@ -414,6 +434,71 @@ __device__ __forceinline__ uint64_t splitmix64_mix(uint64_t x) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
+}
+
+// ---- per-task orientation: tasks that name the same set of configurations have the same bidders, so the sweep runs
+// once per DISTINCT topology mask (a few thousand at a million tasks) and every task reads its mask's result.
+// An open-addressing table of the masks (key = mask, ~0 = empty): insert, number the used slots densely, look up.
+#define PM_INTERN_EMPTY (~0ull)
+__global__ __launch_bounds__(256) void task_intern_insert_kernel(const uint64_t* __restrict__ tmask,
+                                                                 const uint64_t* __restrict__ live, uint32_t u_begin,
+                                                                 uint32_t u_end, uint64_t valid,
+                                                                 unsigned long long* __restrict__ keys, uint32_t h_mask,
+                                                                 uint32_t* __restrict__ overflow) {
+  const uint32_t u = u_begin + blockIdx.x * 256u + threadIdx.x;
+  if (u >= u_end || !((live[u >> 6] >> (u & 63u)) & 1ull)) return;
+  const uint64_t m = tmask[u] & valid;
+  if (m == 0ull) return;  // (names no configuration that exists: no bidder)
+  uint32_t h = (uint32_t)splitmix64_mix(m) & h_mask;
+  for (uint32_t probe = 0; probe <= h_mask; ++probe, h = (h + 1u) & h_mask) {
+    const unsigned long long k = keys[h];
+    if (k == m) return;
+    if (k == PM_INTERN_EMPTY) {
+      const unsigned long long old = atomicCAS(&keys[h], PM_INTERN_EMPTY, (unsigned long long)m);
+      if (old == PM_INTERN_EMPTY || old == m) return;
+    }
+  }
+  *overflow = 1u;
+}
+__global__ __launch_bounds__(256) void task_intern_number_kernel(const unsigned long long* __restrict__ keys,
+                                                                 uint32_t n_slots, uint32_t* __restrict__ vals,
+                                                                 uint32_t* __restrict__ counter,
+                                                                 uint64_t* __restrict__ umask, uint32_t cap_u) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= n_slots) return;
+  const unsigned long long k = keys[s];
+  if (k == PM_INTERN_EMPTY) return;
+  const uint32_t id = atomicAdd(counter, 1u);
+  vals[s] = id;
+  if (id < cap_u) umask[id] = k;
+}
+// results per distinct mask -> per task, at the task's position in the caller's list
+__global__ __launch_bounds__(256) void task_compact_class_kernel(const uint32_t* __restrict__ first_c,
+                                                                 const uint32_t* __restrict__ count_c,
+                                                                 const uint64_t* __restrict__ tmask, uint64_t valid,
+                                                                 const unsigned long long* __restrict__ keys,
+                                                                 const uint32_t* __restrict__ vals, uint32_t h_mask,
+                                                                 uint32_t u_begin, uint32_t u_end,
+                                                                 const uint64_t* __restrict__ live,
+                                                                 const uint32_t* __restrict__ prefix,
+                                                                 uint32_t* __restrict__ first_out,
+                                                                 uint32_t* __restrict__ count_out) {
+  const uint32_t u = u_begin + blockIdx.x * 256u + threadIdx.x;
+  if (u >= u_end) return;
+  const uint64_t w = live[u >> 6];
+  if (!((w >> (u & 63u)) & 1ull)) return;
+  const uint32_t pos = prefix[u >> 6] + (uint32_t)__popcll(w & ((1ull << (u & 63u)) - 1ull));
+  const uint64_t m = tmask[u] & valid;
+  uint32_t first = PM_NONE, count = 0u;
+  if (m != 0ull) {
+    uint32_t h = (uint32_t)splitmix64_mix(m) & h_mask;
+    while (keys[h] != m) h = (h + 1u) & h_mask;  // (every live mask was inserted)
+    const uint32_t id = vals[h];
+    first = first_c[id];
+    count = count_c[id];
+  }
+  first_out[pos] = first;
+  count_out[pos] = count;
 }
 
 // row selector of worker w = the configuration bit of its group (0 when not in a group).  `rows` (optional):
@@ -2740,7 +2825,7 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   __syncthreads();
   uint32_t prop_k = 0, limit = 0, n_seeds = 0;
   const uint32_t max_s = p.max_size[ci];
-  if (p.proximity && n_list <= PM_CARVE_BIG_SLOTS && max_s - 1u < PM_PROP_KMAX) {
+  if (p.proximity && n_list <= PM_CARVE_BIG_SLOTS && max_s - 1u < PM_PROP_KMAX && !(p.debug_mem_above && n_list > p.debug_mem_above)) {
     const uint32_t k = max_s - 1u + PM_PROP_RESERVE;
     prop_k = k < PM_PROP_KMAX ? k : PM_PROP_KMAX;
     if (wave == 0) {
@@ -3086,8 +3171,9 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     //   big   (<= PM_CARVE_BIG_SLOTS):    bitmaps + staged proposal rows in LDS, per-slot arrays in HBM/L2
     //   mem   (larger):                   everything in HBM/L2, exact sweep only
     ctx_set_geometry(c);
-    const bool in_lds = c.n_list <= PM_CARVE_SLOTS;
-    const bool big = !in_lds && c.n_list <= PM_CARVE_BIG_SLOTS;
+    const bool force_mem = p.debug_mem_above && c.n_list > p.debug_mem_above;  // (test hook)
+    const bool in_lds = c.n_list <= PM_CARVE_SLOTS && !force_mem;
+    const bool big = !in_lds && c.n_list <= PM_CARVE_BIG_SLOTS && !force_mem;
     const uint32_t lw = (c.n_list + 63u) >> 6;
     uint64_t* g_alive = p.bits_scratch;
     uint64_t* g_loc = p.bits_scratch + p.bits_stride;
@@ -3332,8 +3418,12 @@ void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const u
   const uint32_t wpp = wps < lds_cap_words ? wps : lds_cap_words;
   const size_t lds = (size_t)(n_planes + 1u) * (wpp | 1u) * sizeof(uint64_t);
   if (n_split > 1u) hipLaunchKernelGGL(pair_init_kernel, dim3(rb), dim3(256), 0, s, first, count, R);
-  hipLaunchKernelGGL(pair_sweep_planes_kernel, dim3(rb, n_split), dim3(256), lds, s, row_sel, R, planes, stride, w0,
-                     w1, n_planes, wps, wpp, first, count, n_split > 1u ? 1u : 0u);
+  if (rb >= 1024u)  // very many rows (a million tasks): four per thread, a quarter of the plane staging
+    hipLaunchKernelGGL(pair_sweep_planes_kernel<4u>, dim3((rb + 3u) / 4u, n_split), dim3(256), lds, s, row_sel, R, planes,
+                       stride, w0, w1, n_planes, wps, wpp, first, count, n_split > 1u ? 1u : 0u);
+  else
+    hipLaunchKernelGGL(pair_sweep_planes_kernel<1u>, dim3(rb, n_split), dim3(256), lds, s, row_sel, R, planes, stride, w0,
+                       w1, n_planes, wps, wpp, first, count, n_split > 1u ? 1u : 0u);
 }
 
 void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
@@ -3359,6 +3449,26 @@ void launch_task_delete(const uint32_t* slots, uint32_t n, uint64_t* tmask, uint
   if (!n) return;
   hipLaunchKernelGGL(task_delete_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, slots, n, tmask, live, planes,
                      stride, n_planes);
+}
+void launch_task_intern(const uint64_t* tmask, const uint64_t* live, uint32_t u_begin, uint32_t u_end, uint64_t valid,
+                        uint64_t* keys, uint32_t n_slots, uint32_t* vals, uint32_t* counter_and_overflow, uint64_t* umask,
+                        uint32_t cap_u, hipStream_t s) {
+  (void)hipMemsetAsync(keys, 0xFF, size_t(n_slots) * 8, s);
+  (void)hipMemsetAsync(counter_and_overflow, 0, 8, s);
+  if (u_end > u_begin)
+    hipLaunchKernelGGL(task_intern_insert_kernel, dim3((u_end - u_begin + 255u) / 256u), dim3(256), 0, s, tmask, live, u_begin,
+                       u_end, valid, (unsigned long long*)keys, n_slots - 1u, counter_and_overflow + 1);
+  hipLaunchKernelGGL(task_intern_number_kernel, dim3((n_slots + 255u) / 256u), dim3(256), 0, s,
+                     (const unsigned long long*)keys, n_slots, vals, counter_and_overflow, umask, cap_u);
+}
+void launch_task_compact_class(const uint32_t* first_c, const uint32_t* count_c, const uint64_t* tmask, uint64_t valid,
+                               const uint64_t* keys, const uint32_t* vals, uint32_t n_slots, uint32_t u_begin,
+                               uint32_t u_end, const uint64_t* live, const uint32_t* prefix, uint32_t* first_out,
+                               uint32_t* count_out, hipStream_t s) {
+  if (u_end <= u_begin) return;
+  hipLaunchKernelGGL(task_compact_class_kernel, dim3((u_end - u_begin + 255u) / 256u), dim3(256), 0, s, first_c, count_c,
+                     tmask, valid, (const unsigned long long*)keys, vals, n_slots - 1u, u_begin, u_end, live, prefix,
+                     first_out, count_out);
 }
 void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint32_t u_begin, uint32_t u_end,
                          const uint64_t* live, const uint32_t* prefix, uint32_t* first_out, uint32_t* count_out,

@@ -132,6 +132,21 @@ class ShardedEngine:
         self.shard = shard_of(address, self.world).astype(np.uint8)
         local.configure(self.rank, self.world, self.shard)
         self.exchanges = 0
+        # bench: time spent in the collectives (device events around every all-gather, read back after the tick)
+        self.time_exchanges = False
+        self.exchange_ms = 0.0
+        self._ev = []
+
+    def _gather(self, recv, send):
+        if self.time_exchanges and send.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.x.all_gather(recv, send)
+            b.record()
+            self._ev.append((a, b))
+        else:
+            self.x.all_gather(recv, send)
+        self.exchanges += 1
 
     def _ctx(self):
         f = getattr(self.local, "stream_ctx", None)
@@ -147,16 +162,19 @@ class ShardedEngine:
                 if not more:
                     break
                 if send is not None:            # the batch's neighbour lists: every rank contributes its share
-                    self.x.all_gather(recv, send)
-                    self.exchanges += 1
+                    self._gather(recv, send)
                 L.carve_validate()
             else:
                 raise RuntimeError("the carve did not finish")
             send, recv = L.match_begin()
             if send is not None:                # the published rows of the owned workers
-                self.x.all_gather(recv, send)
-                self.exchanges += 1
-            return L.tick_end()
+                self._gather(recv, send)
+            stats = L.tick_end()
+            if self._ev:
+                torch.cuda.current_stream().synchronize()
+                self.exchange_ms += sum(a.elapsed_time(b) for a, b in self._ev)
+                self._ev.clear()
+            return stats
 
     def match_per_task(self):
         """north_star orientation: per task the best bid (smallest global worker index) and the number of bidders

@@ -459,6 +459,13 @@ class Engine:
         check(L.pm_debug_hbm_triad(self._h, n_doubles, reps, C.byref(out)))
         return out.value
 
+    def debug_mem_lists_above(self, n: int):
+        """test hook (pm_internal.h): candidate lists longer than n slots take the all-in-HBM carve path; 0 = off"""
+        L = lib()
+        L.pm_debug_mem_lists_above.argtypes = [C.c_void_p, C.c_uint32]
+        L.pm_debug_mem_lists_above.restype = C.c_int32
+        check(L.pm_debug_mem_lists_above(self._h, n))
+
     def lookup(self, worker: int) -> Assignment:
         a = Assignment()
         check(lib().pm_lookup_task_for_worker(self._h, worker, C.byref(a)))

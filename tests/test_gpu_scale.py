@@ -128,6 +128,30 @@ def test_config2_full_size_against_oracle_digest():
     _check_against_golden("cfg2_seed1", 0)
 
 
+def test_config2_seed2_full_size_against_oracle_digest():
+    """a second 1M x 100k swarm (seed 2)"""
+    _check_against_golden("cfg2_seed2", 0)
+
+
+def test_config1_seeded_chooser_against_oracle_digest():
+    """BASELINE configs[1] with the SEEDED chooser (the injected stand-in for rand::rng().choose,
+    scheduler_impl.rs:66-70; chooser_rank_kernel + the r-th-hit pass): groups and every worker's task against the
+    digests of the oracle's own get_task_for_node (tests/golden/scale_digests.json, cfg1_seed1_seeded)."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scale_digests.json")))["cfg1_seed1_seeded"]
+    sw = baseline_config(gold["config"], seed=gold["seed"])
+    eng = E.Engine(group_id_seed=gold["seed"], chooser=E.CHOOSE_SEEDED, chooser_seed=gold["chooser_seed"])
+    host.load_swarm(eng, sw)
+    stats = eng.tick()
+    assert stats["n_formed"] == gold["n_formed"] and stats["n_merged"] == gold["n_merged"]
+    gsha, tbl = _engine_digests(sw, eng)
+    assert gsha == gold["groups_sha256"]
+    assert int((tbl["task"] != NONE).sum()) == gold["n_with_task"]
+    assert _sha(tbl["task"].astype(np.uint32)) == gold["task_sha256"], "per-worker tasks differ (seeded chooser)"
+    eng.close()
+
+
 def test_config1_full_table_against_live_oracle():
     """configs[1]: every worker's (task, applicable count, GROUP_INDEX, GROUP_SIZE, NEXT) against the oracle run
     here, its pair sweep on all host cores (seed 2; seed 1 is pinned by the committed digest)."""
@@ -204,4 +228,58 @@ def test_config1_full_size_properties():
     stats = eng.tick()
     _check_invariants(sw, eng, stats)
     _check_tasks(sw, eng)
+    eng.close()
+
+
+def test_solo_merge_at_baseline_size():
+    """try_merge_solo_groups (mod.rs:631-971) with thousands of solo groups: at BASELINE sizes the committed digests
+    have n_merged = 0, so the merge pass (CARVE_MODE_MERGE: proximity pass with filter_map semantics over the ordered
+    solo list, first-come fallback, dissolve + create bookkeeping) is driven here on purpose — a (1, 1) configuration
+    alone makes every 1-GPU node a solo group, then a (2, 8) configuration is enabled and the solos merge.  Groups
+    and, event by event, the life-cycle feed (per merge: the dissolved solos in batch order, then the merged group —
+    i.e. the creation order of the merged groups) against the oracle."""
+    sw = make_swarm(33, 500, 20000)
+    sw.configs = [("solo-1gpu", 1, 1, "gpu:count=1"), ("octet-1gpu", 2, 8, "gpu:count=1")]
+    sw.topo[:] = -2
+    sw.restricted[:] = False
+    sw.n_topo[:] = 0
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    only_solo = np.array([1, 0], dtype=np.uint8)
+    st = orc.State(nodes, cfgs, enabled=only_solo, tasks=tasks, reference_shaped=False, group_id_seed=4)
+    eng = E.Engine(group_id_seed=4)
+    host.load_swarm(eng, sw, enabled=0b01)
+    eng.enable_group_events()
+    n_solo = eng.form_groups()
+    assert st.try_form_new_groups() == n_solo > 5000
+    assert oracle_groups(st) == engine_groups(eng)
+    assert eng.drain_group_events() == st.drain_events()
+    st.set_enabled(np.array([1, 1], dtype=np.uint8))
+    eng.set_enabled_mask(0b11)
+    n_merged = eng.merge_solo_groups()
+    assert st.try_merge_solo_groups() == n_merged > 500
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    ev = eng.drain_group_events()
+    assert ev == st.drain_events()                                  # merged groups in creation order, solos in batch order
+    assert sum(k == E.GROUP_CREATED for k, *_ in ev) == n_merged
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", [26, 27])
+def test_lists_kept_in_hbm(seed):
+    """carve_step_mem: the carve of a candidate list too long for the LDS bitmaps (> 262,144 candidates of ONE
+    configuration: keys, bitmaps and selection all in HBM / L2, one workgroup-wide argmin round per member, its own
+    slot-bit and band geometry).  A swarm that size costs the oracle hours, so a test hook sends every list longer
+    than 150 slots down that path: form + merge of a 6 k swarm, bit for bit."""
+    sw = make_swarm(seed, 600, 6000)
+    st = oracle_state_for(sw, reference_shaped=False)
+    eng = E.Engine()
+    host.load_swarm(eng, sw)
+    eng.debug_mem_lists_above(150)
+    n_formed = eng.form_groups()
+    assert st.try_form_new_groups() == n_formed > 100
+    assert oracle_groups(st) == engine_groups(eng)
+    stats = eng.last_stats()
+    assert stats["carve_fast_steps"] < 0.5 * stats["carve_steps"]      # (the long lists had no proposals)
+    assert st.try_merge_solo_groups() == eng.merge_solo_groups()
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
     eng.close()

@@ -6,6 +6,8 @@ the reference-shaped mode, tests/test_oracle_groups.py) is run on the seeded swa
 
     cfg1_seed1   baseline_config(1, seed=1)    100k tasks x  10k workers
     cfg2_seed1   baseline_config(2, seed=1)      1M tasks x 100k workers, Zipf-skewed topologies
+    cfg2_seed2   the same with seed 2
+    cfg1_seed1_seeded   cfg1_seed1 with the SEEDED chooser (chooser_seed 77): groups + per-worker task column only
 
 through try_form_new_groups + try_merge_solo_groups (mod.rs:478-628, 631-971) and one get_task_for_node per
 worker (scheduler_impl.rs:11-110, chooser FIRST).  What is kept:
@@ -103,12 +105,37 @@ def digest_of(cfg_index: int, seed: int, threads: int) -> dict:
     }
 
 
+def digest_seeded(cfg_index: int, seed: int, chooser_seed: int) -> dict:
+    """the same swarm with the SEEDED chooser (the injected stand-in for rand::rng().choose, scheduler_impl.rs:66-70):
+    groups and the per-worker task column, every worker through the oracle's own get_task_for_node"""
+    t0 = time.time()
+    sw = baseline_config(cfg_index, seed=seed)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False, group_id_seed=seed,
+                   chooser=orc.CHOOSE_SEEDED, chooser_seed=chooser_seed)
+    n_formed = st.try_form_new_groups()
+    n_merged = st.try_merge_solo_groups()
+    task = np.array([st.get_task_for_node(w) for w in range(sw.W)], dtype=np.int64)
+    task = np.where(task < 0, NONE, task).astype(np.uint32)
+    groups = [(gid, c, mem) for (_s, gid, c, mem, _t) in st.groups()]
+    print(f"  cfg{cfg_index} seed {seed} seeded chooser {chooser_seed}: {len(groups)} groups, {time.time() - t0:.1f} s", flush=True)
+    return {"config": cfg_index, "seed": seed, "chooser_seed": chooser_seed, "W": sw.W, "T": sw.T, "n_groups": len(groups),
+            "n_formed": n_formed, "n_merged": n_merged, "groups_sha256": groups_digest(groups), "task_sha256": sha(task),
+            "n_with_task": int((task != NONE).sum())}
+
+
 def main():
     threads = os.cpu_count() or 1
     out = {}
     if os.path.exists(OUT):
         out = json.load(open(OUT))
-    for name, (ci, seed) in {"cfg1_seed1": (1, 1), "cfg2_seed1": (2, 1)}.items():
+    if len(sys.argv) < 2 or "cfg1_seed1_seeded" in sys.argv[1:]:
+        print("cfg1_seed1_seeded", flush=True)
+        out["cfg1_seed1_seeded"] = digest_seeded(1, 1, 77)
+        with open(OUT, "w") as f:
+            json.dump(out, f, separators=(",", ":"))
+            f.write("\n")
+    for name, (ci, seed) in {"cfg1_seed1": (1, 1), "cfg2_seed1": (2, 1), "cfg2_seed2": (2, 2)}.items():
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         print(name, flush=True)

@@ -27,6 +27,12 @@ for _ in range(reps):
     ms.append(s["ms_total"] if "ms_total" in s else s["ms_carve"])
     carve.append(s["ms_carve"])
 ms.sort(); carve.sort()
+import time
+eng.match_per_task()
+t0 = time.perf_counter()
+for _ in range(3):
+    eng.match_per_task()
+print(f"  pm_match_per_task: {1e3 * (time.perf_counter() - t0) / 3:.3f} ms (incl. the D2H copy of both columns)")
 import ctypes as C
 out = (C.c_ulonglong * 42)()
 E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
