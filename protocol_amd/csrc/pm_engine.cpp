@@ -106,6 +106,8 @@ struct PubTable {
   std::atomic<uint64_t> seq{0};
   std::atomic<uint64_t*> words{nullptr};  // 4 x u64 per row (pm_assignment is 32 bytes, 8-byte aligned)
   std::atomic<uint32_t> n{0};
+  std::atomic<uint32_t> task_shift{0};  // added to every task position read from this buffer: tasks inserted in front
+                                        // of the list since it was written (pm_tasks_insert_front) move them all alike
   size_t cap_rows = 0;
 };
 static_assert(sizeof(pm_assignment) == 32, "published rows are copied as four 64-bit words");
@@ -1220,6 +1222,7 @@ static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
   const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
   t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
   std::atomic_thread_fence(std::memory_order_release);
+  const uint32_t keep_shift = only ? t.task_shift.load(std::memory_order_relaxed) : 0u;  // a full pass resets it
   auto patch = [&](uint32_t w) {
     pm_assignment a = rows[w];
     if (a.group_slot == PM_NONE) return;
@@ -1238,7 +1241,7 @@ static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
       a.group_id = 0;
     } else {
       const uint32_t h = e->groups[slot].task;
-      a.task = h == PM_NONE ? PM_NONE : task_position(e, h);
+      a.task = h == PM_NONE ? PM_NONE : task_position(e, h) - keep_shift;  // (readers add the buffer's shift)
     }
     uint64_t v[4];
     std::memcpy(v, &a, sizeof(a));
@@ -1250,8 +1253,22 @@ static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
       if (w < n) patch(w);
   } else {
     for (uint32_t w = 0; w < n; ++w) patch(w);
+    t.task_shift.store(0, std::memory_order_relaxed);  // (the rows hold current positions again)
   }
   t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
+}
+
+// n tasks were inserted in front of the list: every published position moves back by n — one word instead of a pass
+// over the rows (readers add the buffer's shift to the position they read; the seqlock makes row and shift one unit)
+static void pub_shift_tasks(pm_engine* e, uint32_t n_new) {
+  const int cur = e->pub_cur.load(std::memory_order_relaxed);
+  if (cur < 0) return;
+  PubTable& t = e->pub[cur];
+  const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+  t.seq.store(s0 + 1, std::memory_order_relaxed);
+  std::atomic_thread_fence(std::memory_order_release);
+  t.task_shift.store(t.task_shift.load(std::memory_order_relaxed) + n_new, std::memory_order_relaxed);
+  t.seq.store(s0 + 2, std::memory_order_release);
 }
 
 // D2H of the assignment table + the group task words; the table lands directly in the snapshot buffer that is
@@ -1290,6 +1307,7 @@ static int32_t publish(pm_engine* e) {
     HIPCHK(herr);
   }
   t.n.store(e->W, std::memory_order_relaxed);
+  t.task_shift.store(0, std::memory_order_relaxed);
   t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
   e->pub_cur.store(nx, std::memory_order_release);
   e->h_table = reinterpret_cast<const pm_assignment*>(words);
@@ -2175,7 +2193,7 @@ int32_t pm_tasks_insert_front(pm_engine* e, const pm_task_soa* t) {
   e->T += n;
   e->tprefix_dirty = true;
   e->h_tprefix_valid = false;
-  pub_patch(e, nullptr);  // n new tasks in front of the list: every published position moves back by n
+  pub_shift_tasks(e, n);  // n new tasks in front of the list: every published position moves back by n
   return PM_OK;
 }
 
@@ -2861,6 +2879,7 @@ int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t worker, pm_assignment* 
     if (s1 & 1u) continue;  // two publishes since `cur` was read: take the newer buffer
     const uint64_t* words = t.words.load(std::memory_order_relaxed);
     const uint32_t n = t.n.load(std::memory_order_relaxed);
+    const uint32_t shift = t.task_shift.load(std::memory_order_relaxed);
     uint64_t row[4] = {0, 0, 0, 0};
     const bool in_range = worker < n;
     if (in_range)
@@ -2869,6 +2888,7 @@ int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t worker, pm_assignment* 
     if (t.seq.load(std::memory_order_relaxed) != s1) continue;
     if (!in_range) return set_error(PM_ERANGE, "worker index out of range");
     std::memcpy(out, row, sizeof(*out));
+    if (out->task != PM_NONE) out->task += shift;
     return PM_OK;
   }
 }

@@ -2687,6 +2687,15 @@ __global__ __launch_bounds__(256) void carve_prep_count_kernel(const CarveArgs* 
   const auto D = G((const BatchDesc*)p.desc);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t wave_g = blockIdx.x * PREP_WAVES + wave;
+  if (!p.speculative) {
+    // group_of for the groups the last validation launch appended (idempotent; also runs after the carve ended).
+    // (Beside a validation in flight the validator does it itself.)
+    const uint32_t g_lo = st->g_lo, g_hi = st->g_hi, n_waves = gridDim.x * PREP_WAVES;
+    for (uint32_t g = g_lo + wave_g; g < g_hi; g += n_waves) {
+      const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
+      for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
+    }
+  }
   if (st->state != CARVE_STATE_RUNNING) {
     if (!p.speculative && blockIdx.x == 0 && tid == 0) p.desc->planned = 0u;
     return;
@@ -3286,11 +3295,16 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
   // group_of for everything carved by this launch (FORM), one parallel pass at the end — or, with the external
   // preparation, left to carve_prep_count_kernel (every CU); single-node groups are counted here either way
   const bool ext = (flags_in & CARVE_F_EXTPREP) != 0u;
-  if (p.mode == CARVE_MODE_FORM) {
+  // (a launch with the external preparation runs ONE configuration, c.min_s is its minimum: groups of one node can
+  // only come from a configuration that allows them — otherwise there is nothing to do here, and a loop with a
+  // dependent load per group is a tenth of the launch at 100 k workers)
+  const bool need_pass = !ext || p.speculative || c.min_s <= 1u;
+  if (p.mode == CARVE_MODE_FORM && need_pass) {
     __syncthreads();
     for (uint32_t g = groups_at_entry + wave; g < c.n_groups; g += CARVE_WAVES) {
       const uint32_t off = G(p.g_off)[g], gn = G(p.g_n)[g];
-      for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
+      if (!ext || p.speculative)  // (one batch at a time: the preparation behind this launch does it on every CU)
+        for (uint32_t k = lane; k < gn; k += 64u) G(p.group_of)[G(p.members)[off + k]] = (int32_t)g;
       if (gn == 1u && lane == 0) atomicAdd(&p.status->n_solo, 1u);  // rare
     }
   }

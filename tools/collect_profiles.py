@@ -4,6 +4,7 @@
   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2 --no-extras` (12 matches)
   <tag>_cfg2_kernel_stats.csv  the same for `--config 2 --steps 3 --warmup 1` (BASELINE configs[2], 4 matches)
   <tag>_timeline.txt       per-launch timeline of the last match of that run
+  <tag>_churn_kernel_stats.csv / <tag>_churn_ticks.txt   the cold match + 8 ticks of the configs[4] stream (tools/churn_probe.py)
   <tag>_bench.json         the bench line of the default `bench.py` command (with the CPU baseline)
   <tag>_pmc_traffic.json   HBM bytes per match from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes
 
@@ -54,6 +55,12 @@ def main():
         f"--no-cpu-baseline --no-extras > {out}/trace_cfg2_bench.log 2>&1", env=env)
     run(f"{py} {ROOT}/tools/rocpd_summary.py {os.path.join(d2, 't_results.db')} {out}/{tag}_cfg2_kernel_stats.csv")
 
+    # 1c. BASELINE configs[4] on one GPU: the cold match + 8 churn ticks (tools/churn_probe.py)
+    d3 = os.path.join(out, "trace_churn")
+    run(f"cd /tmp && rocprofv3 --kernel-trace --stats -d {d3} -o t -- {py} {ROOT}/tools/churn_probe.py 8 "
+        f"> {out}/{tag}_churn_ticks.txt 2>&1", env=env)
+    run(f"{py} {ROOT}/tools/rocpd_summary.py {os.path.join(d3, 't_results.db')} {out}/{tag}_churn_kernel_stats.csv")
+
     # 2. PMC passes (counters on their own, no trace domains besides the kernel trace)
     matches = 4  # --steps 3 --warmup 1
     sums = {}
@@ -93,7 +100,7 @@ def main():
             fh.write((line[-1] if line else r.stdout + r.stderr) + "\n")
         print(line[-1] if line else r.stdout[-2000:] + r.stderr[-2000:])
     # drop the bulky raw databases, keep the summaries
-    run(f"rm -rf {out}/trace {out}/trace_cfg2 {out}/pmc_FETCH_SIZE {out}/pmc_WRITE_SIZE")
+    run(f"rm -rf {out}/trace {out}/trace_cfg2 {out}/trace_churn {out}/pmc_FETCH_SIZE {out}/pmc_WRITE_SIZE")
 
 
 if __name__ == "__main__":
