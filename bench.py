@@ -156,9 +156,12 @@ def proposer_split(E, host, sw, seed, steps=3):
         s = eng.tick()
         if k:
             st.append(s)
+    cc = eng.debug_carve_counters()
     eng.close()
     return {"ms": med(st, "ms_propose_kernel"), "proposals": med(st, "proposals"), "keys": med(st, "propose_keys"),
-            "ms_carve_kernel_with_events": med(st, "ms_carve_kernel")}
+            "ms_carve_kernel_with_events": med(st, "ms_carve_kernel"),
+            "index": {"grid": cc["cell_g"], "indexed_positions": cc["n_indexed"], "batches": cc["batches"],
+                      "batches_walked": cc["pruned_batches"], "walks_given_up": cc["prune_fallbacks"]}}
 
 
 def kernel_table(sw, stats, T, W, prop):
@@ -184,6 +187,8 @@ def kernel_table(sw, stats, T, W, prop):
                   "steps": steps, "fast_steps": med(stats, "carve_fast_steps"), "us_per_step": 1e3 * carve_ms / steps,
                   "launches": med(stats, "carve_launches")},
         "carve_propose_kernel": {"ms": prop_ms, "proposals": prop["proposals"], "keys": keys,
+                                 "keys_per_proposal": keys / prop["proposals"] if prop["proposals"] else None,
+                                 "spatial_index": prop.get("index"),
                                  "timing": "separate pass with hipEvents around every proposer launch",
                                  "keys_per_s": keys / (prop_ms * 1e-3) if prop_ms > 0 else None,
                                  "valu_ops_per_key": VALU_OPS_PER_KEY,

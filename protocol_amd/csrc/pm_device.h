@@ -40,6 +40,13 @@ static constexpr uint32_t PM_ROW_COMPLETE = 1u << 31;    // the row lists every 
 static constexpr uint32_t PM_PROP_RESERVE = 64;        // entries beyond max_group_size - 1: the proposer's register holds 64 sorted
                                                        // keys whatever K is, so every row is as long as a row can be (K = 63)
 static constexpr uint32_t PM_PROP_MAX_SEEDS = 16384;   // located slots that get a proposal per configuration
+// spatial index of a carve's located positions (cell_*_kernel): a G x G x G grid over the unit-vector cube [-1, 1]^3,
+// x fastest, so a run of cells along x is one contiguous range of the cell-sorted entries
+static constexpr uint32_t PM_CELL_G_MAX = 64;
+static constexpr uint32_t PM_CELL_TABLE = PM_CELL_G_MAX * PM_CELL_G_MAX * PM_CELL_G_MAX + 2;  // starts of every cell + the end
+static constexpr uint32_t PM_CELL_MIN_N = 6000;        // eligible positions below which no index is built
+static constexpr uint32_t PM_CELL_BIG_N = 40000;       // ... from which the grid is 64^3 instead of 32^3
+static constexpr uint32_t PM_CELL_RMAX = 14;           // rings of cells a seed walks before it falls back to the whole list
 // part | alive, loc bitmaps | wid | site | key | sel_out | BlockRed + s_n
 static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
                                              size_t(PM_CARVE_SLOTS) * 16 + size_t(PM_CARVE_SEL_CAP) * 4 + 1024;
@@ -118,6 +125,14 @@ struct CarveStatus {
   // how validation launches ended: 0 chain: list thinned out, 1 seeds of the batch used up, 2 exact step: thinned out,
   // 3 configuration exhausted, 4 batch prepared for another configuration, 5 batch too stale, 6 configuration not entered
   uint32_t why[8];
+  uint32_t cell_g;          // grid size of the spatial index built for this carve's positions (0 = none)
+  uint32_t n_indexed;       // located positions in the index
+  uint32_t pruned_batches;  // batches whose proposals walked the index instead of the whole list
+  uint32_t prune_fallbacks; // seeds of such batches that gave up on the index (rings exhausted) and swept the list
+#ifdef PM_BATCH_LOG  // (experiment builds, tools/prune_probe.py: what every preparation of the carve produced)
+  uint32_t blog_n;
+  uint32_t blog[3 * 512];   // per preparation: list length (0 = none), seeds, grid of the walk (0 = whole-list sweep)
+#endif
   unsigned long long prop_keys;  // keys (Haversine terms) those sweeps evaluated
   unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
@@ -134,7 +149,7 @@ struct BatchDesc {
   uint32_t valid;            // a candidate list was prepared: configuration `ci`, the first from ci0 on that can be entered
   uint32_t none;             // no configuration from ci0 on can be entered any more
   uint32_t ci, n_list, prop_k, prop_limit, rows_pr, n_seeds;
-  uint32_t _pad;
+  uint32_t cell_g;           // the proposals of this batch walk the spatial index (grid size; 0 = sweep the whole list)
 };
 
 struct CarveArgs {
@@ -191,6 +206,18 @@ struct CarveArgs {
   uint64_t* alive_snap;          // the position bitmap as the preparation saw it (bits_stride words)
   uint32_t speculative;          // the preparation may run beside the validation of the batch in front
   uint32_t debug_mem_above;      // test hook: candidate lists longer than this take the all-in-HBM path (0 = off)
+  // spatial index over the located positions (built once per carve behind the eligible list, see cell_count_kernel)
+  uint32_t* cell_cnt;            // [PM_CELL_TABLE] members per cell while the index is built; zero between builds
+  uint32_t* cell_start;          // [PM_CELL_TABLE] first entry of every cell (+ the end)
+  uint32_t *pos_cell, *pos_rank; // per position: its cell, its rank among the cell's members
+  uint32_t* cs_of_pos;           // per position: its entry in cell order (located positions only)
+  uint32_t* cs_slot;             // per entry: the candidate slot it has in the prepared list, ~0 = none (per batch)
+  double *cs_ux, *cs_uy, *cs_uz; // per entry: unit vector
+  uint32_t* cs_site;             // per entry: site id
+  uint32_t prune_mode;           // 0 never, 1 when it pays (list length vs live fraction), 2 whenever there is an index,
+                                 // 3 = 2 with every seed forced through the whole-list fallback (test hooks)
+  uint32_t prune_factor;         // mode 1: walk when n_list^2 >= prune_factor x (indexed positions)
+  uint32_t walk_cap_div, _pad_w; // seeds of a batch that walks the index: n_list / walk_cap_div
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];
@@ -247,7 +274,8 @@ void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_b
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
 uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, bool speculative, hipStream_t s);  // [plan +] count + place
-void launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t start_ci, hipStream_t s);
+uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound, uint32_t index_min, uint32_t start_ci,
+                           hipStream_t s);  // eligible list [+ spatial index]; returns the launches
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 

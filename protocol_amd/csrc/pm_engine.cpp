@@ -131,8 +131,14 @@ struct pm_engine {
   bool k_sweep_recorded = false, k_compat_recorded = false;
   uint64_t tick_cand_sum = 0;
   unsigned long long carve_prof[32]{};
-  unsigned long long carve_why[10]{};
-  uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above  // CarveStatus::why of the last carve, its batches and its void launches
+  unsigned long long carve_why[14]{};  // CarveStatus::why of the last carve, its batches and void launches, the spatial index
+  uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above
+  uint32_t prune_mode = 1;       // pm_debug_prune_mode / PM_PRUNE_MODE: CarveArgs::prune_mode
+  uint32_t prune_factor = 512;   // PM_PRUNE_FACTOR: CarveArgs::prune_factor (measured crossover)
+  uint32_t walk_cap_div = 0;     // PM_WALK_CAP_DIV: CarveArgs::walk_cap_div (0 = the kernels' default)
+#ifdef PM_BATCH_LOG
+  std::vector<uint32_t> blog;    // the preparations of the last carve (tools/prune_probe.py)
+#endif
   std::mutex mu;
 
   // ---- configuration tables
@@ -228,6 +234,9 @@ struct pm_engine {
                                     // differs in the per-batch scratch, see CarveSet)
   DevBuf<BatchDesc> d_desc;         // [2]
   DevBuf<uint64_t> d_snap;          // [2][stride] position-bitmap snapshots of the preparations
+  // spatial index of a carve's located positions (cell_*_kernel)
+  DevBuf<uint32_t> d_cell_cnt, d_cell_start, d_pos_cell, d_pos_rank, d_cs_of_pos, d_cs_slot, d_cs_site;
+  DevBuf<double> d_cs_u[3];
   DevBuf<uint64_t> d_ikeys, d_umask;  // per-task orientation: table of the distinct topology masks, the masks densely
   DevBuf<uint32_t> d_ivals;
   // per-batch scratch of the SECOND argument block (the first uses the d_cc_* / d_slot_* / d_prop ... members):
@@ -514,6 +523,22 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   const uint32_t stride = uint32_t((cap + 63) / 64);
   HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
   HIPCHK(e->d_snap.ensure(size_t(stride) * 2));
+  if (mode == CARVE_MODE_FORM && e->prune_mode && e->cfg.proximity_enabled) {
+    if (!e->d_cell_cnt.p) {  // (the scan leaves the counts zero behind it: cleared once)
+      HIPCHK(e->d_cell_cnt.ensure(PM_CELL_TABLE));
+      HIPCHK(hipMemsetAsync(e->d_cell_cnt.p, 0, e->d_cell_cnt.cap * sizeof(uint32_t), e->stream));
+    }
+    if (!e->d_cell_start.p) {  // + the scan's block sums and its ticket (zero between scans)
+      HIPCHK(e->d_cell_start.ensure(PM_CELL_TABLE + 384));
+      HIPCHK(hipMemsetAsync(e->d_cell_start.p, 0, e->d_cell_start.cap * sizeof(uint32_t), e->stream));
+    }
+    HIPCHK(e->d_pos_cell.ensure(cap));
+    HIPCHK(e->d_pos_rank.ensure(cap));
+    HIPCHK(e->d_cs_of_pos.ensure(cap));
+    HIPCHK(e->d_cs_slot.ensure(cap));
+    HIPCHK(e->d_cs_site.ensure(cap));
+    for (auto& u : e->d_cs_u) HIPCHK(u.ensure(cap));
+  }
   std::memset(a, 0, sizeof(*a));
   a->mode = mode;
   a->W = e->W;
@@ -570,6 +595,21 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->alive_snap = e->d_snap.p;
   a->speculative = 0;
   a->debug_mem_above = e->debug_mem_above;
+  if (mode == CARVE_MODE_FORM && e->prune_mode && e->cfg.proximity_enabled) {
+    a->prune_mode = e->prune_mode;
+    a->prune_factor = e->prune_factor;
+    a->walk_cap_div = e->walk_cap_div;
+    a->cell_cnt = e->d_cell_cnt.p;
+    a->cell_start = e->d_cell_start.p;
+    a->pos_cell = e->d_pos_cell.p;
+    a->pos_rank = e->d_pos_rank.p;
+    a->cs_of_pos = e->d_cs_of_pos.p;
+    a->cs_slot = e->d_cs_slot.p;
+    a->cs_site = e->d_cs_site.p;
+    a->cs_ux = e->d_cs_u[0].p;
+    a->cs_uy = e->d_cs_u[1].p;
+    a->cs_uz = e->d_cs_u[2].p;
+  }
   return PM_OK;
 }
 
@@ -789,8 +829,9 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r) {
   HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
   if (r->use_props) {
     HIPCHK(hipMemsetAsync(e->d_desc.p, 0, 2 * sizeof(BatchDesc), e->stream));
-    launch_carve_elig(e->d_carve_args.p, e->W, r->start_ci, e->stream);  // the ordered eligible list
-    e->tick_carve_launches += 2;
+    // the ordered eligible list, and the spatial index of its positions when there are enough of them to matter
+    const uint32_t index_min = !r->a.prune_mode ? 0u : r->a.prune_mode >= 2u ? 1u : PM_CELL_MIN_N;
+    e->tick_carve_launches += launch_carve_elig(e->d_carve_args.p, e->W, r->n_bound, index_min, r->start_ci, e->stream);
     if (r->pipelined) {
       // (both streams are idle here: the first call of a carve, or a poll has just drained them)
       hipEvent_t ev = nullptr;
@@ -953,6 +994,13 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   for (int k = 0; k < 8; ++k) e->carve_why[k] = st.why[k];
   e->carve_why[8] = st.n_batches;
   e->carve_why[9] = st.n_void;
+  e->carve_why[10] = st.pruned_batches;
+  e->carve_why[11] = st.prune_fallbacks;
+  e->carve_why[12] = st.cell_g;
+  e->carve_why[13] = st.n_indexed;
+#ifdef PM_BATCH_LOG
+  e->blog.assign(st.blog, st.blog + 3 * std::min<uint32_t>(st.blog_n, 512u));
+#endif
 
   // The new group records stay in HBM for the match; their ids (generate_group_id stream) and empty task
   // words are filled in on the device, and a copy travels to pinned host memory for absorb_groups().
@@ -1556,6 +1604,17 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
   if (!e) return set_error(PM_ENOMEM, "out of host memory");
   e->cfg = *cfg;
   e->id_rng = cfg->group_id_seed;
+  if (const char* v = getenv("PM_PRUNE_MODE")) {  // (experiments: see pm_debug_prune_mode)
+    if (v[0] >= '0' && v[0] <= '3' && !v[1]) e->prune_mode = uint32_t(v[0] - '0');
+  }
+  if (const char* v = getenv("PM_WALK_CAP_DIV")) {
+    const long f = atol(v);
+    if (f > 0 && f < 1000) e->walk_cap_div = uint32_t(f);
+  }
+  if (const char* v = getenv("PM_PRUNE_FACTOR")) {
+    const long f = atol(v);
+    if (f > 0 && f < (1l << 30)) e->prune_factor = uint32_t(f);
+  }
   (void)hipStreamCreateWithFlags(&e->stream_p, hipStreamNonBlocking);  // (without it the carve is not pipelined)
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     delete e;
@@ -1618,6 +1677,9 @@ void pm_engine_destroy(pm_engine* e) {
   if (e->stream_owned) (void)hipStreamDestroy(e->stream_owned);
   if (e->stream_p) (void)hipStreamDestroy(e->stream_p);
   for (hipEvent_t x : e->pipe_ev) (void)hipEventDestroy(x);
+  e->d_cell_cnt.release(); e->d_cell_start.release(); e->d_pos_cell.release(); e->d_pos_rank.release();
+  e->d_cs_of_pos.release(); e->d_cs_slot.release(); e->d_cs_site.release();
+  for (auto& u : e->d_cs_u) u.release();
   e->set2.release(); e->d_desc.release(); e->d_snap.release(); e->d_ikeys.release(); e->d_umask.release(); e->d_ivals.release();
   delete e->form;
   delete e;
@@ -2909,7 +2971,7 @@ int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap)
   std::lock_guard<std::mutex> lk(e->mu);
   const uint32_t n = std::min<uint32_t>(cap, uint32_t(sizeof(e->carve_prof) / sizeof(e->carve_prof[0])));
   std::memcpy(out, e->carve_prof, size_t(n) * sizeof(unsigned long long));
-  for (uint32_t k = 32; k < cap && k < 42; ++k) out[k] = e->carve_why[k - 32];  // (how the validation launches ended)
+  for (uint32_t k = 32; k < cap && k < 46; ++k) out[k] = e->carve_why[k - 32];  // (how the validation launches ended; the index)
   return PM_OK;
 }
 
@@ -2921,6 +2983,26 @@ int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n) {
   e->debug_mem_above = n;
   return PM_OK;
 }
+
+// debug (pm_internal.h): when the proposer walks the spatial index instead of sweeping the whole candidate list —
+// 0 never, 1 when it pays (default), 2 whenever the carve has one (built for any swarm of 64+ positions),
+// 3 = 2 with every seed sent through the whole-list fallback
+int32_t pm_debug_prune_mode(pm_engine* e, uint32_t mode) {
+  if (!e || mode > 3u) return set_error(PM_EINVAL, "prune mode 0..3");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->prune_mode = mode;
+  return PM_OK;
+}
+
+#ifdef PM_BATCH_LOG
+extern "C" int32_t pm_debug_batch_log(pm_engine* e, uint32_t* out, uint32_t cap_words, uint32_t* n_words) {
+  if (!e || !out || !n_words) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  *n_words = uint32_t(e->blog.size());
+  std::memcpy(out, e->blog.data(), sizeof(uint32_t) * std::min<size_t>(cap_words, e->blog.size()));
+  return PM_OK;
+}
+#endif
 
 // debug (pm_internal.h): stream triad over 3 x n_doubles f64 on the engine's stream, best of `reps` -> GB/s
 int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s) {

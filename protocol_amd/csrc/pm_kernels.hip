@@ -2380,6 +2380,255 @@ __device__ __forceinline__ void tile_keys(const CarveArgs& p, const TileBuf& tb,
   }
 }
 
+// ---- Proposals from the spatial index (cell_*_kernel below).  The whole-list sweep above evaluates every candidate
+// for every seed: 13,500 keys to pick 63 at 1M x 100k.  When the list is long and most of the indexed positions are
+// still candidates, a seed instead walks the grid cells around its own cell, ring by ring (Chebyshev distance r in
+// cell coordinates), and stops in front of the first ring that cannot hold anything of interest: every point of a
+// cell at distance r is at least (r - 1) h away in one coordinate, hence in chord length, and what matters to a row
+// is only what lies below its window (near_window: the threshold plus the certificate band).  Inside a ring each lane
+// owns one run of cells along x — a contiguous range of the cell-sorted entries — and skips it when the box of the
+// run is already out of reach of the seed's exact coordinates.  The row, its flags and the near-miss tracker come
+// out bit for bit as the whole-list sweep produces them: both are functions of the SET of candidates below the final
+// window, and the walk sees all of those.
+__device__ __forceinline__ uint32_t cell_g_for(uint32_t n) {
+  return n >= PM_CELL_BIG_N ? PM_CELL_G_MAX : n >= PM_CELL_MIN_N ? PM_CELL_G_MAX / 2u : 0u;
+}
+__device__ __forceinline__ uint32_t cell_coord(double v, uint32_t g) {  // v in [-1, 1]
+  const double t = fmax((v + 1.0) * (double)(g >> 1), 0.0);  // (g / 2 is a power of two: the product is exact)
+  const uint32_t c = (uint32_t)t;
+  return c < g ? c : g - 1u;
+}
+// Lower bound of the key of anything at least `gx, gy, gz` away from the seed along the axes.  The gaps come from cell
+// boundaries, which hold for the stored coordinates up to one rounding of (v + 1); 1e-9 (6 mm) per axis and 1e-6 of
+// the result are far beyond that and beyond the difference between the chord form and the sine form of the key
+// (relative 2^-31 at worst, the certificate band), and nothing next to a cell of 200 km.
+__device__ __forceinline__ uint64_t cell_bound_key(double gx, double gy, double gz, uint32_t SB) {
+  gx = fmax(gx - 1e-9, 0.0);
+  gy = fmax(gy - 1e-9, 0.0);
+  gz = fmax(gz - 1e-9, 0.0);
+  const double a = 0.25 * (gx * gx + gy * gy + gz * gz) * (1.0 - 1e-6);
+  return pack_key((uint64_t)__double_as_longlong(a), 0u, SB);
+}
+// one candidate per lane against the row: the key arithmetic of tile_keys, operands in registers
+__device__ __forceinline__ void offer_candidate(const CarveArgs& p, const SeedGeo& sg, uint32_t ssite, double x, double y,
+                                                double z, uint32_t si, uint32_t t, bool located, bool counts, uint32_t SB,
+                                                uint64_t ulps, NearRow& q, uint32_t& n_mine) {
+  const double dx = x - sg.ux, dy = y - sg.uy, dz = z - sg.uz;
+  double a = 0.25 * fma(dx, dx, fma(dy, dy, dz * dz));
+  const bool same_site = located && si == ssite;
+  const bool near = counts && located && a < PM_A_CHORD_MIN && !same_site;
+  a = same_site ? 0.0 : a;
+  if (__ballot(near)) {
+    if (near) a = hav_a(sg.lat, sg.lon, sg.cos, G(p.cc_lat)[t], G(p.cc_lon)[t], G(p.cc_cos)[t]);
+  }
+  const uint64_t kl = pack_key(located ? (uint64_t)__double_as_longlong(a) : PM_KEY_NOLOC, t, SB);
+  near_row_offer(q, counts ? kl : ~0ull, si, G(p.cc_site), SB, ulps);
+  n_mine += counts ? 1u : 0u;
+}
+// The entries of up to 64 runs — lane l holds run l: first entry b, length len (0 = none) — against the row.  The runs
+// are short (a few cells of a few dozen positions), so they are laid end to end and cut into strides of 64: lane l of a
+// stride finds its run by bisecting the running totals held across the lanes (6 ds_bpermute).  Most entries are not
+// candidates of THIS list (another configuration's, or gone), and the walk of one seed is a chain of memory round trips,
+// not a stream: so the first pass reads only the entries' slot words, four strides per trip, and packs the candidates
+// it finds into the wave's LDS buffer; their coordinates are fetched in a second pass, over full strides.
+#define CELL_BUF 768u  // candidates a wave collects before it drains them (2 words each)
+__device__ __forceinline__ void cell_drain(const CarveArgs& p, uint32_t* wl, uint32_t& nb, uint32_t lane, uint32_t s, bool shared,
+                                           uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps, NearRow& q,
+                                           uint32_t& n_mine) {
+  const auto cs_site = G((const uint32_t*)p.cs_site);
+  const auto cs_x = G((const double*)p.cs_ux);
+  const auto cs_y = G((const double*)p.cs_uy);
+  const auto cs_z = G((const double*)p.cs_uz);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the lanes read what other lanes of the wave packed)
+  for (uint32_t k0 = 0; k0 < nb; k0 += 128u) {
+    uint32_t t[2], si[2];
+    double x[2], y[2], z[2];
+    bool in[2];
+#pragma unroll
+    for (uint32_t v = 0; v < 2u; ++v) {
+      const uint32_t k = k0 + v * 64u + lane;
+      in[v] = k < nb;
+      const uint32_t kc = in[v] ? k : 0u;
+      const uint32_t ic = wl[kc];
+      t[v] = wl[CELL_BUF + kc];
+      x[v] = cs_x[ic];
+      y[v] = cs_y[ic];
+      z[v] = cs_z[ic];
+      si[v] = cs_site[ic];
+    }
+#pragma unroll
+    for (uint32_t v = 0; v < 2u; ++v) {
+      if (!__ballot(in[v])) continue;
+      // (every indexed position has a location; the slots in front of the seed at its own shared site: see tile_keys)
+      const bool counts = in[v] && t[v] != s && !(shared && si[v] == ssite && t[v] < s);
+      offer_candidate(p, sg, ssite, x[v], y[v], z[v], si[v], in[v] ? t[v] : 0u, true, counts, SB, ulps, q, n_mine);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  nb = 0;
+}
+__device__ __forceinline__ void cell_offer_runs(const CarveArgs& p, uint32_t* wl, uint32_t b, uint32_t len, uint32_t lane, uint32_t s,
+                                                bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps,
+                                                NearRow& q, uint32_t& n_mine) {
+  uint32_t incl = len;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o, 64);
+    if ((int)lane >= o) incl += up;
+  }
+  const uint32_t excl = incl - len;
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  const auto cs_slot = G((const uint32_t*)p.cs_slot);
+  uint32_t nb = 0;
+  for (uint32_t f0 = 0; f0 < total; f0 += 256u) {
+    uint32_t t[4], ic[4];
+    bool in[4];
+#pragma unroll
+    for (uint32_t v = 0; v < 4u; ++v) {
+      const uint32_t f = f0 + v * 64u + lane;
+      in[v] = f < total;
+      uint32_t j = 0;
+#pragma unroll
+      for (uint32_t step = 32u; step; step >>= 1) {
+        const uint32_t pv = __shfl(incl, (int)(j + step - 1u), 64);
+        j += pv <= f ? step : 0u;
+      }
+      j = j > 63u ? 63u : j;
+      const uint32_t idx = __shfl(b, (int)j, 64) + (f - __shfl(excl, (int)j, 64));
+      ic[v] = in[v] ? idx : 0u;
+      t[v] = cs_slot[ic[v]];
+    }
+#pragma unroll
+    for (uint32_t v = 0; v < 4u; ++v) {
+      const bool cand = in[v] && t[v] != 0xFFFFFFFFu;
+      const uint64_t m = __ballot(cand);
+      if (cand) {
+        const uint32_t at = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        wl[at] = ic[v];
+        wl[CELL_BUF + at] = t[v];
+      }
+      nb += (uint32_t)__popcll(m);
+    }
+    if (nb > CELL_BUF - 256u) cell_drain(p, wl, nb, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+  }
+  if (nb) cell_drain(p, wl, nb, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+}
+// run qi of ring r around cell (cx, cy, cz): where its entries begin and end in cell_start, and the lower bound of
+// the keys in its box.  false = the run lies outside the grid.
+__device__ __forceinline__ bool cell_run(uint32_t r, uint32_t qi, int cx, int cy, int cz, uint32_t g, double h, const SeedGeo& sg,
+                                         uint32_t SB, uint32_t* lin_b, uint32_t* lin_e, uint64_t* lbk) {
+  const int G1 = (int)g;
+  int dy = 0, dz = 0, x0 = cx, x1 = cx;
+  if (r > 0u) {
+    const uint32_t side = 2u * r, n_full = 8u * r, inner = 2u * r - 1u;
+    if (qi < n_full) {  // the rim of the (2r + 1)^2 square of (dy, dz): whole runs -r .. r along x
+      const uint32_t sd = qi / side, t = qi - sd * side;
+      const int R = (int)r, T = (int)t;
+      dy = sd == 0u ? -R + T : sd == 1u ? R : sd == 2u ? R - T : -R;
+      dz = sd == 0u ? -R : sd == 1u ? -R + T : sd == 2u ? R : R - T;
+      x0 = cx - R;
+      x1 = cx + R;
+    } else {  // the inside of the square: the two end cells x = -r and x = r
+      const uint32_t m = (qi - n_full) >> 1;
+      dy = (int)(m % inner) - (int)(r - 1u);
+      dz = (int)(m / inner) - (int)(r - 1u);
+      x0 = x1 = ((qi - n_full) & 1u) ? cx + (int)r : cx - (int)r;
+    }
+  }
+  const int y = cy + dy, z = cz + dz;
+  const bool ok = y >= 0 && y < G1 && z >= 0 && z < G1 && x1 >= 0 && x0 < G1;
+  x0 = x0 < 0 ? 0 : x0;
+  x1 = x1 >= G1 ? G1 - 1 : x1;
+  // the box of the run against the seed's own coordinates
+  const double xlo = (double)x0 * h - 1.0, xhi = (double)(x1 + 1) * h - 1.0;
+  const double ylo = (double)y * h - 1.0, yhi = ylo + h, zlo = (double)z * h - 1.0, zhi = zlo + h;
+  const double gx = fmax(fmax(xlo - sg.ux, sg.ux - xhi), 0.0), gy = fmax(fmax(ylo - sg.uy, sg.uy - yhi), 0.0),
+               gz = fmax(fmax(zlo - sg.uz, sg.uz - zhi), 0.0);
+  *lbk = cell_bound_key(gx, gy, gz, SB);
+  const uint32_t row = ok ? ((uint32_t)z * g + (uint32_t)y) * g : 0u;
+  *lin_b = row + (uint32_t)(ok ? x0 : 0);
+  *lin_e = row + (uint32_t)(ok ? x1 : 0) + 1u;
+  return ok;
+}
+__device__ __forceinline__ uint32_t ring_runs(uint32_t r) { return r ? 8u * r + 2u * (2u * r - 1u) * (2u * r - 1u) : 1u; }
+// The walk.  Returns the ring in front of which it stopped (>= 2), or 0 = the rings ran out before the row's window
+// closed (a seed far from everything else, or fewer located candidates than a row holds): the caller starts over on
+// the whole list.
+__device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, uint32_t g, uint32_t r_max, uint32_t lane, uint32_t s,
+                                          bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps, NearRow& q,
+                                          uint32_t& n_mine) {
+  const double h = 2.0 / (double)g;
+  const int cx = (int)cell_coord(sg.ux, g), cy = (int)cell_coord(sg.uy, g), cz = (int)cell_coord(sg.uz, g);
+  const auto cstart = G((const uint32_t*)p.cell_start);
+  {
+    // rings 0, 1 and 2 are 1 + 10 + 34 runs: one trip to cell_start for all of them.  Ring 1 always counts (a cell
+    // next door can hold a point a hair away); ring 2 only if the window is still open behind ring 1.
+    static_assert(1u + 10u + 34u <= 64u, "three rings in one wave");
+    const uint32_t r = lane == 0u ? 0u : lane <= 10u ? 1u : 2u, qi = lane == 0u ? 0u : lane <= 10u ? lane - 1u : lane - 11u;
+    uint32_t lb, le;
+    uint64_t lbk;
+    const bool ok = lane < 45u && (r < g) && cell_run(r, qi, cx, cy, cz, g, h, sg, SB, &lb, &le, &lbk);
+    uint32_t b = 0, e = 0;
+    if (ok) {
+      b = cstart[lb];
+      e = cstart[le];
+    }
+    cell_offer_runs(p, wl, b, (ok && lane <= 10u) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+    if (cell_bound_key(h, 0.0, 0.0, SB) > q.tau_hi) return 2u;
+    if (r_max < 2u || g <= 2u) return 0u;
+    cell_offer_runs(p, wl, b, (ok && lane > 10u && !(lbk > q.tau_hi)) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+  }
+  for (uint32_t r = 3u;; ++r) {
+    if (cell_bound_key((double)(r - 1u) * h, 0.0, 0.0, SB) > q.tau_hi) return r;  // nothing of interest from this ring on
+    if (r > r_max || r >= g) return 0u;
+    const uint32_t n_runs = ring_runs(r);
+    for (uint32_t q0 = 0; q0 < n_runs; q0 += 64u) {
+      const uint32_t qi = q0 + lane;
+      uint32_t lb, le;
+      uint64_t lbk;
+      bool ok = qi < n_runs && cell_run(r, qi < n_runs ? qi : 0u, cx, cy, cz, g, h, sg, SB, &lb, &le, &lbk);
+      ok = ok && !(lbk > q.tau_hi);
+      uint32_t b = 0, e = 0;
+      if (ok) {
+        b = cstart[lb];
+        e = cstart[le];
+      }
+      if (!__ballot(ok && e > b)) continue;
+      cell_offer_runs(p, wl, b, ok ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+    }
+  }
+}
+// the whole list by one wave, from L2/HBM (the fallback of cell_walk; four strides per trip for the loads to overlap)
+__device__ __forceinline__ void list_sweep_solo(const CarveArgs& p, uint32_t n_list, uint32_t lane, uint32_t s, bool shared,
+                                             uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps, NearRow& q,
+                                             uint32_t& n_mine) {
+  const auto alive = G((const uint64_t*)p.bits_scratch);
+  const auto loc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
+  for (uint32_t t0 = 0; t0 < n_list; t0 += 256u) {
+    double x[4], y[4], z[4];
+    uint32_t si[4];
+    uint64_t aw[4], lw[4];
+#pragma unroll
+    for (uint32_t v = 0; v < 4u; ++v) {
+      const uint32_t tb = t0 + v * 64u, t = tb + lane, tc = t < n_list ? t : n_list - 1u;
+      const bool w_in = tb < n_list;
+      aw[v] = w_in ? alive[tb >> 6] : 0ull;  // (the bitmaps are zero beyond the list)
+      lw[v] = w_in ? loc[tb >> 6] : 0ull;
+      x[v] = G(p.cc_ux)[tc];
+      y[v] = G(p.cc_uy)[tc];
+      z[v] = G(p.cc_uz)[tc];
+      si[v] = G(p.cc_site)[tc];
+    }
+#pragma unroll
+    for (uint32_t v = 0; v < 4u; ++v) {
+      const uint32_t t = t0 + v * 64u + lane;
+      const bool located = (lw[v] >> lane) & 1ull;
+      const bool counts = ((aw[v] >> lane) & 1ull) && t != s && !(shared && located && si[v] == ssite && t < s);
+      offer_candidate(p, sg, ssite, x[v], y[v], z[v], si[v], counts ? t : 0u, located, counts, SB, ulps, q, n_mine);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa) {
   const CarveArgs& p = *pa;  // argument block in device memory: read through the scalar cache, never copied
   const auto st = G((const CarveStatus*)p.status);
@@ -2402,7 +2651,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   // seed numbers my_rank, my_rank + world, ...
   __shared__ TileBuf tiles[2];
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
-  const uint32_t n_seeds = D->n_seeds;
+  const uint32_t n_seeds = D->n_seeds, cell_g = D->cell_g;
   const uint32_t n_my = world > 1u ? (n_seeds > my_rank ? (n_seeds - my_rank + world - 1u) / world : 0u) : n_seeds;
   const uint32_t n_tiles = (n_list + PROP_TILE - 1u) / PROP_TILE;
   const auto seed_slots = G((const uint32_t*)p.seed_slots);
@@ -2422,7 +2671,34 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
     const bool shared = (ssite & 0x80000000u) != 0u;
     NearRow q = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, 0xFFFFFFFFu};
     uint32_t n_mine = 0;
-    {
+    if (cell_g) {  // (the same for every workgroup of the launch: no barrier on this side)
+      if (valid) {
+        // (the tiles' LDS is free on this side: a candidate buffer per wave)
+        static_assert(4u * 2u * CELL_BUF * sizeof(uint32_t) <= sizeof(tiles), "four candidate buffers in the tiles' LDS");
+        uint32_t* wl = reinterpret_cast<uint32_t*>(tiles) + wave * (2u * CELL_BUF);
+#ifdef PM_BATCH_LOG
+        const uint64_t wt0 = __builtin_amdgcn_s_memtime();
+#endif
+        const uint32_t stop_r = p.prune_mode != 3u ? cell_walk(p, wl, cell_g, PM_CELL_RMAX, lane, s, shared, ssite, sg, SB, WINDOW_ULPS, q, n_mine) : 0u;
+#ifdef PM_BATCH_LOG
+        if (lane == 0) {  // (experiment builds: where the walks stopped, what they cost)
+          const uint64_t dt = __builtin_amdgcn_s_memtime() - wt0;
+          unsigned long long* pr = (unsigned long long*)p.status->prof;
+          atomicAdd(&pr[0], (unsigned long long)dt);
+          atomicMax(&pr[1], (unsigned long long)dt);
+          atomicAdd(&pr[2], 1ull);
+          atomicAdd(&pr[3], (unsigned long long)n_mine);
+          atomicAdd(&pr[16u + (stop_r < 15u ? stop_r : 15u)], 1ull);
+        }
+#endif
+        if (!stop_r) {
+          q = NearRow{~0ull, ~0ull, ~0ull, ~0ull, ~0ull, 0xFFFFFFFFu};
+          n_mine = 0;
+          list_sweep_solo(p, n_list, lane, s, shared, ssite, sg, SB, WINDOW_ULPS, q, n_mine);
+          if (lane == 0) atomicAdd(&p.status->prune_fallbacks, 1u);
+        }
+      }
+    } else {
       TileRegs tr;
       tile_fetch(p, alive, loc, lw, n_list, 0u, tid, tr);
       tile_store(tiles[0], tid, tr);
@@ -2553,6 +2829,9 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
   }
 }
 
+#ifndef PM_PROP_CAP_DIV_WALK
+#define PM_PROP_CAP_DIV_WALK 10u
+#endif
 #ifndef PM_PROP_CAP_DIV_BIG
 #define PM_PROP_CAP_DIV_BIG 10u
 #endif
@@ -2566,13 +2845,14 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
 // proposal is stored in (proposer and validator derive it from these two words).
 // (one wave; the results are valid in every lane)
 __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_list, uint32_t lane, uint32_t* limit_out,
-                                                uint32_t* n_seeds_out) {
+                                                uint32_t* n_seeds_out, bool walk = false) {
   // The configuration is re-prepared (and re-proposed) once half of its list is dead; by then the seed
   // pointer has advanced through roughly the first eighth of the slots (each group removes max_s slots
   // spread over the whole list), so later slots never consume this round's proposals: cap the batch.
   // (big lists: a tenth; measured again with the sorted-lane proposer at 1M x 100k, carve through the stepwise
   // tick: 1/6 26.3 ms, 1/8 22.5, 1/10 22.0, 1/14 22.7; small lists 1/3 .. 1/7 all within 1 %)
-  uint32_t cap = n_list > PM_CARVE_SLOTS ? n_list / PM_PROP_CAP_DIV_BIG : n_list / PM_PROP_CAP_DIV;
+  // (a batch whose seeds walk the spatial index pays per seed, not per seed and candidate: it can afford more of them)
+  uint32_t cap = walk ? n_list / (p.walk_cap_div ? p.walk_cap_div : PM_PROP_CAP_DIV_WALK) : n_list > PM_CARVE_SLOTS ? n_list / PM_PROP_CAP_DIV_BIG : n_list / PM_PROP_CAP_DIV;
   if (cap < 512u) cap = 512u;
   if (cap > PM_PROP_MAX_SEEDS) cap = PM_PROP_MAX_SEEDS;
   const auto g_al = G((const uint64_t*)p.bits_scratch);
@@ -2759,6 +3039,14 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     break;
   }
   const bool none = ci >= p.n_avail;
+  // proposals for this list?  (the configuration and the list length decide: the same answer in every block) ...
+  const bool props = !none && p.proximity && n_list <= PM_CARVE_BIG_SLOTS && p.max_size[ci] - 1u < PM_PROP_KMAX &&
+                     !(p.debug_mem_above && n_list > p.debug_mem_above);
+  // ... and do they walk the spatial index?  A walk visits the indexed positions around the seed whether they are
+  // still candidates or not, the sweep visits the n_list candidates: the walk pays while the list is long and a good
+  // part of the index is still in it.
+  uint32_t cell_g = props ? st->cell_g : 0u;
+  if (cell_g && p.prune_mode == 1u && (uint64_t)n_list * n_list < (uint64_t)p.prune_factor * st->n_indexed) cell_g = 0u;
   if (!none) {
     const uint64_t cbit = 1ull << p.avail_cfg[ci];
     // ---- this block's first slot: candidates of the blocks in front of it
@@ -2801,6 +3089,7 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
       G(p.cc_site)[s] = os;
       s_bits[wave][rank] = has_loc;
     }
+    if (cell_g && i < n && has_loc) G(p.cs_slot)[G((const uint32_t*)p.cs_of_pos)[i]] = c ? off + rank : 0xFFFFFFFFu;
     // the located bits of this wave's slots [off, off + cnt): compacted by rank, ORed into the slot loc bitmap
     // (cleared by carve_prep_count_kernel); at most two words
     __syncthreads();
@@ -2823,6 +3112,10 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     if (tid == 0) {
       p.desc->ci = p.n_avail;
       p.desc->none = 1u;
+#ifdef PM_BATCH_LOG
+      const uint32_t k = p.status->blog_n++;
+      if (k < 512u) p.status->blog[3u * k] = p.status->blog[3u * k + 1u] = p.status->blog[3u * k + 2u] = 0u;
+#endif
     }
     return;
   }
@@ -2834,11 +3127,11 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   __syncthreads();
   uint32_t prop_k = 0, limit = 0, n_seeds = 0;
   const uint32_t max_s = p.max_size[ci];
-  if (p.proximity && n_list <= PM_CARVE_BIG_SLOTS && max_s - 1u < PM_PROP_KMAX && !(p.debug_mem_above && n_list > p.debug_mem_above)) {
+  if (props) {
     const uint32_t k = max_s - 1u + PM_PROP_RESERVE;
     prop_k = k < PM_PROP_KMAX ? k : PM_PROP_KMAX;
     if (wave == 0) {
-      prop_limit_scan(p, n_list, lane, &limit, &n_seeds);
+      prop_limit_scan(p, n_list, lane, &limit, &n_seeds, cell_g != 0u);
       if (lane == 0) {
         s_red[1] = limit;
         s_red[2] = n_seeds;
@@ -2857,7 +3150,17 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     d->prop_limit = limit;
     d->rows_pr = (n_seeds + p.dist_world - 1u) / p.dist_world;
     d->n_seeds = n_seeds;
+    d->cell_g = cell_g;
     d->valid = 1u;
+    if (cell_g) p.status->pruned_batches += 1u;
+#ifdef PM_BATCH_LOG
+    const uint32_t k = p.status->blog_n++;
+    if (k < 512u) {
+      p.status->blog[3u * k] = n_list;
+      p.status->blog[3u * k + 1u] = n_seeds;
+      p.status->blog[3u * k + 2u] = cell_g;
+    }
+#endif
   }
 }
 
@@ -2968,6 +3271,148 @@ __global__ __launch_bounds__(256) void carve_elig_place_kernel(const CarveArgs* 
     st->need_prep = 1u;
     st->g_lo = st->g_hi = st->n_groups;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Spatial index of the carve's located positions (see cell_walk).  Positions never move during a carve — only the
+// candidate lists drawn from them do — so the index is built once, behind the eligible list: a counting sort by grid
+// cell of the unit vectors.
+//   cell_count_kernel   every located position: its cell, and its rank among the cell's members (one atomic)
+//   cell_scan_*_kernel  exclusive scan of the G^3 counts -> cell_start; leaves the counts zero
+//   cell_place_kernel   position -> entry; the entry's unit vector and site, in cell order
+// Per batch, carve_prep_place_kernel then writes the slot every entry has in the prepared list (cs_slot, ~0 = none).
+__global__ __launch_bounds__(256) void cell_count_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;
+  const auto st = G(p.status);
+  if (st->state != CARVE_STATE_RUNNING) return;
+  const uint32_t n = st->n_eligible;
+  const uint32_t g = (p.prune_mode && p.proximity) ? cell_g_for(p.prune_mode >= 2u && n >= 64u && n < PM_CELL_MIN_N ? PM_CELL_MIN_N : n) : 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->cell_g = g;
+    st->n_indexed = 0u;
+  }
+  if (!g) return;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  if (!bit_at(G((const uint64_t*)p.loc_g), i)) {
+    G(p.pos_cell)[i] = 0xFFFFFFFFu;
+    return;
+  }
+  const uint32_t c = (cell_coord(G(p.c_uz)[i], g) * g + cell_coord(G(p.c_uy)[i], g)) * g + cell_coord(G(p.c_ux)[i], g);
+  G(p.pos_cell)[i] = c;
+  G(p.pos_rank)[i] = atomicAdd(&p.cell_cnt[c], 1u);
+}
+
+// the scan, on every CU: 1024 counts per block.  (A single workgroup took 230 us for the 262,144 cells of the 64^3 grid.)
+//   cell_scan_sums_kernel   the sum of every block's counts; the block that finishes last turns the sums into offsets
+//   cell_scan_apply_kernel  every block scans its own counts from its offset, and leaves the counts zero behind it
+#define CELL_SCAN_PER_BLOCK 1024u
+static_assert((PM_CELL_TABLE + CELL_SCAN_PER_BLOCK - 1u) / CELL_SCAN_PER_BLOCK <= 320u, "block sums fit one look of 256 + 64 threads");
+__global__ __launch_bounds__(256) void cell_scan_sums_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;
+  const auto st = G(p.status);
+  if (st->state != CARVE_STATE_RUNNING) return;
+  const uint32_t g = st->cell_g;
+  if (!g) return;
+  const uint32_t total = g * g * g, n_blocks = (total + CELL_SCAN_PER_BLOCK - 1u) / CELL_SCAN_PER_BLOCK;
+  if (blockIdx.x >= n_blocks) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_last;
+  const auto cnt = G((const uint32_t*)p.cell_cnt);
+  const uint32_t i0 = blockIdx.x * CELL_SCAN_PER_BLOCK + tid * 4u;
+  uint32_t v = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) v += i0 + k < total ? cnt[i0 + k] : 0u;
+  v = wave_sum(v);
+  if (lane == 0) s_w[wave] = v;
+  __syncthreads();
+  // the sums and the ticket live behind the starts (cell_start has PM_CELL_TABLE words, the table needs total + 1)
+  const auto blk = p.cell_start + PM_CELL_TABLE;  // [320] sums -> offsets, [320] ticket
+  if (tid == 0) {
+    blk[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __threadfence();
+    s_last = atomicAdd(&blk[320], 1u) == n_blocks - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // exclusive scan of up to 320 block sums by wave 0: five strides of 64
+  if (wave == 0) {
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += 64u) {
+      const uint32_t c = c0 + lane;
+      const uint32_t x = c < n_blocks ? G((const uint32_t*)blk)[c] : 0u;
+      uint32_t incl = x;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += up;
+      }
+      if (c < n_blocks) blk[c] = carry + incl - x;
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) {
+      blk[320] = 0u;  // the ticket, for the next carve
+      p.cell_start[total] = carry;
+      st->n_indexed = carry;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void cell_scan_apply_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;
+  const auto st = G((const CarveStatus*)p.status);
+  if (st->state != CARVE_STATE_RUNNING) return;
+  const uint32_t g = st->cell_g;
+  if (!g) return;
+  const uint32_t total = g * g * g, n_blocks = (total + CELL_SCAN_PER_BLOCK - 1u) / CELL_SCAN_PER_BLOCK;
+  if (blockIdx.x >= n_blocks) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  __shared__ uint32_t s_w[4];
+  const auto cnt = G(p.cell_cnt);
+  const auto start = G(p.cell_start);
+  const uint32_t i0 = blockIdx.x * CELL_SCAN_PER_BLOCK + tid * 4u;
+  uint32_t v[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) v[k] = i0 + k < total ? cnt[i0 + k] : 0u;
+  const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o, 64);
+    if ((int)lane >= o) incl += up;
+  }
+  if (lane == 63u) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t run = G((const uint32_t*)(p.cell_start + PM_CELL_TABLE))[blockIdx.x] + incl - mine;
+  for (uint32_t w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    if (i0 + k < total) {
+      start[i0 + k] = run;
+      cnt[i0 + k] = 0u;
+    }
+    run += v[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void cell_place_kernel(const CarveArgs* __restrict__ pa) {
+  const CarveArgs& p = *pa;
+  const auto st = G((const CarveStatus*)p.status);
+  if (st->state != CARVE_STATE_RUNNING || !st->cell_g) return;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= st->n_eligible) return;
+  const uint32_t c = G((const uint32_t*)p.pos_cell)[i];
+  if (c == 0xFFFFFFFFu) {
+    G(p.cs_of_pos)[i] = 0xFFFFFFFFu;
+    return;
+  }
+  const uint32_t e = G((const uint32_t*)p.cell_start)[c] + G((const uint32_t*)p.pos_rank)[i];
+  G(p.cs_of_pos)[i] = e;
+  G(p.cs_ux)[e] = G((const double*)p.c_ux)[i];
+  G(p.cs_uy)[e] = G((const double*)p.c_uy)[i];
+  G(p.cs_uz)[e] = G((const double*)p.c_uz)[i];
+  G(p.cs_site)[e] = G((const uint32_t*)p.c_site)[i];
 }
 
 __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* __restrict__ pa, uint32_t flags_in,
@@ -3534,11 +3979,21 @@ uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, bool speculative
   hipLaunchKernelGGL(carve_prep_place_kernel, dim3(blocks), dim3(256), 0, s, d_args);
   return speculative ? 3u : 2u;
 }
-void launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t start_ci, hipStream_t s) {
+// n_bound: rows outside any group (an upper bound of the eligible list); index_min: build the spatial index when
+// n_bound reaches it (0 = never; the kernels decide the grid from the real length and may still decline)
+uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound, uint32_t index_min, uint32_t start_ci, hipStream_t s) {
   uint32_t blocks = ((W + 63u) / 64u + PREP_WAVES - 1u) / PREP_WAVES;
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(carve_elig_count_kernel, dim3(blocks), dim3(256), 0, s, d_args);
   hipLaunchKernelGGL(carve_elig_place_kernel, dim3(blocks), dim3(256), 0, s, d_args, start_ci);
+  if (!index_min || n_bound < index_min) return 2u;  // (the status of a fresh carve says cell_g = 0)
+  const uint32_t pb = (n_bound + 255u) / 256u;
+  hipLaunchKernelGGL(cell_count_kernel, dim3(pb), dim3(256), 0, s, d_args);
+  const uint32_t sb = (PM_CELL_TABLE + CELL_SCAN_PER_BLOCK - 1u) / CELL_SCAN_PER_BLOCK;  // (blocks beyond the grid in use return)
+  hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(sb), dim3(256), 0, s, d_args);
+  hipLaunchKernelGGL(cell_scan_apply_kernel, dim3(sb), dim3(256), 0, s, d_args);
+  hipLaunchKernelGGL(cell_place_kernel, dim3(pb), dim3(256), 0, s, d_args);
+  return 6u;
 }
 // group_of for the groups of the last validation launch (the count kernel's first half), e.g. after the carve ended
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s) {

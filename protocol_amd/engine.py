@@ -466,6 +466,26 @@ class Engine:
         L.pm_debug_mem_lists_above.restype = C.c_int32
         check(L.pm_debug_mem_lists_above(self._h, n))
 
+    def debug_carve_counters(self) -> dict:
+        """how the last carve went (pm_internal.h, pm_debug_carve_prof words 32..45): how its validation launches ended,
+        and what the proposer's spatial index did"""
+        L = lib()
+        L.pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
+        L.pm_debug_carve_prof.restype = C.c_int32
+        out = (C.c_ulonglong * 46)()
+        check(L.pm_debug_carve_prof(self._h, out, 46))
+        w = [int(v) for v in out[32:46]]
+        return {"why": w[:8], "batches": w[8], "void_launches": w[9], "pruned_batches": w[10], "prune_fallbacks": w[11],
+                "cell_g": w[12], "n_indexed": w[13]}
+
+    def debug_prune_mode(self, mode: int):
+        """test hook (pm_internal.h): 0 the proposer always sweeps the whole candidate list, 1 it walks the spatial index
+        when that pays (default), 2 whenever the carve has an index, 3 = 2 with every seed through the fallback"""
+        L = lib()
+        L.pm_debug_prune_mode.argtypes = [C.c_void_p, C.c_uint32]
+        L.pm_debug_prune_mode.restype = C.c_int32
+        check(L.pm_debug_prune_mode(self._h, mode))
+
     def lookup(self, worker: int) -> Assignment:
         a = Assignment()
         check(lib().pm_lookup_task_for_worker(self._h, worker, C.byref(a)))
