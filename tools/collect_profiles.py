@@ -25,6 +25,12 @@ def run(cmd, **kw):
     return subprocess.run(cmd, shell=True, **kw)
 
 
+def sane_gpu(py):
+    """a box whose GPU faults on first use (it happens) would hang every rocprofv3 pass below for minutes: check first"""
+    r = subprocess.run(f"timeout 120 {py} -c \"import __graft_entry__ as g; g.smoke()\"", shell=True, cwd=ROOT)
+    return r.returncode == 0
+
+
 def pmc_sum(db, counter):
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
@@ -42,22 +48,25 @@ def main():
     py = sys.executable
     bench = os.path.join(ROOT, "bench.py")
 
+    if not sane_gpu(py):
+        print("GPU sanity check failed: nothing collected")
+        sys.exit(3)
     # 1. kernel trace
     d = os.path.join(out, "trace")
-    run(f"cd /tmp && rocprofv3 --kernel-trace --stats -d {d} -o t -- {py} {bench} --steps 10 --warmup 2 "
+    run(f"cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d {d} -o t -- {py} {bench} --steps 10 --warmup 2 "
         f"--no-cpu-baseline --no-extras > {out}/trace_bench.log 2>&1", env=env)
     db = os.path.join(d, "t_results.db")
     run(f"{py} {ROOT}/tools/rocpd_summary.py {db} {out}/{tag}_kernel_stats.csv")
     run(f"{py} {ROOT}/tools/tick_timeline.py {db} --all > {out}/{tag}_timeline.txt")
     # 1b. the same for BASELINE configs[2] (1M tasks x 100k workers): 4 matches
     d2 = os.path.join(out, "trace_cfg2")
-    run(f"cd /tmp && rocprofv3 --kernel-trace --stats -d {d2} -o t -- {py} {bench} --config 2 --steps 3 --warmup 1 "
+    run(f"cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d {d2} -o t -- {py} {bench} --config 2 --steps 3 --warmup 1 "
         f"--no-cpu-baseline --no-extras > {out}/trace_cfg2_bench.log 2>&1", env=env)
     run(f"{py} {ROOT}/tools/rocpd_summary.py {os.path.join(d2, 't_results.db')} {out}/{tag}_cfg2_kernel_stats.csv")
 
     # 1c. BASELINE configs[4] on one GPU: the cold match + 8 churn ticks (tools/churn_probe.py)
     d3 = os.path.join(out, "trace_churn")
-    run(f"cd /tmp && rocprofv3 --kernel-trace --stats -d {d3} -o t -- {py} {ROOT}/tools/churn_probe.py 8 "
+    run(f"cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d {d3} -o t -- {py} {ROOT}/tools/churn_probe.py 8 "
         f"> {out}/{tag}_churn_ticks.txt 2>&1", env=env)
     run(f"{py} {ROOT}/tools/rocpd_summary.py {os.path.join(d3, 't_results.db')} {out}/{tag}_churn_kernel_stats.csv")
 
@@ -66,7 +75,7 @@ def main():
     sums = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         dd = os.path.join(out, "pmc_" + counter)
-        run(f"cd /tmp && rocprofv3 --pmc {counter} -d {dd} -o p -- {py} {bench} --steps 3 --warmup 1 "
+        run(f"cd /tmp && timeout -k 5 240 rocprofv3 --pmc {counter} -d {dd} -o p -- {py} {bench} --steps 3 --warmup 1 "
             f"--no-cpu-baseline --no-extras > {out}/pmc_{counter}.log 2>&1", env=env)
         try:
             sums[counter] = pmc_sum(os.path.join(dd, "p_results.db"), counter)
@@ -94,7 +103,7 @@ def main():
 
     # 3. the default bench line
     if "--skip-bench" not in sys.argv:
-        r = run(f"{py} {bench}", env=env, capture_output=True, text=True)
+        r = run(f"timeout -k 5 400 {py} {bench}", env=env, capture_output=True, text=True)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         with open(os.path.join(out, f"{tag}_bench.json"), "w") as fh:
             fh.write((line[-1] if line else r.stdout + r.stderr) + "\n")
