@@ -773,6 +773,7 @@ struct FormRun {
   bool use_props = false;
   bool nothing = false;  // no configuration / no worker: nothing to carve
   uint32_t n_bound = 0;  // rows outside any group when the carve starts (>= the eligible list): sizes the prep grids
+  uint32_t n_elig_hint = 0;  // the eligible ones among them, by the host mirror
 };
 
 static int32_t launch_propose_timed(pm_engine* e, const CarveArgs* d_args, uint32_t n_bound, hipStream_t s);
@@ -831,7 +832,8 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r) {
     HIPCHK(hipMemsetAsync(e->d_desc.p, 0, 2 * sizeof(BatchDesc), e->stream));
     // the ordered eligible list, and the spatial index of its positions when there are enough of them to matter
     const uint32_t index_min = !r->a.prune_mode ? 0u : r->a.prune_mode >= 2u ? 1u : PM_CELL_MIN_N;
-    e->tick_carve_launches += launch_carve_elig(e->d_carve_args.p, e->W, r->n_bound, index_min, r->start_ci, e->stream);
+    e->tick_carve_launches += launch_carve_elig(e->d_carve_args.p, e->W, r->n_bound, r->n_elig_hint >= index_min ? index_min : 0u,
+                                                r->start_ci, e->stream);
     if (r->pipelined) {
       // (both streams are idle here: the first call of a carve, or a poll has just drained them)
       hipEvent_t ev = nullptr;
@@ -869,7 +871,16 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
   // per-round preparation kernels are sized by that, not by the table (an incremental tick on a standing swarm
   // prepares lists of a few thousand positions out of a hundred thousand rows)
   r->n_bound = uint32_t(std::count_if(e->h_group_of.begin(), e->h_group_of.end(), [](int32_t g) { return g < 0; }));
-  if (e->h_group_of.size() != e->W) r->n_bound = e->W;
+  // ... and how many of those the kernels will find eligible (mod.rs:492-497), as far as the host mirror knows: only
+  // used to decide whether the spatial index is worth its four launches (a standing swarm's tick: a few thousand)
+  r->n_elig_hint = r->n_bound;
+  if (e->h_group_of.size() == e->W && e->h_flags.size() == e->W) {
+    uint32_t n = 0;
+    for (uint32_t w = 0; w < e->W; ++w)
+      n += (e->h_group_of[w] < 0 && (e->h_flags[w] & PM_W_HEALTHY) && (e->h_flags[w] & PM_W_HAS_P2P)) ? 1u : 0u;
+    r->n_elig_hint = n;
+  }
+  if (e->h_group_of.size() != e->W) r->n_bound = r->n_elig_hint = e->W;
   if (r->n_bound == 0) r->n_bound = 1;
   CarveArgs& a = r->a;
   rc = fill_carve_args(e, &a, CARVE_MODE_FORM, 0);
