@@ -2980,6 +2980,9 @@ __global__ __launch_bounds__(256) void carve_prep_count_kernel(const CarveArgs* 
     if (!p.speculative && blockIdx.x == 0 && tid == 0) p.desc->planned = 0u;
     return;
   }
+#ifdef PM_BATCH_LOG
+  if (blockIdx.x == 0 && tid == 0) p.status->prof[5] = ~0ull;  // (earliest block start of the placement behind this)
+#endif
   uint32_t ci0;
   if (!p.speculative) {  // one batch at a time: the plan is the carve's own state, the same in every block
     ci0 = st->cur_ci;
@@ -3025,6 +3028,10 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   __shared__ uint32_t s_red[PREP_WAVES + 4];
   __shared__ uint32_t s_bits[PREP_WAVES][64];
+#ifdef PM_BATCH_LOG
+  const uint64_t pl_t0 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) atomicMin((unsigned long long*)&p.status->prof[5], (unsigned long long)pl_t0);
+#endif
   const uint32_t n = st->n_eligible, n_words = (n + 63u) >> 6;
   const uint32_t total_available = D->total_available;
   // ---- the next configuration whose loop would be entered (mod.rs:505-519), the same in every block.  (Counts and
@@ -3070,6 +3077,9 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     const uint32_t cnt = (uint32_t)__popcll(bal);
     if (lane == 0) s_red[PREP_WAVES + wave] = cnt;
     __syncthreads();
+#ifdef PM_BATCH_LOG
+    if (tid == 0) atomicAdd((unsigned long long*)&p.status->prof[14], (unsigned long long)(__builtin_amdgcn_s_memtime() - pl_t0));  // loads in
+#endif
     uint32_t off = 0;
 #pragma unroll
     for (uint32_t w = 0; w < PREP_WAVES; ++w) off += s_red[w];
@@ -3102,12 +3112,31 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     }
   }
   // ---- the block that finishes last completes the list and publishes it
-  __threadfence();
+#ifdef PM_BATCH_LOG
+  if (tid == 0) atomicAdd((unsigned long long*)&p.status->prof[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - pl_t0));  // stores issued
+#endif
+  // What the last block reads of the others is the slot loc bitmap, and that is written with device-scope atomics
+  // only: they need no release, just to have been performed before this block's ticket is taken — which a wait for
+  // the wave's outstanding memory operations gives (workgroup-scope fence: s_waitcnt, no cache maintenance).  The
+  // column stores are for the kernels behind this one; the end of the kernel releases them.  (A device-scope fence
+  // here writes the XCD's L2 back once per BLOCK: 25 of the 42 us this kernel took at 100 k positions.)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
+#ifdef PM_BATCH_LOG
+  if (tid == 0) {  // this block, start to ticket: sum, max, count
+    const uint64_t dt = __builtin_amdgcn_s_memtime() - pl_t0;
+    atomicAdd((unsigned long long*)&p.status->prof[8], (unsigned long long)dt);
+    atomicMax((unsigned long long*)&p.status->prof[9], (unsigned long long)dt);
+    atomicAdd((unsigned long long*)&p.status->prof[10], 1ull);
+  }
+#endif
   if (tid == 0) s_red[0] = atomicAdd(&p.prep_counts[PM_MAX_CONFIGS], 1u);
   __syncthreads();
   if (s_red[0] != gridDim.x - 1u) return;
   __threadfence();
+#ifdef PM_BATCH_LOG
+  const uint64_t pl_t1 = __builtin_amdgcn_s_memtime();  // every block is through: the tail begins
+#endif
   if (none) {
     if (tid == 0) {
       p.desc->ci = p.n_avail;
@@ -3154,6 +3183,12 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
     d->valid = 1u;
     if (cell_g) p.status->pruned_batches += 1u;
 #ifdef PM_BATCH_LOG
+    {
+      const uint64_t pl_t2 = __builtin_amdgcn_s_memtime();
+      p.status->prof[11] += pl_t1 - p.status->prof[5];  // first block start -> last block through
+      p.status->prof[12] += pl_t2 - pl_t1;              // the tail
+      p.status->prof[13] += 1ull;
+    }
     const uint32_t k = p.status->blog_n++;
     if (k < 512u) {
       p.status->blog[3u * k] = n_list;
@@ -3246,8 +3281,9 @@ __global__ __launch_bounds__(256) void carve_elig_place_kernel(const CarveArgs* 
     atomicOr(&loc[off >> 6], (unsigned long long)(locm << sh));
     if (sh && (locm >> (64u - sh))) atomicOr(&loc[(off >> 6) + 1u], (unsigned long long)(locm >> (64u - sh)));
   }
-  // ---- the block that finishes last completes the list and publishes it
-  __threadfence();
+  // ---- the block that finishes last completes the list and publishes it (it reads nothing the other blocks wrote
+  // but the ticket: see carve_prep_place_kernel for why this is not a device-scope fence)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (tid == 0) s_red[0] = atomicAdd(&p.prep_counts[PM_MAX_CONFIGS + 1u], 1u);
   __syncthreads();

@@ -40,6 +40,11 @@ walks = int(prof[2])
 if walks:
     print(f"  walks {walks}: mean {prof[0] / walks:.0f} ticks, max {int(prof[1])} ticks, candidates evaluated per walk {prof[3] / walks:.0f}; "
           f"stopped in front of ring (0 = gave up): " + " ".join(f"{k}:{int(prof[16 + k])}" for k in range(16) if prof[16 + k]))
+if prof[13]:
+    nb = int(prof[13])
+    print(f"  placement kernel over {nb} preparations (ticks): first block start -> every block through {prof[11] / nb:.0f}, "
+          f"tail of the last block {prof[12] / nb:.0f}; one block start -> ticket: mean {prof[8] / max(int(prof[10]), 1):.0f}, max {int(prof[9])} "
+          f"(loads in at {prof[14] / max(int(prof[10]), 1):.0f}, stores issued at {prof[15] / max(int(prof[10]), 1):.0f})")
 json.dump({"config": ci, "mode": mode, "carve_ms": sorted(ms), "counters": eng.debug_carve_counters(), "batches": log},
           open(out, "w"))
 print(f"config {ci} mode {mode}: carve {sorted(ms)[1]:.3f} ms, {len(log)} preparations, counters {eng.debug_carve_counters()}")
