@@ -3133,7 +3133,7 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   if (tid == 0) s_red[0] = atomicAdd(&p.prep_counts[PM_MAX_CONFIGS], 1u);
   __syncthreads();
   if (s_red[0] != gridDim.x - 1u) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (see what the other blocks' atomics wrote: invalidate, nothing to write back)
 #ifdef PM_BATCH_LOG
   const uint64_t pl_t1 = __builtin_amdgcn_s_memtime();  // every block is through: the tail begins
 #endif
@@ -3152,8 +3152,7 @@ __global__ __launch_bounds__(256) void carve_prep_place_kernel(const CarveArgs* 
   const auto alive = G(p.bits_scratch);
   for (uint32_t w = tid; w < lw; w += 256u)  // slot alive bitmap: every slot of the fresh list
     alive[w] = (w + 1u < lw || (n_list & 63u) == 0u) ? ~0ull : ((1ull << (n_list & 63u)) - 1ull);
-  __threadfence();
-  __syncthreads();
+  __syncthreads();  // (the scan below reads them back: same workgroup, the barrier's own fence is enough)
   uint32_t prop_k = 0, limit = 0, n_seeds = 0;
   const uint32_t max_s = p.max_size[ci];
   if (props) {
