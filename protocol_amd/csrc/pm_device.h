@@ -158,7 +158,7 @@ struct CarveArgs {
   uint32_t W;
   uint32_t proximity;
   uint32_t debug_uncertain_every;
-  uint32_t rounds_enabled;  // speculative multi-wave validation rounds (carve_variant 0)
+  uint32_t rounds_enabled;  // located steps through the three-wave chain (carve_variant 0 and 4; 2 = wave 0 alone)
   // worker columns
   const uint32_t* wflags;
   const double *lat, *lon, *coslat;

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 //   seed search (bitmap scan) -> Haversine term for every remaining candidate -> top-(max-1)
 //   selection by (key, position) with a wavefront argmin staged through LDS -> commit;
 // almost every step is instead served from the neighbour lists carve_propose_kernel computed on the whole
-// chip (carve_fast_rounds / carve_fast_steps below), which only have to be filtered against the bitmap.
+// chip (carve_chain / carve_fast_steps below), which only have to be filtered against the bitmap.
 //
 // Ordering key.  The reference sorts by d = 6371 * 2 * atan2(sqrt(a), sqrt(1-a)) computed with glibc
 // libm (mod.rs:218-231).  d is a monotone function of a, so the kernel orders by a (f64, polynomial sin: sin_band)
@@ -693,9 +693,8 @@ __global__ __launch_bounds__(256) void newest_kernel(const int64_t* __restrict__
 // kernel's (key, position) order), the selected SET is the reference's.  Otherwise the step is
 // reported as UNCERTAIN and the engine settles exactly that step on the host with glibc.
 
-// (16 waves = 16 seeds per round compiles — the whole kernel then has to fit 128 VGPRs: 103 spilled — and was measured:
-// carve 3.57 ms instead of 2.47 at 100k x 10k, 24.3 instead of 19.2 ms at 1M x 100k; four waves per SIMD share the
-// scalar issue the rounds are bound by)
+// (16 waves compile — the whole kernel then has to fit 128 VGPRs: 103 spilled — and were measured in round 2, with the
+// speculative rounds of that round: carve 3.57 ms instead of 2.47 at 100k x 10k, 24.3 instead of 19.2 ms at 1M x 100k)
 #ifndef CARVE_WAVES
 #define CARVE_WAVES 8
 #endif
@@ -863,7 +862,6 @@ __device__ __forceinline__ void ctx_set_geometry(StepCtx& c) {
 }
 
 enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_AGAIN = 3, FAST_REPROPOSE = 4, FAST_SEQ = 5, FAST_WIDEN = 6 };
-#define LANE_E_MAX 23u  // most row entries a lane of carve_lane_rounds looks at
 
 #ifdef PM_CARVE_PROF_FINE
 #define PROF_COUNT(slot) do { if (lane == 0) G(p.status)->prof[slot] += 1; } while (0)
@@ -889,8 +887,8 @@ __device__ __forceinline__ uint32_t prop_row_of(uint32_t i, uint32_t world, uint
 // only ever REMOVED, the reference's sorted remaining list is the proposal row minus the dead entries,
 // as long as the row still holds enough live entries and the boundary can be certified; otherwise
 // the step is handed to the exact full sweep (FAST_SLOW).  The whole wave looks at one row (lane = entry), so this
-// path sees all 63 entries and re-derives the certificate from the keys; it takes what the lane-per-seed rounds
-// (carve_lane_rounds) hand over — rows that are not certified wholesale, thinned-out rows, wide groups, the last
+// path sees all 63 entries and re-derives the certificate from the keys; it takes what the in-order chain
+// (carve_chain) hands over — rows that are not certified wholesale, thinned-out rows, wide groups, the last
 // partial group of a configuration — and the first-come tail.  At most max_steps steps (FAST_AGAIN when reached).
 template <bool BIG>
 __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref, const uint32_t* l_site,
@@ -2800,7 +2798,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         atomicAdd(&p.status->n_props, 1u);
       }
     }
-    // what the lane-per-seed rounds need to settle a step from the flags alone: is any listed term near the antipode,
+    // what the validator's chain needs to settle a step from the flags alone: is any listed term near the antipode,
     // and from which entry on does the row lie within the certificate band of its LAST entry (a selection that ends
     // in front of that entry has nothing to do with the row's tail) — the validator's own band expression
     uint32_t safe, j_tail = n_k;
@@ -2823,7 +2821,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
                           (tail_ok ? PM_ROW_TAIL_OK : 0u) | (clean ? PM_ROW_CLEAN : 0u) | (tail_clear ? PM_ROW_TAIL_CLEAR : 0u);
     prop_out[(size_t)out_row * PM_PROP_ROW + ((lane + 1u) & 63u)] = lane == 63u ? (uint64_t)meta : mine;
     // ... and the same once more as 32-bit words (flags, slot of entry 0, slot of entry 1, ...): what a lane of
-    // carve_lane_rounds reads — the head of this list, one or two cache lines
+    // the chain's producer reads — 256 coalesced bytes per row
     reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(prop_out + (size_t)out_row * PM_PROP_ROW + PM_PROP_SLOTS)[(lane + 1u) & 63u] =
         lane == 63u ? meta : (uint32_t)(mine & ((1ull << SB) - 1ull));
   }

@@ -120,3 +120,36 @@ def test_small_swarms_many_seeds():
             n, g, c, _ = _carve(sw, mode)
             assert (n, g) == (n_o, g_o), (seed, mode)
             assert c["cell_g"] == 32, c
+
+
+@pytest.mark.parametrize("half", ["north-east", "south-west"])
+def test_edges_of_the_grid(half):
+    """Workers at the poles, on the equator at the axes (unit coordinates of exactly +-1 and 0: the first and the last
+    cell of the grid, and the clamp of cell_coord) and spread over half a globe (no antipodal pairs: those are outside
+    the reference's domain), through the forced walk, the forced fallback and the whole-list sweep, against the oracle."""
+    sw = geo._swarm(seed=77, W=1500)
+    rng = np.random.default_rng(5)
+    W = sw.W
+    sw.has_loc[:] = rng.random(W) < 0.95
+    if half == "north-east":
+        lat = np.round(rng.random(W) * 89.0, 4)
+        lon = np.round(-80.0 + rng.random(W) * 160.0, 4)
+        spots = [(90.0, 0.0), (0.0, 0.0), (0.0, 80.0), (45.0, -80.0)]
+    else:
+        lat = np.round(-rng.random(W) * 89.0, 4)
+        lon = np.round(100.0 + rng.random(W) * 160.0, 4)
+        lon = np.where(lon > 180.0, lon - 360.0, lon)
+        spots = [(-90.0, 0.0), (0.0, 180.0), (0.0, -90.0), (0.0, -180.0)]
+    which = rng.integers(0, 3 * len(spots), W)          # a third of the swarm sits exactly on the spots
+    for k, (la, lo) in enumerate(spots):
+        lat = np.where(which == k, la, lat)
+        lon = np.where(which == k, lo, lon)
+    sw.lat[:] = lat
+    sw.lon[:] = lon
+    st = oracle_state_for(sw, reference_shaped=True)
+    n_o = st.try_form_new_groups()
+    g_o = oracle_groups(st)
+    for mode in (0, 2, 3):
+        n, g, c, _ = _carve(sw, mode)
+        assert (n, g) == (n_o, g_o), mode
+        assert mode == 0 or (c["cell_g"] == 32 and c["pruned_batches"] > 0), c
