@@ -16,6 +16,8 @@ N = 1   BASELINE.json configs[1]: 100k tasks x 10k workers, mixed gpu/mem/storag
           churn      configs[4] on one GPU: 100k workers, per tick +10k tasks (pm_tasks_insert_front), 1 % of the
                      workers leave (pm_on_worker_status) and 1 % brand-new ones join (pm_append_workers)
           per_task   the north_star orientation (pm_match_per_task) timed
+          pools_on_one_gpu  2 / 4 independent configs[1] pools matched concurrently on the one GPU (aggregate rate
+                     and per-match latency): one match is a latency chain on one CU, so pools overlap
           roofline   the dominant kernel sequence (carve) with SURVEY section 8(d)'s algorithmic bytes against HBM —
                      and, because the carve is a dependent chain, `chain`: achieved time per step against a floor
           cpu_baseline  the C oracle (a port of the reference path) on this box's host cores: reference-shaped on
@@ -23,6 +25,9 @@ N = 1   BASELINE.json configs[1]: 100k tasks x 10k workers, mixed gpu/mem/storag
 N > 1   BASELINE.json configs[3]: the SAME 1M x 100k swarm on every rank (strong scaling).  Workers are owned by
         hash(address) % N; the validation chain is replicated, the proposal sweeps and the pair sweep are sharded,
         two kinds of RCCL all-gather per tick (protocol_amd/dist.py).  Every rank ends with identical groups.
+        Beside it: dist.one_gpu_same_workload (the same swarm on one unsharded engine), dist.replicated_ms /
+        sharded_ms / exchange_ms (the Amdahl split), and dist.replicas — N independent pools, one configs[1] swarm per
+        rank, no collective: the weak-scaling counterpart of the N = 1 line.
 """
 from __future__ import annotations
 
@@ -261,6 +266,56 @@ def run_extra_configs2(E, host, seed):
     return out
 
 
+def run_extra_pools(E, host, seed, ks=(2, 4), steps=8):
+    """K independent pools on ONE GPU: K engines (each with its own stream and its own configs[1] swarm), driven from K
+    host threads (the C ABI releases the GIL), each running the N = 1 line's loop.  One match keeps a single workgroup
+    busy most of the time (the validator's chain), so independent pools overlap almost freely: the aggregate rate is
+    what a GPU shared by several orchestrator pools delivers, and the per-match latency is what each of them sees."""
+    import threading
+    from protocol_amd.swarm import baseline_config
+    engines = []
+    for k in range(max(ks)):
+        sw = baseline_config(1, seed=seed + 100 + k)
+        eng = E.Engine(group_id_seed=seed + 100 + k)
+        host.load_swarm(eng, sw)
+        eng.tick()
+        engines.append((eng, sw))
+    out = {"workload": "K x BASELINE configs[1] (one swarm per pool, seeds differ), concurrent cold matches on one GPU",
+           "steps_per_pool": steps, "by_k": {},
+           "note": ("K engines in ONE process, one host thread and one HIP stream each: the runtime multiplexes the streams "
+                    "onto a few hardware queues and serialises launches per device, so this is a lower bound of what K "
+                    "pools in K processes get (two processes sharing the GPU measured 1.87x the one-pool rate: "
+                    "profiles/r03_bench_n2_gloo.json, dist.replicas)")}
+    for K in ks:
+        lat = [[] for _ in range(K)]
+        go = threading.Barrier(K + 1)
+
+        def run(i):
+            eng = engines[i][0]
+            go.wait()
+            for _ in range(steps):
+                eng.reset_groups()
+                t0 = time.perf_counter()
+                eng.tick()
+                lat[i].append(1e3 * (time.perf_counter() - t0))
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+        for t in th:
+            t.start()
+        go.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        pairs = sum(float(engines[i][1].T) * float(engines[i][1].W) for i in range(K)) * steps
+        allm = sorted(x for l in lat for x in l)
+        out["by_k"][str(K)] = {"pair_evals_per_s": pairs / el, "match_ms_p50": allm[len(allm) // 2], "match_ms_max": allm[-1],
+                               "wall_ms": 1e3 * el}
+    for eng, _ in engines:
+        eng.close()
+    return out
+
+
 def run_extra_churn(E, host, seed, ticks=6):
     """BASELINE configs[4] on one GPU (the 8-GPU form is `--gpus 8`): 100k workers; per tick 10k tasks arrive, 1 % of
     the workers die and 1 % brand-new workers join; one incremental match on the standing groups.  The stream is
@@ -477,6 +532,34 @@ def main() -> int:
             out["dist"]["one_gpu_same_workload"] = {"ms_per_step": 1e3 * one, "value": float(T) * float(W) / one,
                                                     "note": "rank 0, unsharded engine, p50 of 3 cold matches"}
             out["dist"]["speedup_vs_one_gpu"] = one / (elapsed / args.steps)
+    if world > 1:
+        # N independent pools: every rank carves its OWN configs[1] swarm (seed + rank) with the loop of the N = 1
+        # line — no data-path collective.  This is how a deployment with several orchestrator pools uses N GPUs, and
+        # the weak-scaling counterpart of the N = 1 line (the sharded tick above is strong scaling of one big pool).
+        sw_r = baseline_config(1, seed=args.seed + rank)
+        eng_r = E.Engine(device=local_rank, group_id_seed=args.seed + rank)
+        host.load_swarm(eng_r, sw_r)
+        k_rep = 10
+        for _ in range(2):
+            eng_r.reset_groups()
+            eng_r.tick()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k_rep):
+            eng_r.reset_groups()
+            eng_r.tick()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_rep = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t_rep, op=dist.ReduceOp.MAX)
+        eng_r.close()
+        el = float(t_rep.item())
+        out["dist"]["replicas"] = {
+            "workload": "one BASELINE configs[1] swarm per rank (seed + rank), independent engines, no collective",
+            "scaling": "weak", "steps": k_rep, "ms_per_step": 1e3 * el / k_rep,
+            "value": world * float(sw_r.T) * float(sw_r.W) * k_rep / el, "unit": "pair-evals/s",
+            "note": "aggregate over the ranks, max-over-ranks time between barriers; compare with the N = 1 line's value"}
     single = rank == 0 and world == 1
     if single and not args.no_extras:
         try:
@@ -522,7 +605,7 @@ def main() -> int:
         out["parity_vs_oracle"] = got == [(gid, c, m) for (_s, gid, c, m, _t) in st.groups()]
     eng.close()
     if single and not args.no_extras:
-        for key, fn in (("configs2", run_extra_configs2), ("churn", run_extra_churn)):
+        for key, fn in (("configs2", run_extra_configs2), ("churn", run_extra_churn), ("pools_on_one_gpu", run_extra_pools)):
             try:
                 out[key] = fn(E, host, args.seed)
             except Exception as ex:
