@@ -50,6 +50,24 @@ static constexpr uint32_t PM_CELL_RMAX = 14;           // rings of cells a seed 
 // part | alive, loc bitmaps | wid | site | key | sel_out | BlockRed + s_n
 static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + size_t(PM_CARVE_SLOTS / 64) * 16 +
                                              size_t(PM_CARVE_SLOTS) * 16 + size_t(PM_CARVE_SEL_CAP) * 4 + 1024;
+// ---- streaming carve (carve_stream_kernel): one launch per try_form_new_groups pass; workgroup 0 validates, the
+// others compute neighbour rows for the seeds a bounded look-ahead in front of the chain
+static constexpr uint32_t PM_STREAM_SQ = 4096;      // seed-ticket ring (8-byte granules): > waves that can hold a claim
+static constexpr uint32_t PM_STREAM_RQ = 1024;      // row ring: rows of tickets t, t + RQ share a slot
+static constexpr uint32_t PM_STREAM_TP = 512;       // tickets whose seed position the validator remembers (LDS)
+static constexpr uint32_t PM_STREAM_LA_MAX = 256;   // look-ahead: tickets issued and not yet handed to the chain
+static constexpr uint32_t PM_STREAM_CTL_WORDS = 64; // control block (u32): see the SC_* indices
+static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 64;
+// control words in global memory (each hot word on its own 64-byte line)
+enum { SC_CLAIM = 0,    // next ticket a proposer wave takes (atomicAdd)
+       SC_QUIT = 16,    // the validator is through: proposers leave
+       SC_CL_LEN = 32,  // length of the candidate list (clist) of the configuration being carved
+       SC_ROWS = 48,    // rows the proposers delivered (statistics)
+       SC_GAVE_UP = 49, // proposer waves that left because nothing was asked of them for too long
+       SC_FINISH = 50   // the carve launch ran (carve_finish_kernel has records to finish)
+};
+// how the rows of a ticket are made (bits 24..25 of the ticket's payload)
+enum { SROW_NONE = 0, SROW_LIST = 1, SROW_WALK = 2, SROW_SWEEP = 3 };
 
 struct CompatArgs {
   uint32_t W, n_cfgs, model_words;
@@ -87,7 +105,8 @@ struct RowUpdateArgs {
 };
 
 enum { CARVE_MODE_FORM = 0, CARVE_MODE_MERGE = 1 };
-enum { CARVE_STATE_RUNNING = 0, CARVE_STATE_DONE = 1, CARVE_STATE_UNCERTAIN = 2, CARVE_STATE_OVERFLOW = 3 };
+enum { CARVE_STATE_RUNNING = 0, CARVE_STATE_DONE = 1, CARVE_STATE_UNCERTAIN = 2, CARVE_STATE_OVERFLOW = 3,
+       CARVE_STATE_ABORTED = 4 };  // ABORTED: a bounded wait inside the launch gave up (what was committed stands)
 // launch flags of carve_kernel
 enum {
   CARVE_F_INIT = 1u << 0,   // build the eligible list + position columns (first launch of a carve)
@@ -125,6 +144,10 @@ struct CarveStatus {
   // how validation launches ended: 0 chain: list thinned out, 1 seeds of the batch used up, 2 exact step: thinned out,
   // 3 configuration exhausted, 4 batch prepared for another configuration, 5 batch too stale, 6 configuration not entered
   uint32_t why[8];
+  uint32_t stream_timeouts; // streaming carve: rows the validator stopped waiting for (the step took the exact sweep)
+  uint32_t stream_tickets;  // streaming carve: seeds handed to the proposers
+  uint32_t stream_switches; // streaming carve: configurations that went from walking the index to the candidate list
+  uint32_t stream_listed;   // streaming carve: configurations entered with a candidate list
   uint32_t cell_g;          // grid size of the spatial index built for this carve's positions (0 = none)
   uint32_t n_indexed;       // located positions in the index
   uint32_t pruned_batches;  // batches whose proposals walked the index instead of the whole list
@@ -218,6 +241,17 @@ struct CarveArgs {
                                  // 3 = 2 with every seed forced through the whole-list fallback (test hooks)
   uint32_t prune_factor;         // mode 1: walk when n_list^2 >= prune_factor x (indexed positions)
   uint32_t walk_cap_div, _pad_w; // seeds of a batch that walks the index: n_list / walk_cap_div
+  // ---- streaming carve (carve_stream_kernel).  Slot == position: cc_* alias c_*, slot_wid aliases order,
+  // bits_scratch = {candidate bitmap of the configuration being carved (the proposers' view), loc_g}, alive_g = the
+  // validator's master bitmap of what no group holds yet.
+  uint32_t stream, stream_tag0;  // stream: 1 = this argument block drives carve_stream_kernel; tag0: first ticket tag
+  uint64_t* cfgbits;             // [n_avail][bits_stride] per configuration (carve order): compatible positions
+  unsigned long long* stream_sq;      // [PM_STREAM_SQ] seed tickets: {tag, position | ci << 18 | mode << 24 | epoch << 26}
+  unsigned long long* stream_row_lo;  // [PM_STREAM_RQ][64] rows: {tag, flags word | low half of the packed key of entry g - 1}
+  unsigned long long* stream_row_hi;  // [PM_STREAM_RQ][64]       {tag, high half}
+  uint32_t* stream_ctl;               // [PM_STREAM_CTL_WORDS] SC_*
+  uint32_t* clist;                    // [W] candidate positions of the configuration being carved (SROW_LIST)
+  uint32_t stream_la, stream_row_spins;  // look-ahead cap (0 = default); polls before the validator gives a row up
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];
@@ -278,6 +312,7 @@ uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound
                            hipStream_t s);  // eligible list [+ spatial index]; returns the launches
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
+hipError_t launch_carve_stream(const CarveArgs* d_args, uint32_t start_ci, uint32_t n_prop_wgs, uint32_t* ctl, hipStream_t s);
 
 }  // namespace pm
 #endif

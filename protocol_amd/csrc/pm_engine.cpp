@@ -131,7 +131,8 @@ struct pm_engine {
   bool k_sweep_recorded = false, k_compat_recorded = false;
   uint64_t tick_cand_sum = 0;
   unsigned long long carve_prof[32]{};
-  unsigned long long carve_why[14]{};  // CarveStatus::why of the last carve, its batches and void launches, the spatial index
+  unsigned long long carve_why[22]{};  // CarveStatus::why of the last carve, its batches and void launches, the spatial
+                                       // index, the streaming carve's counters
   uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above
   uint32_t prune_mode = 1;       // pm_debug_prune_mode / PM_PRUNE_MODE: CarveArgs::prune_mode
   uint32_t prune_factor = 512;   // PM_PRUNE_FACTOR: CarveArgs::prune_factor (measured crossover)
@@ -237,6 +238,14 @@ struct pm_engine {
   // spatial index of a carve's located positions (cell_*_kernel)
   DevBuf<uint32_t> d_cell_cnt, d_cell_start, d_pos_cell, d_pos_rank, d_cs_of_pos, d_cs_slot, d_cs_site;
   DevBuf<double> d_cs_u[3];
+  // streaming carve (carve_stream_kernel): per-configuration bitmaps, ticket and row rings, control block, candidate list
+  DevBuf<uint64_t> d_cfgbits, d_stream_sq, d_stream_row_lo, d_stream_row_hi;
+  DevBuf<uint32_t> d_stream_ctl, d_clist;
+  uint32_t stream_seq = 0;       // launches so far: the tags of a launch's tickets start at stream_seq << 25
+  uint32_t stream_wgs_env = 0;   // PM_STREAM_WGS: proposer workgroups (0 = by the size of the eligible list)
+  uint32_t stream_la_env = 0;    // PM_STREAM_LA: look-ahead cap (0 = the kernel's default)
+  uint32_t n_cus = 256;
+  uint32_t tick_stream_timeouts = 0, tick_stream_tickets = 0, tick_stream_aborts = 0;
   DevBuf<uint64_t> d_ikeys, d_umask;  // per-task orientation: table of the distinct topology masks, the masks densely
   DevBuf<uint32_t> d_ivals;
   // per-batch scratch of the SECOND argument block (the first uses the d_cc_* / d_slot_* / d_prop ... members):
@@ -487,7 +496,7 @@ static size_t carve_lds_bytes(uint32_t /*stride_words*/, bool* in_lds) {
   return PM_CARVE_LDS_BYTES;
 }
 
-static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32_t n_order) {
+static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32_t n_order, bool stream = false) {
   const size_t cap = std::max<size_t>(e->W, 1);
   HIPCHK(e->d_order.ensure(cap));
   HIPCHK(e->d_c_lat.ensure(cap));
@@ -523,6 +532,17 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   const uint32_t stride = uint32_t((cap + 63) / 64);
   HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
   HIPCHK(e->d_snap.ensure(size_t(stride) * 2));
+  if (stream) {
+    HIPCHK(e->d_cfgbits.ensure(size_t(stride) * PM_MAX_CONFIGS));
+    HIPCHK(e->d_clist.ensure(cap));
+    HIPCHK(e->d_stream_ctl.ensure(PM_STREAM_CTL_WORDS));
+    if (!e->d_stream_sq.p) {  // (tags never repeat within 127 launches; the rings are cleared when the counter wraps)
+      HIPCHK(e->d_stream_sq.ensure(PM_STREAM_SQ));
+      HIPCHK(e->d_stream_row_lo.ensure(size_t(PM_STREAM_RQ) * 64));
+      HIPCHK(e->d_stream_row_hi.ensure(size_t(PM_STREAM_RQ) * 64));
+      e->stream_seq = 0;
+    }
+  }
   if (mode == CARVE_MODE_FORM && e->prune_mode && e->cfg.proximity_enabled) {
     if (!e->d_cell_cnt.p) {  // (the scan leaves the counts zero behind it: cleared once)
       HIPCHK(e->d_cell_cnt.ensure(PM_CELL_TABLE));
@@ -544,7 +564,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->W = e->W;
   a->proximity = e->cfg.proximity_enabled;
   a->debug_uncertain_every = e->cfg.debug_uncertain_every;
-  a->rounds_enabled = (e->cfg.carve_variant == 0 || e->cfg.carve_variant == 4) ? 1u : 0u;
+  a->rounds_enabled = (e->cfg.carve_variant == 0 || e->cfg.carve_variant == 3 || e->cfg.carve_variant == 4) ? 1u : 0u;
   a->wflags = e->d_flags.p;
   a->lat = e->d_lat.p;
   a->lon = e->d_lon.p;
@@ -609,6 +629,30 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     a->cs_ux = e->d_cs_u[0].p;
     a->cs_uy = e->d_cs_u[1].p;
     a->cs_uz = e->d_cs_u[2].p;
+  }
+  if (stream) {
+    // slot == position: the per-slot columns ARE the per-position columns, a slot's worker is the eligible list's
+    // entry; d_bits = {published candidate bitmap, loc bitmap, the validator's master bitmap}
+    a->stream = 1;
+    a->cc_lat = a->c_lat;
+    a->cc_lon = a->c_lon;
+    a->cc_cos = a->c_cos;
+    a->cc_ux = a->c_ux;
+    a->cc_uy = a->c_uy;
+    a->cc_uz = a->c_uz;
+    a->cc_site = a->c_site;
+    a->slot_wid = a->order;
+    a->bits_scratch = e->d_bits.p;
+    a->loc_g = e->d_bits.p + stride;
+    a->alive_g = e->d_bits.p + size_t(stride) * 2;
+    a->cfgbits = e->d_cfgbits.p;
+    a->stream_sq = (unsigned long long*)e->d_stream_sq.p;
+    a->stream_row_lo = (unsigned long long*)e->d_stream_row_lo.p;
+    a->stream_row_hi = (unsigned long long*)e->d_stream_row_hi.p;
+    a->stream_ctl = e->d_stream_ctl.p;
+    a->clist = e->d_clist.p;
+    a->stream_la = e->stream_la_env;
+    a->stream_row_spins = 0;
   }
   return PM_OK;
 }
@@ -774,6 +818,9 @@ struct FormRun {
   bool nothing = false;  // no configuration / no worker: nothing to carve
   uint32_t n_bound = 0;  // rows outside any group when the carve starts (>= the eligible list): sizes the prep grids
   uint32_t n_elig_hint = 0;  // the eligible ones among them, by the host mirror
+  bool stream = false;       // one streaming launch (carve_stream_kernel) instead of the batch pipeline
+  bool single_call = true;   // run_form drives the whole carve (the stepwise multi-GPU tick exchanges rows per batch)
+  uint32_t stream_wgs = 0;   // proposer workgroups of the streaming launch
 };
 
 static int32_t launch_propose_timed(pm_engine* e, const CarveArgs* d_args, uint32_t n_bound, hipStream_t s);
@@ -826,6 +873,8 @@ static int32_t pipe_queue_validate(pm_engine* e, FormRun* r) {
   return PM_OK;
 }
 
+static int32_t form_setup_args(pm_engine* e, FormRun* r);
+
 static int32_t form_queue_init(pm_engine* e, FormRun* r) {
   HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
   if (r->use_props) {
@@ -834,6 +883,22 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r) {
     const uint32_t index_min = !r->a.prune_mode ? 0u : r->a.prune_mode >= 2u ? 1u : PM_CELL_MIN_N;
     e->tick_carve_launches += launch_carve_elig(e->d_carve_args.p, e->W, r->n_bound, r->n_elig_hint >= index_min ? index_min : 0u,
                                                 r->start_ci, e->stream);
+    if (r->stream) {  // everything else in one launch (+ the pass that turns positions into worker ids)
+      // every launch tags its tickets and rows from a range of its own (a launch re-armed behind a host-resolved step
+      // must not take the rows of the one before it for its own); the rings are cleared when the counter wraps
+      if (e->stream_seq == 0 || e->stream_seq >= 127) {
+        HIPCHK(hipMemsetAsync(e->d_stream_sq.p, 0, size_t(PM_STREAM_SQ) * 8, e->stream));
+        HIPCHK(hipMemsetAsync(e->d_stream_row_lo.p, 0, size_t(PM_STREAM_RQ) * 64 * 8, e->stream));
+        HIPCHK(hipMemsetAsync(e->d_stream_row_hi.p, 0, size_t(PM_STREAM_RQ) * 64 * 8, e->stream));
+        e->stream_seq = 0;
+      }
+      e->stream_seq += 1;
+      r->a.stream_tag0 = e->stream_seq << 25;
+      HIPCHK(hipMemcpyAsync(&e->d_carve_args.p->stream_tag0, &r->a.stream_tag0, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(launch_carve_stream(e->d_carve_args.p, r->start_ci, r->stream_wgs, e->d_stream_ctl.p, e->stream));
+      e->tick_carve_launches += 2;
+      return PM_OK;
+    }
     if (r->pipelined) {
       // (both streams are idle here: the first call of a carve, or a poll has just drained them)
       hipEvent_t ev = nullptr;
@@ -882,9 +947,34 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
   }
   if (e->h_group_of.size() != e->W) r->n_bound = r->n_elig_hint = e->W;
   if (r->n_bound == 0) r->n_bound = 1;
-  CarveArgs& a = r->a;
-  rc = fill_carve_args(e, &a, CARVE_MODE_FORM, 0);
+  r->st = CarveStatus{};
+  r->st.state = CARVE_STATE_RUNNING;
+  r->st.n_groups = r->g0;
+  r->st.n_members = r->m0;
+  r->single_call = allow_pipeline;
+  r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
+  // The streaming carve: one engine, one call, positions that fit the validator's LDS bitmaps.  Everything else (the
+  // stepwise multi-GPU tick, swarms beyond 262,144 unassigned rows) goes through the batch pipeline.
+  r->stream = r->single_call && r->use_props && e->cfg.carve_variant == 0 && e->dist_world == 1 && r->n_bound <= PM_CARVE_BIG_SLOTS;
+  rc = form_setup_args(e, r);
   if (rc) return rc;
+  HIPCHK(hipEventRecord(e->kev[2], e->stream));
+  return form_queue_init(e, r);  // prepares the first candidate list (all of it when there are no proposals)
+}
+
+// The argument block(s) of a carve, filled and uploaded (again, when a streaming launch gave up and the batch
+// pipeline takes over).
+static int32_t form_setup_args(pm_engine* e, FormRun* r) {
+  const bool allow_pipeline = r->single_call;
+  CarveArgs& a = r->a;
+  int32_t rc = fill_carve_args(e, &a, CARVE_MODE_FORM, 0, r->stream);
+  if (rc) return rc;
+  if (r->stream) {
+    // proposer workgroups: enough waves to cover a row's latency at the chain's pace, by the size of the list
+    uint32_t wgs = e->stream_wgs_env ? e->stream_wgs_env : r->n_elig_hint / 512u + 16u;
+    const uint32_t max_wgs = e->n_cus > 8u ? e->n_cus - 4u : 4u;
+    r->stream_wgs = std::max(1u, std::min(wgs, max_wgs));
+  }
   a.n_avail = uint32_t(r->avail.size());
   for (size_t i = 0; i < r->avail.size(); ++i) {
     a.avail_cfg[i] = r->avail[i];
@@ -899,11 +989,6 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
   a.cap_members = uint32_t(std::min<size_t>(e->d_members.cap, 0xFFFFFFFFu));
   bool in_lds;
   r->lds = carve_lds_bytes(a.bits_stride, &in_lds);
-  r->st = CarveStatus{};
-  r->st.state = CARVE_STATE_RUNNING;
-  r->st.n_groups = r->g0;
-  r->st.n_members = r->m0;
-  r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
   // Two batches in flight on one GPU (the stepwise multi-GPU tick exchanges the rows of every batch through its
   // caller, one batch at a time)
   r->pipelined = allow_pipeline && r->use_props && e->dist_world == 1 && e->stream_p != nullptr && e->cfg.carve_variant == 4;
@@ -915,8 +1000,7 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
     HIPCHK(hipMemcpyAsync(e->d_carve_args.p + 1, &r->b, sizeof(r->b), hipMemcpyHostToDevice, e->stream));
   }
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipEventRecord(e->kev[2], e->stream));
-  return form_queue_init(e, r);  // prepares the first candidate list (all of it when there are no proposals)
+  return PM_OK;
 }
 
 // the proposer launch, bracketed by its own hipEvents when pm_engine_config.time_proposer asks for the split
@@ -979,6 +1063,21 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
       e->prop_ev_used = 0;
     }
     if (r->st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "carve: group arrays overflow");
+    if (r->st.state == CARVE_STATE_ABORTED) {
+      // A bounded wait inside a launch gave up (a GPU shared with other work can keep the proposers of a streaming
+      // launch from running beside its validator).  What was committed stands — every commit is exact — and the carve
+      // continues from there on the batch pipeline, whose launches depend on nothing running beside them.
+      if (!r->stream) return set_error(PM_ENODEV, "carve: a hand-shake inside the validator timed out");
+      e->tick_stream_aborts++;
+      r->stream = false;
+      int32_t rca = form_setup_args(e, r);
+      if (rca) return rca;
+      r->start_ci = r->st.stop_ci;
+      r->st.state = CARVE_STATE_RUNNING;
+      rca = form_queue_init(e, r);
+      if (rca) return rca;
+      return PM_OK;  // (RUNNING: the caller queues propose / validate rounds)
+    }
     if (r->st.state != CARVE_STATE_UNCERTAIN) return PM_OK;
     int32_t rc = host_resolve_form_step(e, r->avail[r->st.stop_ci], &r->st);
     if (rc) return rc;
@@ -999,8 +1098,10 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   e->tick_fast_steps += st.fast_steps;
   e->tick_carve_steps += st.steps_total;
   e->tick_cand_sum += st.cand_sum;
-  e->tick_props += st.n_props;
+  e->tick_props += r->stream && !st.n_props ? st.stream_tickets : st.n_props;
   e->tick_prop_keys += st.prop_keys;
+  e->tick_stream_timeouts += st.stream_timeouts;
+  e->tick_stream_tickets += st.stream_tickets;
   std::memcpy(e->carve_prof, st.prof, sizeof(st.prof));
   for (int k = 0; k < 8; ++k) e->carve_why[k] = st.why[k];
   e->carve_why[8] = st.n_batches;
@@ -1009,6 +1110,14 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   e->carve_why[11] = st.prune_fallbacks;
   e->carve_why[12] = st.cell_g;
   e->carve_why[13] = st.n_indexed;
+  e->carve_why[14] = r->stream ? 1u : 0u;
+  e->carve_why[15] = st.stream_tickets;
+  e->carve_why[16] = st.stream_timeouts;
+  e->carve_why[17] = st.stream_switches;
+  e->carve_why[18] = st.stream_listed;
+  e->carve_why[19] = r->stream_wgs;
+  e->carve_why[20] = e->tick_stream_aborts;
+  e->carve_why[21] = st.slow_steps;
 #ifdef PM_BATCH_LOG
   e->blog.assign(st.blog, st.blog + 3 * std::min<uint32_t>(st.blog_n, 512u));
 #endif
@@ -1066,7 +1175,7 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
       // every poll either ends the carve or follows launches that formed at least one group or moved on to the
       // next configuration: far fewer rounds than this, or the device side is stuck — fail instead of hanging
       if (spins > 4096u + e->W / 8u) return set_error(PM_ENODEV, "carve made no progress");
-      if (r.use_props) {
+      if (r.use_props && !r.stream) {
         rc = form_queue_pairs(e, &r, batch);
         if (rc) return rc;
       }
@@ -1076,10 +1185,11 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
       host_mark("form: status back");
       if (r.st.state == CARVE_STATE_DONE) break;
       if (r.st.state != CARVE_STATE_RUNNING || !r.use_props) return set_error(PM_ENODEV, "carve kernel did not complete");
+      if (r.stream) return set_error(PM_ENODEV, "streaming carve did not complete");  // (it ends DONE, or re-armed above)
       batch = 8u;  // more re-proposal rounds than were queued, or re-armed after a host-resolved step
     }
   }
-  if (!r.nothing && r.use_props) e->form_rounds_hint = r.st.n_batches + r.st.n_void;
+  if (!r.nothing && r.use_props && !r.stream) e->form_rounds_hint = r.st.n_batches + r.st.n_void;
   return form_finish(e, &r, n_formed, defer_absorb);
 }
 
@@ -1626,6 +1736,19 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
     const long f = atol(v);
     if (f > 0 && f < (1l << 30)) e->prune_factor = uint32_t(f);
   }
+  if (const char* v = getenv("PM_STREAM_WGS")) {
+    const long f = atol(v);
+    if (f > 0 && f < 4096) e->stream_wgs_env = uint32_t(f);
+  }
+  if (const char* v = getenv("PM_STREAM_LA")) {
+    const long f = atol(v);
+    if (f > 0 && f <= long(PM_STREAM_LA_MAX)) e->stream_la_env = uint32_t(f);
+  }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
+      e->n_cus = uint32_t(cus);
+  }
   (void)hipStreamCreateWithFlags(&e->stream_p, hipStreamNonBlocking);  // (without it the carve is not pipelined)
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     delete e;
@@ -1670,6 +1793,8 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_site.release(); e->d_c_site.release(); e->d_cc_site.release(); e->d_prop.release(); e->d_prop_send.release(); e->d_seed_map.release(); e->d_seed_prefix.release(); e->d_seed_slots.release(); e->d_prep_block_counts.release(); e->d_prep_counts.release();
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
+  e->d_cfgbits.release(); e->d_stream_sq.release(); e->d_stream_row_lo.release(); e->d_stream_row_hi.release();
+  e->d_stream_ctl.release(); e->d_clist.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
   e->d_table.release(); e->d_task_col.release(); e->d_shard.release(); e->d_own_rows.release(); e->d_xrow.release();
@@ -2681,6 +2806,7 @@ static void tick_reset(pm_engine* e) {
   e->tick_cand_sum = 0;
   e->tick_props = 0;
   e->tick_prop_keys = 0;
+  e->tick_stream_timeouts = e->tick_stream_tickets = e->tick_stream_aborts = 0;
   e->k_ms_propose = 0;
   e->prop_ev_used = 0;
   e->k_ms_compat = e->k_ms_carve = e->k_ms_sweep = 0;
@@ -2982,7 +3108,7 @@ int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap)
   std::lock_guard<std::mutex> lk(e->mu);
   const uint32_t n = std::min<uint32_t>(cap, uint32_t(sizeof(e->carve_prof) / sizeof(e->carve_prof[0])));
   std::memcpy(out, e->carve_prof, size_t(n) * sizeof(unsigned long long));
-  for (uint32_t k = 32; k < cap && k < 46; ++k) out[k] = e->carve_why[k - 32];  // (how the validation launches ended; the index)
+  for (uint32_t k = 32; k < cap && k < 54; ++k) out[k] = e->carve_why[k - 32];  // (how the validation launches ended; the index)
   return PM_OK;
 }
 

@@ -820,7 +820,7 @@ __device__ __forceinline__ uint64_t pack_key(uint64_t key_bits, uint32_t slot, u
   return ((key_bits >> slot_bits) << slot_bits) | slot;
 }
 
-enum { STEP_CONTINUE = 0, STEP_BREAK = 1, STEP_UNCERTAIN = 2, STEP_OVERFLOW = 3 };
+enum { STEP_CONTINUE = 0, STEP_BREAK = 1, STEP_UNCERTAIN = 2, STEP_OVERFLOW = 3, STEP_ABORT = 4 };
 
 #ifdef PM_CARVE_PROF
 #define PROF_DECL uint64_t prof_t0 = __builtin_amdgcn_s_memtime()
@@ -861,7 +861,8 @@ __device__ __forceinline__ void ctx_set_geometry(StepCtx& c) {
   c.band = c.big ? PM_TIE_BAND_BIG : PM_TIE_BAND;
 }
 
-enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_AGAIN = 3, FAST_REPROPOSE = 4, FAST_SEQ = 5, FAST_WIDEN = 6 };
+enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_AGAIN = 3, FAST_REPROPOSE = 4, FAST_SEQ = 5, FAST_WIDEN = 6,
+       FAST_ABORT = 7 };
 
 #ifdef PM_CARVE_PROF_FINE
 #define PROF_COUNT(slot) do { if (lane == 0) G(p.status)->prof[slot] += 1; } while (0)
@@ -890,10 +891,13 @@ __device__ __forceinline__ uint32_t prop_row_of(uint32_t i, uint32_t world, uint
 // path sees all 63 entries and re-derives the certificate from the keys; it takes what the in-order chain
 // (carve_chain) hands over — rows that are not certified wholesale, thinned-out rows, wide groups, the last
 // partial group of a configuration — and the first-come tail.  At most max_steps steps (FAST_AGAIN when reached).
-template <bool BIG>
+// STREAM (carve_stream_kernel): the rows arrive per TICKET — seed_cur is the ticket the chain stopped at (PM_NONE =
+// none), sl_words the validator's ticket table in LDS (StreamLds), a row lives in the granule rings stream_row_lo / _hi
+// under the ticket's tag.
+template <bool BIG, bool STREAM = false>
 __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref, const uint32_t* l_site,
                                              uint64_t* l_alive, const uint64_t* l_loc, uint32_t steps_before,
-                                             uint32_t& seed_cur, uint32_t max_steps) {
+                                             uint32_t& seed_cur, uint32_t max_steps, uint32_t* sl_words = nullptr) {
   StepCtx c = c_ref;  // registers for the whole run (the reference lives in the caller's scratch frame)
   const uint32_t lane = threadIdx.x & 63u;
   // argument-block fields used per step, loaded once: the stores below go through flat pointers the compiler
@@ -920,6 +924,11 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
   auto kill = [A](uint32_t i) {
     __hip_atomic_fetch_and(&A[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
+  // (streaming carve: the proposers' copy of the candidate bitmap follows every removal)
+  const auto candg = G((unsigned long long*)p.bits_scratch);
+  auto mirror = [candg](uint32_t i) {
+    if (STREAM) __hip_atomic_fetch_and(&candg[i >> 6], ~(1ull << (i & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   // (members are recorded as SLOTS and translated to worker ids by one parallel pass after the run)
   auto site_of = [SITE3, l_site](uint32_t sl) -> uint32_t { return BIG ? l_site[sl] : SITE3[sl]; };
   const uint32_t lw = (c.n_list + 63u) >> 6;
@@ -933,7 +942,37 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
     // ---- seed (mod.rs:526-530): the first live located slot = the first live entry of the batch's seed list
     uint32_t f_loc = PM_NONE;
     if (c.proximity) {
-      if (c.prop_k) {
+      if (STREAM) {
+        // Tickets are issued in ascending position order to the located candidates alive at that moment, and
+        // consumed in order: the first ticket from `cur` on whose seed is still alive names the first live located
+        // candidate.  Behind the last ticket issued, the bitmaps say.
+        typedef __attribute__((address_space(3))) uint32_t sl_u32;
+        const sl_u32* const TP = (const sl_u32*)sl_words;
+        const uint32_t t_req = UNI(TP[PM_STREAM_TP]);  // (StreamLds::t_req)
+        while (cur != PM_NONE && cur < t_req) {
+          const uint32_t pos = UNI(TP[cur & (PM_STREAM_TP - 1u)]);
+          if (alive_at(pos)) {
+            f_loc = pos;
+            break;
+          }
+          ++cur;
+        }
+        if (f_loc == PM_NONE) {
+          cur = PM_NONE;
+          for (uint32_t j0 = 0; j0 < lw; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            const uint64_t ll = j < lw ? (A[j] & LOC[j]) : 0ull;
+            const uint64_t nz = __ballot(ll != 0ull);
+            if (nz) {
+              const int src = __builtin_ctzll(nz);
+              const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ll >> 32), src) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ll, src);
+              f_loc = (j0 + src) * 64u + __builtin_ctzll(w);
+              break;
+            }
+          }
+        }
+      } else if (c.prop_k) {
         while (cur < n_seeds) {
           const uint32_t i = cur + lane;
           const uint32_t sl = seed_slots[i < n_seeds ? i : n_seeds - 1u];
@@ -1009,7 +1048,10 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
           const bool mine = ((w >> lane) & 1ull) && rk < need - cnt;
           const uint64_t take = __ballot(mine);
           if (mine) members[mem_off + cnt + rk] = j * 64u + lane;
-          if (lane == 0) A[j] = w & ~take;
+          if (lane == 0) {
+            A[j] = w & ~take;
+            if (STREAM && take) __hip_atomic_fetch_and(&candg[j], ~take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           cnt += __popcll(take);
         }
         if (lane == 0) {
@@ -1037,21 +1079,39 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
 
     PROF_COUNT(22);  // located sequential steps (attempts)
     const uint32_t seed = f_loc;
-    if (c.prop_k == 0 || seed >= c.prop_limit) {  SLOW_RETURN(20); }
+    if (c.prop_k == 0 || seed >= c.prop_limit || (STREAM && cur == PM_NONE)) {  SLOW_RETURN(20); }
     if (dbg_every && ((steps_before + c.steps + 1u) % dbg_every) == 0u) SLOW_RETURN(21);
 
     // ---- the seed's neighbour row: one packed key per lane, ascending.  Candidates with the seed's exact
     // coordinates are at distance 0 and head the row in slot order (only those behind the seed are listed: a live one
     // in front of it would have been the seed).
-    const size_t rbase = (size_t)prop_row_of(cur, world, rows_pr) * PM_PROP_ROW;
-    const uint32_t nk_word = UNI((uint32_t)prop[rbase]);  // the row's flags word
+    const size_t rbase = STREAM ? (size_t)(cur & (PM_STREAM_RQ - 1u)) * 64u : (size_t)prop_row_of(cur, world, rows_pr) * PM_PROP_ROW;
+    uint32_t nk_word;
+    if (STREAM) {  // (granule 0: the flags word under the ticket's tag — a row that never arrived does not carry it)
+      const unsigned long long g0 = __hip_atomic_load(&G(p.stream_row_lo)[rbase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (UNI((uint32_t)(g0 >> 32)) != UNI(p.stream_tag0) + cur) SLOW_RETURN(20);
+      nk_word = UNI((uint32_t)g0);
+    } else {
+      nk_word = UNI((uint32_t)prop[rbase]);  // the row's flags word
+    }
     const uint32_t n_k = nk_word & 0xFFu;
     const bool complete = (nk_word & PM_ROW_COMPLETE) != 0u;
     const bool tail_ok = (nk_word & PM_ROW_TAIL_OK) != 0u;
     const bool row_clean = (nk_word & PM_ROW_CLEAN) != 0u;
     const bool tail_clear = (nk_word & PM_ROW_TAIL_CLEAR) != 0u;
     const bool row_safe = (nk_word & PM_ROW_SAFE) != 0u;
-    const uint64_t e = lane < n_k ? prop[rbase + 1u + lane] : ~0ull;
+    uint64_t e;
+    if (STREAM) {  // entry `lane` = granules lane + 1 of the two rings (low and high half of the packed key)
+      const uint32_t gi = (lane + 1u) & 63u;
+      const unsigned long long lo = __hip_atomic_load(&G(p.stream_row_lo)[rbase + gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long hi = __hip_atomic_load(&G(p.stream_row_hi)[rbase + gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t tag = UNI(p.stream_tag0) + cur;
+      const bool ok = lane >= n_k || ((uint32_t)(lo >> 32) == tag && (uint32_t)(hi >> 32) == tag);
+      if (__ballot(!ok)) SLOW_RETURN(20);
+      e = lane < n_k ? ((hi << 32) | (lo & 0xFFFFFFFFull)) : ~0ull;
+    } else {
+      e = lane < n_k ? prop[rbase + 1u + lane] : ~0ull;
+    }
     const uint32_t slot = (uint32_t)(e & SLOT_MASK);
     const bool alive = lane < n_k && alive_at(slot);
     const uint64_t am = __ballot(alive);
@@ -1095,10 +1155,12 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
     // first `want` live entries in key order
     if (sel) {
       kill(slot);
+      mirror(slot);
       members[c.mem_off + 1u + rank] = slot;
     }
     if (lane == 0) {
       kill(seed);
+      mirror(seed);
       members[c.mem_off] = seed;
       g_cfg[c.n_groups] = c.cfg;
       g_n[c.n_groups] = want + 1u;
@@ -1328,7 +1390,7 @@ __device__ __noinline__ void carve_chain_produce(const CarveArgs& p, const StepC
 }
 
 // ---- collector (wave 2): serves RUN commands until QUIT
-template <bool BIG>
+template <bool BIG, bool STREAM = false>
 __device__ __noinline__ void carve_chain_collect(const CarveArgs& p, const StepCtx& c, uint32_t* l_buf) {
   constexpr uint32_t R = CHAIN_RING;
   const uint32_t lane = threadIdx.x & 63u;
@@ -1377,8 +1439,14 @@ __device__ __noinline__ void carve_chain_collect(const CarveArgs& p, const StepC
           const uint64_t a = ((uint64_t)UNI((uint32_t)(av >> 32)) << 32) | UNI((uint32_t)av);
           if (a) {  // a committed step: the seed and its `want` nearest live neighbours, in key order
             const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a, 0u));
-            if (((a >> lane) & 1ull) && rk <= want)
-              L.STAGE[staged * group_n + rk] = L.RE[r * 64u + lane];  // slots (translated to worker ids after the run)
+            if (((a >> lane) & 1ull) && rk <= want) {
+              const uint32_t sl = L.RE[r * 64u + lane];
+              L.STAGE[staged * group_n + rk] = sl;  // slots (translated to worker ids after the run)
+              // (streaming carve: the proposers' copy of the candidate bitmap follows the chain, a few steps behind)
+              if (STREAM)
+                __hip_atomic_fetch_and(&G((uint32_t*)p.bits_scratch)[sl >> 5], ~(1u << (sl & 31u)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
             staged += 1u;
             if ((staged + 1u) * group_n > CHAIN_STAGE_WORDS) write_out();
           }
@@ -1625,7 +1693,7 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
   CH_MARK(ct_stop);
   if (aborted) {
     if (lane == 0u) cc_st(&L.CC[CC_ABORT], 1u);
-    action = FAST_OVERFLOW;  // (reported as an error; never seen)
+    action = FAST_ABORT;  // a hand-shake inside the workgroup timed out: reported as CARVE_STATE_ABORTED (never seen)
   }
   c.n_groups = base_groups + commits;
   c.mem_off = base_mem + commits * group_n;
@@ -1655,6 +1723,241 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
   return action;
 }
 
+// One exact step of a configuration (the reference's filter + sort + take, mod.rs:511-561, evaluated as it stands):
+// keys for every live candidate, two-level selection (DPP argmin rounds per wave, 8-way merge), certificate, commit.
+// The whole workgroup; three LDS-only barriers.  STEP_CONTINUE = one group committed.
+template <bool BIG>
+__device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, StepCtx& c, const uint32_t* l_wid,
+                                             uint64_t* l_key, uint64_t* l_alive, const uint64_t* l_loc, uint64_t* part,
+                                             uint32_t* sel_out, uint32_t steps_before, unsigned long long* mirror) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
+  constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
+  const uint32_t lw = (c.n_list + 63u) >> 6;
+  auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
+  // FORM: `while total_available >= min` (mod.rs:507) with `compatible < min => break` (:517-519).
+  // MERGE: `while remaining_groups.len() >= min` (mod.rs:695).
+  if (!((c.mode == CARVE_MODE_MERGE || c.total_available >= c.min_s) && c.n_cand >= c.min_s && c.n_cand > 0))
+    return STEP_BREAK;
+  PROF_DECL;
+  // ---- seed: first live slot with a location, else first live slot (mod.rs:526-530); every wave finds
+  // it redundantly from the bitmaps with one ballot per 64 words (no barrier, no shuffle tree)
+  uint32_t f_loc = PM_NONE, f_any = PM_NONE;
+  for (uint32_t j0 = 0; j0 < lw && (f_loc == PM_NONE || f_any == PM_NONE); j0 += 64u) {
+    const uint32_t j = j0 + lane;
+    const uint64_t al = j < lw ? l_alive[j] : 0ull;
+    const uint64_t ll = j < lw ? (al & l_loc[j]) : 0ull;
+    if (f_any == PM_NONE) {
+      const uint64_t nz = __ballot(al != 0ull);
+      if (nz) {
+        const int src = __builtin_ctzll(nz);
+        const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(al >> 32), src) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)al, src);
+        f_any = (j0 + src) * 64u + __builtin_ctzll(w);
+      }
+    }
+    if (f_loc == PM_NONE) {
+      const uint64_t nz = __ballot(ll != 0ull);
+      if (nz) {
+        const int src = __builtin_ctzll(nz);
+        const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ll >> 32), src) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ll, src);
+        f_loc = (j0 + src) * 64u + __builtin_ctzll(w);
+      }
+    }
+  }
+
+  const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // fill to max (mod.rs:545-551)
+  uint32_t seed = f_any;
+  bool use_dist = false, located_only = false;
+  uint64_t last = 0;
+  uint32_t n_sel = 0, total = 0;
+
+  // attempt 0: FORM, or MERGE with proximity (mod.rs:762-821); attempt 1: MERGE first-come (:824-848)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (c.mode == CARVE_MODE_FORM) {
+      if (attempt == 1) break;
+      seed = f_any;
+      use_dist = false;
+      if (c.proximity && f_loc != PM_NONE) {  // seed = first WITH a location
+        seed = f_loc;
+        use_dist = true;
+      }  // else first-come (:553-561), or a seed without location makes the sort a no-op (:238)
+      located_only = false;
+    } else if (attempt == 0) {
+      if (!(c.proximity && f_loc != PM_NONE)) continue;
+      seed = f_loc;
+      use_dist = true;
+      located_only = true;
+    } else {
+      if (!(total == 0 || (total < c.max_s && total < c.min_s))) break;
+      seed = f_any;
+      use_dist = false;
+      located_only = false;
+    }
+
+    // ---- keys (registers only; the seed's coordinates are one uniform load each)
+    const double slat = G(p.cc_lat)[seed], slon = G(p.cc_lon)[seed], scos = G(p.cc_cos)[seed];
+    uint64_t lmin = ~0ull;
+    for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+      uint64_t k = ~0ull;
+      if (s != seed && bit_at(l_alive, s)) {
+        if (!use_dist) {
+          k = s;
+        } else if (bit_at(l_loc, s)) {
+          k = pack_key((uint64_t)__double_as_longlong(
+                           hav_a(slat, slon, scos, G(p.cc_lat)[s], G(p.cc_lon)[s], G(p.cc_cos)[s])), s, SB);
+        } else if (!located_only) {
+          k = pack_key(PM_KEY_NOLOC, s, SB);
+        }
+      }
+      l_key[s] = k;
+      lmin = k < lmin ? k : lmin;
+    }
+      n_sel = 0;
+    last = 0;
+    if (want > 0) {
+      if (want <= PM_CARVE_PART) {
+        // ---- level 1: this wave's `want` smallest, DPP argmin rounds, no barrier
+        uint32_t cnt = 0;
+        while (cnt < want) {
+          const uint64_t v = wave_min_u64(lmin);
+          if (v == ~0ull) break;
+          if (lane == 0) part[wave * PM_CARVE_PART + cnt] = v;
+          ++cnt;
+          if (lmin == v) {  // the owning lane advances to its next element (keys are unique)
+            uint64_t m = ~0ull;
+            for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+              const uint64_t k = l_key[s];
+              m = (k > v && k < m) ? k : m;
+            }
+            lmin = m;
+          }
+        }
+        if (lane == 0) red.part_n[wave] = cnt;
+              lds_barrier();
+              // ---- level 2: merge of the waves' sorted partial lists, redundantly in every wave
+        uint32_t ptr = 0;
+        const uint32_t my_n = lane < CARVE_WAVES ? red.part_n[lane] : 0u;
+        uint64_t head = my_n ? part[lane * PM_CARVE_PART] : ~0ull;
+        uint64_t mine = ~0ull;
+        while (n_sel < want) {
+          const uint64_t v = wave_min_u64(head);
+          if (v == ~0ull) break;
+          if (lane == n_sel) mine = v;
+          last = v;
+          ++n_sel;
+          if (head == v) {
+            ++ptr;
+            head = ptr < my_n ? part[lane * PM_CARVE_PART + ptr] : ~0ull;
+          }
+        }
+        if (wave == 0 && lane < n_sel) sel_out[lane] = (uint32_t)(mine & ((1ull << SB) - 1ull));
+            } else {
+        // ---- wide groups: one workgroup-wide round per member (wave argmin -> LDS -> fold)
+        while (n_sel < want) {
+          const uint64_t v = wave_min_u64(lmin);
+          if (lane == 0) part[wave] = v;
+          lds_barrier();
+          uint64_t b = ~0ull;
+#pragma unroll
+          for (uint32_t k = 0; k < CARVE_WAVES; ++k) b = part[k] < b ? part[k] : b;
+          lds_barrier();
+          if (b == ~0ull) break;
+          const uint32_t bs = (uint32_t)(b & ((1ull << SB) - 1ull));
+          if (tid == 0) {
+            if (n_sel < PM_CARVE_SEL_CAP)
+              sel_out[n_sel] = bs;
+            else if (c.mem_off + 1u + n_sel < p.cap_members)
+              G(p.members)[c.mem_off + 1u + n_sel] = wid_of(bs);
+          }
+          last = b;
+          ++n_sel;
+          if (lmin == b) {
+            uint64_t m = ~0ull;
+            for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+              const uint64_t k = l_key[s];
+              m = (k > b && k < m) ? k : m;
+            }
+            lmin = m;
+          }
+        }
+      }
+    }
+    total = 1u + n_sel;
+    if (c.mode == CARVE_MODE_FORM) break;
+    if (attempt == 0 && want > 0 && want <= PM_CARVE_PART) lds_barrier();  // part/part_n reused by attempt 1
+  }
+  if (total == 0) return STEP_BREAK;                                   // MERGE: nothing selectable
+  if (c.mode == CARVE_MODE_FORM && total < c.min_s) return STEP_BREAK;  // mod.rs:564-566
+  if (c.mode == CARVE_MODE_MERGE && total < 2u) return STEP_BREAK;      // is_merge_beneficial (mod.rs:868-870)
+
+  // ---- exactness certificate for a distance-ordered selection (see the comment above carve_kernel)
+  int uncertain = p.debug_uncertain_every && use_dist &&
+                  ((steps_before + c.steps + 1u) % p.debug_uncertain_every) == 0u;
+  const uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
+  const uint64_t last_key = (last >> SB) << SB;
+  if (use_dist && n_sel > 0 && last_key != noloc_key) {
+    const uint32_t ls = (uint32_t)(last & ((1ull << SB) - 1ull));
+    const double a_m = __longlong_as_double((long long)last_key);
+    const double band = a_m * band_rel + 1e-300;
+    const double mlat = G(p.cc_lat)[ls], mlon = G(p.cc_lon)[ls];  // uniform loads
+    if (a_m > PM_A_MAX_SAFE) uncertain = 1;
+    for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+      const uint64_t k = l_key[s];
+      const uint64_t kb = (k >> SB) << SB;
+      const double a = __longlong_as_double((long long)kb);
+      const bool near = k != ~0ull && kb != noloc_key && fabs(a - a_m) <= band;
+      if (near && (G(p.cc_lat)[s] != mlat || G(p.cc_lon)[s] != mlon)) uncertain = 1;
+    }
+  }
+  const uint64_t ub = __ballot(uncertain != 0);
+  if (lane == 0) red.flag[wave] = ub != 0ull;
+  lds_barrier();
+  uint32_t any = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < CARVE_WAVES; ++k) any |= red.flag[k];
+  if (any) {
+    if (tid == 0) G(p.status)->stop_seed = l_wid[seed];
+    return STEP_UNCERTAIN;
+  }
+  if (c.n_groups >= p.cap_groups || c.mem_off + total > p.cap_members) return STEP_OVERFLOW;
+
+  // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): selected slots =
+  // seed + every key <= last.  Each wave owns whole bitmap words (slot>>6 == j*16 + wave): ballot writes them.
+  for (uint32_t wj = wave; wj < lw; wj += CARVE_WAVES) {  // wave-uniform
+    const uint32_t s = wj * 64u + lane;
+    const bool was = bit_at(l_alive, s);
+    const bool sel = was && (s == seed || (n_sel > 0 && l_key[s] <= last));
+    const uint64_t nw = __ballot(was && !sel);
+    const uint64_t ow = __ballot(was);
+    if (lane == 0) {
+      l_alive[wj] = nw;
+      // (streaming carve: the proposers' copy of the bitmap follows every removal)
+      if (mirror && ow != nw) __hip_atomic_fetch_and(&mirror[wj], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (wave == 0) {  // group record + members: LDS -> fire-and-forget global stores
+    if (lane == 0) {
+      G(p.members)[c.mem_off] = wid_of(seed);
+      G(p.g_cfg)[c.n_groups] = c.cfg;
+      G(p.g_n)[c.n_groups] = total;
+      G(p.g_off)[c.n_groups] = c.mem_off;
+    }
+    const uint32_t lim = n_sel < PM_CARVE_SEL_CAP ? n_sel : PM_CARVE_SEL_CAP;
+    for (uint32_t r = lane; r < lim; r += 64u) G(p.members)[c.mem_off + 1u + r] = wid_of(sel_out[r]);
+  }
+  lds_barrier();
+  PROF_MARK(22);  // one exact step
+  c.n_groups += 1;
+  c.mem_off += total;
+  c.cand_sum += c.n_cand;
+  c.n_cand -= total;
+  c.total_available -= total;  // mod.rs:586
+  c.steps += 1;
+  return STEP_CONTINUE;
+}
+
 // LDS carve of one candidate list of at most PM_CARVE_SLOTS slots: worker ids, site ids, packed keys,
 // the alive / loc bitmaps and the per-wave partial selections all live in LDS (slot s is owned by thread
 // s % CARVE_THREADS).  Fast steps come from the proposals; a slow step is the exact full sweep: keys for every
@@ -1667,11 +1970,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
                                           const uint64_t* l_loc, uint64_t* part, uint32_t* sel_out,
                                           uint32_t* l_stage, uint32_t steps_before) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
-  constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
-  const uint32_t lw = (c.n_list + 63u) >> 6;
   const bool have_props = c.mode == CARVE_MODE_FORM && c.use_props;
-  auto wid_of = [](uint32_t sl) -> uint32_t { return sl; };  // members are recorded as SLOTS (translated after the run)
   uint32_t seed_cur = 0;  // wave 0: how far into the batch's seed list the carve has come
   const ChainLds CL = chain_lds(l_stage);
   for (;;) {
@@ -1692,7 +1991,7 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
           if (chain) {
             act = carve_chain<BIG>(p, c, l_stage, steps_before, seed_cur, cmd_seq);
             PROF_MARK(0);
-            if (act == FAST_OVERFLOW || act == FAST_REPROPOSE) break;
+            if (act == FAST_OVERFLOW || act == FAST_REPROPOSE || act == FAST_ABORT) break;
           }
           act = carve_fast_steps<BIG>(p, c, l_site, l_alive, l_loc, steps_before, seed_cur,
                                       (chain && act == FAST_SLOW) ? 1u : 0xFFFFFFFFu);
@@ -1727,223 +2026,13 @@ __device__ __noinline__ int carve_run_lds(const CarveArgs& p, BlockRed& red, Ste
       lds_barrier();  // the mailbox is rewritten after the next slow step
       if (act == FAST_DONE) return STEP_BREAK;
       if (act == FAST_OVERFLOW) return STEP_OVERFLOW;
+      if (act == FAST_ABORT) return STEP_ABORT;
       if (act == FAST_REPROPOSE) return STEP_CONTINUE;  // re-prepare: next proposal batch
     }
-    // FORM: `while total_available >= min` (mod.rs:507) with `compatible < min => break` (:517-519).
-    // MERGE: `while remaining_groups.len() >= min` (mod.rs:695).
-    if (!((c.mode == CARVE_MODE_MERGE || c.total_available >= c.min_s) && c.n_cand >= c.min_s && c.n_cand > 0))
-      return STEP_BREAK;
-    PROF_DECL;
-    // ---- seed: first live slot with a location, else first live slot (mod.rs:526-530); every wave finds
-    // it redundantly from the bitmaps with one ballot per 64 words (no barrier, no shuffle tree)
-    uint32_t f_loc = PM_NONE, f_any = PM_NONE;
-    for (uint32_t j0 = 0; j0 < lw && (f_loc == PM_NONE || f_any == PM_NONE); j0 += 64u) {
-      const uint32_t j = j0 + lane;
-      const uint64_t al = j < lw ? l_alive[j] : 0ull;
-      const uint64_t ll = j < lw ? (al & l_loc[j]) : 0ull;
-      if (f_any == PM_NONE) {
-        const uint64_t nz = __ballot(al != 0ull);
-        if (nz) {
-          const int src = __builtin_ctzll(nz);
-          const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(al >> 32), src) << 32) |
-                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)al, src);
-          f_any = (j0 + src) * 64u + __builtin_ctzll(w);
-        }
-      }
-      if (f_loc == PM_NONE) {
-        const uint64_t nz = __ballot(ll != 0ull);
-        if (nz) {
-          const int src = __builtin_ctzll(nz);
-          const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ll >> 32), src) << 32) |
-                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ll, src);
-          f_loc = (j0 + src) * 64u + __builtin_ctzll(w);
-        }
-      }
+    {
+      const int rc = carve_exact_step<BIG>(p, red, c, l_wid, l_key, l_alive, l_loc, part, sel_out, steps_before, nullptr);
+      if (rc != STEP_CONTINUE) return rc;
     }
-
-    const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // fill to max (mod.rs:545-551)
-    uint32_t seed = f_any;
-    bool use_dist = false, located_only = false;
-    uint64_t last = 0;
-    uint32_t n_sel = 0, total = 0;
-
-    // attempt 0: FORM, or MERGE with proximity (mod.rs:762-821); attempt 1: MERGE first-come (:824-848)
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      if (c.mode == CARVE_MODE_FORM) {
-        if (attempt == 1) break;
-        seed = f_any;
-        use_dist = false;
-        if (c.proximity && f_loc != PM_NONE) {  // seed = first WITH a location
-          seed = f_loc;
-          use_dist = true;
-        }  // else first-come (:553-561), or a seed without location makes the sort a no-op (:238)
-        located_only = false;
-      } else if (attempt == 0) {
-        if (!(c.proximity && f_loc != PM_NONE)) continue;
-        seed = f_loc;
-        use_dist = true;
-        located_only = true;
-      } else {
-        if (!(total == 0 || (total < c.max_s && total < c.min_s))) break;
-        seed = f_any;
-        use_dist = false;
-        located_only = false;
-      }
-
-      // ---- keys (registers only; the seed's coordinates are one uniform load each)
-      const double slat = G(p.cc_lat)[seed], slon = G(p.cc_lon)[seed], scos = G(p.cc_cos)[seed];
-      uint64_t lmin = ~0ull;
-      for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
-        uint64_t k = ~0ull;
-        if (s != seed && bit_at(l_alive, s)) {
-          if (!use_dist) {
-            k = s;
-          } else if (bit_at(l_loc, s)) {
-            k = pack_key((uint64_t)__double_as_longlong(
-                             hav_a(slat, slon, scos, G(p.cc_lat)[s], G(p.cc_lon)[s], G(p.cc_cos)[s])), s, SB);
-          } else if (!located_only) {
-            k = pack_key(PM_KEY_NOLOC, s, SB);
-          }
-        }
-        l_key[s] = k;
-        lmin = k < lmin ? k : lmin;
-      }
-        n_sel = 0;
-      last = 0;
-      if (want > 0) {
-        if (want <= PM_CARVE_PART) {
-          // ---- level 1: this wave's `want` smallest, DPP argmin rounds, no barrier
-          uint32_t cnt = 0;
-          while (cnt < want) {
-            const uint64_t v = wave_min_u64(lmin);
-            if (v == ~0ull) break;
-            if (lane == 0) part[wave * PM_CARVE_PART + cnt] = v;
-            ++cnt;
-            if (lmin == v) {  // the owning lane advances to its next element (keys are unique)
-              uint64_t m = ~0ull;
-              for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
-                const uint64_t k = l_key[s];
-                m = (k > v && k < m) ? k : m;
-              }
-              lmin = m;
-            }
-          }
-          if (lane == 0) red.part_n[wave] = cnt;
-                lds_barrier();
-                // ---- level 2: merge of the waves' sorted partial lists, redundantly in every wave
-          uint32_t ptr = 0;
-          const uint32_t my_n = lane < CARVE_WAVES ? red.part_n[lane] : 0u;
-          uint64_t head = my_n ? part[lane * PM_CARVE_PART] : ~0ull;
-          uint64_t mine = ~0ull;
-          while (n_sel < want) {
-            const uint64_t v = wave_min_u64(head);
-            if (v == ~0ull) break;
-            if (lane == n_sel) mine = v;
-            last = v;
-            ++n_sel;
-            if (head == v) {
-              ++ptr;
-              head = ptr < my_n ? part[lane * PM_CARVE_PART + ptr] : ~0ull;
-            }
-          }
-          if (wave == 0 && lane < n_sel) sel_out[lane] = (uint32_t)(mine & ((1ull << SB) - 1ull));
-              } else {
-          // ---- wide groups: one workgroup-wide round per member (wave argmin -> LDS -> fold)
-          while (n_sel < want) {
-            const uint64_t v = wave_min_u64(lmin);
-            if (lane == 0) part[wave] = v;
-            lds_barrier();
-            uint64_t b = ~0ull;
-#pragma unroll
-            for (uint32_t k = 0; k < CARVE_WAVES; ++k) b = part[k] < b ? part[k] : b;
-            lds_barrier();
-            if (b == ~0ull) break;
-            const uint32_t bs = (uint32_t)(b & ((1ull << SB) - 1ull));
-            if (tid == 0) {
-              if (n_sel < PM_CARVE_SEL_CAP)
-                sel_out[n_sel] = bs;
-              else if (c.mem_off + 1u + n_sel < p.cap_members)
-                G(p.members)[c.mem_off + 1u + n_sel] = wid_of(bs);
-            }
-            last = b;
-            ++n_sel;
-            if (lmin == b) {
-              uint64_t m = ~0ull;
-              for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
-                const uint64_t k = l_key[s];
-                m = (k > b && k < m) ? k : m;
-              }
-              lmin = m;
-            }
-          }
-        }
-      }
-      total = 1u + n_sel;
-      if (c.mode == CARVE_MODE_FORM) break;
-      if (attempt == 0 && want > 0 && want <= PM_CARVE_PART) lds_barrier();  // part/part_n reused by attempt 1
-    }
-    if (total == 0) return STEP_BREAK;                                   // MERGE: nothing selectable
-    if (c.mode == CARVE_MODE_FORM && total < c.min_s) return STEP_BREAK;  // mod.rs:564-566
-    if (c.mode == CARVE_MODE_MERGE && total < 2u) return STEP_BREAK;      // is_merge_beneficial (mod.rs:868-870)
-
-    // ---- exactness certificate for a distance-ordered selection (see the comment above carve_kernel)
-    int uncertain = p.debug_uncertain_every && use_dist &&
-                    ((steps_before + c.steps + 1u) % p.debug_uncertain_every) == 0u;
-    const uint64_t noloc_key = (PM_KEY_NOLOC >> SB) << SB;
-    const uint64_t last_key = (last >> SB) << SB;
-    if (use_dist && n_sel > 0 && last_key != noloc_key) {
-      const uint32_t ls = (uint32_t)(last & ((1ull << SB) - 1ull));
-      const double a_m = __longlong_as_double((long long)last_key);
-      const double band = a_m * band_rel + 1e-300;
-      const double mlat = G(p.cc_lat)[ls], mlon = G(p.cc_lon)[ls];  // uniform loads
-      if (a_m > PM_A_MAX_SAFE) uncertain = 1;
-      for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
-        const uint64_t k = l_key[s];
-        const uint64_t kb = (k >> SB) << SB;
-        const double a = __longlong_as_double((long long)kb);
-        const bool near = k != ~0ull && kb != noloc_key && fabs(a - a_m) <= band;
-        if (near && (G(p.cc_lat)[s] != mlat || G(p.cc_lon)[s] != mlon)) uncertain = 1;
-      }
-    }
-    const uint64_t ub = __ballot(uncertain != 0);
-    if (lane == 0) red.flag[wave] = ub != 0ull;
-    lds_barrier();
-    uint32_t any = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < CARVE_WAVES; ++k) any |= red.flag[k];
-    if (any) {
-      if (tid == 0) G(p.status)->stop_seed = l_wid[seed];
-      return STEP_UNCERTAIN;
-    }
-    if (c.n_groups >= p.cap_groups || c.mem_off + total > p.cap_members) return STEP_OVERFLOW;
-
-    // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): selected slots =
-    // seed + every key <= last.  Each wave owns whole bitmap words (slot>>6 == j*16 + wave): ballot writes them.
-    for (uint32_t wj = wave; wj < lw; wj += CARVE_WAVES) {  // wave-uniform
-      const uint32_t s = wj * 64u + lane;
-      const bool was = bit_at(l_alive, s);
-      const bool sel = was && (s == seed || (n_sel > 0 && l_key[s] <= last));
-      const uint64_t nw = __ballot(was && !sel);
-      if (lane == 0) l_alive[wj] = nw;
-    }
-    if (wave == 0) {  // group record + members: LDS -> fire-and-forget global stores
-      if (lane == 0) {
-        G(p.members)[c.mem_off] = wid_of(seed);
-        G(p.g_cfg)[c.n_groups] = c.cfg;
-        G(p.g_n)[c.n_groups] = total;
-        G(p.g_off)[c.n_groups] = c.mem_off;
-      }
-      const uint32_t lim = n_sel < PM_CARVE_SEL_CAP ? n_sel : PM_CARVE_SEL_CAP;
-      for (uint32_t r = lane; r < lim; r += 64u) G(p.members)[c.mem_off + 1u + r] = wid_of(sel_out[r]);
-    }
-    lds_barrier();
-    PROF_MARK(22);  // one exact step
-    c.n_groups += 1;
-    c.mem_off += total;
-    c.cand_sum += c.n_cand;
-    c.n_cand -= total;
-    c.total_available -= total;  // mod.rs:586
-    c.steps += 1;
     // drop dead slots once more than half of the list is gone.  With proposals this also ends the launch:
     // the list is re-prepared and the next propose / validate pair continues with fresh neighbour lists.
     if (c.n_cand * (have_props ? PM_THIN_DIV : 2u) < (have_props ? c.n_start : c.n_list) && c.n_list > (have_props ? 256u : CARVE_THREADS)) {
@@ -2465,6 +2554,7 @@ __device__ __forceinline__ void cell_drain(const CarveArgs& p, uint32_t* wl, uin
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   nb = 0;
 }
+template <bool STREAM = false>
 __device__ __forceinline__ void cell_offer_runs(const CarveArgs& p, uint32_t* wl, uint32_t b, uint32_t len, uint32_t lane, uint32_t s,
                                                 bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps,
                                                 NearRow& q, uint32_t& n_mine) {
@@ -2496,9 +2586,18 @@ __device__ __forceinline__ void cell_offer_runs(const CarveArgs& p, uint32_t* wl
       ic[v] = in[v] ? idx : 0u;
       t[v] = cs_slot[ic[v]];
     }
+    // (streaming carve: an entry's slot is its position for the whole carve; whether it is a candidate of the
+    // configuration being carved, and still free, is one bit of the validator's published bitmap)
+    uint32_t cw[4] = {~0u, ~0u, ~0u, ~0u};
+    if (STREAM) {
+      const auto candg = G((const uint32_t*)p.bits_scratch);
+#pragma unroll
+      for (uint32_t v = 0; v < 4u; ++v)
+        cw[v] = __hip_atomic_load(&candg[(in[v] ? t[v] : 0u) >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (uint32_t v = 0; v < 4u; ++v) {
-      const bool cand = in[v] && t[v] != 0xFFFFFFFFu;
+      const bool cand = in[v] && t[v] != 0xFFFFFFFFu && (!STREAM || ((cw[v] >> (t[v] & 31u)) & 1u) != 0u);
       const uint64_t m = __ballot(cand);
       if (cand) {
         const uint32_t at = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -2552,6 +2651,7 @@ __device__ __forceinline__ uint32_t ring_runs(uint32_t r) { return r ? 8u * r + 
 // The walk.  Returns the ring in front of which it stopped (>= 2), or 0 = the rings ran out before the row's window
 // closed (a seed far from everything else, or fewer located candidates than a row holds): the caller starts over on
 // the whole list.
+template <bool STREAM = false>
 __device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, uint32_t g, uint32_t r_max, uint32_t lane, uint32_t s,
                                           bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps, NearRow& q,
                                           uint32_t& n_mine) {
@@ -2571,10 +2671,10 @@ __device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, 
       b = cstart[lb];
       e = cstart[le];
     }
-    cell_offer_runs(p, wl, b, (ok && lane <= 10u) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+    cell_offer_runs<STREAM>(p, wl, b, (ok && lane <= 10u) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
     if (cell_bound_key(h, 0.0, 0.0, SB) > q.tau_hi) return 2u;
     if (r_max < 2u || g <= 2u) return 0u;
-    cell_offer_runs(p, wl, b, (ok && lane > 10u && !(lbk > q.tau_hi)) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+    cell_offer_runs<STREAM>(p, wl, b, (ok && lane > 10u && !(lbk > q.tau_hi)) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
   }
   for (uint32_t r = 3u;; ++r) {
     if (cell_bound_key((double)(r - 1u) * h, 0.0, 0.0, SB) > q.tau_hi) return r;  // nothing of interest from this ring on
@@ -2592,11 +2692,12 @@ __device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, 
         e = cstart[le];
       }
       if (!__ballot(ok && e > b)) continue;
-      cell_offer_runs(p, wl, b, ok ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+      cell_offer_runs<STREAM>(p, wl, b, ok ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
     }
   }
 }
 // the whole list by one wave, from L2/HBM (the fallback of cell_walk; four strides per trip for the loads to overlap)
+template <bool STREAM = false>
 __device__ __forceinline__ void list_sweep_solo(const CarveArgs& p, uint32_t n_list, uint32_t lane, uint32_t s, bool shared,
                                              uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps, NearRow& q,
                                              uint32_t& n_mine) {
@@ -2610,7 +2711,8 @@ __device__ __forceinline__ void list_sweep_solo(const CarveArgs& p, uint32_t n_l
     for (uint32_t v = 0; v < 4u; ++v) {
       const uint32_t tb = t0 + v * 64u, t = tb + lane, tc = t < n_list ? t : n_list - 1u;
       const bool w_in = tb < n_list;
-      aw[v] = w_in ? alive[tb >> 6] : 0ull;  // (the bitmaps are zero beyond the list)
+      // (the bitmaps are zero beyond the list; streaming carve: the validator clears bits while this runs)
+      aw[v] = !w_in ? 0ull : STREAM ? __hip_atomic_load(&alive[tb >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : alive[tb >> 6];
       lw[v] = w_in ? loc[tb >> 6] : 0ull;
       x[v] = G(p.cc_ux)[tc];
       y[v] = G(p.cc_uy)[tc];
@@ -2625,6 +2727,96 @@ __device__ __forceinline__ void list_sweep_solo(const CarveArgs& p, uint32_t n_l
       offer_candidate(p, sg, ssite, x[v], y[v], z[v], si[v], counts ? t : 0u, located, counts, SB, ulps, q, n_mine);
     }
   }
+}
+
+// The finished register of a seed's sweep -> its row: *mine_out = this lane's entry (~0 beyond the row's K entries);
+// returns the flags word (PM_ROW_*, entries in bits 0..7, first entry within the band of the last one in bits 8..15).
+__device__ __forceinline__ uint32_t near_row_finish(const CarveArgs& p, const NearRow& q, bool valid, uint32_t K, uint32_t SB,
+                                                    double TIE_BAND, uint32_t lane, uint64_t* mine_out) {
+  // ---- the K nearest in (key, slot) order are lanes 0 .. K-1 of the row; lane K holds the first unlisted one
+  const uint32_t n_tot = valid ? (uint32_t)__popcll(__ballot(q.key != ~0ull)) : 0u;
+  const uint32_t n_k = n_tot < K ? n_tot : K;
+  const uint64_t beyond = n_tot > K ? readlane_u64(q.key, K) : ~0ull;
+  const uint64_t mine = lane < n_k ? q.key : ~0ull;
+  const uint64_t noloc_kb = (PM_KEY_NOLOC >> SB) << SB;
+  // row certificates the validator can rely on instead of re-deriving them at every step:
+  //  clean      — no two neighbouring entries within the band of each other sit at different sites (entries in
+  //               between are within the band too, so this covers every pair of the row)
+  //  tail_clear — the first candidate NOT in the row is further than the band from the last entry
+  //  tail_ok    — otherwise: everything unlisted within the band of the last entry sits at that entry's site
+  uint32_t clean = 1, tail_clear = 0, tail_ok = 0;
+  int tail_bad = 0;
+  uint64_t e_last = 0;
+  double a_last = 0.0, band2 = 0.0;
+  uint32_t site_last = 0;
+  if (valid) {
+    const uint64_t kb = (mine >> SB) << SB;
+    const uint32_t my_site = (lane < n_k && kb != noloc_kb) ? G(p.cc_site)[(uint32_t)(mine & ((1ull << SB) - 1ull))] : 0u;
+    const uint64_t nkb_lo = __shfl_down((uint32_t)kb, 1, 64), nkb_hi = __shfl_down((uint32_t)(kb >> 32), 1, 64);
+    const uint64_t nkb = (nkb_hi << 32) | nkb_lo;
+    const uint32_t nsite = __shfl_down(my_site, 1, 64);
+    int bad = 0;
+    if (lane + 1u < n_k && kb != noloc_kb && nkb != noloc_kb) {
+      const double a0 = __longlong_as_double((long long)kb), a1 = __longlong_as_double((long long)nkb);
+      if (a1 - a0 <= a1 * (4.0 * TIE_BAND) + 1e-300 && nsite != my_site) bad = 1;
+    }
+    clean = __ballot(bad) == 0ull;
+  }
+  if (valid && n_k == K) {
+    e_last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 1) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 1);
+    const uint64_t kb_last = (e_last >> SB) << SB;
+    const uint64_t kb_beyond = (beyond >> SB) << SB;
+    if (beyond == ~0ull || kb_last == noloc_kb) {
+      tail_clear = 1;  // nothing unlisted, or only location-less candidates (exact ties, larger slots)
+    } else if (kb_beyond == noloc_kb) {
+      tail_clear = 1;
+    } else {
+      a_last = __longlong_as_double((long long)kb_last);
+      const double a_b = __longlong_as_double((long long)kb_beyond);
+      if (a_b - a_last > a_b * (4.0 * TIE_BAND) + 1e-300) {
+        tail_clear = 1;
+      } else {
+        site_last = G(p.cc_site)[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
+        band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
+        // The unlisted candidates closest to the last entry are lanes K .. 63 of the sorted register; whatever
+        // else came near the row during the sweep is summarised in the tracker (see NearRow): of those, only
+        // the nearest one that does NOT sit at the last entry's site can break the certificate.
+        if (lane >= K && lane < n_tot) {
+          const uint64_t kb2 = (q.key >> SB) << SB;
+          if (kb2 != noloc_kb && __longlong_as_double((long long)kb2) - a_last <= band2 &&
+              G(p.cc_site)[(uint32_t)(q.key & ((1ull << SB) - 1ull))] != site_last)
+            tail_bad = 1;
+        }
+        const uint64_t other = q.s1 != site_last ? q.m1 : q.m2;
+        const uint64_t kb_o = (other >> SB) << SB;
+        if (other != ~0ull && kb_o != noloc_kb && __longlong_as_double((long long)kb_o) - a_last <= band2) tail_bad = 1;
+        tail_ok = __ballot(tail_bad) == 0ull;
+      }
+    }
+  }
+  // what the validator's chain needs to settle a step from the flags alone: is any listed term near the antipode,
+  // and from which entry on does the row lie within the certificate band of its LAST entry (a selection that ends
+  // in front of that entry has nothing to do with the row's tail) — the validator's own band expression
+  uint32_t safe, j_tail = n_k;
+  {
+    const uint64_t kb = (mine >> SB) << SB;
+    const bool located = lane < n_k && kb != noloc_kb;
+    const double a_l = __longlong_as_double((long long)kb);
+    safe = __ballot(located && a_l > PM_A_MAX_SAFE) == 0ull;
+    if (n_k > 0u) {
+      const uint64_t kb_le = (readlane_u64(mine, n_k - 1u) >> SB) << SB;
+      if (kb_le != noloc_kb) {
+        const double a_le = __longlong_as_double((long long)kb_le);
+        const uint64_t within = __ballot(located && (a_le - a_l) <= a_l * TIE_BAND + 1e-300);
+        j_tail = within ? (uint32_t)__builtin_ctzll(within) : n_k;
+      }
+    }
+  }
+  const uint32_t meta = n_k | (j_tail << 8) | (safe ? PM_ROW_SAFE : 0u) | ((n_k < K) ? PM_ROW_COMPLETE : 0u) |
+                        (tail_ok ? PM_ROW_TAIL_OK : 0u) | (clean ? PM_ROW_CLEAN : 0u) | (tail_clear ? PM_ROW_TAIL_CLEAR : 0u);
+  *mine_out = mine;
+  return meta;
 }
 
 __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __restrict__ pa) {
@@ -2710,69 +2902,8 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
       }
     }
     PP_MARK(pt_sweep);
-    // ---- the K nearest in (key, slot) order are lanes 0 .. K-1 of the row; lane K holds the first unlisted one
-    const uint32_t n_tot = valid ? (uint32_t)__popcll(__ballot(q.key != ~0ull)) : 0u;
-    const uint32_t n_k = n_tot < K ? n_tot : K;
-    const uint64_t beyond = n_tot > K ? readlane_u64(q.key, K) : ~0ull;
-    const uint64_t mine = lane < n_k ? q.key : ~0ull;
-    PP_MARK(pt_pop);
-    const uint64_t noloc_kb = (PM_KEY_NOLOC >> SB) << SB;
-    // row certificates the validator can rely on instead of re-deriving them at every step:
-    //  clean      — no two neighbouring entries within the band of each other sit at different sites (entries in
-    //               between are within the band too, so this covers every pair of the row)
-    //  tail_clear — the first candidate NOT in the row is further than the band from the last entry
-    //  tail_ok    — otherwise: everything unlisted within the band of the last entry sits at that entry's site
-    uint32_t clean = 1, tail_clear = 0, tail_ok = 0;
-    int tail_bad = 0;
-    uint64_t e_last = 0;
-    double a_last = 0.0, band2 = 0.0;
-    uint32_t site_last = 0;
-    if (valid) {
-      const uint64_t kb = (mine >> SB) << SB;
-      const uint32_t my_site = (lane < n_k && kb != noloc_kb) ? G(p.cc_site)[(uint32_t)(mine & ((1ull << SB) - 1ull))] : 0u;
-      const uint64_t nkb_lo = __shfl_down((uint32_t)kb, 1, 64), nkb_hi = __shfl_down((uint32_t)(kb >> 32), 1, 64);
-      const uint64_t nkb = (nkb_hi << 32) | nkb_lo;
-      const uint32_t nsite = __shfl_down(my_site, 1, 64);
-      int bad = 0;
-      if (lane + 1u < n_k && kb != noloc_kb && nkb != noloc_kb) {
-        const double a0 = __longlong_as_double((long long)kb), a1 = __longlong_as_double((long long)nkb);
-        if (a1 - a0 <= a1 * (4.0 * TIE_BAND) + 1e-300 && nsite != my_site) bad = 1;
-      }
-      clean = __ballot(bad) == 0ull;
-    }
-    if (valid && n_k == K) {
-      e_last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)K - 1) << 32) |
-               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)K - 1);
-      const uint64_t kb_last = (e_last >> SB) << SB;
-      const uint64_t kb_beyond = (beyond >> SB) << SB;
-      if (beyond == ~0ull || kb_last == noloc_kb) {
-        tail_clear = 1;  // nothing unlisted, or only location-less candidates (exact ties, larger slots)
-      } else if (kb_beyond == noloc_kb) {
-        tail_clear = 1;
-      } else {
-        a_last = __longlong_as_double((long long)kb_last);
-        const double a_b = __longlong_as_double((long long)kb_beyond);
-        if (a_b - a_last > a_b * (4.0 * TIE_BAND) + 1e-300) {
-          tail_clear = 1;
-        } else {
-          site_last = G(p.cc_site)[(uint32_t)(e_last & ((1ull << SB) - 1ull))];
-          band2 = a_last * (4.0 * TIE_BAND) + 1e-300;
-          // The unlisted candidates closest to the last entry are lanes K .. 63 of the sorted register; whatever
-          // else came near the row during the sweep is summarised in the tracker (see NearRow): of those, only
-          // the nearest one that does NOT sit at the last entry's site can break the certificate.
-          if (lane >= K && lane < n_tot) {
-            const uint64_t kb2 = (q.key >> SB) << SB;
-            if (kb2 != noloc_kb && __longlong_as_double((long long)kb2) - a_last <= band2 &&
-                G(p.cc_site)[(uint32_t)(q.key & ((1ull << SB) - 1ull))] != site_last)
-              tail_bad = 1;
-          }
-          const uint64_t other = q.s1 != site_last ? q.m1 : q.m2;
-          const uint64_t kb_o = (other >> SB) << SB;
-          if (other != ~0ull && kb_o != noloc_kb && __longlong_as_double((long long)kb_o) - a_last <= band2) tail_bad = 1;
-          tail_ok = __ballot(tail_bad) == 0ull;
-        }
-      }
-    }
+    uint64_t mine;
+    const uint32_t meta = near_row_finish(p, q, valid, K, SB, TIE_BAND, lane, &mine);
     if (!valid) continue;  // (the workgroup's last seeds may be fewer than four)
     PP_MARK(pt_flags);
 #ifdef PM_PROP_PROF
@@ -2798,27 +2929,7 @@ __global__ __launch_bounds__(256) void carve_propose_kernel(const CarveArgs* __r
         atomicAdd(&p.status->n_props, 1u);
       }
     }
-    // what the validator's chain needs to settle a step from the flags alone: is any listed term near the antipode,
-    // and from which entry on does the row lie within the certificate band of its LAST entry (a selection that ends
-    // in front of that entry has nothing to do with the row's tail) — the validator's own band expression
-    uint32_t safe, j_tail = n_k;
-    {
-      const uint64_t kb = (mine >> SB) << SB;
-      const bool located = lane < n_k && kb != noloc_kb;
-      const double a_l = __longlong_as_double((long long)kb);
-      safe = __ballot(located && a_l > PM_A_MAX_SAFE) == 0ull;
-      if (n_k > 0u) {
-        const uint64_t kb_le = (readlane_u64(mine, n_k - 1u) >> SB) << SB;
-        if (kb_le != noloc_kb) {
-          const double a_le = __longlong_as_double((long long)kb_le);
-          const uint64_t within = __ballot(located && (a_le - a_l) <= a_l * TIE_BAND + 1e-300);
-          j_tail = within ? (uint32_t)__builtin_ctzll(within) : n_k;
-        }
-      }
-    }
     // the row: the flags word, then the K sorted entries
-    const uint32_t meta = n_k | (j_tail << 8) | (safe ? PM_ROW_SAFE : 0u) | ((n_k < K) ? PM_ROW_COMPLETE : 0u) |
-                          (tail_ok ? PM_ROW_TAIL_OK : 0u) | (clean ? PM_ROW_CLEAN : 0u) | (tail_clear ? PM_ROW_TAIL_CLEAR : 0u);
     prop_out[(size_t)out_row * PM_PROP_ROW + ((lane + 1u) & 63u)] = lane == 63u ? (uint64_t)meta : mine;
     // ... and the same once more as 32-bit words (flags, slot of entry 0, slot of entry 1, ...): what a lane of
     // the chain's producer reads — 256 coalesced bytes per row
@@ -3222,6 +3333,8 @@ __global__ __launch_bounds__(256) void carve_elig_count_kernel(const CarveArgs* 
     s_c[wave] = (uint32_t)__popcll(bal);
     if (j < ((p.W + 63u) >> 6)) G(p.loc_g)[j] = 0ull;  // (the positions are a subset of the rows)
   }
+  // (streaming carve: the per-configuration bitmaps of compatible positions, ORed in by the placement)
+  if (p.stream && lane < p.n_avail && j < ((p.W + 63u) >> 6)) G(p.cfgbits)[(size_t)lane * p.bits_stride + j] = 0ull;
   if (blockIdx.x == 0 && tid <= PM_MAX_CONFIGS + 1u) p.prep_counts[tid] = 0u;  // totals and both tickets
   __syncthreads();
   if (tid == 0) {
@@ -3239,6 +3352,7 @@ __global__ __launch_bounds__(256) void carve_elig_place_kernel(const CarveArgs* 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   __shared__ uint32_t s_red[2 * PREP_WAVES + 2];
   __shared__ uint32_t s_bits[PREP_WAVES][64];
+  __shared__ uint64_t s_cm[PREP_WAVES][64];
   // ---- this block's first position: eligible rows of the blocks in front of it
   uint32_t part = 0;
   for (uint32_t b = tid; b < blockIdx.x; b += 256u) part += G((const uint32_t*)p.prep_block_counts)[(size_t)b * PM_MAX_CONFIGS];
@@ -3266,8 +3380,10 @@ __global__ __launch_bounds__(256) void carve_elig_place_kernel(const CarveArgs* 
     G(p.c_uy)[i] = G(p.uy)[w];
     G(p.c_uz)[i] = G(p.uz)[w];
     G(p.c_site)[i] = G(p.site)[w];
-    G(p.c_compat)[i] = G(p.compat)[w];
+    const uint64_t cmw = G(p.compat)[w];
+    G(p.c_compat)[i] = cmw;
     s_bits[wave][rank] = has_loc;
+    s_cm[wave][rank] = cmw;
   }
   // the located bits of this wave's positions [off, off + cnt): compacted by rank, ORed into loc_g (at most two words)
   __syncthreads();
@@ -3277,6 +3393,18 @@ __global__ __launch_bounds__(256) void carve_elig_place_kernel(const CarveArgs* 
     const uint32_t sh = off & 63u;
     atomicOr(&loc[off >> 6], (unsigned long long)(locm << sh));
     if (sh && (locm >> (64u - sh))) atomicOr(&loc[(off >> 6) + 1u], (unsigned long long)(locm >> (64u - sh)));
+  }
+  if (p.stream) {  // the same for every configuration of the carve order: which of these positions are compatible
+    const uint64_t cmr = lane < cnt ? s_cm[wave][lane] : 0ull;
+    const uint32_t sh = off & 63u;
+    for (uint32_t ci = 0; ci < p.n_avail; ++ci) {
+      const uint64_t bits = __ballot((cmr >> p.avail_cfg[ci]) & 1ull);
+      if (lane == 0 && bits) {
+        const auto cb = (unsigned long long*)(p.cfgbits + (size_t)ci * p.bits_stride);
+        atomicOr(&cb[off >> 6], (unsigned long long)(bits << sh));
+        if (sh && (bits >> (64u - sh))) atomicOr(&cb[(off >> 6) + 1u], (unsigned long long)(bits >> (64u - sh)));
+      }
+    }
   }
   // ---- the block that finishes last completes the list and publishes it (it reads nothing the other blocks wrote
   // but the ticket: see carve_prep_place_kernel for why this is not a device-scope fence)
@@ -3442,6 +3570,7 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const CarveArgs* __rest
   }
   const uint32_t e = G((const uint32_t*)p.cell_start)[c] + G((const uint32_t*)p.pos_rank)[i];
   G(p.cs_of_pos)[i] = e;
+  if (p.stream) G(p.cs_slot)[e] = i;  // (streaming carve: slot == position, for the whole carve)
   G(p.cs_ux)[e] = G((const double*)p.c_ux)[i];
   G(p.cs_uy)[e] = G((const double*)p.c_uy)[i];
   G(p.cs_uz)[e] = G((const double*)p.c_uz)[i];
@@ -3756,8 +3885,8 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     }
     __syncthreads();
     PROF_MARK(12);
-    if (rc == STEP_UNCERTAIN || rc == STEP_OVERFLOW) {
-      exit_state = rc == STEP_UNCERTAIN ? CARVE_STATE_UNCERTAIN : CARVE_STATE_OVERFLOW;
+    if (rc == STEP_UNCERTAIN || rc == STEP_OVERFLOW || rc == STEP_ABORT) {
+      exit_state = rc == STEP_UNCERTAIN ? CARVE_STATE_UNCERTAIN : rc == STEP_ABORT ? CARVE_STATE_ABORTED : CARVE_STATE_OVERFLOW;
       stop_ci = ci;
       break;
     }
@@ -3813,6 +3942,8 @@ __global__ __launch_bounds__(CARVE_THREADS) void carve_kernel(const CarveArgs* _
     if (!(flags_in & CARVE_F_INIT)) st->n_batches += 1;
   }
 }
+
+#include "pm_stream.inc"
 
 // ------------------------------------------------------------------------------------------------
 // launchers (called from pm_engine.cpp)
