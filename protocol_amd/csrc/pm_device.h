@@ -52,22 +52,24 @@ static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + si
                                              size_t(PM_CARVE_SLOTS) * 16 + size_t(PM_CARVE_SEL_CAP) * 4 + 1024;
 // ---- streaming carve (carve_stream_kernel): one launch per try_form_new_groups pass; workgroup 0 validates, the
 // others compute neighbour rows for the seeds a bounded look-ahead in front of the chain
-static constexpr uint32_t PM_STREAM_SQ = 4096;      // seed-ticket ring (8-byte granules): > waves that can hold a claim
-static constexpr uint32_t PM_STREAM_RQ = 1024;      // row ring: rows of tickets t, t + RQ share a slot
-static constexpr uint32_t PM_STREAM_TP = 512;       // tickets whose seed position the validator remembers (LDS)
-static constexpr uint32_t PM_STREAM_LA_MAX = 256;   // look-ahead: tickets issued and not yet handed to the chain
+static constexpr uint32_t PM_STREAM_SQ = 8192;      // seed-ticket ring (8-byte granules): > waves that can hold a claim
+static constexpr uint32_t PM_STREAM_RQ = 8192;      // row ring: rows of tickets t, t + RQ share a slot
+static constexpr uint32_t PM_STREAM_TP = 4096;      // tickets whose seed position the validator remembers (LDS)
+static constexpr uint32_t PM_STREAM_LA_MAX = 3072;  // look-ahead: tickets issued and not yet handed to the chain
 static constexpr uint32_t PM_STREAM_CTL_WORDS = 64; // control block (u32): see the SC_* indices
-static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 64;
+static constexpr uint32_t PM_STREAM_PROP_WAVES = 4; // waves of a proposer workgroup that build rows (one per SIMD)
+static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 128;
 // control words in global memory (each hot word on its own 64-byte line)
 enum { SC_CLAIM = 0,    // next ticket a proposer wave takes (atomicAdd)
        SC_QUIT = 16,    // the validator is through: proposers leave
-       SC_CL_LEN = 32,  // length of the candidate list (clist) of the configuration being carved
        SC_ROWS = 48,    // rows the proposers delivered (statistics)
        SC_GAVE_UP = 49, // proposer waves that left because nothing was asked of them for too long
-       SC_FINISH = 50   // the carve launch ran (carve_finish_kernel has records to finish)
+       SC_FINISH = 50,  // the carve launch ran (carve_finish_kernel has records to finish)
+       SC_TRACE = 51    // PM_CARVE_PROF builds: events written to the trace buffer
 };
+static constexpr uint32_t PM_STREAM_TRACE_CAP = 1u << 17;  // events (two u64 each) of a PM_CARVE_PROF build's timeline
 // how the rows of a ticket are made (bits 24..25 of the ticket's payload)
-enum { SROW_NONE = 0, SROW_LIST = 1, SROW_WALK = 2, SROW_SWEEP = 3 };
+enum { SROW_NONE = 0, SROW_BITMAP = 1, SROW_WALK = 2, SROW_SWEEP = 3 };
 
 struct CompatArgs {
   uint32_t W, n_cfgs, model_words;
@@ -146,8 +148,12 @@ struct CarveStatus {
   uint32_t why[8];
   uint32_t stream_timeouts; // streaming carve: rows the validator stopped waiting for (the step took the exact sweep)
   uint32_t stream_tickets;  // streaming carve: seeds handed to the proposers
-  uint32_t stream_switches; // streaming carve: configurations that went from walking the index to the candidate list
-  uint32_t stream_listed;   // streaming carve: configurations entered with a candidate list
+  uint32_t stream_switches; // streaming carve: configurations that went from walking the index to sweeping the bitmap
+  uint32_t stream_listed;   // streaming carve: configurations entered sweeping the bitmap
+  uint32_t stream_pre_used; // streaming carve: configurations that started on tickets issued ahead
+  uint32_t stream_pre_lost; // streaming carve: tickets issued ahead for a configuration that was not the next one
+  uint32_t stream_refreshes; // streaming carve: times a configuration's outstanding tickets were dropped and issued afresh
+  uint32_t _pad_sr;
   uint32_t cell_g;          // grid size of the spatial index built for this carve's positions (0 = none)
   uint32_t n_indexed;       // located positions in the index
   uint32_t pruned_batches;  // batches whose proposals walked the index instead of the whole list
@@ -157,7 +163,7 @@ struct CarveStatus {
   uint32_t blog[3 * 512];   // per preparation: list length (0 = none), seeds, grid of the walk (0 = whole-list sweep)
 #endif
   unsigned long long prop_keys;  // keys (Haversine terms) those sweeps evaluated
-  unsigned long long prof[32];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
+  unsigned long long prof[48];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
 // A proposal batch as its preparation describes it (carve_plan_kernel + carve_prep_*_kernel write it, the proposer
@@ -242,16 +248,17 @@ struct CarveArgs {
   uint32_t prune_factor;         // mode 1: walk when n_list^2 >= prune_factor x (indexed positions)
   uint32_t walk_cap_div, _pad_w; // seeds of a batch that walks the index: n_list / walk_cap_div
   // ---- streaming carve (carve_stream_kernel).  Slot == position: cc_* alias c_*, slot_wid aliases order,
-  // bits_scratch = {candidate bitmap of the configuration being carved (the proposers' view), loc_g}, alive_g = the
-  // validator's master bitmap of what no group holds yet.
+  // bits_scratch = {the published `free` bitmap (positions no group holds yet — the proposers' view, a few commits
+  // behind), loc_g}, alive_g = the validator's own master copy of it (brought up to date between configurations).
   uint32_t stream, stream_tag0;  // stream: 1 = this argument block drives carve_stream_kernel; tag0: first ticket tag
   uint64_t* cfgbits;             // [n_avail][bits_stride] per configuration (carve order): compatible positions
-  unsigned long long* stream_sq;      // [PM_STREAM_SQ] seed tickets: {tag, position | ci << 18 | mode << 24 | epoch << 26}
+  unsigned long long* stream_sq;      // [PM_STREAM_SQ] seed tickets: {tag, position | ci << 18 | mode << 24}
   unsigned long long* stream_row_lo;  // [PM_STREAM_RQ][64] rows: {tag, flags word | low half of the packed key of entry g - 1}
   unsigned long long* stream_row_hi;  // [PM_STREAM_RQ][64]       {tag, high half}
   uint32_t* stream_ctl;               // [PM_STREAM_CTL_WORDS] SC_*
-  uint32_t* clist;                    // [W] candidate positions of the configuration being carved (SROW_LIST)
   uint32_t stream_la, stream_row_spins;  // look-ahead cap (0 = default); polls before the validator gives a row up
+  uint32_t stream_la_div, _pad_s;        // look-ahead = candidates / (la_div x (max_group_size - 1)) (0 = default)
+  unsigned long long* stream_trace;      // PM_CARVE_PROF builds: [PM_STREAM_TRACE_CAP][2] {s_memtime, type | a << 8 | b << 32}
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
   uint32_t avail_cfg[PM_MAX_CONFIGS];

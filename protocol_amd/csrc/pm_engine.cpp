@@ -130,8 +130,8 @@ struct pm_engine {
   float k_ms_compat = 0, k_ms_carve = 0, k_ms_sweep = 0;
   bool k_sweep_recorded = false, k_compat_recorded = false;
   uint64_t tick_cand_sum = 0;
-  unsigned long long carve_prof[32]{};
-  unsigned long long carve_why[22]{};  // CarveStatus::why of the last carve, its batches and void launches, the spatial
+  unsigned long long carve_prof[48]{};
+  unsigned long long carve_why[24]{};  // CarveStatus::why of the last carve, its batches and void launches, the spatial
                                        // index, the streaming carve's counters
   uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above
   uint32_t prune_mode = 1;       // pm_debug_prune_mode / PM_PRUNE_MODE: CarveArgs::prune_mode
@@ -239,11 +239,12 @@ struct pm_engine {
   DevBuf<uint32_t> d_cell_cnt, d_cell_start, d_pos_cell, d_pos_rank, d_cs_of_pos, d_cs_slot, d_cs_site;
   DevBuf<double> d_cs_u[3];
   // streaming carve (carve_stream_kernel): per-configuration bitmaps, ticket and row rings, control block, candidate list
-  DevBuf<uint64_t> d_cfgbits, d_stream_sq, d_stream_row_lo, d_stream_row_hi;
-  DevBuf<uint32_t> d_stream_ctl, d_clist;
+  DevBuf<uint64_t> d_cfgbits, d_stream_sq, d_stream_row_lo, d_stream_row_hi, d_stream_trace;
+  DevBuf<uint32_t> d_stream_ctl;
   uint32_t stream_seq = 0;       // launches so far: the tags of a launch's tickets start at stream_seq << 25
   uint32_t stream_wgs_env = 0;   // PM_STREAM_WGS: proposer workgroups (0 = by the size of the eligible list)
   uint32_t stream_la_env = 0;    // PM_STREAM_LA: look-ahead cap (0 = the kernel's default)
+  uint32_t stream_la_div_env = 0;  // PM_STREAM_LA_DIV: look-ahead divisor (0 = the kernel's default)
   uint32_t n_cus = 256;
   uint32_t tick_stream_timeouts = 0, tick_stream_tickets = 0, tick_stream_aborts = 0;
   DevBuf<uint64_t> d_ikeys, d_umask;  // per-task orientation: table of the distinct topology masks, the masks densely
@@ -534,7 +535,6 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_snap.ensure(size_t(stride) * 2));
   if (stream) {
     HIPCHK(e->d_cfgbits.ensure(size_t(stride) * PM_MAX_CONFIGS));
-    HIPCHK(e->d_clist.ensure(cap));
     HIPCHK(e->d_stream_ctl.ensure(PM_STREAM_CTL_WORDS));
     if (!e->d_stream_sq.p) {  // (tags never repeat within 127 launches; the rings are cleared when the counter wraps)
       HIPCHK(e->d_stream_sq.ensure(PM_STREAM_SQ));
@@ -650,8 +650,12 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     a->stream_row_lo = (unsigned long long*)e->d_stream_row_lo.p;
     a->stream_row_hi = (unsigned long long*)e->d_stream_row_hi.p;
     a->stream_ctl = e->d_stream_ctl.p;
-    a->clist = e->d_clist.p;
+#ifdef PM_CARVE_PROF
+    HIPCHK(e->d_stream_trace.ensure(size_t(PM_STREAM_TRACE_CAP) * 2));
+    a->stream_trace = (unsigned long long*)e->d_stream_trace.p;
+#endif
     a->stream_la = e->stream_la_env;
+    a->stream_la_div = e->stream_la_div_env;
     a->stream_row_spins = 0;
   }
   return PM_OK;
@@ -971,7 +975,7 @@ static int32_t form_setup_args(pm_engine* e, FormRun* r) {
   if (rc) return rc;
   if (r->stream) {
     // proposer workgroups: enough waves to cover a row's latency at the chain's pace, by the size of the list
-    uint32_t wgs = e->stream_wgs_env ? e->stream_wgs_env : r->n_elig_hint / 512u + 16u;
+    uint32_t wgs = e->stream_wgs_env ? e->stream_wgs_env : r->n_elig_hint / 64u + 48u;
     const uint32_t max_wgs = e->n_cus > 8u ? e->n_cus - 4u : 4u;
     r->stream_wgs = std::max(1u, std::min(wgs, max_wgs));
   }
@@ -1118,6 +1122,8 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   e->carve_why[19] = r->stream_wgs;
   e->carve_why[20] = e->tick_stream_aborts;
   e->carve_why[21] = st.slow_steps;
+  e->carve_why[22] = st.stream_pre_used;
+  e->carve_why[23] = st.stream_pre_lost;
 #ifdef PM_BATCH_LOG
   e->blog.assign(st.blog, st.blog + 3 * std::min<uint32_t>(st.blog_n, 512u));
 #endif
@@ -1740,6 +1746,10 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
     const long f = atol(v);
     if (f > 0 && f < 4096) e->stream_wgs_env = uint32_t(f);
   }
+  if (const char* v = getenv("PM_STREAM_LA_DIV")) {
+    const long f = atol(v);
+    if (f > 0 && f < 4096) e->stream_la_div_env = uint32_t(f);
+  }
   if (const char* v = getenv("PM_STREAM_LA")) {
     const long f = atol(v);
     if (f > 0 && f <= long(PM_STREAM_LA_MAX)) e->stream_la_env = uint32_t(f);
@@ -1794,7 +1804,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_cfgbits.release(); e->d_stream_sq.release(); e->d_stream_row_lo.release(); e->d_stream_row_hi.release();
-  e->d_stream_ctl.release(); e->d_clist.release();
+  e->d_stream_ctl.release(); e->d_stream_trace.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
   e->d_table.release(); e->d_task_col.release(); e->d_shard.release(); e->d_own_rows.release(); e->d_xrow.release();
@@ -3106,9 +3116,25 @@ int32_t pm_device_task_column(pm_engine* e, uint64_t* device_ptr, uint32_t* n) {
 int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap) {
   if (!e || !out) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
-  const uint32_t n = std::min<uint32_t>(cap, uint32_t(sizeof(e->carve_prof) / sizeof(e->carve_prof[0])));
+  const uint32_t n = std::min<uint32_t>(cap, 32u);
   std::memcpy(out, e->carve_prof, size_t(n) * sizeof(unsigned long long));
-  for (uint32_t k = 32; k < cap && k < 54; ++k) out[k] = e->carve_why[k - 32];  // (how the validation launches ended; the index)
+  for (uint32_t k = 32; k < cap && k < 56; ++k) out[k] = e->carve_why[k - 32];
+  for (uint32_t k = 56; k < cap && k < 72; ++k) out[k] = e->carve_prof[k - 56 + 32];  // (phase counters 32..47)  // (how the validation launches ended; the index)
+  return PM_OK;
+}
+
+// debug (PM_CARVE_PROF builds): the timeline of the last streaming carve launch — up to cap events of two u64 each
+// {s_memtime, type | a << 8 | b << 32}; *n = events recorded
+extern "C" int32_t pm_debug_stream_trace(pm_engine* e, unsigned long long* out, uint32_t cap, uint32_t* n) {
+  if (!e || !out || !n) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  *n = 0;
+  if (!e->d_stream_trace.p || !e->d_stream_ctl.p) return PM_OK;
+  uint32_t cnt = 0;
+  HIPCHK(hipMemcpy(&cnt, e->d_stream_ctl.p + SC_TRACE, 4, hipMemcpyDeviceToHost));
+  cnt = std::min<uint32_t>(cnt, std::min<uint32_t>(cap, PM_STREAM_TRACE_CAP));
+  if (cnt) HIPCHK(hipMemcpy(out, e->d_stream_trace.p, size_t(cnt) * 16, hipMemcpyDeviceToHost));
+  *n = cnt;
   return PM_OK;
 }
 

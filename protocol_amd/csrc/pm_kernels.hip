@@ -862,7 +862,7 @@ __device__ __forceinline__ void ctx_set_geometry(StepCtx& c) {
 }
 
 enum { FAST_DONE = 0, FAST_SLOW = 1, FAST_OVERFLOW = 2, FAST_AGAIN = 3, FAST_REPROPOSE = 4, FAST_SEQ = 5, FAST_WIDEN = 6,
-       FAST_ABORT = 7 };
+       FAST_ABORT = 7, FAST_TAIL = 8, FAST_TINY = 9, FAST_RANOUT = 10 };
 
 #ifdef PM_CARVE_PROF_FINE
 #define PROF_COUNT(slot) do { if (lane == 0) G(p.status)->prof[slot] += 1; } while (0)
@@ -1019,6 +1019,7 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
     const uint32_t want = c.max_s - 1u < c.n_cand - 1u ? c.max_s - 1u : c.n_cand - 1u;  // mod.rs:545-551
     if (c.n_groups >= cap_groups || c.mem_off + want + 1u > cap_members) FAST_RETURN(FAST_OVERFLOW);
 
+    if (STREAM && f_loc == PM_NONE) FAST_RETURN(FAST_TAIL);  // (the whole workgroup drains the tail: stream_first_come)
     if (f_loc == PM_NONE) {
       // no located candidate (or proximity off): the group is the first `want + 1` live slots in input
       // order (mod.rs:553-561; a seed without location makes the sort a no-op, :238).
@@ -1116,7 +1117,25 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
     const bool alive = lane < n_k && alive_at(slot);
     const uint64_t am = __ballot(alive);
     const uint32_t rank = __popcll(am & ((1ull << lane) - 1ull));
-    if ((uint32_t)__popcll(am) < want) {  SLOW_RETURN(25); }  // row exhausted by earlier groups
+#ifdef PM_CARVE_PROF  // (timeline of the streaming carve: a row that ran out — entries, live ones, wanted, flags)
+    if (STREAM && (uint32_t)__popcll(am) < want && lane == 0 && p.stream_trace) {
+      const uint32_t ti_ = atomicAdd(&p.stream_ctl[SC_TRACE], 1u);
+      if (ti_ < PM_STREAM_TRACE_CAP) {
+        p.stream_trace[2u * ti_] = __builtin_amdgcn_s_memtime();
+        p.stream_trace[2u * ti_ + 1u] = 14ull | ((unsigned long long)((n_k | ((uint32_t)__popcll(am) << 8) | (want << 16)) & 0xFFFFFFu) << 8) |
+                                        ((unsigned long long)(nk_word >> 16) << 32);
+      }
+    }
+#endif
+    if ((uint32_t)__popcll(am) < want) {  // row exhausted by earlier groups
+      if (STREAM) {  // (the streaming carve wants to know: the rows requested along with this one are as old)
+#ifdef PM_CARVE_PROF
+        if (lane == 0) G(p.status)->prof[25] += 1;
+#endif
+        FAST_RETURN(FAST_RANOUT);
+      }
+      SLOW_RETURN(25);
+    }
     const bool sel = alive && rank < want;
     // the proposer certified the whole row (clean, safe) and its tail (complete / tail_clear): nothing left to prove
     if (want > 0 && !(row_clean && row_safe && (complete || tail_clear))) {
@@ -1214,12 +1233,12 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
 #define CHAIN_BLOCK 8u
 #endif
 #ifndef CHAIN_RING
-#define CHAIN_RING 32u                                 // rows parked in LDS (a power of two, >= 2 blocks)
-#endif
+#define CHAIN_RING 64u                                 // rows parked in LDS (a power of two, >= 2 blocks; 32 until the
+#endif                                                 // streaming carve's four parkers filled it faster than it drained)
 // LDS layout of the chain inside the (idle) key array, in 32-bit words: per ring entry and lane (bitmap word address,
 // bit) as one 64-bit word and the slot; per ring entry the seed number, the digested flags and the live mask; the
 // control block; then the member buffer
-#define CHAIN_RING_WORDS (3u * CHAIN_RING * 64u + 4u * CHAIN_RING + 16u)
+#define CHAIN_RING_WORDS (3u * CHAIN_RING * 64u + 5u * CHAIN_RING + 16u)
 #define CHAIN_STAGE_WORDS (PM_CARVE_SLOTS * 2u - CHAIN_RING_WORDS)
 // control words (u32 index into the control block)
 enum { CC_HEAD = 0, CC_CRIT = 1, CC_TAIL = 2, CC_CMD = 3, CC_ACK1 = 4, CC_ACK2 = 5, CC_START = 6, CC_DONE = 7,
@@ -1236,7 +1255,7 @@ __device__ __forceinline__ void cc_st(chain_lds_u32* p, uint32_t v) {
 }
 struct ChainLds {
   chain_lds_u64 *RAB, *Q;
-  chain_lds_u32 *RE, *RI, *RM, *CC, *STAGE;
+  chain_lds_u32 *RE, *RI, *RM, *RS, *CC, *STAGE;  // (RS: streaming carve — entry q of a run is parked when RS[q % R] == q + 1)
 };
 __device__ __forceinline__ ChainLds chain_lds(uint32_t* l_buf) {
   ChainLds L;
@@ -1245,7 +1264,8 @@ __device__ __forceinline__ ChainLds chain_lds(uint32_t* l_buf) {
   L.RE = (chain_lds_u32*)(L.Q + CHAIN_RING);
   L.RI = L.RE + CHAIN_RING * 64u;
   L.RM = L.RI + CHAIN_RING;
-  L.CC = L.RM + CHAIN_RING;
+  L.RS = L.RM + CHAIN_RING;
+  L.CC = L.RS + CHAIN_RING;
   L.STAGE = L.CC + 16u;
   return L;
 }
@@ -1726,11 +1746,17 @@ __device__ __noinline__ int carve_chain(const CarveArgs& p, StepCtx& c_ref, uint
 // One exact step of a configuration (the reference's filter + sort + take, mod.rs:511-561, evaluated as it stands):
 // keys for every live candidate, two-level selection (DPP argmin rounds per wave, 8-way merge), certificate, commit.
 // The whole workgroup; three LDS-only barriers.  STEP_CONTINUE = one group committed.
-template <bool BIG>
+// SPARSE (streaming carve, where slot == position and a list is as long as the eligible list whatever is left of it):
+// the sweeps run over the live candidates only — `cl` lists their slots, ascending, n_cl of them, keys are indexed
+// like `cl` — so a step costs what is left, not what there was.
+template <bool BIG, bool SPARSE = false>
 __device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, StepCtx& c, const uint32_t* l_wid,
                                              uint64_t* l_key, uint64_t* l_alive, const uint64_t* l_loc, uint64_t* part,
-                                             uint32_t* sel_out, uint32_t steps_before, unsigned long long* mirror) {
+                                             uint32_t* sel_out, uint32_t steps_before, unsigned long long* mirror,
+                                             const uint32_t* cl = nullptr, uint32_t n_cl = 0u) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_it = SPARSE ? n_cl : c.n_list;  // entries the sweeps run over
+  auto slot_of = [cl](uint32_t i) -> uint32_t { return SPARSE ? cl[i] : i; };
   constexpr uint32_t SB = BIG ? PM_CARVE_SLOT_BITS_BIG : PM_CARVE_SLOT_BITS;
   constexpr double band_rel = BIG ? PM_TIE_BAND_BIG : PM_TIE_BAND;
   const uint32_t lw = (c.n_list + 63u) >> 6;
@@ -1799,9 +1825,10 @@ __device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, 
     // ---- keys (registers only; the seed's coordinates are one uniform load each)
     const double slat = G(p.cc_lat)[seed], slon = G(p.cc_lon)[seed], scos = G(p.cc_cos)[seed];
     uint64_t lmin = ~0ull;
-    for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
+    for (uint32_t i = tid; i < n_it; i += CARVE_THREADS) {
+      const uint32_t s = slot_of(i);
       uint64_t k = ~0ull;
-      if (s != seed && bit_at(l_alive, s)) {
+      if (s != seed && (SPARSE || bit_at(l_alive, s))) {
         if (!use_dist) {
           k = s;
         } else if (bit_at(l_loc, s)) {
@@ -1811,7 +1838,7 @@ __device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, 
           k = pack_key(PM_KEY_NOLOC, s, SB);
         }
       }
-      l_key[s] = k;
+      l_key[i] = k;
       lmin = k < lmin ? k : lmin;
     }
       n_sel = 0;
@@ -1827,8 +1854,8 @@ __device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, 
           ++cnt;
           if (lmin == v) {  // the owning lane advances to its next element (keys are unique)
             uint64_t m = ~0ull;
-            for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
-              const uint64_t k = l_key[s];
+            for (uint32_t i = tid; i < n_it; i += CARVE_THREADS) {
+              const uint64_t k = l_key[i];
               m = (k > v && k < m) ? k : m;
             }
             lmin = m;
@@ -1875,8 +1902,8 @@ __device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, 
           ++n_sel;
           if (lmin == b) {
             uint64_t m = ~0ull;
-            for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
-              const uint64_t k = l_key[s];
+            for (uint32_t i = tid; i < n_it; i += CARVE_THREADS) {
+              const uint64_t k = l_key[i];
               m = (k > b && k < m) ? k : m;
             }
             lmin = m;
@@ -1903,8 +1930,9 @@ __device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, 
     const double band = a_m * band_rel + 1e-300;
     const double mlat = G(p.cc_lat)[ls], mlon = G(p.cc_lon)[ls];  // uniform loads
     if (a_m > PM_A_MAX_SAFE) uncertain = 1;
-    for (uint32_t s = tid; s < c.n_list; s += CARVE_THREADS) {
-      const uint64_t k = l_key[s];
+    for (uint32_t i = tid; i < n_it; i += CARVE_THREADS) {
+      const uint32_t s = slot_of(i);
+      const uint64_t k = l_key[i];
       const uint64_t kb = (k >> SB) << SB;
       const double a = __longlong_as_double((long long)kb);
       const bool near = k != ~0ull && kb != noloc_key && fabs(a - a_m) <= band;
@@ -1925,16 +1953,27 @@ __device__ __noinline__ int carve_exact_step(const CarveArgs& p, BlockRed& red, 
 
   // ---- commit (create_group_atomically mod.rs:299-322; healthy_nodes.retain :585): selected slots =
   // seed + every key <= last.  Each wave owns whole bitmap words (slot>>6 == j*16 + wave): ballot writes them.
-  for (uint32_t wj = wave; wj < lw; wj += CARVE_WAVES) {  // wave-uniform
-    const uint32_t s = wj * 64u + lane;
-    const bool was = bit_at(l_alive, s);
-    const bool sel = was && (s == seed || (n_sel > 0 && l_key[s] <= last));
-    const uint64_t nw = __ballot(was && !sel);
-    const uint64_t ow = __ballot(was);
-    if (lane == 0) {
-      l_alive[wj] = nw;
-      // (streaming carve: the proposers' copy of the bitmap follows every removal)
-      if (mirror && ow != nw) __hip_atomic_fetch_and(&mirror[wj], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (SPARSE) {  // (a handful of bits among the live candidates: one atomic each, here and in the published copy)
+    for (uint32_t i = tid; i < n_it; i += CARVE_THREADS) {
+      const uint32_t s = slot_of(i);
+      if (s == seed || (n_sel > 0 && l_key[i] <= last)) {
+        atomicAnd((unsigned long long*)&l_alive[s >> 6], ~(1ull << (s & 63u)));
+        if (mirror) __hip_atomic_fetch_and(&mirror[s >> 6], ~(1ull << (s & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else {
+    for (uint32_t wj = wave; wj < lw; wj += CARVE_WAVES) {  // wave-uniform
+      const uint32_t s = wj * 64u + lane;
+      const bool was = bit_at(l_alive, s);
+      const bool sel = was && (s == seed || (n_sel > 0 && l_key[s] <= last));
+      const uint64_t nw = __ballot(was && !sel);
+      const uint64_t ow = __ballot(was);
+      if (lane == 0) {
+        l_alive[wj] = nw;
+        // (streaming carve: the published bitmap of free positions follows every removal — it holds every
+        // configuration's candidates, so only the bits this step took are cleared)
+        if (mirror && ow != nw) __hip_atomic_fetch_and(&mirror[wj], ~(ow ^ nw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   if (wave == 0) {  // group record + members: LDS -> fire-and-forget global stores
@@ -2557,7 +2596,8 @@ __device__ __forceinline__ void cell_drain(const CarveArgs& p, uint32_t* wl, uin
 template <bool STREAM = false>
 __device__ __forceinline__ void cell_offer_runs(const CarveArgs& p, uint32_t* wl, uint32_t b, uint32_t len, uint32_t lane, uint32_t s,
                                                 bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps,
-                                                NearRow& q, uint32_t& n_mine) {
+                                                NearRow& q, uint32_t& n_mine,
+                                                const uint32_t* cfg32 = nullptr) {
   uint32_t incl = len;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -2589,11 +2629,14 @@ __device__ __forceinline__ void cell_offer_runs(const CarveArgs& p, uint32_t* wl
     // (streaming carve: an entry's slot is its position for the whole carve; whether it is a candidate of the
     // configuration being carved, and still free, is one bit of the validator's published bitmap)
     uint32_t cw[4] = {~0u, ~0u, ~0u, ~0u};
-    if (STREAM) {
-      const auto candg = G((const uint32_t*)p.bits_scratch);
+    if (STREAM) {  // free (the validator's published bitmap, a little behind) and compatible with the configuration
+      const auto freeg = G((const uint32_t*)p.bits_scratch);
+      const auto cfgb = G(cfg32);
 #pragma unroll
-      for (uint32_t v = 0; v < 4u; ++v)
-        cw[v] = __hip_atomic_load(&candg[(in[v] ? t[v] : 0u) >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t v = 0; v < 4u; ++v) {
+        const uint32_t wi = (in[v] ? t[v] : 0u) >> 5;
+        cw[v] = __hip_atomic_load(&freeg[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cfgb[wi];
+      }
     }
 #pragma unroll
     for (uint32_t v = 0; v < 4u; ++v) {
@@ -2654,7 +2697,8 @@ __device__ __forceinline__ uint32_t ring_runs(uint32_t r) { return r ? 8u * r + 
 template <bool STREAM = false>
 __device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, uint32_t g, uint32_t r_max, uint32_t lane, uint32_t s,
                                           bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps, NearRow& q,
-                                          uint32_t& n_mine) {
+                                          uint32_t& n_mine,
+                                          const uint32_t* cfg32 = nullptr) {
   const double h = 2.0 / (double)g;
   const int cx = (int)cell_coord(sg.ux, g), cy = (int)cell_coord(sg.uy, g), cz = (int)cell_coord(sg.uz, g);
   const auto cstart = G((const uint32_t*)p.cell_start);
@@ -2671,10 +2715,10 @@ __device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, 
       b = cstart[lb];
       e = cstart[le];
     }
-    cell_offer_runs<STREAM>(p, wl, b, (ok && lane <= 10u) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+    cell_offer_runs<STREAM>(p, wl, b, (ok && lane <= 10u) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine, cfg32);
     if (cell_bound_key(h, 0.0, 0.0, SB) > q.tau_hi) return 2u;
     if (r_max < 2u || g <= 2u) return 0u;
-    cell_offer_runs<STREAM>(p, wl, b, (ok && lane > 10u && !(lbk > q.tau_hi)) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+    cell_offer_runs<STREAM>(p, wl, b, (ok && lane > 10u && !(lbk > q.tau_hi)) ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine, cfg32);
   }
   for (uint32_t r = 3u;; ++r) {
     if (cell_bound_key((double)(r - 1u) * h, 0.0, 0.0, SB) > q.tau_hi) return r;  // nothing of interest from this ring on
@@ -2692,7 +2736,7 @@ __device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, 
         e = cstart[le];
       }
       if (!__ballot(ok && e > b)) continue;
-      cell_offer_runs<STREAM>(p, wl, b, ok ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine);
+      cell_offer_runs<STREAM>(p, wl, b, ok ? e - b : 0u, lane, s, shared, ssite, sg, SB, ulps, q, n_mine, cfg32);
     }
   }
 }
@@ -2700,7 +2744,8 @@ __device__ __forceinline__ uint32_t cell_walk(const CarveArgs& p, uint32_t* wl, 
 template <bool STREAM = false>
 __device__ __forceinline__ void list_sweep_solo(const CarveArgs& p, uint32_t n_list, uint32_t lane, uint32_t s, bool shared,
                                              uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps, NearRow& q,
-                                             uint32_t& n_mine) {
+                                             uint32_t& n_mine,
+                                             const uint64_t* cfg64 = nullptr) {
   const auto alive = G((const uint64_t*)p.bits_scratch);
   const auto loc = G((const uint64_t*)p.bits_scratch) + p.bits_stride;
   for (uint32_t t0 = 0; t0 < n_list; t0 += 256u) {
@@ -2712,7 +2757,7 @@ __device__ __forceinline__ void list_sweep_solo(const CarveArgs& p, uint32_t n_l
       const uint32_t tb = t0 + v * 64u, t = tb + lane, tc = t < n_list ? t : n_list - 1u;
       const bool w_in = tb < n_list;
       // (the bitmaps are zero beyond the list; streaming carve: the validator clears bits while this runs)
-      aw[v] = !w_in ? 0ull : STREAM ? __hip_atomic_load(&alive[tb >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : alive[tb >> 6];
+      aw[v] = !w_in ? 0ull : STREAM ? (__hip_atomic_load(&alive[tb >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & G(cfg64)[tb >> 6]) : alive[tb >> 6];
       lw[v] = w_in ? loc[tb >> 6] : 0ull;
       x[v] = G(p.cc_ux)[tc];
       y[v] = G(p.cc_uy)[tc];
@@ -3422,8 +3467,11 @@ __global__ __launch_bounds__(256) void carve_elig_place_kernel(const CarveArgs* 
   __syncthreads();
   const uint32_t n = s_red[1] + s_red[2] + s_red[3] + s_red[4];
   const uint32_t n_words = (n + 63u) >> 6;
-  for (uint32_t j = tid; j < n_words; j += 256u)
-    G(p.alive_g)[j] = (j + 1u < n_words || (n & 63u) == 0u) ? ~0ull : ((1ull << (n & 63u)) - 1ull);
+  for (uint32_t j = tid; j < n_words; j += 256u) {
+    const uint64_t all = (j + 1u < n_words || (n & 63u) == 0u) ? ~0ull : ((1ull << (n & 63u)) - 1ull);
+    G(p.alive_g)[j] = all;
+    if (p.stream) G(p.bits_scratch)[j] = all;  // (streaming carve: the published copy of "what no group holds yet")
+  }
   if (tid <= PM_MAX_CONFIGS + 1u) p.prep_counts[tid] = 0u;  // totals + tickets of the first list preparation
   if (tid == 0) {
     st->n_eligible = n;

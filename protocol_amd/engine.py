@@ -472,9 +472,9 @@ class Engine:
         L = lib()
         L.pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
         L.pm_debug_carve_prof.restype = C.c_int32
-        out = (C.c_ulonglong * 54)()
-        check(L.pm_debug_carve_prof(self._h, out, 54))
-        w = [int(v) for v in out[32:54]]
+        out = (C.c_ulonglong * 56)()
+        check(L.pm_debug_carve_prof(self._h, out, 56))
+        w = [int(v) for v in out[32:56]]
         return {"why": w[:8], "batches": w[8], "void_launches": w[9], "pruned_batches": w[10], "prune_fallbacks": w[11],
                 "cell_g": w[12], "n_indexed": w[13],
                 # the streaming carve (carve_variant 0): did the last carve stream, seeds handed to the proposers, rows the
@@ -482,7 +482,8 @@ class Engine:
                 # configurations entered with a list, proposer workgroups, launches that gave up (-> batch pipeline),
                 # steps that took the exact sweep
                 "stream": w[14], "stream_tickets": w[15], "stream_timeouts": w[16], "stream_switches": w[17],
-                "stream_listed": w[18], "stream_wgs": w[19], "stream_aborts": w[20], "slow_steps": w[21]}
+                "stream_listed": w[18], "stream_wgs": w[19], "stream_aborts": w[20], "slow_steps": w[21],
+                "stream_pre_used": w[22], "stream_pre_lost": w[23]}
 
     def debug_prune_mode(self, mode: int):
         """test hook (pm_internal.h): 0 the proposer always sweeps the whole candidate list, 1 it walks the spatial index
