@@ -948,10 +948,12 @@ __device__ __noinline__ int carve_fast_steps(const CarveArgs& p, StepCtx& c_ref,
         // candidate.  Behind the last ticket issued, the bitmaps say.
         typedef __attribute__((address_space(3))) uint32_t sl_u32;
         const sl_u32* const TP = (const sl_u32*)sl_words;
-        const uint32_t t_req = UNI(TP[PM_STREAM_TP]);  // (StreamLds::t_req)
+        const uint32_t t_req = UNI(TP[PM_STREAM_SLW_TREQ]);
+        const uint32_t ci_now = (UNI(TP[PM_STREAM_SLW_PAY]) >> 18) & 63u;  // (tickets of other configurations are skipped)
         while (cur != PM_NONE && cur < t_req) {
-          const uint32_t pos = UNI(TP[cur & (PM_STREAM_TP - 1u)]);
-          if (alive_at(pos)) {
+          const uint32_t tp = UNI(TP[cur & (PM_STREAM_TP - 1u)]);
+          const uint32_t pos = tp & 0x3FFFFu;
+          if ((tp >> 18) == ci_now && alive_at(pos)) {
             f_loc = pos;
             break;
           }
