@@ -309,7 +309,9 @@ typedef struct {
   float ms_compat_kernel, ms_carve_kernel, ms_sweep_kernel;
   uint32_t n_groups, n_formed, n_merged;
   uint32_t carve_steps;         /* groups carved + merge selections done on the GPU */
-  uint32_t carve_fast_steps;    /* of which committed straight from a neighbour-list proposal */
+  uint32_t carve_fast_steps;    /* of which committed without an exact sweep by the whole workgroup: straight from a
+                                   neighbour-list proposal, first-come, or (streaming carve) in registers at the end of
+                                   a configuration's located phase */
   uint32_t host_resolved_steps; /* carve steps whose near-tie was settled by the exact host path */
   uint32_t carve_launches;
   uint64_t pair_evals;          /* T x W of the sweep */

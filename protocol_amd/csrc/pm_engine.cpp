@@ -245,6 +245,7 @@ struct pm_engine {
   uint32_t stream_wgs_env = 0;   // PM_STREAM_WGS: proposer workgroups (0 = by the size of the eligible list)
   uint32_t stream_la_env = 0;    // PM_STREAM_LA: look-ahead cap (0 = the kernel's default)
   uint32_t stream_la_div_env = 0;  // PM_STREAM_LA_DIV: look-ahead divisor (0 = the kernel's default)
+  uint32_t stream_row_spins_env = 0;  // PM_STREAM_ROW_SPINS: polls before the validator gives a row up (0 = default)
   uint32_t n_cus = 256;
   uint32_t tick_stream_timeouts = 0, tick_stream_tickets = 0, tick_stream_aborts = 0;
   DevBuf<uint64_t> d_ikeys, d_umask;  // per-task orientation: table of the distinct topology masks, the masks densely
@@ -656,7 +657,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
 #endif
     a->stream_la = e->stream_la_env;
     a->stream_la_div = e->stream_la_div_env;
-    a->stream_row_spins = 0;
+    a->stream_row_spins = e->stream_row_spins_env;
   }
   return PM_OK;
 }
@@ -959,7 +960,8 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
   r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
   // The streaming carve: one engine, one call, positions that fit the validator's LDS bitmaps.  Everything else (the
   // stepwise multi-GPU tick, swarms beyond 262,144 unassigned rows) goes through the batch pipeline.
-  r->stream = r->single_call && r->use_props && e->cfg.carve_variant == 0 && e->dist_world == 1 && r->n_bound <= PM_CARVE_BIG_SLOTS;
+  r->stream = r->single_call && r->use_props && e->cfg.carve_variant == 0 && e->dist_world == 1 && r->n_bound <= PM_CARVE_BIG_SLOTS &&
+              !e->debug_mem_above;  // (the test hook for the all-in-HBM lists is the batch pipeline's)
   rc = form_setup_args(e, r);
   if (rc) return rc;
   HIPCHK(hipEventRecord(e->kev[2], e->stream));
@@ -1745,6 +1747,10 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
   if (const char* v = getenv("PM_STREAM_WGS")) {
     const long f = atol(v);
     if (f > 0 && f < 4096) e->stream_wgs_env = uint32_t(f);
+  }
+  if (const char* v = getenv("PM_STREAM_ROW_SPINS")) {  // (tests: a validator that hardly waits for its rows)
+    const long f = atol(v);
+    if (f > 0 && f < (1l << 24)) e->stream_row_spins_env = uint32_t(f);
   }
   if (const char* v = getenv("PM_STREAM_LA_DIV")) {
     const long f = atol(v);

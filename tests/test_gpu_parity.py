@@ -721,3 +721,22 @@ def test_task_deltas_equal_a_fresh_upload():
         assert a.T == b.T == len(masks)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("env", [{"PM_STREAM_LA": "24"}, {"PM_STREAM_WGS": "1"}, {"PM_STREAM_ROW_SPINS": "1", "PM_STREAM_WGS": "2"},
+                                 {"PM_STREAM_LA": "1024", "PM_STREAM_LA_DIV": "16"}])
+def test_streaming_carve_under_pressure(env, monkeypatch):
+    """The streaming carve (carve_variant 0) with its knobs turned the wrong way: a look-ahead of two dozen tickets, a
+    single proposer workgroup, a validator that gives a row up after one poll (every such seed is a step for the exact
+    sweep), a window far too wide (rows run out of live entries: exact steps, refreshes).  None of it may change a group."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for sw in (baseline_config(0, seed=3), make_swarm(31, 2000, 3000), baseline_config(1, seed=2)):
+        st = oracle_state_for(sw, reference_shaped=(sw.W <= 2048), group_id_seed=7)
+        eng = E.Engine(group_id_seed=7)
+        host.load_swarm(eng, sw)
+        assert st.try_form_new_groups() == eng.form_groups()
+        assert oracle_groups(st) == engine_groups(eng), env
+        c = eng.debug_carve_counters()
+        assert c["stream"] == 1 and c["stream_aborts"] == 0, c
+        eng.close()
