@@ -208,8 +208,12 @@ def kernel_table(sw, stats, T, W, prop):
                   "launches": med(stats, "carve_launches")},
         "carve_propose_kernel": {"ms": prop_ms, "proposals": prop["proposals"], "keys": keys,
                                  "keys_per_proposal": keys / prop["proposals"] if prop["proposals"] else None,
+                                 "proposals_per_group": prop["proposals"] / steps,
                                  "spatial_index": prop.get("index"),
-                                 "timing": "separate pass with hipEvents around every proposer launch",
+                                 "timing": ("separate pass with hipEvents around every proposer launch" if prop_ms > 0 else
+                                            "streaming carve: the proposer workgroups run INSIDE carve_stream_kernel, "
+                                            "concurrently with the validator's chain — no launch of their own to time; "
+                                            "proposals = tickets issued, keys from a separate counting pass"),
                                  "keys_per_s": keys / (prop_ms * 1e-3) if prop_ms > 0 else None,
                                  "valu_ops_per_key": VALU_OPS_PER_KEY,
                                  "valu_frac": (keys * VALU_OPS_PER_KEY / (prop_ms * 1e-3) / VALU_LANE_OPS) if prop_ms > 0 else None,
@@ -225,8 +229,11 @@ def chain_model(steps, carve_ms, prop_ms):
     floor_us = 3.0 * LDS_ROUND_TRIP_CYC / (CLOCK_GHZ * 1e3)
     val_ms = max(carve_ms - prop_ms, 0.0)
     return {"model": ("group g+1's seed depends on what group g removed: a chain of dependent steps; floor per step = 3 "
-                      "dependent LDS round trips (row -> live bits -> kill) of ~50 cycles at 2.4 GHz; the preparation "
-                      "and proposer launches between the validation launches are on the chain too (one batch at a time)"),
+                      "dependent LDS round trips (row -> live bits -> kill) of ~50 cycles at 2.4 GHz.  Streaming carve "
+                      "(carve_variant 0): ONE launch, the rows are made by the other workgroups while the chain runs, so "
+                      "what is left on the chain besides the steps is waiting for rows at the start of a configuration; "
+                      "batch pipeline (variant 3): the preparation and proposer launches between the validation "
+                      "launches are on the chain too"),
             "steps": steps, "floor_us_per_step": floor_us, "achieved_us_per_step": 1e3 * carve_ms / max(steps, 1),
             "validate_only_us_per_step": 1e3 * val_ms / max(steps, 1),
             "frac": floor_us / (1e3 * carve_ms / max(steps, 1)) if carve_ms > 0 else None}
@@ -248,16 +255,16 @@ def run_extra_configs2(E, host, seed):
     out = {"workload": "BASELINE configs[2]: 1M tasks x 100k workers, Zipf-skewed topologies, cold match",
            "steps": len(stats), "ms_per_match": med(stats, "ms_total"), "groups": int(stats[-1]["n_groups"]),
            "pair_evals_per_s": sw.T * sw.W / (med(stats, "ms_total") * 1e-3),
-           "carve_ms": med(stats, "ms_carve"), "propose_ms": prop["ms"],
-           "validate_ms": prop["ms_carve_kernel_with_events"] - prop["ms"],
+           "carve_ms": med(stats, "ms_carve"), "carve_kernel_ms": med(stats, "ms_carve_kernel"),
+           "carve_launches": med(stats, "carve_launches"),
            "sweep_ms": med(stats, "ms_sweep"), "compat_ms": med(stats, "ms_compat"), "publish_ms": med(stats, "ms_publish"),
            "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
-           "roofline": {"bound": "valu", "kernel": "carve_propose_kernel",
-                        "achieved": (kt["carve_propose_kernel"]["keys_per_s"] or 0.0) * VALU_OPS_PER_KEY / 1e12,
-                        "peak": VALU_LANE_OPS / 1e12, "unit": "T lane-ops/s",
-                        "frac": kt["carve_propose_kernel"]["valu_frac"],
-                        "note": (f"keys x {VALU_OPS_PER_KEY:.0f} VALU lane-ops (ISA count) / summed proposer launch time; "
-                                 "peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz")},
+           "roofline": {"bound": "latency-chain", "kernel": "carve_stream_kernel (the dominant kernel of this match)",
+                        "achieved": kt["carve"]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (kt["carve"]["GB/s"] or 0.0) / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic("configs2_carve")[0],
+                        "note": ("SURVEY 8(d) accounting (W_remaining*20+8 bytes per step) over the carve's launch sequence; "
+                                 "what binds it is the dependent chain of steps — see `chain` (floor per step vs achieved)")},
            "kernels": kt,
            "chain": chain_model(kt["carve"]["steps"], kt["carve"]["ms"], kt["carve_propose_kernel"]["ms"])}
     # the north_star orientation at this size (the first call allocates its buffers: not timed)
@@ -316,6 +323,39 @@ def run_extra_pools(E, host, seed, ks=(2, 4), steps=8):
     return out
 
 
+def run_extra_merge(E, host, seed, reps=3):
+    """try_merge_solo_groups (mod.rs:631-971) on its own workload: 100k workers, ~5,000 standing solo groups, a (2, 8)
+    configuration gets enabled and pm_merge_solo_groups merges them.  The digest covers the life-cycle feed of the merge
+    (per merged group, in creation order: the dissolved solos in batch order, then the new group) —
+    tests/test_gpu_scale.py::test_solo_merge_of_the_bench_workload checks the same digest against the oracle."""
+    from protocol_amd.swarm import events_digest, solo_merge_swarm
+    sw = solo_merge_swarm(seed)
+    eng = E.Engine(group_id_seed=seed)
+    host.load_swarm(eng, sw, enabled=0b01)
+    eng.enable_group_events()
+    ms, digest, n_solo, n_merged, launches = [], None, 0, 0, 0
+    for k in range(reps + 1):
+        eng.reset_groups()
+        eng.set_enabled_mask(0b01)
+        n_solo = eng.form_groups()
+        eng.drain_group_events()
+        eng.set_enabled_mask(0b11)
+        t0 = time.perf_counter()
+        n_merged = eng.merge_solo_groups()
+        dt = 1e3 * (time.perf_counter() - t0)
+        ev = eng.drain_group_events()
+        if k:
+            ms.append(dt)
+        if digest is None:   # (group ids continue the engine's id stream: the first pass is the seeded one)
+            digest = events_digest(ev)
+    eng.close()
+    return {"workload": "100k workers, ~5,000 solo groups of a (1, 1) configuration; a (2, 8) configuration is enabled and "
+                        "pm_merge_solo_groups merges them",
+            "workers": int(sw.W), "solos": int(n_solo), "merged_groups": int(n_merged), "ms_p50": statistics.median(ms),
+            "ms": ms, "events_digest": digest,
+            "note": "host bookkeeping is linear in the solos (dead-marking + one compaction, one host wait per kernel launch)"}
+
+
 def run_extra_churn(E, host, seed, ticks=6):
     """BASELINE configs[4] on one GPU (the 8-GPU form is `--gpus 8`): 100k workers; per tick 10k tasks arrive, 1 % of
     the workers die and 1 % brand-new workers join; one incremental match on the standing groups.  The stream is
@@ -357,7 +397,7 @@ def run_extra_churn(E, host, seed, ticks=6):
     return {"workload": ("BASELINE configs[4] on one GPU: 100k workers, per tick +10k tasks (pm_tasks_insert_front), 1% "
                          "workers die (one pm_on_worker_status_many call), 1% brand-new workers (pm_append_workers), incremental "
                          "pm_tick on the standing groups"),
-            "pinned_by": "tests/golden/churn_digests.json (the first three ticks of this stream against the oracle)",
+            "pinned_by": "tests/golden/churn_digests.json (all eight ticks of this stream — the two warm-up ticks and the six timed ones — against the oracle)",
             "ticks": len(out_ticks), "cold_match_ms": s0["ms_total"],
             "ms_per_tick": m("status_ms") + m("append_ms") + m("tasks_ms") + m("match_ms"),
             "split_ms_p50": {k: m(k) for k in ("status_ms", "append_ms", "tasks_ms", "match_ms", "carve_ms", "sweep_ms",
@@ -484,7 +524,9 @@ def main() -> int:
         "phase_ms_p50": {k: med(stats, k) for k in ("ms_compat", "ms_carve", "ms_merge", "ms_sweep", "ms_publish")},
         "groups": int(stats[-1]["n_groups"]), "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
         "roofline": {"bound": "latency-chain",
-                     "kernel": "carve (preparation + carve_propose_kernel + carve_kernel launch sequence)",
+                     "kernel": ("carve_stream_kernel (+ its list preparation and carve_finish_kernel: one launch sequence, "
+                                "one hipEvent pair)" if args.carve_variant == 0 else
+                                "carve (preparation + carve_propose_kernel + carve_kernel launch sequence)"),
                      "achieved": carve["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (carve["GB/s"] or 0.0) / HBM_PEAK_GBS,
                      "bound_note": ("achieved / peak / frac are the contract's HBM accounting (algorithmic bytes over the "
@@ -605,7 +647,8 @@ def main() -> int:
         out["parity_vs_oracle"] = got == [(gid, c, m) for (_s, gid, c, m, _t) in st.groups()]
     eng.close()
     if single and not args.no_extras:
-        for key, fn in (("configs2", run_extra_configs2), ("churn", run_extra_churn), ("pools_on_one_gpu", run_extra_pools)):
+        for key, fn in (("configs2", run_extra_configs2), ("churn", run_extra_churn), ("merge", run_extra_merge),
+                        ("pools_on_one_gpu", run_extra_pools)):
             try:
                 out[key] = fn(E, host, args.seed)
             except Exception as ex:

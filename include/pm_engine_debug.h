@@ -1,0 +1,43 @@
+/* pm_engine_debug.h — test hooks and instrumentation of libpm_engine.so.
+ *
+ * NOT part of the drop-in boundary (include/pm_engine.h is; the Rust shim binds nothing from here).  These entry
+ * points exist for tests/, tools/ and bench.py: they force code paths a test could not otherwise reach, or read
+ * counters back.  They are exported by every build of the library so that the tests run against the shipped binary;
+ * tests/test_host_helpers.py checks that each one declared here is exported.
+ */
+#ifndef PM_ENGINE_DEBUG_H
+#define PM_ENGINE_DEBUG_H
+
+#include "pm_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Counters of the last carve.  out[0..32) and out[56..72): s_memtime phase counters (all zero unless the library was
+ * built with -DPM_CARVE_PROF: tools/stream_prof.py, tools/carve_prof.py); out[32..56): how the carve went — reasons
+ * its launches ended, index geometry, streaming-carve tickets / timeouts / switches (protocol_amd/engine.py
+ * debug_carve_counters names them).  Copies min(cap, 72) words. */
+int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap);
+
+/* Timeline of the last streaming carve launch (PM_CARVE_PROF builds; otherwise *n = 0): up to cap events of two words
+ * {s_memtime, type | a << 8 | b << 32}; tools/stream_trace.py decodes them. */
+int32_t pm_debug_stream_trace(pm_engine* e, unsigned long long* out, uint32_t cap, uint32_t* n);
+
+/* Test hook: candidate lists longer than n slots take the all-in-HBM carve path (carve_step_mem), which otherwise
+ * needs more than 262,144 candidates of one configuration; 0 = off. */
+int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n);
+
+/* Test hook / experiment: when the proposers walk the spatial index instead of sweeping the whole candidate list —
+ * 0 never, 1 when it pays (default), 2 whenever the carve has an index, 3 = 2 with every seed forced through the
+ * whole-list fallback.  (PM_PRUNE_MODE in the environment sets the default of new engines.) */
+int32_t pm_debug_prune_mode(pm_engine* e, uint32_t mode);
+
+/* Stream triad (a = b + 3c, f64) over 3 x n_doubles on the engine's stream, best of reps: the measured HBM rate
+ * bench.py cites beside the roofline's 8 TB/s. */
+int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

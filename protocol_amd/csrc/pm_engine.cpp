@@ -1574,31 +1574,48 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
   std::vector<uint32_t> avail;
   available_order(e->cfgs.data(), uint32_t(e->cfgs.size()), e->enabled, &avail);
   uint32_t merged = 0;
+  // Linear in the number of solo groups: the list is never erased from in the middle (a merged group's old slots are
+  // marked dead and dropped by ONE compaction at the end — the order that leaves is the order erase + push_back leaves,
+  // mod.rs:903-942), group_of is patched for the merged workers only, the workers used by earlier batches are a byte
+  // per worker, and a relaunch costs one host wait.
+  std::vector<uint8_t> used(std::max<size_t>(e->W, 1), 0);
+  std::vector<uint32_t> slots, rem, order, b_n, b_off, mem;
+  std::vector<std::vector<uint32_t>> batches;
+  CarveArgs a;
+  CarveStatus st{}, st_in{};
   for (uint32_t cfg : avail) {  // mod.rs:654
     const pm_config_row& c = e->cfgs[cfg];
+    compact_groups(e);  // (what the previous configuration merged away)
     // get_all_groups (sorted by id string) -> find_compatible_solo_groups (mod.rs:712-734)
-    std::vector<uint32_t> slots;
+    slots.clear();
     for (uint32_t s = 0; s < e->groups.size(); ++s)
       if (e->groups[s].members.size() == 1 && ((e->h_compat[e->groups[s].members[0]] >> cfg) & 1ull)) slots.push_back(s);
-    std::sort(slots.begin(), slots.end(),
-              [&](uint32_t a, uint32_t b) { return hex_id_less(e->groups[a].id, e->groups[b].id); });
     if (slots.size() < c.min_group_size) continue;  // mod.rs:688-691
-    std::vector<uint32_t> rem;
+    std::sort(slots.begin(), slots.end(),
+              [&](uint32_t x, uint32_t y) { return hex_id_less(e->groups[x].id, e->groups[y].id); });
+    rem.clear();
     for (uint32_t s : slots) rem.push_back(e->groups[s].members[0]);
 
     // ---- selection of all batches for this configuration on the GPU (carve kernel, MERGE mode)
-    std::vector<std::vector<uint32_t>> batches;
+    batches.clear();
     {
       rc = push_groups(e);
       if (rc) return rc;
-      std::vector<uint32_t> order = rem;
+      order = rem;
+      auto mark_used = [&](const std::vector<uint32_t>& b) {
+        for (uint32_t w : b) used[w] = 1;
+      };
+      auto drop_used = [&]() {  // the workers of `rem` no batch has taken, in `rem`'s order
+        order.clear();
+        for (uint32_t w : rem)
+          if (!used[w]) order.push_back(w);
+      };
       const size_t cap = std::max<size_t>(e->W, 1);
       HIPCHK(e->d_m_cfg.ensure(cap));
       HIPCHK(e->d_m_n.ensure(cap));
       HIPCHK(e->d_m_off.ensure(cap));
       HIPCHK(e->d_m_members.ensure(cap));
       for (;;) {
-        CarveArgs a;
         rc = fill_carve_args(e, &a, CARVE_MODE_MERGE, uint32_t(order.size()));
         if (rc) return rc;
         a.n_avail = 1;
@@ -1613,39 +1630,36 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
         a.cap_members = uint32_t(cap);
         bool in_lds;
         const size_t lds = carve_lds_bytes(a.bits_stride, &in_lds);
-        CarveStatus st{};
-        st.state = CARVE_STATE_RUNNING;
-        st.steps_total = e->tick_carve_steps;
-        if (!order.empty())
-          HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->d_status.p, &st, sizeof(st), hipMemcpyHostToDevice, e->stream));
+        st_in = CarveStatus{};
+        st_in.state = CARVE_STATE_RUNNING;
+        st_in.steps_total = e->tick_carve_steps;
+        // a launch makes at most order.size() / 2 batches out of at most order.size() members: the three arrays come
+        // back at that bound together with the status — ONE wait per launch
+        const size_t n_o = order.size(), nb_max = std::max<size_t>(n_o / 2, 1);
+        b_n.resize(nb_max);
+        b_off.resize(nb_max);
+        mem.resize(std::max<size_t>(n_o, 1));
+        if (n_o) HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), n_o * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_status.p, &st_in, sizeof(st_in), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
         HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, 0, lds, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));  // `a` is a stack object
-        e->tick_carve_launches++;
         HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(b_n.data(), e->d_m_n.p, nb_max * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(b_off.data(), e->d_m_off.p, nb_max * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(mem.data(), e->d_m_members.p, mem.size() * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
+        e->tick_carve_launches++;
         if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "merge: batch arrays overflow");
         if (st.state != CARVE_STATE_DONE && st.state != CARVE_STATE_UNCERTAIN)
           return set_error(PM_ENODEV, "merge kernel did not complete");
         const uint32_t nb = st.n_groups;
-        if (nb) {
-          std::vector<uint32_t> b_n(nb), b_off(nb), mem(st.n_members);
-          HIPCHK(hipMemcpyAsync(b_n.data(), e->d_m_n.p, nb * 4, hipMemcpyDeviceToHost, e->stream));
-          HIPCHK(hipMemcpyAsync(b_off.data(), e->d_m_off.p, nb * 4, hipMemcpyDeviceToHost, e->stream));
-          HIPCHK(hipMemcpyAsync(mem.data(), e->d_m_members.p, size_t(st.n_members) * 4, hipMemcpyDeviceToHost, e->stream));
-          HIPCHK(hipStreamSynchronize(e->stream));
-          for (uint32_t k = 0; k < nb; ++k)
-            batches.emplace_back(mem.begin() + b_off[k], mem.begin() + b_off[k] + b_n[k]);
+        if (nb > nb_max || st.n_members > mem.size()) return set_error(PM_ENODEV, "merge: more batches than candidates");
+        for (uint32_t k = 0; k < nb; ++k) {
+          batches.emplace_back(mem.begin() + b_off[k], mem.begin() + b_off[k] + b_n[k]);
+          mark_used(batches.back());
         }
         e->tick_carve_steps = st.steps_total;
-        auto drop_used = [&](const std::vector<uint32_t>& used) {
-          order.erase(std::remove_if(order.begin(), order.end(),
-                                     [&](uint32_t w) { return std::find(used.begin(), used.end(), w) != used.end(); }),
-                      order.end());
-        };
-        order = rem;
-        for (const auto& b : batches) drop_used(b);
+        drop_used();
         if (st.state == CARVE_STATE_DONE) break;
         // UNCERTAIN: settle exactly this selection on the host, then let the kernel continue
         if (order.size() < c.min_group_size) break;
@@ -1654,10 +1668,12 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
         e->tick_host_resolved++;
         e->tick_carve_steps++;
         if (b.size() < 2) break;
-        batches.push_back(b);
-        drop_used(b);
+        mark_used(b);
+        batches.push_back(std::move(b));
+        drop_used();
         if (order.size() < c.min_group_size) break;
       }
+      for (uint32_t w : rem) used[w] = 0;
     }
 
     // ---- apply the batches in order (is_merge_beneficial / should_switch_tasks / execute_group_merge)
@@ -1678,20 +1694,20 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
       rc = pick_task_for_config(e, cfg, gr.id, &gr.task);  // find_best_task_for_group, mod.rs:896
       if (rc) return rc;
       if (gr.task != PM_NONE) gr.task_uid = e->tasks_have_uid ? e->h_tuid[gr.task] : task_position(e, gr.task);
-      std::vector<uint32_t> old_slots;
-      for (uint32_t w : b) old_slots.push_back(uint32_t(e->h_group_of[w]));
-      for (uint32_t s : old_slots) log_group_event(e, PM_GROUP_DESTROYED, e->groups[s]);  // send_merge_webhooks,
-      log_group_event(e, PM_GROUP_CREATED, gr);                                            // mod.rs:974-1000
-      std::sort(old_slots.rbegin(), old_slots.rend());
-      for (uint32_t s : old_slots) e->groups.erase(e->groups.begin() + s);  // mod.rs:903-921
-      e->groups.push_back(std::move(gr));                                    // mod.rs:924-942
-      std::fill(e->h_group_of.begin(), e->h_group_of.end(), -1);
-      for (size_t g = 0; g < e->groups.size(); ++g)
-        for (uint32_t w : e->groups[g].members) e->h_group_of[w] = int32_t(g);
+      for (uint32_t w : b) log_group_event(e, PM_GROUP_DESTROYED, e->groups[e->h_group_of[w]]);  // send_merge_webhooks,
+      log_group_event(e, PM_GROUP_CREATED, gr);                                                   // mod.rs:974-1000
+      const int32_t slot_new = int32_t(e->groups.size());
+      for (uint32_t w : b) {  // mod.rs:903-921: the solo groups go (dropped from the list by compact_groups)
+        e->groups[e->h_group_of[w]].dead = true;
+        e->n_dead_groups++;
+        e->h_group_of[w] = slot_new;
+      }
+      e->groups.push_back(std::move(gr));  // mod.rs:924-942
       e->groups_dirty = true;
       ++merged;
     }
   }
+  compact_groups(e);
   if (n_merged) *n_merged = merged;
   return PM_OK;
 }
@@ -2347,10 +2363,32 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
 // tasks are the newest, i.e. they sort in FRONT of get_all_tasks (:79, created_at desc).  Only the new rows
 // travel; the bit planes are patched in the words they fall into; nothing else moves, so every claimed task
 // keeps its handle.
+static int32_t tasks_insert_front_locked(pm_engine* e, const pm_task_soa* t);
+
 int32_t pm_tasks_insert_front(pm_engine* e, const pm_task_soa* t) {
   if (!e || !t) return set_error(PM_EINVAL, "null argument");
-  if (t->n && (!t->topo_mask || !t->created_at)) return set_error(PM_EINVAL, "null task column");
   std::lock_guard<std::mutex> lk(e->mu);
+  return tasks_insert_front_locked(e, t);
+}
+
+// pm_tasks_insert_front and, with republish != 0, pm_match's pair sweep + claim + publish on the standing groups under
+// the same lock: a group that holds no task is offered the new one before the next tick, as the reference would offer
+// it at that group's next heartbeat (scheduler_impl.rs:33-74).  No carve.
+int32_t pm_tasks_insert_front_ex(pm_engine* e, const pm_task_soa* t, uint32_t republish) {
+  if (!e || !t) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  int32_t rc = tasks_insert_front_locked(e, t);
+  if (rc || !republish || !t->n) return rc;
+  if (e->dist_world > 1) return set_error(PM_ESTATE, "multi-GPU engine: the republish belongs to the stepwise tick");
+  if (!e->have_cfgs || !e->have_workers) return PM_OK;  // (nothing to match yet: the next tick publishes)
+  ABSORB_PENDING(e);
+  rc = run_match(e, false, nullptr);
+  if (rc) return rc;
+  return publish(e);
+}
+
+static int32_t tasks_insert_front_locked(pm_engine* e, const pm_task_soa* t) {
+  if (t->n && (!t->topo_mask || !t->created_at)) return set_error(PM_EINVAL, "null task column");
   HIPCHK(hipSetDevice(e->cfg.device));
   if (!e->have_tasks) return set_error(PM_ESTATE, "tasks must be uploaded first (an empty table is fine)");
   if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
@@ -3117,8 +3155,7 @@ int32_t pm_device_task_column(pm_engine* e, uint64_t* device_ptr, uint32_t* n) {
   return PM_OK;
 }
 
-// debug (not part of the public header, declared in pm_internal.h): phase tick counters of the last carve
-// (PM_CARVE_PROF builds); copies min(cap, 32) entries
+// debug (include/pm_engine_debug.h): counters of the last carve; copies min(cap, 72) words
 int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap) {
   if (!e || !out) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
@@ -3131,7 +3168,7 @@ int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap)
 
 // debug (PM_CARVE_PROF builds): the timeline of the last streaming carve launch — up to cap events of two u64 each
 // {s_memtime, type | a << 8 | b << 32}; *n = events recorded
-extern "C" int32_t pm_debug_stream_trace(pm_engine* e, unsigned long long* out, uint32_t cap, uint32_t* n) {
+int32_t pm_debug_stream_trace(pm_engine* e, unsigned long long* out, uint32_t cap, uint32_t* n) {
   if (!e || !out || !n) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   *n = 0;
@@ -3144,7 +3181,7 @@ extern "C" int32_t pm_debug_stream_trace(pm_engine* e, unsigned long long* out, 
   return PM_OK;
 }
 
-// debug (pm_internal.h): candidate lists longer than `n` slots take the all-in-HBM carve path (carve_step_mem), which
+// debug (include/pm_engine_debug.h): candidate lists longer than `n` slots take the all-in-HBM carve path (carve_step_mem), which
 // otherwise needs more than 262,144 candidates for one configuration; 0 = off
 int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n) {
   if (!e) return set_error(PM_EINVAL, "null argument");
@@ -3153,7 +3190,7 @@ int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n) {
   return PM_OK;
 }
 
-// debug (pm_internal.h): when the proposer walks the spatial index instead of sweeping the whole candidate list —
+// debug (include/pm_engine_debug.h): when the proposer walks the spatial index instead of sweeping the whole candidate list —
 // 0 never, 1 when it pays (default), 2 whenever the carve has one (built for any swarm of 64+ positions),
 // 3 = 2 with every seed sent through the whole-list fallback
 int32_t pm_debug_prune_mode(pm_engine* e, uint32_t mode) {
@@ -3173,7 +3210,7 @@ extern "C" int32_t pm_debug_batch_log(pm_engine* e, uint32_t* out, uint32_t cap_
 }
 #endif
 
-// debug (pm_internal.h): stream triad over 3 x n_doubles f64 on the engine's stream, best of `reps` -> GB/s
+// debug (include/pm_engine_debug.h): stream triad over 3 x n_doubles f64 on the engine's stream, best of `reps` -> GB/s
 int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s) {
   if (!e || !gb_per_s || !n_doubles) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);

@@ -40,14 +40,6 @@ inline uint64_t splitmix64_mix(uint64_t x) {
 
 }  // namespace pm
 
-// debug export (PM_CARVE_PROF builds): copies min(cap, 32) phase counters of the last carve
-extern "C" int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap);
-// test hook: candidate lists longer than n slots go through the all-in-HBM carve path (0 = off)
-extern "C" int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n);
-// test hook / experiment: when the proposer walks the spatial index of the carve's positions instead of sweeping the
-// whole candidate list: 0 never, 1 when it pays (default), 2 whenever the carve has an index, 3 = 2 with every seed
-// forced through the whole-list fallback.  (PM_PRUNE_MODE in the environment sets the default of new engines.)
-extern "C" int32_t pm_debug_prune_mode(pm_engine* e, uint32_t mode);
-// stream triad (a = b + 3c, f64) on the engine's stream: the measured HBM rate bench.py cites
-extern "C" int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s);
+// test hooks and instrumentation: declared in include/pm_engine_debug.h (not part of the drop-in boundary)
+#include "pm_engine_debug.h"
 #endif

@@ -96,7 +96,7 @@ EXPORTS = [
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
-    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_delete", "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
+    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
     "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
 ]
 
@@ -301,10 +301,15 @@ class Engine:
         check(lib().pm_upload_tasks(self._h, C.byref(soa)))
         self.T = soa.n
 
-    def tasks_insert_front(self, topo_mask, created_at, uid=None):
-        """new tasks, newest first; they sort in front of the table (on_task_created)"""
+    def tasks_insert_front(self, topo_mask, created_at, uid=None, republish=False):
+        """new tasks, newest first; they sort in front of the table (on_task_created).  republish: also run pm_match's
+        pair sweep + claim + publish on the standing groups (pm_tasks_insert_front_ex), so that a group holding no task
+        is served the new one before the next tick"""
         soa, keep = self._task_soa(topo_mask, created_at, uid)
-        check(lib().pm_tasks_insert_front(self._h, C.byref(soa)))
+        if republish:
+            check(lib().pm_tasks_insert_front_ex(self._h, C.byref(soa), 1))
+        else:
+            check(lib().pm_tasks_insert_front(self._h, C.byref(soa)))
         self.T += soa.n
 
     def tasks_delete(self, uids) -> int:

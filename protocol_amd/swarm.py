@@ -295,3 +295,26 @@ def baseline_config(i: int, seed: int = 1, scale: float = 1.0) -> Swarm:
     if i == 4:
         return make_swarm(seed, sz(10_000), sz(100_000))
     raise ValueError(i)
+
+
+def solo_merge_swarm(seed: int = 1, W: int = 100000, solos: int = 5000, T: int = 1000) -> Swarm:
+    """The merge pass's own workload (try_merge_solo_groups, mod.rs:631-971; bench.py `merge`, tests/test_gpu_scale.py):
+    W workers of which exactly `solos` healthy 1-GPU nodes match a (1, 1) configuration — formed with only that
+    configuration enabled they are `solos` single-node groups — and a (2, 8) configuration over the same nodes that,
+    once enabled, merges them.  Enable masks: 0b01 to form the solos, 0b11 to merge."""
+    sw = make_swarm(seed, T, W, zipf=(W >= 100000))
+    sw.configs = [("solo-1gpu", 1, 1, "gpu:count=1"), ("octet-1gpu", 2, 8, "gpu:count=1")]
+    sw.topo[:] = -2
+    sw.restricted[:] = False
+    sw.n_topo[:] = 0
+    one = np.nonzero((sw.gpu_count == 1) & (sw.status == ST_HEALTHY))[0]
+    if len(one) < solos:
+        raise ValueError(f"only {len(one)} healthy 1-GPU nodes among {W} workers")
+    sw.status[one[solos:]] = ST_UNHEALTHY
+    return sw
+
+
+def events_digest(events) -> str:
+    """digest of a life-cycle feed [(kind, group id, config, members)] in the order it was emitted"""
+    import hashlib
+    return hashlib.sha256(repr([(int(k), int(g), int(c), [int(w) for w in m]) for k, g, c, m in events]).encode()).hexdigest()[:16]

@@ -166,6 +166,7 @@ extern "C" {
     fn pm_set_addr_ranks(e: *mut c_void, ranks: *const u32, n: u32) -> i32;
     fn pm_upload_tasks(e: *mut c_void, t: *const pm_task_soa) -> i32;
     fn pm_tasks_insert_front(e: *mut c_void, rows: *const pm_task_soa) -> i32;
+    fn pm_tasks_insert_front_ex(e: *mut c_void, rows: *const pm_task_soa, republish: u32) -> i32;
     fn pm_tasks_delete(e: *mut c_void, uids: *const u64, n: u32, n_deleted: *mut u32) -> i32;
     fn pm_on_worker_status(e: *mut c_void, worker: u32, flags_new: u32, dead: u32) -> i32;
     fn pm_on_worker_status_many(e: *mut c_void, workers: *const u32, flags_new: *const u32, dead: *const u32, n: u32) -> i32;
@@ -256,6 +257,10 @@ pub struct GpuMatchPlugin {
     upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>,
     /// as in NodeGroupsPlugin (mod.rs:107, 124): the plugins told about every group created / destroyed
     webhook_plugins: Option<Vec<WebhookPlugin>>,
+    /// on_task_created also re-matches the standing groups (pm_tasks_insert_front_ex, republish = 1): a group that
+    /// holds no task is served the new one at its next heartbeat, as in the reference (scheduler_impl.rs:33-74),
+    /// instead of after the next tick.  Costs one pair sweep + publish (~0.2 ms at 100k x 10k) per created task.
+    pub republish_on_insert: bool,
 }
 
 unsafe impl Send for GpuMatchPlugin {}
@@ -280,7 +285,7 @@ impl GpuMatchPlugin {
         }
         let mut this = Self { engine, config_names: templates.iter().map(|t| t.name.clone()).collect(),
                               req_models: Vec::new(), nodes: Default::default(), tasks: Default::default(),
-                              upload_counter, webhook_plugins };
+                              upload_counter, webhook_plugins, republish_on_insert: false };
         this.set_configs(&templates);
         // an empty worker / task table, so that the delta calls have something to extend
         let empty = RowColumns::default();
@@ -476,17 +481,30 @@ impl GpuMatchPlugin {
         check(unsafe { pm_set_enabled_mask(self.engine, enabled) })
     }
 
-    /// Full snapshot: `task_store.get_all_tasks()` (task_store.rs:57-82, already created_at-desc).  Start-up and
-    /// the fallback when a delta does not apply.
-    pub fn sync_tasks(&self, tasks: Vec<Task>) -> Result<()> {
+    // LOCK ORDER: `nodes`, then `tasks`, then the engine's own mutex (taken inside every pm_* call but the look-up).
+    // The engine reports a task as a POSITION in `tasks`, and it re-derives the published positions inside
+    // pm_tasks_insert_front / pm_tasks_delete / pm_upload_tasks — so the Vec and the engine's table change under ONE
+    // write lock, and filter_tasks holds the read lock from the look-up to the index: a heartbeat never pairs a
+    // position of the new table with the old Vec (or the other way round).  (The reference binds group -> task by id,
+    // scheduler_impl.rs:62-82, and has no such window; this is what keeps the shim from having one.)
+
+    /// the snapshot upload with `tasks` already locked for writing
+    fn sync_tasks_locked(&self, guard: &mut Vec<Task>, tasks: Vec<Task>) -> Result<()> {
         let masks: Vec<u64> = tasks.iter().map(|t| self.topology_mask(t)).collect();
         let created: Vec<i64> = tasks.iter().map(|t| t.created_at).collect();
         let uid: Vec<u64> = tasks.iter().map(task_uid).collect();
         let soa = pm_task_soa { n: tasks.len() as u32, topo_mask: masks.as_ptr(), created_at: created.as_ptr(), uid: uid.as_ptr() };
         check(unsafe { pm_upload_tasks(self.engine, &soa) })?;
         self.push_enabled(&tasks)?;
-        *self.tasks.write() = tasks;
+        *guard = tasks;
         Ok(())
+    }
+
+    /// Full snapshot: `task_store.get_all_tasks()` (task_store.rs:57-82, already created_at-desc).  Start-up and
+    /// the fallback when a delta does not apply.
+    pub fn sync_tasks(&self, tasks: Vec<Task>) -> Result<()> {
+        let mut guard = self.tasks.write();
+        self.sync_tasks_locked(&mut guard, tasks)
     }
 
     /// TaskStore observer (task_store.rs:46-52 -> on_task_created, mod.rs:1224-1243): the new task is the newest, so
@@ -494,8 +512,10 @@ impl GpuMatchPlugin {
     pub fn on_task_created(&self, task: &Task, all_tasks: impl FnOnce() -> Vec<Task>) -> Result<()> {
         let (mask, created, uid) = (self.topology_mask(task), task.created_at, task_uid(task));
         let soa = pm_task_soa { n: 1, topo_mask: &mask, created_at: &created, uid: &uid };
-        if unsafe { pm_tasks_insert_front(self.engine, &soa) } != 0 { return self.sync_tasks(all_tasks()); }
-        let mut tasks = self.tasks.write();
+        let mut tasks = self.tasks.write();                 // (before the engine call: see LOCK ORDER)
+        let rc = if self.republish_on_insert { unsafe { pm_tasks_insert_front_ex(self.engine, &soa, 1) } }
+                 else { unsafe { pm_tasks_insert_front(self.engine, &soa) } };
+        if rc != 0 { return self.sync_tasks_locked(&mut tasks, all_tasks()); }
         tasks.insert(0, task.clone());
         self.push_enabled(&tasks)
     }
@@ -504,8 +524,8 @@ impl GpuMatchPlugin {
     pub fn on_task_deleted(&self, task: &Task) -> Result<()> {
         let uid = task_uid(task);
         let mut n = 0u32;
+        let mut tasks = self.tasks.write();                 // (before the engine call: see LOCK ORDER)
         check(unsafe { pm_tasks_delete(self.engine, &uid, 1, &mut n) })?;
-        let mut tasks = self.tasks.write();
         tasks.retain(|t| t.id != task.id);
         self.push_enabled(&tasks)?;
         drop(tasks);
@@ -570,14 +590,19 @@ impl GpuMatchPlugin {
     /// deleted task or a dead node dissolved — no tick needed in between.)
     /// SchedulerPlugin::filter_tasks (plugins/mod.rs:66-78): lock-free lookup + the `${...}` templating the
     /// reference does at scheduler_impl.rs:112-205 (GROUP_INDEX, GROUP_SIZE, NEXT_P2P_ADDRESS, GROUP_ID, upload count).
+    /// `_tasks` is ignored — and with the edit of `Scheduler::get_task_for_node` shown in INTEGRATION.md ("The task list
+    /// per heartbeat") the scheduler does not even load it: the plugin serves from its own copy, kept current by the
+    /// task observers.
     pub(crate) fn filter_tasks(&self, _tasks: &[Task], node_address: &Address) -> Result<Vec<Task>> {
         let nodes = self.nodes.read();
         let Some(&w) = nodes.index.get(node_address) else { return Ok(vec![]) };
         let mut a = pm_assignment::default();
+        let tasks = self.tasks.read();                      // held from the look-up to the index (see LOCK ORDER)
         if unsafe { pm_lookup_task_for_worker(self.engine, w, &mut a) } != 0 || a.task == PM_NONE {
             return Ok(vec![]);
         }
-        let Some(mut task) = self.tasks.read().get(a.task as usize).cloned() else { return Ok(vec![]) };
+        let Some(mut task) = tasks.get(a.task as usize).cloned() else { return Ok(vec![]) };
+        drop(tasks);
         let group_id = format!("{:x}", a.group_id);                                   // generate_group_id, mod.rs:1489-1493
         let gid = CString::new(group_id.as_str())?;
         let next = CString::new(nodes.p2p_ids.get(a.next_worker as usize).cloned().unwrap_or_default())?;

@@ -11,6 +11,13 @@ protocol_amd.engine).  The "store" is a protocol_amd.swarm.Swarm; a node is a ro
                                          their current ranks), new rows (pm_append_workers + pm_set_addr_ranks), then
                                          the two-call pm_drain_group_events
   sync_tasks / on_task_created / on_task_deleted / handle_status_change / tick     as named
+  Scheduler(store, [shim])               Scheduler::get_task_for_node with the INTEGRATION.md edit: a chain headed by
+                                         the engine's plugin does not load the store's task list
+
+Locks: the Rust shim's `tasks` RwLock is modelled by a flag — the observers hold it for writing from BEFORE the engine
+call until the Vec has changed (lock order: nodes, tasks, engine mutex), and filter_tasks, which takes it for reading
+before the look-up, raises WouldBlock while it is held (in Rust the heartbeat waits there).  `mid_observer` is called
+between the two halves of an observer: the place where another thread's heartbeat could land.
 """
 from __future__ import annotations
 
@@ -26,9 +33,43 @@ _ROW_FIELDS = ("flags", "gpu_count", "gpu_mem_mb", "gpu_model_class", "cpu_cores
                "lat", "lon")
 
 
+class WouldBlock(Exception):
+    """filter_tasks met the `tasks` write lock: the Rust heartbeat waits here until the observer is through"""
+
+
+class TaskStore:
+    """the store side of Scheduler::get_task_for_node: hands out the task list, counts how often it was asked"""
+
+    def __init__(self):
+        self.tasks: list = []
+        self.loads = 0
+
+    def get_all_tasks(self):
+        self.loads += 1
+        return list(self.tasks)
+
+
+class Scheduler:
+    """scheduler/mod.rs:9-36 with the edit of INTEGRATION.md ("The task list per heartbeat")"""
+
+    def __init__(self, store: TaskStore, plugins: list):
+        self.store, self.plugins = store, plugins
+
+    def get_task_for_node(self, node: int):
+        head = self.plugins[0] if self.plugins else None
+        all_tasks = [] if isinstance(head, ShimReplay) else self.store.get_all_tasks()
+        for plugin in self.plugins:
+            all_tasks = plugin.filter_tasks(all_tasks, node)
+        return all_tasks[0] if all_tasks else None
+
+
 class ShimReplay:
     def __init__(self, sw, **engine_kw):
         self.sw = sw
+        self.tasks_write_locked = False                        # the `tasks` RwLock, write side
+        self.mid_observer = None                               # called between the halves of a task observer
+        self.hold_tasks_lock = True                            # False = the round-3 order (engine call, THEN the lock)
+        self.republish_on_insert = False                       # GpuMatchPlugin::republish_on_insert
         self.eng = E.Engine(**engine_kw)                       # pm_engine_config_default + pm_engine_create
         cfg_rows, alt_rows, self.req_models = host.pack_configs(sw.configs)
         self.eng.set_configs(cfg_rows, alt_rows)               # set_configs
@@ -145,24 +186,43 @@ class ShimReplay:
     def _push_enabled(self):
         self.eng.set_enabled_mask(self._enabled)
 
+    def _between_halves(self):
+        if self.mid_observer is not None:
+            self.mid_observer()
+
     def sync_tasks(self, masks, created, uid, enabled):
-        self.eng.upload_tasks(masks, created, uid)
-        self._enabled = enabled
-        self._push_enabled()
-        self.tasks = [int(u) for u in uid]
+        self.tasks_write_locked = self.hold_tasks_lock         # let mut guard = self.tasks.write();
+        try:
+            self.eng.upload_tasks(masks, created, uid)         # sync_tasks_locked
+            self._enabled = enabled
+            self._push_enabled()
+            self._between_halves()
+            self.tasks = [int(u) for u in uid]
+        finally:
+            self.tasks_write_locked = False
 
     def on_task_created(self, mask, created, uid, enabled):
-        self.eng.tasks_insert_front(np.array([mask], dtype=np.uint64), np.array([created], dtype=np.int64),
-                                    np.array([uid], dtype=np.uint64))
-        self.tasks.insert(0, int(uid))
-        self._enabled = enabled
-        self._push_enabled()
+        self.tasks_write_locked = self.hold_tasks_lock         # let mut tasks = self.tasks.write();  (before the engine)
+        try:
+            self.eng.tasks_insert_front(np.array([mask], dtype=np.uint64), np.array([created], dtype=np.int64),
+                                        np.array([uid], dtype=np.uint64), republish=self.republish_on_insert)
+            self._between_halves()
+            self.tasks.insert(0, int(uid))
+            self._enabled = enabled
+            self._push_enabled()
+        finally:
+            self.tasks_write_locked = False
 
     def on_task_deleted(self, uid, enabled):
-        assert self.eng.tasks_delete(np.array([uid], dtype=np.uint64)) == 1
-        self.tasks.remove(int(uid))
-        self._enabled = enabled
-        self._push_enabled()
+        self.tasks_write_locked = self.hold_tasks_lock         # let mut tasks = self.tasks.write();  (before the engine)
+        try:
+            assert self.eng.tasks_delete(np.array([uid], dtype=np.uint64)) == 1
+            self._between_halves()
+            self.tasks.remove(int(uid))
+            self._enabled = enabled
+            self._push_enabled()
+        finally:
+            self.tasks_write_locked = False                    # drop(tasks)
         self._emit_group_webhooks()
 
     def handle_status_change(self, node: int, healthy: bool, dead: bool):
@@ -182,15 +242,22 @@ class ShimReplay:
         self._emit_group_webhooks()
         return s
 
-    def filter_tasks(self, node: int):
-        """-> uid of the task the node gets, or None (pm_lookup_task_for_worker + the shim's Vec<Task> by position)"""
+    def filter_tasks(self, *args):
+        """filter_tasks(node) -> uid of the task the node gets, or None; filter_tasks(tasks, node) -> [uid] or [] (the
+        plugin-chain form: `tasks` is ignored, as in the Rust).  tasks.read() is taken BEFORE pm_lookup_task_for_worker
+        and kept until the Vec<Task> has been indexed."""
+        node = args[-1]
+        as_list = len(args) == 2
         w = self.index.get(int(node))
         if w is None:
-            return None
+            return [] if as_list else None
+        if self.tasks_write_locked:                            # let tasks = self.tasks.read();
+            raise WouldBlock
         a = self.eng.lookup(w)
-        if a.task == 0xFFFFFFFF or a.task >= len(self.tasks):
-            return None
-        return self.tasks[a.task]
+        uid = None if (a.task == 0xFFFFFFFF or a.task >= len(self.tasks)) else self.tasks[a.task]
+        if as_list:
+            return [] if uid is None else [uid]
+        return uid
 
     def close(self):
         self.eng.close()

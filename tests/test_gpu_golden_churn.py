@@ -2,7 +2,7 @@
 against committed oracle digests (tests/golden/churn_digests.json, tools/make_golden_churn.py):
 
   * BASELINE configs[4] — the churn stream of bench.py's `churn` sub-object (protocol_amd/churn.py): the cold match on
-    100k workers, then three ticks of 1000 deaths + 1000 appended workers + 10k tasks in front of the list; groups,
+    100k workers, then all eight ticks (the two warm-up ticks and the six bench.py times) of 1000 deaths + 1000 appended workers + 10k tasks in front of the list; groups,
     every worker's task and the group life-cycle feed after every tick, on one engine and on two in-process ranks;
   * pm_match_per_task (north_star orientation) at BASELINE configs[1] and [2]: every task's best bid and bidder count.
 """

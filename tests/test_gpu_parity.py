@@ -568,6 +568,68 @@ def test_lookups_between_ticks_follow_task_deltas_and_deaths():
     eng.close()
 
 
+def test_insert_front_with_republish_serves_idle_groups_at_once():
+    """pm_tasks_insert_front_ex(rows, republish = 1): the reference offers a new task to a group that holds none at that
+    group's next heartbeat (get_task_for_node: no current task -> pick among the applicable ones and claim,
+    scheduler_impl.rs:33-74).  The plain insertion leaves such a group unserved until the next tick; with the
+    republish flag the call re-matches the standing groups (pair sweep + claim + publish, no carve) and every worker is
+    served what the oracle's heartbeat serves it — while groups that already hold a task keep it."""
+    sw = make_swarm(19, 300, 1500)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks[:0], reference_shaped=False)
+    eng = E.Engine()
+    cfg_rows, alt_rows, req_models = host.pack_configs(sw.configs)
+    eng.set_configs(cfg_rows, alt_rows)
+    eng.set_model_table(host.build_model_table(req_models, sw.model_names), len(req_models), len(sw.model_names))
+    eng.upload_workers(host.pack_workers(sw))
+    masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+    eng.upload_tasks(masks[:0], created[:0], uid[:0])                 # no task yet: every group is formed idle
+    eng.set_enabled_mask(sw.enabled_mask())
+    eng.tick()
+    st.try_form_new_groups()
+    st.try_merge_solo_groups()
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng)) and len(st.groups()) > 50
+    served = lambda: [(-1 if eng.lookup(w).task == NONE else eng.lookup(w).task) for w in range(sw.W)]
+    assert set(served()) == {-1}
+    cur = tasks[:0]
+    t_next = int(created.max()) + 1
+
+    def insert(rows_idx, republish):
+        nonlocal cur, t_next
+        n = len(rows_idx)
+        c_new = (t_next + np.arange(n, 0, -1)).astype(created.dtype)
+        t_next += n + 1
+        eng.tasks_insert_front(masks[rows_idx], c_new, (uid[rows_idx] + np.uint64(t_next << 20)).astype(uid.dtype), republish=republish)
+        new_rows = tasks[rows_idx].copy()
+        new_rows["created_at"] = c_new
+        old_n = len(cur)
+        cur = np.concatenate([new_rows, cur])
+        st.set_tasks(cur)
+        st.remap_tasks(np.arange(old_n) + n)
+
+    # ---- a few tasks of few topologies, plain insertion: nobody is served before the next tick ...
+    few = np.nonzero(masks == masks[0])[0][:3]
+    insert(few, republish=False)
+    assert set(served()) == {-1}
+    # ---- ... the same with the flag: every group the oracle's heartbeat serves is served, the rest stay idle
+    insert(np.nonzero(masks == masks[1])[0][:3], republish=True)
+    want = [st.get_task_for_node(w) for w in range(sw.W)]
+    assert served() == want
+    n_first = sum(t >= 0 for t in want)
+    assert 0 < n_first
+    # ---- more tasks: groups that hold a task keep it (under its new position), idle ones are offered the new list
+    insert(np.arange(40, 80), republish=True)
+    want = [st.get_task_for_node(w) for w in range(sw.W)]
+    assert served() == want
+    assert sum(t >= 0 for t in want) > n_first
+    # ---- and the next tick agrees
+    eng.tick()
+    st.try_form_new_groups()
+    st.try_merge_solo_groups()
+    assert served() == [st.get_task_for_node(w) for w in range(sw.W)]
+    eng.close()
+
+
 def test_group_event_feed_semantics():
     """off by default; a drain with buffers that are too small reports the sizes and drains nothing; switching the
     feed off clears it; pm_reset_groups logs nothing"""

@@ -133,13 +133,16 @@ def test_config2_seed2_full_size_against_oracle_digest():
     _check_against_golden("cfg2_seed2", 0)
 
 
-def test_config1_seeded_chooser_against_oracle_digest():
-    """BASELINE configs[1] with the SEEDED chooser (the injected stand-in for rand::rng().choose,
+@pytest.mark.parametrize("name", ["cfg1_seed1_seeded", "cfg2_seed1_seeded"])
+def test_seeded_chooser_against_oracle_digest(name):
+    """BASELINE configs[1] and configs[2] with the SEEDED chooser (the injected stand-in for rand::rng().choose,
     scheduler_impl.rs:66-70; chooser_rank_kernel + the r-th-hit pass): groups and every worker's task against the
-    digests of the oracle's own get_task_for_node (tests/golden/scale_digests.json, cfg1_seed1_seeded)."""
+    digests of the oracle's own get_task_for_node (tests/golden/scale_digests.json)."""
     import json
     import os
-    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scale_digests.json")))["cfg1_seed1_seeded"]
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scale_digests.json"))).get(name)
+    if gold is None:
+        pytest.skip(f"{name} not in tests/golden/scale_digests.json (tools/make_golden_scale.py {name})")
     sw = baseline_config(gold["config"], seed=gold["seed"])
     eng = E.Engine(group_id_seed=gold["seed"], chooser=E.CHOOSE_SEEDED, chooser_seed=gold["chooser_seed"])
     host.load_swarm(eng, sw)
@@ -261,6 +264,29 @@ def test_solo_merge_at_baseline_size():
     ev = eng.drain_group_events()
     assert ev == st.drain_events()                                  # merged groups in creation order, solos in batch order
     assert sum(k == E.GROUP_CREATED for k, *_ in ev) == n_merged
+    eng.close()
+
+
+def test_solo_merge_of_the_bench_workload():
+    """bench.py's `merge` leg (100k workers, 5,000 solo groups merged by a newly enabled (2, 8) configuration): groups and
+    the life-cycle feed in creation order — the digest the bench line carries — against the oracle."""
+    from protocol_amd.swarm import events_digest, solo_merge_swarm
+    sw = solo_merge_swarm(1)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=np.array([1, 0], dtype=np.uint8), tasks=tasks, reference_shaped=False, group_id_seed=1)
+    eng = E.Engine(group_id_seed=1)
+    host.load_swarm(eng, sw, enabled=0b01)
+    eng.enable_group_events()
+    assert eng.form_groups() == st.try_form_new_groups() > 4500      # (the 5,000 less those without usable specs)
+    eng.drain_group_events()
+    st.drain_events()
+    st.set_enabled(np.array([1, 1], dtype=np.uint8))
+    eng.set_enabled_mask(0b11)
+    n_merged = eng.merge_solo_groups()
+    assert st.try_merge_solo_groups() == n_merged > 550
+    ev = eng.drain_group_events()
+    assert events_digest(ev) == events_digest(st.drain_events())
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
     eng.close()
 
 

@@ -12,7 +12,7 @@ from protocol_amd import engine as E
 from protocol_amd import host
 from protocol_amd.swarm import make_swarm
 from helpers import engine_groups, oracle_groups
-from shim_replay import ShimReplay
+from shim_replay import Scheduler, ShimReplay, TaskStore, WouldBlock
 from test_gpu_ingest import _WORKER_FIELDS
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +58,8 @@ def test_shim_call_sequence_tracks_the_oracle():
     st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks[:0], reference_shaped=False)
     # ---- the shim
     shim = ShimReplay(sw)
+    store = TaskStore()
+    scheduler = Scheduler(store, [shim])                   # the heartbeat's entry: scheduler/mod.rs:26-36
     masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
     shim.sync_tasks(masks, created, uid, sw.enabled_mask())            # start-up: the full snapshot
     st.set_tasks(tasks)
@@ -127,7 +129,7 @@ def test_shim_call_sequence_tracks_the_oracle():
         st.try_merge_solo_groups()
         for i, node in enumerate(first_seen[:len(shim.rows)]):        # (the oracle claims on this call)
             t = st.get_task_for_node(i)
-            assert shim.filter_tasks(node) == (None if t < 0 else cur_uid[t]), (k, node)
+            assert scheduler.get_task_for_node(node) == (None if t < 0 else cur_uid[t]), (k, node)
         assert sorted(oracle_groups(st)) == sorted(engine_groups(shim.eng)), f"interval {k}"
         ev = st.drain_events()
         assert shim.events == ev, f"interval {k}: the webhook feed differs"
@@ -135,4 +137,54 @@ def test_shim_call_sequence_tracks_the_oracle():
         n_destroyed += sum(e[0] == E.GROUP_DESTROYED for e in ev)
         shim.events.clear()
     assert n_created > 100 and n_destroyed > 20 and len(shim.rows) == len(first_seen)
+    assert store.loads == 0, "a chain headed by the engine's plugin must not load the store's task list per heartbeat"
+    shim.close()
+
+
+def test_heartbeat_between_the_halves_of_a_task_observer():
+    """The engine re-publishes the list positions INSIDE pm_tasks_insert_front / pm_tasks_delete; the shim's Vec<Task>
+    changes after the call.  A heartbeat landing in between must wait (the observer holds tasks.write() from before the
+    engine call), and gets the right task afterwards; with the round-3 order (lock taken after the call) the same
+    heartbeat is served the NEIGHBOURING task — which is what this test is for."""
+    sw = make_swarm(41, 40, 600)
+    shim = ShimReplay(sw)
+    masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+    shim.sync_tasks(masks, created, uid, sw.enabled_mask())
+    shim.sync_nodes(np.arange(sw.W), {n for n in range(sw.W)})
+    shim.tick()
+    served = {n: shim.filter_tasks(n) for n in range(sw.W)}
+    grouped = [n for n, t in served.items() if t is not None]
+    assert len(grouped) > 50
+    seen_mid = {}
+
+    def heartbeat_mid(expect_block):
+        def hook():
+            for n in grouped[:32]:
+                try:
+                    seen_mid[n] = shim.filter_tasks(n)
+                    assert not expect_block
+                except WouldBlock:
+                    assert expect_block
+                    seen_mid[n] = "waits"
+        return hook
+
+    # ---- with the lock order of the shim: the heartbeat waits, then reads the same task as before
+    t_max = int(created.max())
+    shim.mid_observer = heartbeat_mid(True)
+    shim.on_task_created(int(masks[0]), t_max + 1, 1 << 42, sw.enabled_mask())
+    assert all(v == "waits" for v in seen_mid.values()) and len(seen_mid) == 32
+    assert all(shim.filter_tasks(n) == served[n] for n in grouped)
+    victim = next(u for u in reversed(shim.tasks) if u not in set(served.values()) and u != 1 << 42)   # an unclaimed task, deep in the list
+    seen_mid.clear()
+    shim.on_task_deleted(victim, sw.enabled_mask())
+    assert all(v == "waits" for v in seen_mid.values()) and len(seen_mid) == 32
+    assert all(shim.filter_tasks(n) == served[n] for n in grouped)
+    # ---- the round-3 order, for contrast: positions of the new table paired with the old Vec
+    shim.hold_tasks_lock = False
+    seen_mid.clear()
+    shim.mid_observer = heartbeat_mid(False)
+    shim.on_task_created(int(masks[1]), t_max + 2, (1 << 42) + 1, sw.enabled_mask())
+    assert any(seen_mid[n] != served[n] for n in grouped[:32]), "the window this test guards did not open"
+    shim.mid_observer = None
+    assert all(shim.filter_tasks(n) == served[n] for n in grouped)
     shim.close()

@@ -32,6 +32,29 @@ def test_library_exports_every_declared_symbol():
     assert L.pm_abi_version() == 2
 
 
+def test_library_exports_every_debug_hook():
+    """include/pm_engine_debug.h: the test hooks and counters tests/, tools/ and bench.py call.  Not part of the drop-in
+    boundary (the Rust shim binds none of them), but exported by the shipped library, with the declared arity."""
+    hdr = open(os.path.join(ROOT, "include", "pm_engine_debug.h")).read()
+    protos = _c_prototypes(hdr)
+    assert set(protos) == {"pm_debug_carve_prof", "pm_debug_stream_trace", "pm_debug_mem_lists_above", "pm_debug_prune_mode",
+                           "pm_debug_hbm_triad"}
+    L = E.lib()
+    for name in protos:
+        assert hasattr(L, name), f"{name} declared in pm_engine_debug.h but not exported"
+    shim = open(os.path.join(ROOT, "rust", "gpu_match_plugin.rs")).read()
+    assert "pm_debug_" not in shim
+    public = open(os.path.join(ROOT, "include", "pm_engine.h")).read()
+    assert not re.findall(r"\b(pm_debug_[a-z_]+)\s*\(", public)
+    # every pm_debug_* the Python side calls is declared there
+    used = set()
+    for sub in ("protocol_amd", "tests", "tools"):
+        for fn in os.listdir(os.path.join(ROOT, sub)):
+            if fn.endswith(".py"):
+                used |= set(re.findall(r"\.(pm_debug_[a-z_]+)\b", open(os.path.join(ROOT, sub, fn)).read()))
+    assert used - {"pm_debug_batch_log"} <= set(protos), used - set(protos)   # (batch_log: -DPM_BATCH_LOG builds only)
+
+
 def _c_prototypes(text):
     """{name: number of parameters} of the `int32_t|void|... pm_*(...)` prototypes in a C header"""
     out = {}

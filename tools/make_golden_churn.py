@@ -3,7 +3,7 @@
 GPU box (tests/golden/churn_digests.json):
 
   churn      BASELINE configs[4] exactly as bench.py's `churn` sub-object drives it (protocol_amd/churn.py,
-             seed 1, 8 ticks planned): the cold match on 100k workers x 10k tasks, then the first three ticks —
+             seed 1, 8 ticks planned): the cold match on 100k workers x 10k tasks, then all eight ticks (the two warm-up ticks and the six bench.py times) —
              1000 deaths (groups dissolve, status_update_impl.rs:17-29), 1000 appended workers (mod.rs:487-497),
              10k tasks in front of the list, try_form_new_groups + try_merge_solo_groups, one get_task_for_node
              per worker.  Per tick: sha256 of the groups (sorted by id: ids | configs | sizes | members in BTreeSet
@@ -34,7 +34,7 @@ from protocol_amd.swarm import baseline_config  # noqa: E402
 
 NONE = 0xFFFFFFFF
 OUT = os.path.join(ROOT, "tests", "golden", "churn_digests.json")
-CHURN_SEED, CHURN_TICKS_PLANNED, CHURN_TICKS_PINNED = 1, 8, 3
+CHURN_SEED, CHURN_TICKS_PLANNED, CHURN_TICKS_PINNED = 1, 8, 8
 
 
 def sha(*arrays) -> str:

@@ -8,6 +8,7 @@ the reference-shaped mode, tests/test_oracle_groups.py) is run on the seeded swa
     cfg2_seed1   baseline_config(2, seed=1)      1M tasks x 100k workers, Zipf-skewed topologies
     cfg2_seed2   the same with seed 2
     cfg1_seed1_seeded   cfg1_seed1 with the SEEDED chooser (chooser_seed 77): groups + per-worker task column only
+    cfg2_seed1_seeded   cfg2_seed1 likewise
 
 through try_form_new_groups + try_merge_solo_groups (mod.rs:478-628, 631-971) and one get_task_for_node per
 worker (scheduler_impl.rs:11-110, chooser FIRST).  What is kept:
@@ -129,12 +130,13 @@ def main():
     out = {}
     if os.path.exists(OUT):
         out = json.load(open(OUT))
-    if len(sys.argv) < 2 or "cfg1_seed1_seeded" in sys.argv[1:]:
-        print("cfg1_seed1_seeded", flush=True)
-        out["cfg1_seed1_seeded"] = digest_seeded(1, 1, 77)
-        with open(OUT, "w") as f:
-            json.dump(out, f, separators=(",", ":"))
-            f.write("\n")
+    for name, ci in {"cfg1_seed1_seeded": 1, "cfg2_seed1_seeded": 2}.items():
+        if len(sys.argv) < 2 or name in sys.argv[1:]:
+            print(name, flush=True)
+            out[name] = digest_seeded(ci, 1, 77)
+            with open(OUT, "w") as f:
+                json.dump(out, f, separators=(",", ":"))
+                f.write("\n")
     for name, (ci, seed) in {"cfg1_seed1": (1, 1), "cfg2_seed1": (2, 1), "cfg2_seed2": (2, 2)}.items():
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
