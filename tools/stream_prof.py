@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from protocol_amd import build as B
 
-prof_lib = os.path.join(ROOT, "protocol_amd", "libpm_engine_prof.so")
+prof_lib = os.environ.get("PM_PROF_LIB") or os.path.join(ROOT, "protocol_amd", "libpm_engine_prof.so")
 if not os.environ.get("PM_PROF_NO_BUILD"):
     B.build(force=True, defines=["PM_CARVE_PROF"] + os.environ.get("PM_EXTRA_DEFINES", "").split(), out=prof_lib)
 B.LIB_PATH = prof_lib

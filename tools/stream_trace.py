@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from protocol_amd import build as B
 
-prof_lib = os.path.join(ROOT, "protocol_amd", "libpm_engine_prof.so")
+prof_lib = os.environ.get("PM_PROF_LIB") or os.path.join(ROOT, "protocol_amd", "libpm_engine_prof.so")
 if not os.environ.get("PM_PROF_NO_BUILD"):
     B.build(force=True, defines=["PM_CARVE_PROF"], out=prof_lib)
 B.LIB_PATH = prof_lib
@@ -76,7 +76,7 @@ tpu = span / max(1e3 * s["ms_carve_kernel"] - 45.0, 1.0)
 us = lambda t: (t - t0) / tpu
 print(f"T={T} W={W}: carve {s['ms_carve_kernel']:.3f} ms, {n.value} events over {span} ticks ({tpu:.0f} ticks per us)")
 if dump:
-    names = {1: "config", 2: "wait", 3: "go", 4: "tickets", 5: "parked", 6: "run", 7: "end", 8: "row", 9: "exact", 10: "fast", 11: "probe", 12: "tail", 13: "tiny", 14: "ranout"}
+    names = {1: "config", 2: "wait", 3: "go", 4: "tickets", 5: "parked", 6: "run", 7: "end", 8: "row", 9: "exact", 10: "fast", 11: "probe", 12: "tail", 13: "tiny", 14: "ranout", 15: "small"}
     with open(dump, "w") as f:
         for t, ty, a, b in ev:
             f.write(f"{us(t):10.2f} {str(names.get(ty, ty)):8s} {a:8d} {b:10d}\n")
@@ -111,6 +111,25 @@ for k in range(len(cfgs) - 1):
     print(f"  {ci:3d} {n_cand:5d} {us(t_in):10.1f} {(seg[-1][0] - t_in) / tpu:7.1f} {len(runs):5d} {commits:7d} {wsum:8.1f} ({len(waits):3d}) "
           f"{first_wait:10.1f} {len(rows):12d} {row_avg:12.1f} {issued:8d}")
 print(f"  chain waits in total: {tot_wait:.1f} us")
+# the end of every configuration: chain over -> located rest in registers (stream_small) -> first-come tail -> next configuration
+print("  cfg   chain_over_us  to_small_us  small_us (groups)  first_come_us  to_next_config_us")
+tot = [0.0, 0.0, 0.0, 0.0]
+for k in range(len(cfgs) - 1):
+    seg = ev[cfgs[k]:cfgs[k + 1]]
+    nxt = ev[cfgs[k + 1]][0] if cfgs[k + 1] < len(ev) else seg[-1][0]
+    ends = [e for e in seg if e[1] in (7, 9, 10)]
+    t_over = ends[-1][0] if ends else seg[0][0]
+    sm_in = [e for e in seg if e[1] == 15]
+    sm_out = [e for e in seg if e[1] == 13]
+    tl = [e for e in seg if e[1] == 12]
+    t_a = sm_in[-1][0] if sm_in else t_over
+    t_b = sm_out[-1][0] if sm_out else t_a
+    t_c = tl[-1][0] if tl else t_b
+    g0 = ends[-1][3] if (ends and ends[-1][1] != 7) else None
+    d = [(t_a - t_over) / tpu, (t_b - t_a) / tpu, (t_c - t_b) / tpu, (nxt - t_c) / tpu]
+    tot = [x + y for x, y in zip(tot, d)]
+    print(f"  {seg[0][2]:3d} {us(t_over):14.1f} {d[0]:12.1f} {d[1]:9.1f} {d[2]:14.1f} {d[3]:18.1f}")
+print(f"  totals (us): to_small {tot[0]:.1f}, small {tot[1]:.1f}, first_come {tot[2]:.1f}, to_next_config {tot[3]:.1f}")
 # the longest waits
 allw = []
 w0 = None
