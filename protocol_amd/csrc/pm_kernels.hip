@@ -765,11 +765,19 @@ struct BlockRed {
   uint32_t _spare1, _spare2;
 };
 
-// sin on [-pi/2, pi/2] as an odd Taylor polynomial to x^19 (|rel err| < 1e-15 there); larger arguments
-// (longitude differences beyond 180 degrees) take the OCML path.  The certificate band (2^-35) is four
-// orders of magnitude wider than this error.
+// sin on [-pi/2, pi/2] as an odd Taylor polynomial to x^19 (|rel err| < 1e-15 there).  Half a longitude difference
+// beyond 180 degrees lies in (pi/2, pi]: reflected, sin(x) = sin(pi - x) with pi in two pieces (the reflection is
+// exact to 1e-32) — those are two of every five pairs of a world-wide swarm, and the OCML path they used to take
+// (argument reduction with a table in memory) cost a wave more than everything else in a step of stream_small or a
+// sweep of carve_exact_step.  Only what is no difference of two longitudes still goes there.  The certificate band
+// (2^-35) is four orders of magnitude wider than this error.
 __device__ __forceinline__ double sin_band(double x) {
-  if (fabs(x) > 1.5707963267948966) return sin(x);
+  double ax = fabs(x);
+  if (ax > 1.5707963267948966) {
+    if (ax > 3.2) return sin(x);
+    ax = (3.141592653589793116 - ax) + 1.2246467991473532e-16;
+    x = x < 0.0 ? -ax : ax;
+  }
   const double z = x * x;
   double p = -8.2206352466243297e-18;               // -1/19!
   p = fma(p, z, 2.8114572543455206e-15);            //  1/17!
@@ -1422,6 +1430,10 @@ __device__ __noinline__ void carve_chain_collect(const CarveArgs& p, const StepC
   const auto g_n = G(p.g_n);
   const auto g_off = G(p.g_off);
   const uint32_t group_n = UNI(c.max_s), want = group_n - 1u, cfg = UNI(c.cfg);
+  // (read HERE, once: inside the loop the compiler re-reads the argument block behind every store it cannot prove
+  // unaliased — a round trip to L2 per collected entry, four times what the chain takes to commit one: the collector
+  // fell behind, the ring looked full to the parkers, and the chain ran dry in front of a full ring)
+  const auto free32 = G((uint32_t*)p.bits_scratch);
   uint32_t seen = 0u;
   for (;;) {
     uint32_t cmd = chain_wait_cmd(L, seen);
@@ -1466,8 +1478,7 @@ __device__ __noinline__ void carve_chain_collect(const CarveArgs& p, const StepC
               L.STAGE[staged * group_n + rk] = sl;  // slots (translated to worker ids after the run)
               // (streaming carve: the proposers' copy of the candidate bitmap follows the chain, a few steps behind)
               if (STREAM)
-                __hip_atomic_fetch_and(&G((uint32_t*)p.bits_scratch)[sl >> 5], ~(1u << (sl & 31u)), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_and(&free32[sl >> 5], ~(1u << (sl & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             staged += 1u;
             if ((staged + 1u) * group_n > CHAIN_STAGE_WORDS) write_out();
