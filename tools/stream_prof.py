@@ -59,5 +59,7 @@ print(f"  proposer rows: bitmap sweep {row(o[10], o[12])}; index walk {row(o[13]
 print(f"  a row on average: ticket seen -> candidates swept {us(o[59]) / max(o[12] + o[14] + o[29], 1):.2f} us, finished and written "
       f"{us(o[60]) / max(o[12] + o[14] + o[29], 1):.2f} us, {o[61] / max(o[12] + o[14] + o[29], 1):.0f} candidates evaluated")
 print(f"  bitmap sweeps: {o[62 + 2]} passes {us(o[62]) / max(o[62 + 2], 1):.2f} us each, {o[62 + 3]} batches of 256 {us(o[62 + 1]) / max(o[62 + 3], 1):.2f} us each")
+print(f"  stream_small: {o[66 + 5]} groups; per group (us): seed {us(o[66]) / max(o[71], 1):.2f}, keys {us(o[67]) / max(o[71], 1):.2f}, "
+      f"selection {us(o[68]) / max(o[71], 1):.2f}, certificate {us(o[69]) / max(o[71], 1):.2f}, commit {us(o[70]) / max(o[71], 1):.2f}")
 print(f"  exact-sweep reasons: no row {o[20]}, debug hook {o[21]}, row exhausted {o[25]}, certificate {o[31]}")
 eng.close()
