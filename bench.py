@@ -133,7 +133,7 @@ def cpu_baseline(sw, budget_s: float = 25.0) -> dict:
     }
 
 
-def pmc_traffic(kernel: str):
+def pmc_traffic(kernel: str, key: str = "hbm_bytes_per_match"):
     """HBM bytes per full-swarm match from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json: FETCH_SIZE
     and WRITE_SIZE collected in separate runs of this same command, newest round first).  A constant read from a
     committed profile, not a measurement of this run; None if absent."""
@@ -141,7 +141,7 @@ def pmc_traffic(kernel: str):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             with open(path) as f:
-                v = json.load(f).get(kernel, {}).get("hbm_bytes_per_match")
+                v = json.load(f).get(kernel, {}).get(key)
             if v is not None:
                 return v, os.path.basename(path)
         except Exception:
@@ -273,11 +273,12 @@ def run_extra_configs2(E, host, seed):
     return out
 
 
-def run_extra_pools(E, host, seed, ks=(2, 4), steps=8):
-    """K independent pools on ONE GPU: K engines (each with its own stream and its own configs[1] swarm), driven from K
-    host threads (the C ABI releases the GIL), each running the N = 1 line's loop.  One match keeps a single workgroup
-    busy most of the time (the validator's chain), so independent pools overlap almost freely: the aggregate rate is
-    what a GPU shared by several orchestrator pools delivers, and the per-match latency is what each of them sees."""
+def run_extra_pools(E, host, seed, ks=(2, 4, 8), steps=8):
+    """K independent pools on ONE GPU in one process: K engines (each with its own stream and its own configs[1] swarm),
+    driven from K host threads (the C ABI releases the GIL), each running the N = 1 line's loop.  The carve's launch keeps
+    a workgroup resident on every CU it uses, so every engine is told its share of the CUs (pm_set_carve_workgroups):
+    K launches then run side by side instead of queueing behind one another.  The aggregate rate is what a GPU shared by
+    several orchestrator pools delivers, the per-match latency what each of them sees."""
     import threading
     from protocol_amd.swarm import baseline_config
     engines = []
@@ -287,13 +288,24 @@ def run_extra_pools(E, host, seed, ks=(2, 4), steps=8):
         host.load_swarm(eng, sw)
         eng.tick()
         engines.append((eng, sw))
+    # the one-pool rate of the same loop (engine 0 alone, the whole GPU)
+    t1 = []
+    for _ in range(steps):
+        engines[0][0].reset_groups()
+        t0 = time.perf_counter()
+        engines[0][0].tick()
+        t1.append(time.perf_counter() - t0)
+    one = statistics.median(t1)
+    one_rate = float(engines[0][1].T) * float(engines[0][1].W) / one
     out = {"workload": "K x BASELINE configs[1] (one swarm per pool, seeds differ), concurrent cold matches on one GPU",
-           "steps_per_pool": steps, "by_k": {},
-           "note": ("K engines in ONE process, one host thread and one HIP stream each: the runtime multiplexes the streams "
-                    "onto a few hardware queues and serialises launches per device, so this is a lower bound of what K "
-                    "pools in K processes get (two processes sharing the GPU measured 1.87x the one-pool rate: "
-                    "profiles/r03_bench_n2_gloo.json, dist.replicas)")}
+           "steps_per_pool": steps, "one_pool": {"match_ms_p50": 1e3 * one, "pair_evals_per_s": one_rate}, "by_k": {},
+           "note": ("K engines in ONE process, one host thread and one HIP stream each; every engine takes (CUs - K) / K "
+                    "row-making workgroups for its carve (pm_set_carve_workgroups).  x_one_pool = aggregate rate / the rate "
+                    "of one pool that has the GPU to itself")}
     for K in ks:
+        share = max(16, (248 - K) // K)
+        for i in range(K):
+            engines[i][0].set_carve_workgroups(share)
         lat = [[] for _ in range(K)]
         go = threading.Barrier(K + 1)
 
@@ -316,8 +328,8 @@ def run_extra_pools(E, host, seed, ks=(2, 4), steps=8):
         el = time.perf_counter() - t0
         pairs = sum(float(engines[i][1].T) * float(engines[i][1].W) for i in range(K)) * steps
         allm = sorted(x for l in lat for x in l)
-        out["by_k"][str(K)] = {"pair_evals_per_s": pairs / el, "match_ms_p50": allm[len(allm) // 2], "match_ms_max": allm[-1],
-                               "wall_ms": 1e3 * el}
+        out["by_k"][str(K)] = {"carve_workgroups_per_pool": share, "pair_evals_per_s": pairs / el, "x_one_pool": pairs / el / one_rate,
+                               "match_ms_p50": allm[len(allm) // 2], "match_ms_max": allm[-1], "wall_ms": 1e3 * el}
     for eng, _ in engines:
         eng.close()
     return out
@@ -402,7 +414,11 @@ def run_extra_churn(E, host, seed, ticks=6):
             "ms_per_tick": m("status_ms") + m("append_ms") + m("tasks_ms") + m("match_ms"),
             "split_ms_p50": {k: m(k) for k in ("status_ms", "append_ms", "tasks_ms", "match_ms", "carve_ms", "sweep_ms",
                                                "publish_ms")},
-            "formed_per_tick_p50": m("formed"), "groups": out_ticks[-1]["groups"]}
+            "formed_per_tick_p50": m("formed"), "groups": out_ticks[-1]["groups"],
+            "carve_hbm_bytes_per_tick": pmc_traffic("churn_carve", "hbm_bytes_per_tick")[0],
+            "note": ("ms_per_tick is the SUM of the four phases' medians (status + append + tasks + match), each timed on its "
+                     "own with the host clock; tools/churn_probe.py (profiles/*_churn_ticks.txt) times the tick call alone "
+                     "and prints single ticks, so the two differ by the delta calls (0.4 - 0.5 ms) and by what a median hides")}
 
 
 def main() -> int:

@@ -375,6 +375,13 @@ typedef struct {
   uint64_t bytes_per_rank;
 } pm_dist_xfer;
 
+/* Several engines (pools) matching on ONE GPU at the same time: the carve's launch keeps a workgroup resident on every
+ * CU it uses for as long as it runs — the validator and the workgroups that make its neighbour rows — so K launches run
+ * side by side only if each takes its share: n = (CUs of the device - K) / K row-making workgroups per engine.  A
+ * 10k-worker swarm loses a few percent with 48 instead of ~200 of them; without the call (n == 0: sized by the swarm,
+ * up to every CU) a second engine's launch queues behind the first one's.  tests/test_gpu_parity.py
+ * (test_pools_share_one_gpu), bench.py `pools_on_one_gpu`. */
+int32_t pm_set_carve_workgroups(pm_engine*, uint32_t n);
 /* All work of this engine goes to the caller's HIP stream (hipStream_t), e.g. the stream its RCCL calls use, so
  * kernels and collectives are ordered without host synchronisation.  NULL = back to the engine's own stream. */
 int32_t pm_set_stream(pm_engine*, void* hip_stream);

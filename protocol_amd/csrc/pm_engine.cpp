@@ -2939,6 +2939,17 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
 // ------------------------------------------------------------------------------------------------
 // multi-GPU: ownership, the stepwise tick and its two exchanges (see include/pm_engine.h)
 
+// Pools sharing one GPU: the carve's launch keeps one workgroup per CU resident from its first configuration to its
+// last (the validator + its row-making workgroups), so K engines matching at the same time fit side by side only if
+// each asks for its share of the CUs.  0 = by the size of the eligible list (a pool with the GPU to itself).
+int32_t pm_set_carve_workgroups(pm_engine* e, uint32_t n) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  if (n > 4096u) return set_error(PM_EINVAL, "carve workgroups 0..4096");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->stream_wgs_env = n;
+  return PM_OK;
+}
+
 int32_t pm_set_stream(pm_engine* e, void* hip_stream) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);

@@ -96,7 +96,7 @@ EXPORTS = [
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
-    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
+    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_set_carve_workgroups", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
     "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
 ]
 
@@ -311,6 +311,11 @@ class Engine:
         else:
             check(lib().pm_tasks_insert_front(self._h, C.byref(soa)))
         self.T += soa.n
+
+    def set_carve_workgroups(self, n: int):
+        """row-making workgroups of the carve's launch (0 = by the size of the swarm): the share of the GPU this engine
+        takes when several pools match on it at the same time"""
+        check(lib().pm_set_carve_workgroups(self._h, int(n)))
 
     def tasks_delete(self, uids) -> int:
         u = _arr(uids, np.uint64)

@@ -630,6 +630,53 @@ def test_insert_front_with_republish_serves_idle_groups_at_once():
     eng.close()
 
 
+def test_pools_share_one_gpu():
+    """pm_set_carve_workgroups: four engines (four pools, their own swarms) matched at the same time from four host
+    threads, each with a quarter of the CUs for its carve — and once more with a share of ONE row-making workgroup, the
+    smallest launch there is.  Whatever the share, and whatever the other pools are doing on the GPU meanwhile, every
+    pool's groups are the oracle's."""
+    import threading
+    K = 4
+    pools = []
+    for k in range(K):
+        sw = make_swarm(50 + k, 400, 3000 + 500 * k)
+        eng = E.Engine(group_id_seed=7 + k)
+        host.load_swarm(eng, sw)
+        pools.append((eng, sw))
+    want = []
+    for k, (eng, sw) in enumerate(pools):
+        st = oracle_state_for(sw, reference_shaped=False, group_id_seed=7 + k)
+        st.try_form_new_groups()
+        st.try_merge_solo_groups()
+        want.append(oracle_groups(st))
+    for share in (60, 1, 0):
+        for eng, _ in pools:
+            eng.set_carve_workgroups(share)
+        got = [None] * K
+        go = threading.Barrier(K)
+
+        def run(i):
+            eng = pools[i][0]
+            go.wait()
+            for _ in range(3):
+                eng.reset_groups()
+                eng.tick()
+            got[i] = engine_groups(eng)
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        # (group ids continue each engine's own stream across the repeats: compare configurations and members)
+        strip = lambda gs: [(c, m) for (_gid, c, m, _task) in gs]
+        for i in range(K):
+            assert strip(got[i]) == strip(want[i]), (share, i)
+            assert pools[i][0].debug_carve_counters()["stream"] == 1
+    for eng, _ in pools:
+        eng.close()
+
+
 def test_group_event_feed_semantics():
     """off by default; a drain with buffers that are too small reports the sizes and drains nothing; switching the
     feed off clears it; pm_reset_groups logs nothing"""

@@ -6,7 +6,9 @@
   <tag>_timeline.txt       per-launch timeline of the last match of that run
   <tag>_churn_kernel_stats.csv / <tag>_churn_ticks.txt   the cold match + 8 ticks of the configs[4] stream (tools/churn_probe.py)
   <tag>_bench.json         the bench line of the default `bench.py` command (with the CPU baseline)
-  <tag>_pmc_traffic.json   HBM bytes per match from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes
+  <tag>_pmc_traffic.json   HBM bytes per match from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes: configs[1], configs[2]
+                           (configs2_*) and per tick of the configs[4] stream (churn_*)
+  <tag>_sq_counters.json   SQ_* counters of the carve's launch (waves, wait share, VALU issue)
 
 usage: python tools/collect_profiles.py <tag> [--skip-bench]
 Copy the files you want judged into profiles/ afterwards.
@@ -92,6 +94,66 @@ def main():
         traffic[g] = {"FETCH_SIZE_KB_per_match": f / matches, "WRITE_SIZE_KB_per_match": w / matches,
                       "hbm_bytes_per_match": (f + w) * 1024.0 / matches,
                       "hbm_bytes_per_match_fetch_x2": (2 * f + w) * 1024.0 / matches}
+    # 2b. the same two passes for BASELINE configs[2] (3 matches) and for the configs[4] stream (cold match + 8 ticks, and
+    # the cold match alone: a tick's traffic is the difference / 8)
+    def passes(name, cmd):
+        res = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            dd = os.path.join(out, f"pmc_{name}_{counter}")
+            run(f"cd /tmp && timeout -k 5 300 rocprofv3 --pmc {counter} -d {dd} -o p -- {cmd} > {out}/pmc_{name}_{counter}.log 2>&1", env=env)
+            try:
+                res[counter] = pmc_sum(os.path.join(dd, "p_results.db"), counter)
+            except Exception as ex:  # noqa: BLE001
+                print("pmc pass failed:", name, counter, ex)
+                res[counter] = {}
+            run(f"rm -rf {dd}")
+        return res
+
+    def grouped(res, div):
+        o = {}
+        for g, pats in groups.items():
+            f = sum(t for k, (t, _n) in res.get("FETCH_SIZE", {}).items() if any(p in k for p in pats))
+            w = sum(t for k, (t, _n) in res.get("WRITE_SIZE", {}).items() if any(p in k for p in pats))
+            o[g] = {"FETCH_SIZE_KB": f / div, "WRITE_SIZE_KB": w / div, "hbm_bytes": (f + w) * 1024.0 / div,
+                    "hbm_bytes_fetch_x2": (2 * f + w) * 1024.0 / div}
+        return o
+
+    if "--skip-extra-pmc" not in sys.argv:
+        c2 = grouped(passes("cfg2", f"{py} {bench} --config 2 --steps 2 --warmup 1 --no-cpu-baseline --no-extras"), 3)
+        for g, v in c2.items():
+            traffic["configs2_" + g] = {"FETCH_SIZE_KB_per_match": v["FETCH_SIZE_KB"], "WRITE_SIZE_KB_per_match": v["WRITE_SIZE_KB"],
+                                        "hbm_bytes_per_match": v["hbm_bytes"], "hbm_bytes_per_match_fetch_x2": v["hbm_bytes_fetch_x2"]}
+        ch8 = grouped(passes("churn8", f"{py} {ROOT}/tools/churn_probe.py 8"), 1)
+        ch0 = grouped(passes("churn0", f"{py} {ROOT}/tools/churn_probe.py 0"), 1)
+        for g in groups:
+            traffic["churn_" + g] = {
+                "hbm_bytes_cold_match": ch0[g]["hbm_bytes"],
+                "hbm_bytes_per_tick": (ch8[g]["hbm_bytes"] - ch0[g]["hbm_bytes"]) / 8.0,
+                "hbm_bytes_per_tick_fetch_x2": (ch8[g]["hbm_bytes_fetch_x2"] - ch0[g]["hbm_bytes_fetch_x2"]) / 8.0}
+        traffic["_note_configs2_churn"] = ("configs2_*: `bench.py --config 2 --steps 2 --warmup 1` (3 matches), per match.  churn_*: "
+                                           "tools/churn_probe.py 8 (cold match + 8 ticks) minus tools/churn_probe.py 0 (the cold "
+                                           "match alone), per tick; kernels launched by the worker / task deltas between the ticks "
+                                           "are outside the three groups.")
+    # 2c. what the carve's launch did with its waves: SQ counters of carve_stream_kernel (one validator workgroup whose
+    # chain is a dependent sequence, proposer workgroups whose waves compute one row each: a latency-bound kernel)
+    if "--skip-extra-pmc" not in sys.argv:
+        sq = {}
+        for cset in ("SQ_WAVES SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES SQ_WAIT_ANY", "SQ_INSTS_VALU SQ_INSTS_SALU", "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"):
+            dd = os.path.join(out, "pmc_sq")
+            run(f"cd /tmp && timeout -k 5 240 rocprofv3 --pmc {cset} -d {dd} -o p -- {py} {bench} --steps 3 --warmup 1 "
+                f"--no-cpu-baseline --no-extras > {out}/pmc_sq.log 2>&1", env=env)
+            for counter in cset.split():
+                try:
+                    got = pmc_sum(os.path.join(dd, "p_results.db"), counter)
+                    sq[counter] = {k.split("(")[0][-48:]: t / max(n, 1) for k, (t, n) in got.items() if "carve_stream" in k or "pair_sweep" in k}
+                except Exception as ex:  # noqa: BLE001
+                    sq[counter] = {"error": repr(ex)}
+            run(f"rm -rf {dd}")
+        sq["_note"] = ("per dispatch (sum over the dispatches of 4 matches / their number), `bench.py --steps 3 --warmup 1`; "
+                       "SQ_WAIT_ANY / SQ_WAVE_CYCLES = share of resident-wave cycles spent waiting; SQ_INSTS_VALU / "
+                       "SQ_WAVE_CYCLES = VALU issue per resident-wave cycle")
+        with open(os.path.join(out, f"{tag}_sq_counters.json"), "w") as fh:
+            json.dump(sq, fh, indent=1)
     traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python bench.py --steps 3 "
                         "--warmup 1` (4 full-swarm matches each); values are per match = sum over the kernels' "
                         "dispatches / 4.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a wide "
