@@ -108,6 +108,8 @@ struct PubTable {
   std::atomic<uint32_t> n{0};
   std::atomic<uint32_t> task_shift{0};  // added to every task position read from this buffer: tasks inserted in front
                                         // of the list since it was written (pm_tasks_insert_front) move them all alike
+  std::atomic<uint32_t> cleared{0};     // the groups the rows name are gone (pm_reset_groups): every row reads as "no
+                                        // group, no task" until the next publish
   size_t cap_rows = 0;
 };
 static_assert(sizeof(pm_assignment) == 32, "published rows are copied as four 64-bit words");
@@ -329,6 +331,19 @@ static void reset_groups_locked(pm_engine* e) {
   e->h_group_of.assign(e->W, -1);
   e->id_rng = e->cfg.group_id_seed;
   e->groups_dirty = true;
+  // The published rows name slots and ids of the list that just went (and the id stream restarts: the same ids will
+  // name other groups): a heartbeat before the next publish is told "no group", and pub_patch resolves nothing
+  // against the new list.
+  e->groups_epoch++;
+  const int cur = e->pub_cur.load(std::memory_order_relaxed);
+  if (cur >= 0) {
+    PubTable& t = e->pub[cur];
+    const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+    t.seq.store(s0 + 1, std::memory_order_relaxed);
+    std::atomic_thread_fence(std::memory_order_release);
+    t.cleared.store(1u, std::memory_order_relaxed);
+    t.seq.store(s0 + 2, std::memory_order_release);
+  }
 }
 
 // dissolve_group (mod.rs:1423-1487).  A status storm dissolves hundreds of groups per tick; removing each from
@@ -1054,9 +1069,19 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
   for (;;) {
     HIPCHK(hipEventRecord(e->kev[3], e->stream));
     HIPCHK(hipMemcpyAsync(&r->st, e->d_status.p, sizeof(r->st), hipMemcpyDeviceToHost, e->stream));
+    // (the batch descriptors: on the engine's stream with the status — a blocking copy on the null stream was a second
+    // driver round trip per poll; the streaming carve has none)
+    const bool want_desc = r->use_props && !r->stream;
+    if (want_desc && !r->pipelined)
+      HIPCHK(hipMemcpyAsync(r->desc, e->d_desc.p, sizeof(r->desc), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (r->pipelined) HIPCHK(hipStreamSynchronize(e->stream_p));  // (a preparation queued behind the last validation)
-    if (r->use_props) HIPCHK(hipMemcpy(r->desc, e->d_desc.p, sizeof(r->desc), hipMemcpyDeviceToHost));
+    if (r->pipelined) {
+      HIPCHK(hipStreamSynchronize(e->stream_p));  // (a preparation queued behind the last validation)
+      if (want_desc) {
+        HIPCHK(hipMemcpyAsync(r->desc, e->d_desc.p, sizeof(r->desc), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+      }
+    }
     {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
@@ -1393,6 +1418,7 @@ static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
       if (!e->groups[g].dead) slot_of_id.emplace(e->groups[g].id, uint32_t(g));
   }
   PubTable& t = e->pub[cur];
+  if (t.cleared.load(std::memory_order_relaxed)) return;  // (pm_reset_groups: no row of this buffer names a group of this list)
   const uint32_t n = t.n.load(std::memory_order_relaxed);
   pm_assignment* rows = reinterpret_cast<pm_assignment*>(t.words.load(std::memory_order_relaxed));
   if (!rows || !n) return;
@@ -1485,6 +1511,7 @@ static int32_t publish(pm_engine* e) {
   }
   t.n.store(e->W, std::memory_order_relaxed);
   t.task_shift.store(0, std::memory_order_relaxed);
+  t.cleared.store(0, std::memory_order_relaxed);
   t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
   e->pub_cur.store(nx, std::memory_order_release);
   e->h_table = reinterpret_cast<const pm_assignment*>(words);
@@ -3144,6 +3171,7 @@ int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t worker, pm_assignment* 
     const uint64_t* words = t.words.load(std::memory_order_relaxed);
     const uint32_t n = t.n.load(std::memory_order_relaxed);
     const uint32_t shift = t.task_shift.load(std::memory_order_relaxed);
+    const uint32_t cleared = t.cleared.load(std::memory_order_relaxed);
     uint64_t row[4] = {0, 0, 0, 0};
     const bool in_range = worker < n;
     if (in_range)
@@ -3152,6 +3180,12 @@ int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t worker, pm_assignment* 
     if (t.seq.load(std::memory_order_relaxed) != s1) continue;
     if (!in_range) return set_error(PM_ERANGE, "worker index out of range");
     std::memcpy(out, row, sizeof(*out));
+    if (cleared) {  // (pm_reset_groups since this buffer was written)
+      std::memset(out, 0, sizeof(*out));
+      out->task = PM_NONE;
+      out->group_slot = PM_NONE;
+      out->next_worker = PM_NONE;
+    }
     if (out->task != PM_NONE) out->task += shift;
     return PM_OK;
   }

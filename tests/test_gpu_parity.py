@@ -677,6 +677,30 @@ def test_pools_share_one_gpu():
         eng.close()
 
 
+def test_lookups_after_reset_groups_say_no_group():
+    """pm_reset_groups (and pm_upload_workers without keep_groups) drops every group and restarts the id stream: a
+    heartbeat before the next publish must not be served a row that names a slot or an id of the old list, and a task
+    delta in between must not resolve such a row against the new one."""
+    sw = make_swarm(23, 200, 900)
+    eng = E.Engine(group_id_seed=5)
+    host.load_swarm(eng, sw)
+    eng.tick()
+    grouped = [w for w in range(sw.W) if eng.lookup(w).group_slot != NONE]
+    assert len(grouped) > 100
+    eng.reset_groups()
+    for w in range(sw.W):
+        a = eng.lookup(w)
+        assert a.group_slot == NONE and a.task == NONE and a.group_size == 0
+    # new groups with the SAME ids (the id stream restarted), not yet published; a task delta patches the published rows
+    eng.form_groups()
+    masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+    eng.tasks_insert_front(masks[:3], created.max() + np.arange(3, 0, -1).astype(created.dtype), (uid[:3] + np.uint64(1 << 40)).astype(uid.dtype))
+    assert all(eng.lookup(w).group_slot == NONE for w in range(sw.W))
+    eng.tick()
+    assert sum(eng.lookup(w).group_slot != NONE for w in range(sw.W)) == len(grouped)
+    eng.close()
+
+
 def test_group_event_feed_semantics():
     """off by default; a drain with buffers that are too small reports the sizes and drains nothing; switching the
     feed off clears it; pm_reset_groups logs nothing"""
