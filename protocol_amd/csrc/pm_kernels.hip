@@ -377,6 +377,23 @@ __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t*
   out[r] = res;
 }
 
+// wave-wide inclusive prefix sum in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16, then the row ends carried
+// over with row_bcast 15 / 31): no LDS traffic.  (Six __shfl_up are six ds_bpermute round trips, ~130 cycles each — a
+// third of a pass of the bitmap sweep and of the ticketer's look.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_step(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v = dpp_add_step<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add_step<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add_step<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add_step<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // ---- task table deltas (the table grows downwards: new tasks sit in front of the old ones)
 // live prefix: prefix[j] = live tasks in words [w_begin, j); one workgroup, 64-word passes
 __global__ __launch_bounds__(64) void task_prefix_kernel(const uint64_t* __restrict__ live, uint32_t w_begin,
@@ -386,12 +403,7 @@ __global__ __launch_bounds__(64) void task_prefix_kernel(const uint64_t* __restr
   for (uint32_t j0 = w_begin; j0 < w_end; j0 += 64u) {
     const uint32_t j = j0 + lane;
     const uint32_t cnt = j < w_end ? (uint32_t)__popcll(live[j]) : 0u;
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o, 64);
-      if ((int)lane >= o) incl += up;
-    }
+    const uint32_t incl = wave_incl_scan_u32(cnt);
     if (j < w_end) prefix[j] = acc + incl - cnt;
     acc += __shfl(incl, 63, 64);
   }
@@ -2611,12 +2623,7 @@ __device__ __forceinline__ void cell_offer_runs(const CarveArgs& p, uint32_t* wl
                                                 bool shared, uint32_t ssite, const SeedGeo& sg, uint32_t SB, uint64_t ulps,
                                                 NearRow& q, uint32_t& n_mine,
                                                 const uint32_t* cfg32 = nullptr) {
-  uint32_t incl = len;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = __shfl_up(incl, o, 64);
-    if ((int)lane >= o) incl += up;
-  }
+  const uint32_t incl = wave_incl_scan_u32(len);
   const uint32_t excl = incl - len;
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const auto cs_slot = G((const uint32_t*)p.cs_slot);
@@ -3032,12 +3039,7 @@ __device__ __forceinline__ void prop_limit_scan(const CarveArgs& p, uint32_t n_l
     const uint32_t j = j0 + lane;
     const uint64_t m = j < lwp ? (g_al[j] & g_lc[j]) : 0ull;  // bits beyond n_list are zero in both bitmaps
     const uint32_t cnt = (uint32_t)__popcll(m);
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o, 64);
-      if ((int)lane >= o) incl += up;
-    }
+    const uint32_t incl = wave_incl_scan_u32(cnt);
     const uint64_t over = __ballot(acc + incl >= cap);
     const uint32_t last = over ? (uint32_t)__builtin_ctzll(over) : 63u;  // last word of this pass inside the batch
     if (j < lwp && lane <= last) {
@@ -3565,12 +3567,7 @@ __global__ __launch_bounds__(256) void cell_scan_sums_kernel(const CarveArgs* __
     for (uint32_t c0 = 0; c0 < n_blocks; c0 += 64u) {
       const uint32_t c = c0 + lane;
       const uint32_t x = c < n_blocks ? G((const uint32_t*)blk)[c] : 0u;
-      uint32_t incl = x;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += up;
-      }
+      const uint32_t incl = wave_incl_scan_u32(x);
       if (c < n_blocks) blk[c] = carry + incl - x;
       carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
@@ -3598,12 +3595,7 @@ __global__ __launch_bounds__(256) void cell_scan_apply_kernel(const CarveArgs* _
 #pragma unroll
   for (uint32_t k = 0; k < 4u; ++k) v[k] = i0 + k < total ? cnt[i0 + k] : 0u;
   const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-  uint32_t incl = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = __shfl_up(incl, o, 64);
-    if ((int)lane >= o) incl += up;
-  }
+  const uint32_t incl = wave_incl_scan_u32(mine);
   if (lane == 63u) s_w[wave] = incl;
   __syncthreads();
   uint32_t run = G((const uint32_t*)(p.cell_start + PM_CELL_TABLE))[blockIdx.x] + incl - mine;
