@@ -330,6 +330,46 @@ def run_extra_pools(E, host, seed, ks=(2, 4, 8), steps=8):
         allm = sorted(x for l in lat for x in l)
         out["by_k"][str(K)] = {"carve_workgroups_per_pool": share, "pair_evals_per_s": pairs / el, "x_one_pool": pairs / el / one_rate,
                                "match_ms_p50": allm[len(allm) // 2], "match_ms_max": allm[-1], "wall_ms": 1e3 * el}
+    # ---- the same pools through pm_tick_many: ONE call per round of K matches — from one host thread (the carves are
+    # started before the first is waited for), and with the library's thread-per-engine variant (K threads inside the
+    # library: no Python between the calls, so what is left of the difference to K processes is the HIP runtime's)
+    try:
+        tm = {"note": ("pm_tick_many(engines, K): per round K x pm_reset_groups + ONE call; x_one_pool = aggregate rate / the "
+                       "one-pool rate above; match_ms = per pool, device time from the start of its tick to its published "
+                       "table (pm_stats.ms_total); `staged` = one host thread walks the engines (start every carve, then "
+                       "finish each, then publish each), `threads` = a host thread per engine inside the library"),
+              "by_k": {}}
+        for K in tuple(ks) + (16,):
+            while len(engines) < K:
+                k = len(engines)
+                sw = baseline_config(1, seed=seed + 100 + k)
+                eng = E.Engine(group_id_seed=seed + 100 + k)
+                host.load_swarm(eng, sw)
+                eng.tick()
+                engines.append((eng, sw))
+            share = max(8, (248 - K) // K)
+            batch = [engines[i][0] for i in range(K)]
+            for eng in batch:
+                eng.set_carve_workgroups(share)
+            pairs = sum(float(engines[i][1].T) * float(engines[i][1].W) for i in range(K)) * steps
+            row = {"carve_workgroups_per_pool": share}
+            for mode, threads in (("staged", False), ("threads", True)):
+                for eng in batch:       # (one untimed round: the engines' first launch with this share)
+                    eng.reset_groups()
+                E.tick_many(batch, threads=threads)
+                lat, t0 = [], time.perf_counter()
+                for _ in range(steps):
+                    for eng in batch:
+                        eng.reset_groups()
+                    lat += [s["ms_total"] for s in E.tick_many(batch, threads=threads)]
+                el = time.perf_counter() - t0
+                lat.sort()
+                row[mode] = {"pair_evals_per_s": pairs / el, "x_one_pool": pairs / el / one_rate,
+                             "round_ms": 1e3 * el / steps, "match_ms_p50": lat[len(lat) // 2], "match_ms_max": lat[-1]}
+            tm["by_k"][str(K)] = row
+        out["tick_many"] = tm
+    except Exception as ex:
+        out["tick_many"] = {"error": repr(ex)}
     for eng, _ in engines:
         eng.close()
     return out

@@ -382,6 +382,18 @@ typedef struct {
  * up to every CU) a second engine's launch queues behind the first one's.  tests/test_gpu_parity.py
  * (test_pools_share_one_gpu), bench.py `pools_on_one_gpu`. */
 int32_t pm_set_carve_workgroups(pm_engine*, uint32_t n);
+/* pm_tick for n engines (pools) in ONE call from ONE host thread: every engine's carve is started on its own stream
+ * before the first is waited for, so the launches are resident side by side (pm_set_carve_workgroups first) and the
+ * host is never inside two HIP calls at once; per engine the device work is pm_tick's, in pm_tick's order, and what
+ * it publishes is what pm_tick would have published.  stats: n entries or NULL; stats[i].ms_total = device time from
+ * the start of engine i's tick to its published table, i.e. the latency pool i sees inside the batch.  An engine that
+ * fails leaves the batch (in the state a failed pm_tick leaves it in), the others finish; the call returns the first
+ * failure.  The reference runs one pool per orchestrator process (run_group_management_loop, mod.rs:180-203): this is
+ * the entry point for a process that serves several.
+ *   flags: 0, or PM_TICK_MANY_THREADS = one host thread per engine, each calling pm_tick (for comparison: K threads
+ *   meet in the HIP runtime's locks — bench.py `pools_on_one_gpu`). */
+#define PM_TICK_MANY_THREADS 1u
+int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uint32_t flags);
 /* All work of this engine goes to the caller's HIP stream (hipStream_t), e.g. the stream its RCCL calls use, so
  * kernels and collectives are ordered without host synchronisation.  NULL = back to the engine's own stream. */
 int32_t pm_set_stream(pm_engine*, void* hip_stream);

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(HERE, "libpm_engine.so")
 SOURCES = ["pm_kernels.hip", "pm_engine.cpp", "pm_host.cpp"]
-HEADERS = ["pm_device.h", "pm_internal.h"]
+HEADERS = ["pm_device.h", "pm_internal.h", "pm_stream.inc"]
 
 
 def _hipcc() -> str:
@@ -27,7 +27,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "pm_engine.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, h) for h in ("pm_engine.h", "pm_engine_debug.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

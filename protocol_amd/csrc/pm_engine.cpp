@@ -20,9 +20,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1195,10 +1197,11 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   return PM_OK;
 }
 
-static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = false) {
-  FormRun r;
-  int32_t rc = form_begin(e, &r, /*allow_pipeline=*/true);
-  if (rc) return rc;
+// The part of a single-call carve behind form_begin: wait for what was queued, queue more rounds if the carve needs
+// them, take the result in.  (Split from the beginning so that pm_tick_many can start the carves of several engines
+// before it waits for the first.)
+static int32_t run_form_rest(pm_engine* e, FormRun& r, uint32_t* n_formed, bool defer_absorb) {
+  int32_t rc = PM_OK;
   if (!r.nothing) {
     // (propose, validate, prepare) rounds are queued blindly and the ones behind a finished carve return at once —
     // at ~5 us per empty launch.  The first queue is sized by what the previous carve of this engine needed (a
@@ -1224,6 +1227,13 @@ static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = fa
   }
   if (!r.nothing && r.use_props && !r.stream) e->form_rounds_hint = r.st.n_batches + r.st.n_void;
   return form_finish(e, &r, n_formed, defer_absorb);
+}
+
+static int32_t run_form(pm_engine* e, uint32_t* n_formed, bool defer_absorb = false) {
+  FormRun r;
+  int32_t rc = form_begin(e, &r, /*allow_pipeline=*/true);
+  if (rc) return rc;
+  return run_form_rest(e, r, n_formed, defer_absorb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2961,6 +2971,122 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   host_mark("tick: published");
   if (rc) return rc;
   return tick_stats(e, stats, n_formed, n_merged);
+}
+
+// Several pools, one call.  A match is mostly one long launch the host waits for (the streaming carve), so an
+// orchestrator process that serves K pools (K engines) gains nothing from calling pm_tick K times in a row, and K host
+// threads calling it side by side meet in the HIP runtime's locks (bench `pools_on_one_gpu`: 1.5x at K = 4 where four
+// PROCESSES reach 3.3x).  Here ONE thread walks the engines three times — start every engine's carve on its own
+// stream; as the carves finish, queue each engine's group records, pair sweep and claim; take the results in and
+// publish — so the K carve launches are resident side by side (give every engine its share of the CUs first:
+// pm_set_carve_workgroups) and the host is never inside two HIP calls at once.  Per engine the sequence of device
+// work is exactly pm_tick's: same kernels, same order, same stream.
+//   PM_TICK_MANY_THREADS: one host thread per engine, each calling pm_tick (kept to measure the runtime's share).
+int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uint32_t flags) {
+  if (!engines || n == 0) return set_error(PM_EINVAL, "null argument");
+  if (n > 1024u) return set_error(PM_EINVAL, "more than 1024 engines in one call");
+  if (flags & ~uint32_t(PM_TICK_MANY_THREADS)) return set_error(PM_EINVAL, "unknown flag");
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!engines[i]) return set_error(PM_EINVAL, "null engine");
+    for (uint32_t j = 0; j < i; ++j)
+      if (engines[j] == engines[i]) return set_error(PM_EINVAL, "the same engine twice in one call");
+  }
+  if (flags & PM_TICK_MANY_THREADS) {
+    std::vector<int32_t> rcs(n, PM_OK);
+    std::vector<std::string> msgs(n);
+    std::vector<std::thread> th;
+    th.reserve(n);
+    for (uint32_t i = 0; i < n; ++i)
+      th.emplace_back([&, i] {
+        rcs[i] = pm_tick(engines[i], stats ? &stats[i] : nullptr);
+        if (rcs[i]) msgs[i] = g_last_error;  // (thread-local: carried to the caller's thread below)
+      });
+    for (std::thread& t : th) t.join();
+    for (uint32_t i = 0; i < n; ++i)
+      if (rcs[i]) return set_error(rcs[i], msgs[i]);
+    return PM_OK;
+  }
+  // every engine's lock for the whole call, taken in address order (two overlapping calls cannot cross)
+  std::vector<pm_engine*> by_addr(engines, engines + n);
+  std::sort(by_addr.begin(), by_addr.end(), [](const pm_engine* a, const pm_engine* b) { return std::less<const pm_engine*>()(a, b); });
+  std::vector<std::unique_lock<std::mutex>> locks;
+  locks.reserve(n);
+  for (pm_engine* e : by_addr) locks.emplace_back(e->mu);
+  for (uint32_t i = 0; i < n; ++i) {
+    pm_engine* e = engines[i];
+    if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
+      return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
+    if (e->dist_world > 1) return set_error(PM_ESTATE, "multi-GPU engine: use the stepwise tick (pm_dist_tick_begin ...)");
+    if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
+  }
+  std::vector<std::unique_ptr<FormRun>> runs(n);
+  std::vector<uint32_t> n_formed(n, 0), n_merged(n, 0);
+  // An engine that fails leaves the walk (its state is what a failed pm_tick leaves); the others finish their tick.
+  // The call reports the first failure.
+  std::vector<int32_t> rcs(n, PM_OK);
+  std::vector<std::string> msgs(n);
+  auto failed = [&](uint32_t i, int32_t rc) {
+    rcs[i] = rc;
+    msgs[i] = g_last_error;
+  };
+  // ---- 1: compatibility masks, the eligible list, the carve's launch(es) — nothing here waits for a carve
+  for (uint32_t i = 0; i < n; ++i) {
+    pm_engine* e = engines[i];
+    auto stage = [&]() -> int32_t {
+      HIPCHK(hipSetDevice(e->cfg.device));
+      tick_reset(e);
+      HIPCHK(hipEventRecord(e->ev[0], e->stream));
+      e->compat_dirty = true;
+      int32_t rc = ensure_compat(e);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(e->ev[1], e->stream));
+      runs[i].reset(new (std::nothrow) FormRun());
+      if (!runs[i]) return set_error(PM_ENOMEM, "out of host memory");
+      return form_begin(e, runs[i].get(), /*allow_pipeline=*/true);
+    };
+    const int32_t rc = stage();
+    if (rc) failed(i, rc);
+  }
+  // ---- 2: in launch order (the first carve started is the first to end): the carve's result, the merge pass, the
+  // pair sweep and the claim, queued behind it on the engine's stream
+  for (uint32_t i = 0; i < n; ++i) {
+    if (rcs[i]) continue;
+    pm_engine* e = engines[i];
+    auto stage = [&]() -> int32_t {
+      HIPCHK(hipSetDevice(e->cfg.device));
+      int32_t rc = run_form_rest(e, *runs[i], &n_formed[i], /*defer_absorb=*/true);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(e->ev[2], e->stream));
+      rc = run_merge(e, &n_merged[i]);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(e->ev[3], e->stream));
+      rc = run_match(e, false, nullptr);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(e->ev[4], e->stream));
+      return PM_OK;
+    };
+    const int32_t rc = stage();
+    runs[i].reset();
+    if (rc) failed(i, rc);
+  }
+  // ---- 3: the host copy of the new groups, the published table
+  for (uint32_t i = 0; i < n; ++i) {
+    if (rcs[i]) continue;
+    pm_engine* e = engines[i];
+    auto stage = [&]() -> int32_t {
+      HIPCHK(hipSetDevice(e->cfg.device));
+      int32_t rc = absorb_groups(e);
+      if (rc) return rc;
+      rc = publish(e);
+      if (rc) return rc;
+      return tick_stats(e, stats ? &stats[i] : nullptr, n_formed[i], n_merged[i]);
+    };
+    const int32_t rc = stage();
+    if (rc) failed(i, rc);
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (rcs[i]) return set_error(rcs[i], msgs[i]);
+  return PM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -96,7 +96,7 @@ EXPORTS = [
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
-    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_set_carve_workgroups", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
+    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_set_carve_workgroups", "pm_tick_many", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
     "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
 ]
 
@@ -147,6 +147,7 @@ def lib() -> C.CDLL:
         L.pm_newest_task.argtypes = [vp, C.POINTER(u32)]
         L.pm_tick.argtypes = [vp, C.POINTER(Stats)]
         L.pm_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.pm_tick_many.argtypes = [C.POINTER(vp), u32, C.POINTER(Stats), u32]
         L.pm_lookup_task_for_worker.argtypes = [vp, u32, C.POINTER(Assignment)]
         L.pm_device_task_column.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
         L.pm_append_workers.argtypes = [vp, C.POINTER(WorkerSoa), C.POINTER(u32)]
@@ -188,6 +189,20 @@ def check(rc: int) -> int:
 
 def _arr(a, dtype) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+TICK_MANY_THREADS = 1
+
+
+def tick_many(engines, threads: bool = False) -> list:
+    """pm_tick_many: one match per engine (pool), all of them in one call — the carves started before the first is
+    waited for, from one host thread (threads=True: one host thread per engine inside the library, for comparison).
+    Returns the engines' stats in order."""
+    n = len(engines)
+    hs = (C.c_void_p * n)(*[e._h for e in engines])
+    st = (Stats * n)()
+    check(lib().pm_tick_many(hs, n, st, TICK_MANY_THREADS if threads else 0))
+    return [s.as_dict() for s in st]
 
 
 class Engine:

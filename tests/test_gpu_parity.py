@@ -677,6 +677,71 @@ def test_pools_share_one_gpu():
         eng.close()
 
 
+def test_tick_many_is_pm_tick_per_engine():
+    """pm_tick_many: four pools matched in ONE call (carves started before the first is waited for, one host thread; and
+    with the library's thread-per-engine variant) end where four separate pm_tick calls end: the oracle's groups, the same
+    group ids, and row for row the same published table.  An engine that cannot tick fails the call and leaves the others'
+    results standing."""
+    K = 4
+    pools = []
+    for k in range(K):
+        sw = make_swarm(70 + k, 300 + 40 * k, 2500 + 700 * k)
+        eng = E.Engine(group_id_seed=11 + k)
+        host.load_swarm(eng, sw)
+        pools.append((eng, sw))
+    engines = [eng for eng, _ in pools]
+    row = lambda a: (a.task, a.group_slot, a.group_index, a.group_size, a.next_worker, a.group_id)
+    table = lambda eng, sw: [row(eng.lookup(w)) for w in range(sw.W)]
+    solo = []
+    for k, (eng, sw) in enumerate(pools):
+        st = oracle_state_for(sw, reference_shaped=False, group_id_seed=11 + k)
+        st.try_form_new_groups()
+        st.try_merge_solo_groups()
+        s = eng.tick()
+        want = [st.get_task_for_node(w) for w in range(sw.W)]   # (a group claims its task at its first heartbeat)
+        assert [eng.lookup(w).task if eng.lookup(w).task != NONE else -1 for w in range(sw.W)] == want
+        assert sorted(engine_groups(eng)) == sorted(oracle_groups(st))
+        solo.append((engine_groups(eng), table(eng, sw), s))
+    for threads in (False, True):
+        for share in (60, 0):
+            for eng in engines:
+                eng.reset_groups()
+                eng.set_carve_workgroups(share)
+            stats = E.tick_many(engines, threads=threads)
+            assert len(stats) == K
+            for i, (eng, sw) in enumerate(pools):
+                assert engine_groups(eng) == solo[i][0], (threads, share, i)
+                assert table(eng, sw) == solo[i][1], (threads, share, i)
+                for key in ("n_groups", "n_formed", "n_merged", "pair_evals"):
+                    assert stats[i][key] == solo[i][2][key], (key, threads, share, i)
+                assert stats[i]["pair_evals"] == sw.T * sw.W and stats[i]["ms_total"] > 0.0
+                assert eng.last_stats()["n_groups"] == solo[i][2]["n_groups"]
+            # an incremental batch on the standing groups: nothing forms, nothing moves
+            stats = E.tick_many(engines, threads=threads)
+            for i, (eng, sw) in enumerate(pools):
+                assert stats[i]["n_formed"] == 0 and table(eng, sw) == solo[i][1]
+    # a subset, in another order
+    for eng in engines:
+        eng.reset_groups()
+    stats = E.tick_many([engines[2], engines[0]])
+    assert [s["n_groups"] for s in stats] == [solo[2][2]["n_groups"], solo[0][2]["n_groups"]]
+    assert table(*pools[2]) == solo[2][1] and table(*pools[0]) == solo[0][1]
+    assert all(engines[1].lookup(w).group_slot == NONE for w in range(pools[1][1].W))  # (not in the batch: still reset)
+    # argument checks; an engine without tasks fails the call before any engine is touched
+    bare = E.Engine()
+    with pytest.raises(E.EngineError):
+        E.tick_many([engines[0], engines[0]])
+    with pytest.raises(E.EngineError):
+        E.tick_many([engines[1], bare])
+    assert all(engines[1].lookup(w).group_slot == NONE for w in range(pools[1][1].W))
+    with pytest.raises(E.EngineError):
+        E.tick_many([engines[1], bare], threads=True)   # (per-engine pm_tick: engine 1 ticks, the bare one reports)
+    assert table(*pools[1]) == solo[1][1]
+    bare.close()
+    for eng in engines:
+        eng.close()
+
+
 def test_lookups_after_reset_groups_say_no_group():
     """pm_reset_groups (and pm_upload_workers without keep_groups) drops every group and restarts the id stream: a
     heartbeat before the next publish must not be served a row that names a slot or an id of the old list, and a task
