@@ -31,6 +31,7 @@
 #include "pm_device.h"
 #include "pm_engine.h"
 #include "pm_internal.h"
+#include "pm_members.h"
 
 namespace pm {
 
@@ -94,7 +95,7 @@ struct Group {
   uint32_t cfg;
   uint32_t task;      // index into the current task table or PM_NONE
   uint64_t task_uid;  // identity of the claimed task across uploads
-  std::vector<uint32_t> members;  // carve order; BTreeSet order is derived from addr_rank
+  MemberList members;  // carve order; BTreeSet order is derived from addr_rank (pm_members.h: small lists need no heap)
   bool dead = false;              // dissolved, not yet removed from the list (compact_groups)
 };
 
@@ -425,9 +426,13 @@ static int32_t push_groups(pm_engine* e) {
   }
   if (!members.empty())
     HIPCHK(hipMemcpyAsync(e->d_members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice, e->stream));
-  if (e->W)
-    HIPCHK(hipMemcpyAsync(e->d_group_of.p, e->h_group_of.data(), size_t(e->W) * 4, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));  // the staging vectors die here
+  if (e->W) {
+    if (G == 0)  // no group holds a worker (a cold match behind pm_reset_groups): every row is -1, nothing is staged
+      HIPCHK(hipMemsetAsync(e->d_group_of.p, 0xFF, size_t(e->W) * 4, e->stream));
+    else
+      HIPCHK(hipMemcpyAsync(e->d_group_of.p, e->h_group_of.data(), size_t(e->W) * 4, hipMemcpyHostToDevice, e->stream));
+  }
+  if (G) HIPCHK(hipStreamSynchronize(e->stream));  // the staging vectors die here
   e->d_n_groups = uint32_t(G);
   e->d_n_members = uint32_t(members.size());
   e->groups_dirty = false;
@@ -1486,9 +1491,27 @@ static void pub_shift_tasks(pm_engine* e, uint32_t n_new) {
 
 // D2H of the assignment table + the group task words; the table lands directly in the snapshot buffer that is
 // not current (pinned host memory, written by the copy engine between the odd and the even mark of its sequence
-// counter — see PubTable), which then becomes the published one.
-static int32_t publish(pm_engine* e) {
-  const size_t G = e->groups.size();
+// counter — see PubTable), which then becomes the published one.  In two halves, so that a tick can queue the copies
+// right behind the claim and build its host copy of the new groups (absorb_groups) while they travel: publish_begin
+// marks the buffer and queues the copies, publish_end waits for them, flips the buffers and takes the groups' task
+// words in (the host list must be complete by then: it has d_n_groups entries once the last carve is absorbed).
+struct PubRun {
+  int nx = 0;
+  uint64_t s0 = 0;
+  uint64_t* words = nullptr;
+  size_t G = 0;
+};
+
+static void publish_abandon(pm_engine* e, const PubRun& pr) {
+  (void)hipStreamSynchronize(e->stream);  // (nothing may still be writing the buffer when it reads as stable again)
+  PubTable& t = e->pub[pr.nx];
+  t.n.store(0, std::memory_order_relaxed);  // contents undefined: nothing to look up in this buffer
+  t.seq.store(pr.s0 + 2, std::memory_order_release);
+}
+
+// G: the group count the task words are copied for — groups.size(), or, in front of absorb_groups, the device's count
+// (d_n_groups == groups.size() once the last carve is absorbed)
+static int32_t publish_begin(pm_engine* e, PubRun* pr, size_t G) {
   if (e->h_gtask_cap < G) {
     if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
     e->h_gtask_pinned = nullptr;
@@ -1497,7 +1520,6 @@ static int32_t publish(pm_engine* e) {
     HIPCHK(hipHostMalloc((void**)&e->h_gtask_pinned, cap * sizeof(uint32_t)));
     e->h_gtask_cap = cap;
   }
-  const uint32_t* g_task = e->h_gtask_pinned;
   const int cur = e->pub_cur.load(std::memory_order_relaxed);
   const int nx = cur < 0 ? 0 : (cur ^ 1);
   PubTable& t = e->pub[nx];
@@ -1509,22 +1531,40 @@ static int32_t publish(pm_engine* e) {
   const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
   t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
   std::atomic_thread_fence(std::memory_order_release);
+  pr->nx = nx;
+  pr->s0 = s0;
+  pr->words = words;
+  pr->G = G;
   hipError_t herr = hipSuccess;
   if (e->W) herr = hipMemcpyAsync(words, e->d_table.p, sizeof(pm_assignment) * e->W, hipMemcpyDeviceToHost, e->stream);
   if (herr == hipSuccess && G)
     herr = hipMemcpyAsync(e->h_gtask_pinned, e->d_g_task_next.p, G * 4, hipMemcpyDeviceToHost, e->stream);
-  if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
   if (herr != hipSuccess) {
-    t.n.store(0, std::memory_order_relaxed);          // contents undefined: nothing to look up in this buffer
-    t.seq.store(s0 + 2, std::memory_order_release);
+    publish_abandon(e, *pr);
     HIPCHK(herr);
   }
+  return PM_OK;
+}
+
+static int32_t publish_end(pm_engine* e, const PubRun& pr) {
+  PubTable& t = e->pub[pr.nx];
+  const hipError_t herr = hipStreamSynchronize(e->stream);
+  if (herr != hipSuccess) {
+    publish_abandon(e, pr);
+    HIPCHK(herr);
+  }
+  const size_t G = e->groups.size();
+  if (G != pr.G) {  // (the copies were sized by the device's group count in front of absorb_groups: see publish_begin)
+    publish_abandon(e, pr);
+    return set_error(PM_ESTATE, "publish: the host group list and the device group arrays disagree");
+  }
+  const uint32_t* g_task = e->h_gtask_pinned;
   t.n.store(e->W, std::memory_order_relaxed);
   t.task_shift.store(0, std::memory_order_relaxed);
   t.cleared.store(0, std::memory_order_relaxed);
-  t.seq.store(s0 + 2, std::memory_order_release);  // even: stable
-  e->pub_cur.store(nx, std::memory_order_release);
-  e->h_table = reinterpret_cast<const pm_assignment*>(words);
+  t.seq.store(pr.s0 + 2, std::memory_order_release);  // even: stable
+  e->pub_cur.store(pr.nx, std::memory_order_release);
+  e->h_table = reinterpret_cast<const pm_assignment*>(pr.words);
   e->pub_groups_epoch = e->groups_epoch;
   for (size_t g = 0; g < G; ++g) {
     e->groups[g].task = g_task[g];
@@ -1532,6 +1572,13 @@ static int32_t publish(pm_engine* e) {
   }
   std::swap(e->d_g_task, e->d_g_task_next);
   return PM_OK;
+}
+
+static int32_t publish(pm_engine* e) {
+  PubRun pr;
+  int32_t rc = publish_begin(e, &pr, e->groups.size());
+  if (rc) return rc;
+  return publish_end(e, pr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2964,10 +3011,17 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   if (rc) return rc;
   host_mark("tick: match queued");
   HIPCHK(hipEventRecord(e->ev[4], e->stream));
-  rc = absorb_groups(e);
+  // the table's copies travel while the host builds its copy of the new groups
+  PubRun pr;
+  rc = publish_begin(e, &pr, e->d_n_groups);
   if (rc) return rc;
+  rc = absorb_groups(e);
+  if (rc) {
+    publish_abandon(e, pr);
+    return rc;
+  }
   host_mark("tick: groups absorbed");
-  rc = publish(e);
+  rc = publish_end(e, pr);
   host_mark("tick: published");
   if (rc) return rc;
   return tick_stats(e, stats, n_formed, n_merged);
@@ -3020,6 +3074,7 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
     if (e->dist_phase != 0) return set_error(PM_ESTATE, "a stepwise tick is in progress");
   }
   std::vector<std::unique_ptr<FormRun>> runs(n);
+  std::vector<PubRun> pubs(n);
   std::vector<uint32_t> n_formed(n, 0), n_merged(n, 0);
   // An engine that fails leaves the walk (its state is what a failed pm_tick leaves); the others finish their tick.
   // The call reports the first failure.
@@ -3063,7 +3118,7 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
       rc = run_match(e, false, nullptr);
       if (rc) return rc;
       HIPCHK(hipEventRecord(e->ev[4], e->stream));
-      return PM_OK;
+      return publish_begin(e, &pubs[i], e->d_n_groups);  // (the table's copies: behind the claim, in front of the host's wait)
     };
     const int32_t rc = stage();
     runs[i].reset();
@@ -3076,8 +3131,11 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
     auto stage = [&]() -> int32_t {
       HIPCHK(hipSetDevice(e->cfg.device));
       int32_t rc = absorb_groups(e);
-      if (rc) return rc;
-      rc = publish(e);
+      if (rc) {
+        publish_abandon(e, pubs[i]);
+        return rc;
+      }
+      rc = publish_end(e, pubs[i]);
       if (rc) return rc;
       return tick_stats(e, stats ? &stats[i] : nullptr, n_formed[i], n_merged[i]);
     };

@@ -283,3 +283,21 @@ def test_parser_differential_fuzz_product_vs_oracle():
         else:
             n_panic += 1
     assert n_ok > 200 and n_err > 200      # the generator reaches both sides of the grammar
+
+
+def test_member_list_of_a_group_record(tmp_path):
+    """protocol_amd/csrc/pm_members.h (the member list of the engine's host-side group records: inline up to eight members,
+    heap beyond) against std::vector under the operations absorb_groups / compact_groups / run_merge perform —
+    tests/cpp/members_test.cpp, built here with g++ (address + UB sanitizers when they link)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    src = os.path.join(ROOT, "tests", "cpp", "members_test.cpp")
+    exe = str(tmp_path / "members_test")
+    base = [gxx, "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-I", os.path.join(ROOT, "protocol_amd", "csrc"), src, "-o", exe]
+    if subprocess.run(base + ["-fsanitize=address,undefined"], capture_output=True).returncode != 0:
+        subprocess.check_call(base)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "members_test ok" in out.stdout, out.stdout + out.stderr
