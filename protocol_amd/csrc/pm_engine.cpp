@@ -279,6 +279,8 @@ struct pm_engine {
   DevBuf<uint32_t> d_task_col;
   const pm_assignment* h_table = nullptr;  // the snapshot published last (host side of the lock-free look-up)
   uint64_t groups_epoch = 0, pub_groups_epoch = ~0ull;  // slot numbering of e->groups / the one the published rows use
+  std::unordered_map<uint64_t, uint32_t> slot_of_id;    // pub_patch: group id -> slot under numbering slot_of_id_epoch
+  uint64_t slot_of_id_epoch = ~0ull;
   // pinned staging for the group records a carve appended (absorbed into the host list by absorb_groups)
   uint32_t* h_gstage = nullptr;
   size_t h_gstage_cap = 0;
@@ -1426,24 +1428,24 @@ static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
   if (cur < 0) return;  // nothing published
   // the published rows name their group by the slot it had then; if the list has been compacted since, by its id
   const bool by_id = e->pub_groups_epoch != e->groups_epoch;
-  std::unordered_map<uint64_t, uint32_t> slot_of_id;
-  if (by_id) {
+  // (id -> slot, built once per numbering of the list — a status storm calls this once per worker: slots move only when
+  // the epoch does, a group dissolved since is found and seen dead, and the published rows, written before the epoch
+  // moved, name no group appended since)
+  std::unordered_map<uint64_t, uint32_t>& slot_of_id = e->slot_of_id;
+  if (by_id && e->slot_of_id_epoch != e->groups_epoch) {
+    slot_of_id.clear();
     slot_of_id.reserve(e->groups.size() * 2);
-    for (size_t g = 0; g < e->groups.size(); ++g)
-      if (!e->groups[g].dead) slot_of_id.emplace(e->groups[g].id, uint32_t(g));
+    for (size_t g = 0; g < e->groups.size(); ++g) slot_of_id.emplace(e->groups[g].id, uint32_t(g));
+    e->slot_of_id_epoch = e->groups_epoch;
   }
   PubTable& t = e->pub[cur];
   if (t.cleared.load(std::memory_order_relaxed)) return;  // (pm_reset_groups: no row of this buffer names a group of this list)
   const uint32_t n = t.n.load(std::memory_order_relaxed);
   pm_assignment* rows = reinterpret_cast<pm_assignment*>(t.words.load(std::memory_order_relaxed));
   if (!rows || !n) return;
-  const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
-  t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
-  std::atomic_thread_fence(std::memory_order_release);
-  const uint32_t keep_shift = only ? t.task_shift.load(std::memory_order_relaxed) : 0u;  // a full pass resets it
-  auto patch = [&](uint32_t w) {
-    pm_assignment a = rows[w];
-    if (a.group_slot == PM_NONE) return;
+  // one row as it reads now; keep_shift: what readers of the buffer the row goes to add to a position
+  auto patched = [&](pm_assignment a, uint32_t keep_shift) -> pm_assignment {
+    if (a.group_slot == PM_NONE) return a;
     uint32_t slot = a.group_slot;
     if (by_id) {
       const auto it = slot_of_id.find(a.group_id);
@@ -1461,16 +1463,46 @@ static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
       const uint32_t h = e->groups[slot].task;
       a.task = h == PM_NONE ? PM_NONE : task_position(e, h) - keep_shift;  // (readers add the buffer's shift)
     }
+    return a;
+  };
+  auto store_row = [](pm_assignment* dst, const pm_assignment& a) {
     uint64_t v[4];
     std::memcpy(v, &a, sizeof(a));
-    uint64_t* dst = reinterpret_cast<uint64_t*>(&rows[w]);
-    for (int k = 0; k < 4; ++k) __atomic_store_n(&dst[k], v[k], __ATOMIC_RELAXED);
+    uint64_t* d = reinterpret_cast<uint64_t*>(dst);
+    for (int k = 0; k < 4; ++k) __atomic_store_n(&d[k], v[k], __ATOMIC_RELAXED);
   };
-  if (only) {
+  if (!only) {
+    // Every row: written to the buffer that is NOT current, which then becomes the current one — exactly what a
+    // publish does — so a heartbeat thread never waits for a pass over W rows (in place, the buffer's sequence counter
+    // would be odd for the whole pass and every look-up would spin on it).
+    const int nx = cur ^ 1;
+    PubTable& d = e->pub[nx];
+    uint64_t* dw = nullptr;
+    if (pub_buffer(e, d, n, &dw) == PM_OK && dw) {
+      pm_assignment* drows = reinterpret_cast<pm_assignment*>(dw);
+      const uint64_t d0 = d.seq.load(std::memory_order_relaxed);
+      d.seq.store(d0 + 1, std::memory_order_relaxed);  // odd: being written
+      std::atomic_thread_fence(std::memory_order_release);
+      for (uint32_t w = 0; w < n; ++w) store_row(&drows[w], patched(rows[w], 0u));
+      d.n.store(n, std::memory_order_relaxed);
+      d.task_shift.store(0, std::memory_order_relaxed);  // (the rows hold current positions)
+      d.cleared.store(0, std::memory_order_relaxed);
+      d.seq.store(d0 + 2, std::memory_order_release);  // even: stable
+      e->pub_cur.store(nx, std::memory_order_release);
+      e->h_table = drows;
+      return;
+    }
+    // (no pinned memory for the other buffer: in place — look-ups retry until the pass is through)
+  }
+  const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
+  t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
+  std::atomic_thread_fence(std::memory_order_release);
+  if (only) {  // a dissolved group's members: a handful of rows, in place
+    const uint32_t keep_shift = t.task_shift.load(std::memory_order_relaxed);
     for (uint32_t w : *only)
-      if (w < n) patch(w);
+      if (w < n) store_row(&rows[w], patched(rows[w], keep_shift));
   } else {
-    for (uint32_t w = 0; w < n; ++w) patch(w);
+    for (uint32_t w = 0; w < n; ++w) store_row(&rows[w], patched(rows[w], 0u));
     t.task_shift.store(0, std::memory_order_relaxed);  // (the rows hold current positions again)
   }
   t.seq.store(s0 + 2, std::memory_order_release);  // even: stable

@@ -17,6 +17,16 @@
 
 #include "pm_device.h"
 
+// gfx950 only, and not as a formality: beside the CDNA4 instruction forms (DPP row shifts, ds_bpermute, s_memtime) the
+// placement kernels' last-block hand-over (carve_prep_place_kernel, carve_elig_place_kernel) pairs a WORKGROUP-scope
+// release with an agent-scope acquire.  That is less than the HSA memory model asks for; it holds here because what the
+// last block reads of the others was written by agent-scope atomics, which on this target are performed at the shared
+// L2 side once the issuing wave's vmcnt has drained (no-return atomics count under vmcnt, there is no vscnt), and
+// because the engine never runs in tgsplit mode.  On a target without those properties the release must be agent-scope.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "pm_kernels.hip is written for gfx950 (MI355X): see the note on the placement kernels' fences above"
+#endif
+
 namespace pm {
 
 // ------------------------------------------------------------------------------------------------
