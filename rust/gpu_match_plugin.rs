@@ -182,6 +182,8 @@ extern "C" {
     // multi-GPU (one process per GPU; the all-gathers are ncclAllGather on the stream handed to pm_set_stream)
     fn pm_set_stream(e: *mut c_void, hip_stream: *mut c_void) -> i32;
     fn pm_set_carve_workgroups(e: *mut c_void, n: u32) -> i32;
+    // (several pools served by one orchestrator process: one match per engine in one call — not used by the one-pool plugin below)
+    fn pm_tick_many(engines: *const *mut c_void, n: u32, stats: *mut pm_stats, flags: u32) -> i32;
     fn pm_dist_configure(e: *mut c_void, rank: u32, world: u32, shard_of_worker: *const u8) -> i32;
     fn pm_dist_tick_begin(e: *mut c_void) -> i32;
     fn pm_dist_carve_next(e: *mut c_void, x: *mut pm_dist_xfer, more: *mut u32) -> i32;
