@@ -50,6 +50,7 @@ FP64_VECTOR_TFLOPS = 78.6               # half the FP32 vector rate (157.3 TFLOP
 FLOP_PER_KEY = 9.0                      # chord form of the Haversine term: 3 subtractions, 1 multiply, 2 fma, 1 scale
 VALU_OPS_PER_KEY = 45.0                 # proposer hot loop, counted in the gfx950 ISA: ~40 VALU instructions per
                                         # 64-key stride (LDS reads aside) + the amortised insertions, per lane = per key
+HIP_HW_QUEUES = "16"                    # hardware queues asked of the HIP runtime (GPU_MAX_HW_QUEUES; its default is 4)
 LDS_ROUND_TRIP_CYC, CLOCK_GHZ = 50.0, 2.4   # MI355X_MICROARCH.md: ds_read issue->use ~50 cycles
 
 
@@ -299,9 +300,12 @@ def run_extra_pools(E, host, seed, ks=(2, 4, 8), steps=8):
     one_rate = float(engines[0][1].T) * float(engines[0][1].W) / one
     out = {"workload": "K x BASELINE configs[1] (one swarm per pool, seeds differ), concurrent cold matches on one GPU",
            "steps_per_pool": steps, "one_pool": {"match_ms_p50": 1e3 * one, "pair_evals_per_s": one_rate}, "by_k": {},
+           "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
            "note": ("K engines in ONE process, one host thread and one HIP stream each; every engine takes (CUs - K) / K "
                     "row-making workgroups for its carve (pm_set_carve_workgroups).  x_one_pool = aggregate rate / the rate "
-                    "of one pool that has the GPU to itself")}
+                    "of one pool that has the GPU to itself.  hip_hw_queues = GPU_MAX_HW_QUEUES of this process: with the "
+                    "runtime's default of 4 the engines' streams share hardware queues and K = 4 reaches 1.4x "
+                    "(profiles/r04_pools_hw_queues.json: the same legs under 4, 8, 16 and 32 queues)")}
     for K in ks:
         share = max(16, (248 - K) // K)
         for i in range(K):
@@ -332,7 +336,7 @@ def run_extra_pools(E, host, seed, ks=(2, 4, 8), steps=8):
                                "match_ms_p50": allm[len(allm) // 2], "match_ms_max": allm[-1], "wall_ms": 1e3 * el}
     # ---- the same pools through pm_tick_many: ONE call per round of K matches — from one host thread (the carves are
     # started before the first is waited for), and with the library's thread-per-engine variant (K threads inside the
-    # library: no Python between the calls, so what is left of the difference to K processes is the HIP runtime's)
+    # library: no Python between the calls)
     try:
         tm = {"note": ("pm_tick_many(engines, K): per round K x pm_reset_groups + ONE call; x_one_pool = aggregate rate / the "
                        "one-pool rate above; match_ms = per pool, device time from the start of its tick to its published "
@@ -476,6 +480,12 @@ def main() -> int:
     ap.add_argument("--check", action="store_true", help="also verify the groups against the oracle (slow)")
     args = ap.parse_args()
 
+    # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
+    # says otherwise) and runs two streams that share one in turn: with K engines (a carve stream + a side stream each)
+    # in one process, K = 4 pools matched one behind the other in pairs (1.4x the one-pool rate; 3.4x with 8 or more
+    # queues — `pools_on_one_gpu`).  Read once, when the runtime starts: set before anything touches HIP.  One engine
+    # is indifferent to it (1.31 vs 1.32 ms per match).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", HIP_HW_QUEUES)
     import torch
     import torch.distributed as dist
 

@@ -380,7 +380,13 @@ typedef struct {
  * side by side only if each takes its share: n = (CUs of the device - K) / K row-making workgroups per engine.  A
  * 10k-worker swarm loses a few percent with 48 instead of ~200 of them; without the call (n == 0: sized by the swarm,
  * up to every CU) a second engine's launch queues behind the first one's.  tests/test_gpu_parity.py
- * (test_pools_share_one_gpu), bench.py `pools_on_one_gpu`. */
+ * (test_pools_share_one_gpu), bench.py `pools_on_one_gpu`.
+ *   The process must also give the HIP runtime enough hardware queues: it multiplexes a process's streams onto
+ * GPU_MAX_HW_QUEUES of them (environment, read once when the runtime starts; 4 by default) and two streams on one queue
+ * run in turn.  An engine owns two streams, so with the default the third engine's carve already waits behind another
+ * engine's: K = 4 pools reach 1.4x the one-pool rate with 4 queues, 3.3x with 8 or more (profiles/r04_pools_hw_queues.json).
+ * Set GPU_MAX_HW_QUEUES >= 2 K (16 is a good value up to K = 8; 32 oversubscribes the device's queue slots) before the
+ * first HIP call of the process — INTEGRATION.md "Several pools on one GPU". */
 int32_t pm_set_carve_workgroups(pm_engine*, uint32_t n);
 /* pm_tick for n engines (pools) in ONE call from ONE host thread: every engine's carve is started on its own stream
  * before the first is waited for, so the launches are resident side by side (pm_set_carve_workgroups first) and the
@@ -390,8 +396,9 @@ int32_t pm_set_carve_workgroups(pm_engine*, uint32_t n);
  * fails leaves the batch (in the state a failed pm_tick leaves it in), the others finish; the call returns the first
  * failure.  The reference runs one pool per orchestrator process (run_group_management_loop, mod.rs:180-203): this is
  * the entry point for a process that serves several.
- *   flags: 0, or PM_TICK_MANY_THREADS = one host thread per engine, each calling pm_tick (for comparison: K threads
- *   meet in the HIP runtime's locks — bench.py `pools_on_one_gpu`). */
+ *   flags: 0, or PM_TICK_MANY_THREADS = one host thread per engine, each calling pm_tick (for comparison: with
+ *   enough hardware queues the two are within 10 % of each other up to K = 4; at K = 8 the one-thread walk keeps its
+ *   3.1x where the threads fall to 2.4x — bench.py `pools_on_one_gpu.tick_many`). */
 #define PM_TICK_MANY_THREADS 1u
 int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uint32_t flags);
 /* All work of this engine goes to the caller's HIP stream (hipStream_t), e.g. the stream its RCCL calls use, so

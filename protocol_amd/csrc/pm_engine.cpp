@@ -3060,14 +3060,16 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
 }
 
 // Several pools, one call.  A match is mostly one long launch the host waits for (the streaming carve), so an
-// orchestrator process that serves K pools (K engines) gains nothing from calling pm_tick K times in a row, and K host
-// threads calling it side by side meet in the HIP runtime's locks (bench `pools_on_one_gpu`: 1.5x at K = 4 where four
-// PROCESSES reach 3.3x).  Here ONE thread walks the engines three times — start every engine's carve on its own
-// stream; as the carves finish, queue each engine's group records, pair sweep and claim; take the results in and
-// publish — so the K carve launches are resident side by side (give every engine its share of the CUs first:
-// pm_set_carve_workgroups) and the host is never inside two HIP calls at once.  Per engine the sequence of device
-// work is exactly pm_tick's: same kernels, same order, same stream.
-//   PM_TICK_MANY_THREADS: one host thread per engine, each calling pm_tick (kept to measure the runtime's share).
+// orchestrator process that serves K pools (K engines) gains nothing from calling pm_tick K times in a row.  Here ONE
+// thread walks the engines three times — start every engine's carve on its own stream; as the carves finish, queue each
+// engine's group records, pair sweep and claim; take the results in and publish — so the K carve launches are resident
+// side by side (give every engine its share of the CUs first: pm_set_carve_workgroups; give the process enough hardware
+// queues: GPU_MAX_HW_QUEUES >= 2 K, see include/pm_engine.h — with the runtime's 4 the engines' streams share queues
+// and the launches run in turn whoever starts them) and the host is never inside two HIP calls at once.  Per engine
+// the sequence of device work is exactly pm_tick's: same kernels, same order, same stream.  With 16 queues: K = 4
+// 2.8x, K = 8 3.1x the one-pool rate (K host threads calling pm_tick: 3.3x and 1.6x from Python, 3.0x and 2.4x from
+// threads inside the library).
+//   PM_TICK_MANY_THREADS: one host thread per engine, each calling pm_tick (kept for that comparison).
 int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uint32_t flags) {
   if (!engines || n == 0) return set_error(PM_EINVAL, "null argument");
   if (n > 1024u) return set_error(PM_EINVAL, "more than 1024 engines in one call");

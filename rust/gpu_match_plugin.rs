@@ -277,6 +277,14 @@ impl GpuMatchPlugin {
     pub fn new(templates: Vec<NodeGroupConfiguration>, device: i32,
                upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>,
                webhook_plugins: Option<Vec<WebhookPlugin>>) -> Self {
+        // Hardware queues for the HIP runtime (read once, at the first HIP call of the process — which is the
+        // pm_engine_create below, the orchestrator uses HIP for nothing else): it maps a process's streams onto 4 of
+        // them by default and runs two streams that share one in turn; an engine owns two streams, so a process that
+        // serves several pools on one GPU needs >= 2 per pool (include/pm_engine.h, pm_set_carve_workgroups).  One
+        // pool is indifferent to the value.  Left alone if the operator has set it.
+        if std::env::var_os("GPU_MAX_HW_QUEUES").is_none() {
+            std::env::set_var("GPU_MAX_HW_QUEUES", "16");
+        }
         let mut cfg: pm_engine_config = unsafe { std::mem::zeroed() };
         unsafe { pm_engine_config_default(&mut cfg) };
         cfg.device = device;
