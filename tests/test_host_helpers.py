@@ -109,6 +109,83 @@ def test_rust_shim_binds_the_header_as_declared():
         assert rs_fields(name) == c_fields(name), name
 
 
+_C_BASE = {"uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "float": "f32",
+           "double": "f64", "char": "c_char", "void": "c_void", "pm_engine": "c_void", "size_t": "usize",
+           "unsigned long long": "u64"}
+
+
+def _c_decl_to_rust(decl: str) -> str:
+    """One C declarator ('const uint32_t* flags', 'pm_engine* const* engines', 'uint32_t') as the Rust FFI type that has
+    its layout: '*const u32', '*const *mut c_void', 'u32' (a pointer's target is const if the qualifier stands in
+    front of that '*'; the opaque pm_engine is c_void on the Rust side)."""
+    toks = re.findall(r"[A-Za-z_]\w*|\*", decl)
+    is_type = lambda t: t in ("const", "unsigned", "long", "int", "struct") or t in _C_BASE or t.startswith("pm_") or t.endswith("_t")
+    if toks and toks[-1] != "*" and not is_type(toks[-1]):
+        toks = toks[:-1]  # the parameter / field name
+    i, target_const, base = 0, False, []
+    while i < len(toks) and toks[i] != "*":
+        if toks[i] == "const":
+            target_const = True
+        else:
+            base.append(toks[i])
+        i += 1
+    ty = _C_BASE.get(" ".join(base), " ".join(base))
+    while i < len(toks):
+        assert toks[i] == "*", decl
+        ty = ("*const " if target_const else "*mut ") + ty
+        target_const = False
+        i += 1
+        if i < len(toks) and toks[i] == "const":
+            target_const = True
+            i += 1
+    return ty
+
+
+def test_rust_shim_types_are_the_headers_types():
+    """... and with the same TYPES: every parameter and return type of the extern block and every field of the repr(C)
+    structs, translated from the C declaration (uint32_t -> u32, const T* -> *const T, pm_engine* -> *mut c_void,
+    size_t -> usize), is what the shim wrote.  A width or a const / mut slip is an ABI bug no test over the C ABI sees."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pm_engine.h")).read(), flags=re.S)
+    rs = open(os.path.join(ROOT, "rust", "gpu_match_plugin.rs")).read()
+    norm = lambda t: re.sub(r"\s+", " ", t.strip())
+    protos = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(pm_[a-z_0-9]+)\s*\(([^;{}]*?)\)\s*;", hdr):
+        ret, args = m.group(1).strip().split("\n")[-1].strip(), m.group(3).strip()
+        params = [] if args in ("", "void") else [_c_decl_to_rust(a) for a in args.split(",")]
+        protos[m.group(2)] = (None if ret == "void" else _c_decl_to_rust(ret + " x"), params)
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    n = 0
+    for m in re.finditer(r"fn (pm_[a-z_0-9]+)\s*\((.*?)\)\s*(?:->\s*([\w:*<> ]+))?;", block, flags=re.S):
+        name, args, ret = m.group(1), m.group(2).strip(), m.group(3)
+        params = [norm(a.split(":", 1)[1]) for a in args.split(",") if a.strip()]
+        assert ((norm(ret) if ret else None), params) == protos[name], (name, ret, params, protos[name])
+        n += 1
+    assert n >= 30
+    # the structs: (field, type) in order
+    def c_struct(name):
+        body = re.findall(r"typedef struct(?: \w+)?\s*\{([^{}]*)\}\s*" + name + r"\s*;", hdr, flags=re.S)[0]
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            parts = decl.split(",")          # 'float a, b' / 'const uint32_t *x, *y'
+            head = parts[0]
+            base = re.match(r"\s*((?:const\s+)?[A-Za-z_]\w*(?:\s+long\s+long)?)", head).group(1)
+            out.append(_c_decl_to_rust(head))
+            out += [_c_decl_to_rust(base + " " + more) for more in parts[1:]]
+        return out
+
+    def rs_struct(name):
+        body = re.search(r"pub struct " + name + r"\s*\{(.*?)\n\}", rs, flags=re.S).group(1)
+        return [norm(t) for t in re.findall(r"pub \w+\s*:\s*([^,\n]+?)\s*(?:,|\n|$)", body)]
+
+    for name in ("pm_engine_config", "pm_worker_soa", "pm_task_soa", "pm_config_row", "pm_gpu_alt_row", "pm_assignment",
+                 "pm_group_event", "pm_stats", "pm_dist_xfer", "pm_group_vars"):
+        assert rs_struct(name) == c_struct(name), (name, rs_struct(name), c_struct(name))
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="this check is for boxes without a GPU")
 def test_engine_fails_loudly_without_gpu():
     with pytest.raises(E.EngineError) as ei:
