@@ -45,5 +45,44 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
     return out
 
 
+# ---- the host side above the C ABI, compiled: protocol_amd/plugin (GpuMatchPlugin, Scheduler — the C++ twin of
+# rust/gpu_match_plugin.rs).  Plain C++17, no HIP: g++, linked against libpm_engine.so next to it.
+PLUGIN_DIR = os.path.join(HERE, "plugin")
+PLUGIN_LIB = os.path.join(HERE, "libpm_plugin.so")
+PLUGIN_SOURCES = ["gpu_match_plugin.cpp"]
+PLUGIN_HEADERS = ["gpu_match_plugin.hpp"]
+
+
+def _cxx() -> str:
+    for cand in (shutil.which("g++"), shutil.which("c++"), _hipcc()):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("no C++ compiler found")
+
+
+def plugin_needs_build() -> bool:
+    if not os.path.exists(PLUGIN_LIB):
+        return True
+    t = os.path.getmtime(PLUGIN_LIB)
+    deps = [os.path.join(PLUGIN_DIR, f) for f in PLUGIN_SOURCES + PLUGIN_HEADERS] + [os.path.join(INCLUDE, "pm_engine.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_plugin(force: bool = False, verbose: bool = False) -> str:
+    """libpm_plugin.so: its pm_* symbols are libpm_engine.so's (found beside it through $ORIGIN)."""
+    build()  # (the engine library it links against)
+    if not force and not plugin_needs_build():
+        return PLUGIN_LIB
+    cmd = [_cxx(), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-I", PLUGIN_DIR,
+           *[os.path.join(PLUGIN_DIR, s) for s in PLUGIN_SOURCES], "-L", HERE, "-lpm_engine", "-Wl,-rpath,$ORIGIN",
+           "-lpthread", "-o", PLUGIN_LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(PLUGIN_LIB + ".tmp", PLUGIN_LIB)
+    return PLUGIN_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_plugin(force=True, verbose=True))

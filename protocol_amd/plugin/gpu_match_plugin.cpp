@@ -1,0 +1,596 @@
+// gpu_match_plugin.cpp — see gpu_match_plugin.hpp.  Statement for statement the sequence of rust/gpu_match_plugin.rs
+// over the C ABI (include/pm_engine.h); comments name the Rust function or the reference lines a block follows.
+#include "gpu_match_plugin.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+
+namespace orchestrator {
+
+namespace {
+
+// str::replace: every non-overlapping match, left to right
+std::string replace_all(std::string s, const std::string& from, const std::string& to) {
+  if (from.empty()) return s;
+  size_t at = 0;
+  while ((at = s.find(from, at)) != std::string::npos) {
+    s.replace(at, from.size(), to);
+    at += to.size();
+  }
+  return s;
+}
+
+std::string hex_lower(uint64_t v) {  // format!("{:x}", v): generate_group_id, mod.rs:1489-1493
+  char buf[24];
+  std::snprintf(buf, sizeof(buf), "%llx", (unsigned long long)v);
+  return buf;
+}
+
+// the two-call convention of the pm_host_* string helpers: size, then fill
+template <typename F>
+std::string render(F&& f, const std::function<void(int32_t)>& check) {
+  size_t need = 0;
+  check(f(nullptr, 0, &need));
+  std::string buf(need, '\0');
+  check(f(buf.data(), need, &need));
+  if (!buf.empty()) buf.pop_back();  // the terminating NUL
+  return buf;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ model types
+
+VolumeMount VolumeMount::replace_labels(const std::string& task_id, const std::optional<std::string>& node_address,
+                                        int64_t now) const {
+  VolumeMount out = *this;
+  for (std::string* p : {&out.host_path, &out.container_path}) {
+    *p = replace_all(*p, "${TASK_ID}", task_id);
+    if (node_address) *p = replace_all(*p, "${NODE_ADDRESS}", *node_address);
+    *p = replace_all(*p, "${TIMESTAMP}", std::to_string(now));
+  }
+  return out;
+}
+
+bool Task::operator==(const Task& o) const {
+  auto mounts_eq = [](const std::optional<std::vector<VolumeMount>>& a, const std::optional<std::vector<VolumeMount>>& b) {
+    if (a.has_value() != b.has_value()) return false;
+    if (!a) return true;
+    if (a->size() != b->size()) return false;
+    for (size_t i = 0; i < a->size(); ++i)
+      if ((*a)[i].host_path != (*b)[i].host_path || (*a)[i].container_path != (*b)[i].container_path) return false;
+    return true;
+  };
+  return id == o.id && name == o.name && image == o.image && created_at == o.created_at &&
+         allowed_topologies == o.allowed_topologies && env_vars == o.env_vars && cmd == o.cmd &&
+         mounts_eq(volume_mounts, o.volume_mounts);
+}
+
+uint64_t task_uid(const Task& t) {
+  // Uuid::as_u64_pair().1: the second eight bytes, big-endian = the last sixteen hex digits of the text form
+  uint64_t v = 0;
+  int digits = 0;
+  for (size_t i = t.id.size(); i-- > 0 && digits < 16;) {
+    const char c = t.id[i];
+    uint64_t d;
+    if (c >= '0' && c <= '9') d = uint64_t(c - '0');
+    else if (c >= 'a' && c <= 'f') d = uint64_t(c - 'a' + 10);
+    else if (c >= 'A' && c <= 'F') d = uint64_t(c - 'A' + 10);
+    else continue;  // '-'
+    v |= d << (4 * digits);
+    ++digits;
+  }
+  return v;
+}
+
+std::vector<Task> NewestTaskPlugin::filter_tasks(const std::vector<Task>& tasks, const Address&) {
+  if (tasks.empty()) return {};
+  // Iterator::max_by_key returns the LAST of several maxima
+  const Task* best = &tasks[0];
+  for (const Task& t : tasks)
+    if (t.created_at >= best->created_at) best = &t;
+  return {*best};
+}
+
+// ------------------------------------------------------------------------------------------------ the plugin
+
+bool GpuMatchPlugin::Row::operator==(const Row& o) const {
+  // (f64 compared like Rust's derived PartialEq: by value)
+  return flags == o.flags && gpu_count == o.gpu_count && gpu_mem == o.gpu_mem && gpu_class == o.gpu_class &&
+         cpu_cores == o.cpu_cores && ram == o.ram && storage == o.storage && lat == o.lat && lon == o.lon;
+}
+
+void GpuMatchPlugin::RowColumns::push(const Row& r, uint32_t rank) {
+  flags.push_back(r.flags);
+  gpu_count.push_back(r.gpu_count);
+  gpu_mem.push_back(r.gpu_mem);
+  gpu_class.push_back(r.gpu_class);
+  cpu_cores.push_back(r.cpu_cores);
+  ram.push_back(r.ram);
+  storage.push_back(r.storage);
+  addr_rank.push_back(rank);
+  lat.push_back(r.lat);
+  lon.push_back(r.lon);
+}
+
+pm_worker_soa GpuMatchPlugin::RowColumns::soa() const {
+  pm_worker_soa w{};
+  w.n = uint32_t(flags.size());
+  w.flags = flags.data();
+  w.gpu_count = gpu_count.data();
+  w.gpu_mem_mb = gpu_mem.data();
+  w.gpu_model_class = gpu_class.data();
+  w.cpu_cores = cpu_cores.data();
+  w.ram_mb = ram.data();
+  w.storage_gb = storage.data();
+  w.price = nullptr;
+  w.addr_rank = addr_rank.data();
+  w.lat = lat.data();
+  w.lon = lon.data();
+  return w;
+}
+
+void GpuMatchPlugin::check(int32_t rc) const {
+  if (rc == PM_OK) return;
+  const char* msg = pm_last_error();
+  throw EngineError(rc, "pm_engine error " + std::to_string(rc) + ": " + (msg ? msg : ""));
+}
+
+GpuMatchPlugin::GpuMatchPlugin(std::vector<NodeGroupConfiguration> templates, int32_t device, UploadCounter upload_counter,
+                               std::vector<std::shared_ptr<WebhookPlugin>> webhook_plugins)
+    : upload_counter_(std::move(upload_counter)), webhook_plugins_(std::move(webhook_plugins)) {
+  // Hardware queues for the HIP runtime: read once, at the first HIP call of the process (the pm_engine_create
+  // below).  See rust/gpu_match_plugin.rs GpuMatchPlugin::new and include/pm_engine.h (pm_set_carve_workgroups).
+  setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0);
+  {
+    std::set<std::string> seen;
+    for (const NodeGroupConfiguration& t : templates)
+      if (!seen.insert(t.name).second) throw std::invalid_argument("Configuration names must be unique");  // mod.rs:142-144
+  }
+  pm_engine_config cfg;
+  pm_engine_config_default(&cfg);
+  cfg.device = device;
+  check(pm_engine_create(&cfg, &engine_));
+  try {
+    for (const NodeGroupConfiguration& t : templates) config_names_.push_back(t.name);
+    set_configs(templates);
+    // an empty worker / task table, so that the delta calls have something to extend
+    RowColumns empty;
+    const pm_worker_soa w = empty.soa();
+    check(pm_upload_workers(engine_, &w, 0));
+    check(pm_enable_group_events(engine_, 1));  // the webhook feed
+    const uint64_t no_uid = 0;
+    pm_task_soa t{};
+    t.n = 0;
+    t.uid = &no_uid;  // (non-null: "the tasks have ids")
+    check(pm_upload_tasks(engine_, &t));
+  } catch (...) {
+    pm_engine_destroy(engine_);
+    engine_ = nullptr;
+    throw;
+  }
+}
+
+GpuMatchPlugin::~GpuMatchPlugin() {
+  if (engine_) pm_engine_destroy(engine_);
+}
+
+// NodeGroupConfiguration + its requirement string -> pm_config_row / pm_gpu_alt_row (set_configs of the Rust shim;
+// the field-by-field projection there is pm_host_parse_requirements here, the same product parser the tests pin to
+// the reference's vectors)
+void GpuMatchPlugin::set_configs(const std::vector<NodeGroupConfiguration>& templates) {
+  std::vector<pm_config_row> rows;
+  std::vector<pm_gpu_alt_row> alts;
+  for (const NodeGroupConfiguration& t : templates) {
+    pm_config_row row{};
+    if (t.compute_requirements) {
+      std::vector<pm_gpu_alt_row> a(64);
+      std::string models(t.compute_requirements->size() + 64 + 1, '\0');
+      int32_t rc = pm_host_parse_requirements(t.compute_requirements->c_str(), &row, a.data(), uint32_t(a.size()),
+                                              models.data(), models.size());
+      if (rc == PM_ERANGE) {  // more alternatives than the first guess
+        a.resize(std::max<size_t>(row.alt_count, 1024));
+        rc = pm_host_parse_requirements(t.compute_requirements->c_str(), &row, a.data(), uint32_t(a.size()), models.data(),
+                                        models.size());
+      }
+      if (rc != PM_OK)
+        throw std::invalid_argument("compute_requirements of '" + t.name + "': " + (pm_last_error() ? pm_last_error() : ""));
+      row.flags |= PM_R_HAS_REQ;
+      row.alt_begin = uint32_t(alts.size());
+      for (uint32_t k = 0; k < row.alt_count; ++k) {
+        pm_gpu_alt_row g = a[k];
+        if (g.flags & PM_G_MODEL) {  // (model_row comes back as a byte offset into `models`)
+          const std::string m(models.c_str() + g.model_row);
+          g.model_row = uint32_t(req_models_.size());
+          req_models_.push_back(m);
+        }
+        alts.push_back(g);
+      }
+    }
+    row.min_group_size = uint32_t(t.min_group_size);
+    row.max_group_size = uint32_t(t.max_group_size);
+    rows.push_back(row);
+  }
+  const int32_t rc = pm_set_configs(engine_, rows.data(), uint32_t(rows.size()), alts.data(), uint32_t(alts.size()));
+  if (rc == PM_EINVAL) throw std::invalid_argument("Plugin configuration is invalid");  // mod.rs:145-147
+  check(rc);
+  push_model_table(NodeTable{});
+}
+
+// The substring rule of GpuSpecs::meets (shared/models/node.rs:463-484), evaluated once per (requirement model,
+// interned spec model) pair by the library; re-sent whenever a new spec model shows up.
+void GpuMatchPlugin::push_model_table(const NodeTable& nodes) const {
+  std::vector<const char*> spec_p, req_p;
+  for (const std::string& s : nodes.spec_models) spec_p.push_back(s.c_str());
+  for (const std::string& s : req_models_) req_p.push_back(s.c_str());
+  const size_t words = (spec_p.size() + 31) / 32;
+  std::vector<uint32_t> bits(std::max<size_t>(req_p.size() * words, 1), 0u);
+  check(pm_host_build_model_table(req_p.data(), uint32_t(req_p.size()), spec_p.data(), uint32_t(spec_p.size()), bits.data()));
+  check(pm_set_model_table(engine_, bits.data(), uint32_t(req_p.size()), uint32_t(spec_p.size())));
+}
+
+// Projection of one OrchestratorNode (orchestrator/src/models/node.rs:11-37) into the SoA row.
+GpuMatchPlugin::Row GpuMatchPlugin::project(const OrchestratorNode& node, NodeTable& table, bool* new_model) {
+  Row r;
+  if (node.status == NodeStatus::Healthy) r.flags |= PM_W_HEALTHY;
+  if (node.p2p_id) r.flags |= PM_W_HAS_P2P;
+  if (node.location) {
+    r.flags |= PM_W_HAS_LOC;
+    r.lat = node.location->latitude;
+    r.lon = node.location->longitude;
+  }
+  if (node.compute_specs) {
+    const ComputeSpecs& s = *node.compute_specs;
+    r.flags |= PM_W_HAS_SPECS;
+    if (s.gpu) {
+      r.flags |= PM_W_HAS_GPU;
+      if (s.gpu->count) { r.flags |= PM_W_GPU_COUNT; r.gpu_count = *s.gpu->count; }
+      if (s.gpu->memory_mb) { r.flags |= PM_W_GPU_MEM; r.gpu_mem = *s.gpu->memory_mb; }
+      if (s.gpu->model) {
+        r.flags |= PM_W_GPU_MODEL;
+        auto it = table.spec_model_index.find(*s.gpu->model);
+        if (it == table.spec_model_index.end()) {
+          *new_model = true;
+          table.spec_models.push_back(*s.gpu->model);
+          it = table.spec_model_index.emplace(*s.gpu->model, uint32_t(table.spec_models.size() - 1)).first;
+        }
+        r.gpu_class = it->second;
+      }
+    }
+    if (s.cpu) {
+      r.flags |= PM_W_HAS_CPU;
+      if (s.cpu->cores) { r.flags |= PM_W_CPU_CORES; r.cpu_cores = *s.cpu->cores; }
+    }
+    if (s.ram_mb) { r.flags |= PM_W_RAM; r.ram = *s.ram_mb; }
+    if (s.storage_gb) { r.flags |= PM_W_STORAGE; r.storage = *s.storage_gb; }
+  }
+  return r;
+}
+
+// rank of address.to_string() in byte order (BTreeSet<String>, mod.rs:424-434) among the first `known` rows: one
+// pass over the sorted row list
+std::vector<uint32_t> GpuMatchPlugin::address_ranks(const std::vector<uint32_t>& by_address, size_t known) {
+  std::vector<uint32_t> rank(known, 0u);
+  uint32_t r = 0;
+  for (uint32_t i : by_address)
+    if (i < known) rank[i] = r++;
+  return rank;
+}
+
+void GpuMatchPlugin::sync_nodes(const std::vector<OrchestratorNode>& snapshot) {
+  {
+    std::unique_lock<std::shared_mutex> lk(nodes_mu_);
+    NodeTable& t = nodes_;
+    bool new_model = false;
+    std::vector<bool> seen(t.rows.size(), false);
+    RowColumns appended, updated;
+    std::vector<uint32_t> upd_idx;
+    for (const OrchestratorNode& node : snapshot) {
+      const Row row = project(node, t, &new_model);
+      const auto it = t.index.find(node.address);
+      if (it != t.index.end()) {
+        const size_t i = it->second;
+        if (i < seen.size()) seen[i] = true;   // (an address twice in one snapshot: the second one finds the row just appended)
+        t.p2p_ids[i] = node.p2p_id.value_or(std::string());
+        if (t.rows[i] != row || !t.present[i]) {
+          t.rows[i] = row;
+          t.present[i] = true;
+          if (i < seen.size()) {
+            upd_idx.push_back(uint32_t(i));
+            updated.push(row, 0);  // ranks are replaced below
+          }
+        }
+      } else {
+        const uint32_t i = uint32_t(t.rows.size());
+        t.index.emplace(node.address, i);
+        t.addresses.push_back(node.address);
+        t.address_strings.push_back(node.address.to_string());
+        t.p2p_ids.push_back(node.p2p_id.value_or(std::string()));
+        t.rows.push_back(row);
+        t.present.push_back(true);
+        const std::string& key = t.address_strings[i];
+        const auto at = std::partition_point(t.by_address.begin(), t.by_address.end(),
+                                             [&](uint32_t j) { return t.address_strings[j] < key; });
+        t.by_address.insert(at, i);
+        appended.push(row, i);
+      }
+    }
+    if (new_model) push_model_table(t);
+    // nodes that left the store: tombstone (their group dissolves, like a death; status_update_impl.rs:17-29)
+    std::vector<uint32_t> gone, gone_flags;
+    for (size_t i = 0; i < seen.size(); ++i)
+      if (!seen[i] && t.present[i]) {
+        t.present[i] = false;
+        t.rows[i].flags &= ~uint32_t(PM_W_HEALTHY);
+        gone.push_back(uint32_t(i));
+        gone_flags.push_back(t.rows[i].flags);
+      }
+    if (!gone.empty()) {
+      const std::vector<uint32_t> dead(gone.size(), 1u);
+      check(pm_on_worker_status_many(engine_, gone.data(), gone_flags.data(), dead.data(), uint32_t(gone.size())));
+    }
+    if (!upd_idx.empty()) {
+      // keep the ranks the engine already has for rewritten rows (ranks among the rows it knows: the new ones of
+      // this snapshot are sent behind this call)
+      const std::vector<uint32_t> ranks = address_ranks(t.by_address, seen.size());
+      for (size_t k = 0; k < upd_idx.size(); ++k) updated.addr_rank[k] = ranks[upd_idx[k]];
+      const pm_worker_soa w = updated.soa();
+      check(pm_update_workers(engine_, upd_idx.data(), &w));
+    }
+    if (!appended.flags.empty()) {
+      // (a row appended by this very snapshot may have been rewritten by a later entry of it: send what it is now)
+      for (size_t k = 0; k < appended.flags.size(); ++k) {
+        const Row& r = t.rows[seen.size() + k];
+        appended.flags[k] = r.flags;
+        appended.gpu_count[k] = r.gpu_count;
+        appended.gpu_mem[k] = r.gpu_mem;
+        appended.gpu_class[k] = r.gpu_class;
+        appended.cpu_cores[k] = r.cpu_cores;
+        appended.ram[k] = r.ram;
+        appended.storage[k] = r.storage;
+        appended.lat[k] = r.lat;
+        appended.lon[k] = r.lon;
+      }
+      uint32_t first = 0;
+      const pm_worker_soa w = appended.soa();
+      check(pm_append_workers(engine_, &w, &first));
+      if (first != seen.size()) throw EngineError(PM_ESTATE, "the engine's worker table and the plugin's row map disagree");
+      // a new address shifts the global ranks of the others: GROUP_INDEX only needs the relative order
+      const std::vector<uint32_t> ranks = address_ranks(t.by_address, t.rows.size());
+      check(pm_set_addr_ranks(engine_, ranks.data(), uint32_t(ranks.size())));
+    }
+  }
+  emit_group_webhooks();  // tombstoned nodes dissolved their groups
+}
+
+// scheduler_impl.rs:44-59: any None on the way => every configuration allowed
+uint64_t GpuMatchPlugin::topology_mask(const Task& t) const {
+  if (!t.allowed_topologies) return ~0ull;
+  uint64_t m = 0;
+  for (const std::string& name : *t.allowed_topologies) {
+    const auto it = std::find(config_names_.begin(), config_names_.end(), name);
+    if (it != config_names_.end()) m |= 1ull << size_t(it - config_names_.begin());
+  }
+  return m;
+}
+
+void GpuMatchPlugin::push_enabled(const std::vector<Task>& tasks) const {
+  // available_node_group_configs: every topology some task names (on_task_created, mod.rs:1224-1243)
+  uint64_t enabled = 0;
+  for (const Task& t : tasks) {
+    const uint64_t m = topology_mask(t);
+    if (m != ~0ull) enabled |= m;
+  }
+  check(pm_set_enabled_mask(engine_, enabled));
+}
+
+// The engine reports a task as a POSITION in `tasks_`, and it re-derives the published positions inside
+// pm_tasks_insert_front / pm_tasks_delete / pm_upload_tasks — so the list and the engine's table change under ONE
+// write lock, and filter_tasks holds the read lock from the look-up to the index: a heartbeat never pairs a position
+// of the new table with the old list (or the other way round).
+
+void GpuMatchPlugin::sync_tasks_locked(std::vector<Task>& guard, std::vector<Task> tasks) {
+  std::vector<uint64_t> masks, uid;
+  std::vector<int64_t> created;
+  for (const Task& t : tasks) {
+    masks.push_back(topology_mask(t));
+    created.push_back(t.created_at);
+    uid.push_back(task_uid(t));
+  }
+  const uint64_t no_uid = 0;
+  pm_task_soa soa{};
+  soa.n = uint32_t(tasks.size());
+  soa.topo_mask = masks.data();
+  soa.created_at = created.data();
+  soa.uid = tasks.empty() ? &no_uid : uid.data();
+  check(pm_upload_tasks(engine_, &soa));
+  push_enabled(tasks);
+  guard = std::move(tasks);
+}
+
+void GpuMatchPlugin::sync_tasks(std::vector<Task> tasks) {
+  std::unique_lock<std::shared_mutex> guard(tasks_mu_);
+  sync_tasks_locked(tasks_, std::move(tasks));
+}
+
+void GpuMatchPlugin::on_task_created(const Task& task, const std::function<std::vector<Task>()>& all_tasks) {
+  const uint64_t mask = topology_mask(task), uid = task_uid(task);
+  const int64_t created = task.created_at;
+  pm_task_soa soa{};
+  soa.n = 1;
+  soa.topo_mask = &mask;
+  soa.created_at = &created;
+  soa.uid = &uid;
+#ifndef PM_PLUGIN_TEST_ROUND3_LOCK_ORDER
+  std::unique_lock<std::shared_mutex> guard(tasks_mu_);  // (before the engine call: see LOCK ORDER)
+  const int32_t rc = republish_on_insert.load() ? pm_tasks_insert_front_ex(engine_, &soa, 1) : pm_tasks_insert_front(engine_, &soa);
+#else  // the order the round-3 review found in the Rust shim (engine first, lock second): built only by the test that
+       // shows tests/cpp/plugin_test.cpp sees it
+  const int32_t rc = republish_on_insert.load() ? pm_tasks_insert_front_ex(engine_, &soa, 1) : pm_tasks_insert_front(engine_, &soa);
+  std::unique_lock<std::shared_mutex> guard(tasks_mu_);
+#endif
+  if (rc != PM_OK) {  // equal or older timestamps: the snapshot
+    sync_tasks_locked(tasks_, all_tasks());
+    return;
+  }
+  tasks_.insert(tasks_.begin(), task);
+  push_enabled(tasks_);
+}
+
+void GpuMatchPlugin::on_task_deleted(const Task& task) {
+  const uint64_t uid = task_uid(task);
+  uint32_t n = 0;
+  {
+    std::unique_lock<std::shared_mutex> guard(tasks_mu_);  // (before the engine call: see LOCK ORDER)
+    check(pm_tasks_delete(engine_, &uid, 1, &n));
+    tasks_.erase(std::remove_if(tasks_.begin(), tasks_.end(), [&](const Task& t) { return t.id == task.id; }), tasks_.end());
+    push_enabled(tasks_);
+  }
+  emit_group_webhooks();  // dissolve_group's send_group_destroyed, mod.rs:1469-1481
+}
+
+pm_stats GpuMatchPlugin::tick() {
+  pm_stats s{};
+  check(pm_tick(engine_, &s));
+  emit_group_webhooks();
+  return s;
+}
+
+// Drains the engine's group life-cycle feed into send_group_created / send_group_destroyed, in the order the
+// reference emits them.  Runs after everything that can create or dissolve groups.
+void GpuMatchPlugin::emit_group_webhooks() {
+  uint32_t ne = 0, nm = 0;
+  int32_t rc = pm_drain_group_events(engine_, nullptr, 0, nullptr, 0, &ne, &nm);
+  if (rc == PM_OK) return;  // empty log
+  // (another thread may log events between the size query and the drain: grow and try again; a drain that still
+  // fails is left for the next call — it is not the tick that failed)
+  std::vector<pm_group_event> events;
+  std::vector<uint32_t> members;
+  bool drained = false;
+  for (int attempt = 0; attempt < 8 && !drained; ++attempt) {
+    events.resize(ne);
+    members.resize(nm);
+    const uint32_t cap_e = ne, cap_m = nm;
+    rc = pm_drain_group_events(engine_, events.data(), cap_e, members.data(), cap_m, &ne, &nm);
+    if (rc == PM_OK) drained = true;
+    else if (rc != PM_ERANGE) return;
+  }
+  if (!drained) return;
+  if (webhook_plugins_.empty()) return;
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  for (uint32_t k = 0; k < ne; ++k) {
+    const pm_group_event& ev = events[k];
+    const std::string id = hex_lower(ev.group_id);
+    const std::string& name = config_names_[ev.config];
+    std::vector<std::string> nodes;
+    for (uint32_t j = 0; j < ev.n_members; ++j) nodes.push_back(nodes_.address_strings[members[ev.member_begin + j]]);  // group.nodes order
+    for (const auto& p : webhook_plugins_) {
+      try {
+        if (ev.kind == PM_GROUP_CREATED) p->send_group_created(id, name, nodes);
+        else p->send_group_destroyed(id, name, nodes);
+      } catch (const std::exception& e) {  // as in the reference: logged, not fatal
+        std::fprintf(stderr, "Failed to send group webhook: %s\n", e.what());
+      }
+    }
+  }
+}
+
+// SchedulerPlugin::filter_tasks (plugins/mod.rs:66-78): lock-free look-up + the `${...}` templating the reference does
+// at scheduler_impl.rs:112-205 (GROUP_INDEX, GROUP_SIZE, NEXT_P2P_ADDRESS, GROUP_ID, upload count).
+std::vector<Task> GpuMatchPlugin::filter_tasks(const std::vector<Task>&, const Address& node_address) {
+  std::shared_lock<std::shared_mutex> nodes(nodes_mu_);
+  const auto it = nodes_.index.find(node_address);
+  if (it == nodes_.index.end()) return {};
+  const uint32_t w = it->second;
+  pm_assignment a{};
+  Task task;
+  {
+    std::shared_lock<std::shared_mutex> tasks(tasks_mu_);  // held from the look-up to the index (see LOCK ORDER)
+    if (pm_lookup_task_for_worker(engine_, w, &a) != PM_OK || a.task == PM_NONE) return {};
+    if (a.task >= tasks_.size()) return {};
+    task = tasks_[a.task];
+  }
+  const std::string group_id = hex_lower(a.group_id);
+  const std::string next = a.next_worker < nodes_.p2p_ids.size() ? nodes_.p2p_ids[a.next_worker] : std::string();
+  const std::string count = std::to_string(upload_counter_ ? upload_counter_(node_address, group_id) : 0);
+  pm_group_vars vars{};
+  vars.group_index = a.group_index;
+  vars.group_size = a.group_size;
+  vars.next_p2p_address = next.c_str();
+  vars.group_id = group_id.c_str();
+  vars.total_upload_count = count.c_str();
+  const auto chk = [this](int32_t rc) { check(rc); };
+  const auto group_vars = [&](const std::string& s) {
+    return render([&](char* o, size_t c, size_t* n) { return pm_host_group_vars(s.c_str(), &vars, o, c, n); }, chk);
+  };
+  if (!task.env_vars) task.env_vars.emplace();
+  (*task.env_vars)["GROUP_INDEX"] = std::to_string(a.group_index);  // scheduler_impl.rs:161
+  for (auto& kv : *task.env_vars) kv.second = group_vars(kv.second);
+  if (task.cmd)
+    for (std::string& arg : *task.cmd) arg = group_vars(arg);
+  if (task.volume_mounts)  // scheduler_impl.rs:185-200
+    for (VolumeMount& m : *task.volume_mounts)
+      for (std::string* path : {&m.host_path, &m.container_path})
+        *path = render([&](char* o, size_t c, size_t* n) { return pm_host_volume_vars(path->c_str(), group_id.c_str(), o, c, n); }, chk);
+  return {task};
+}
+
+void GpuMatchPlugin::handle_status_change(const OrchestratorNode& node) {
+  uint32_t dead = 0;
+  {
+    std::unique_lock<std::shared_mutex> lk(nodes_mu_);
+    const auto it = nodes_.index.find(node.address);
+    if (it == nodes_.index.end()) return;
+    const uint32_t w = it->second;
+    uint32_t flags = nodes_.rows[w].flags & ~uint32_t(PM_W_HEALTHY);
+    if (node.status == NodeStatus::Healthy) flags |= PM_W_HEALTHY;
+    nodes_.rows[w].flags = flags;
+    dead = (node.status == NodeStatus::Dead || node.status == NodeStatus::LowBalance) ? 1u : 0u;
+    check(pm_on_worker_status(engine_, w, flags, dead));
+  }
+  if (dead) emit_group_webhooks();  // the whole group was dissolved (status_update_impl.rs:17-29)
+}
+
+size_t GpuMatchPlugin::known_nodes() const {
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  return nodes_.rows.size();
+}
+
+std::optional<uint32_t> GpuMatchPlugin::row_of(const Address& a) const {
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  const auto it = nodes_.index.find(a);
+  if (it == nodes_.index.end()) return std::nullopt;
+  return it->second;
+}
+
+// ------------------------------------------------------------------------------------------------ the scheduler
+
+Scheduler::Scheduler(std::shared_ptr<TaskStore> task_store, std::vector<std::shared_ptr<SchedulerPlugin>> plugins)
+    : task_store_(std::move(task_store)), plugins_(std::move(plugins)) {
+  if (plugins_.empty()) plugins_.push_back(std::make_shared<NewestTaskPlugin>());
+}
+
+std::optional<Task> Scheduler::get_task_for_node(const Address& node_address, int64_t now) {
+  // INTEGRATION.md "The task list per heartbeat": LRANGE + T x GET + T x serde per heartbeat (task_store.rs:57-82) is
+  // what the reference pays here; a chain headed by the engine's plugin is served from the plugin's own list
+  std::vector<Task> all_tasks;
+  if (!plugins_.front()->serves_from_own_task_list()) all_tasks = task_store_->get_all_tasks();
+  for (const auto& plugin : plugins_) all_tasks = plugin->filter_tasks(all_tasks, node_address);
+  if (all_tasks.empty()) return std::nullopt;
+  Task task = all_tasks[0];
+  const std::string addr = node_address.to_string();
+  const auto vars = [&](const std::string& s) { return replace_all(replace_all(s, "${TASK_ID}", task.id), "${NODE_ADDRESS}", addr); };
+  if (task.env_vars)
+    for (auto& kv : *task.env_vars) kv.second = vars(kv.second);
+  if (task.cmd)
+    for (std::string& arg : *task.cmd) arg = vars(arg);
+  if (task.volume_mounts)
+    for (VolumeMount& m : *task.volume_mounts) m = m.replace_labels(task.id, addr, now);
+  return task;
+}
+
+}  // namespace orchestrator

@@ -1,0 +1,513 @@
+// plugin_test.cpp — the compiled host side (protocol_amd/plugin/gpu_match_plugin.cpp: GpuMatchPlugin, Scheduler,
+// NewestTaskPlugin) run against tests/cpp/mock_engine.cpp, a CPU stand-in for libpm_engine.so behind the same C ABI.
+// Checked here: what the plugin SENDS over the ABI and in which order (the mock logs every call), its row map and
+// address ranks, the task list under deltas, the templating of the returned task, the webhook feed, the constructor's
+// contract, and — with real threads, under ThreadSanitizer in tests/test_host_helpers.py — the lock order that keeps a
+// heartbeat from pairing a position of the new task table with the old list.  Ports of the reference's own tests:
+//   scheduler/mod.rs:87-104  test_get_task_for_node        -> scheduler_returns_the_stores_task
+//   scheduler/mod.rs:106-160 test_variable_replacement     -> scheduler_replaces_task_and_node_variables
+//   newest_task/mod.rs:27-60 test_filter_tasks             -> newest_task_plugin_picks_the_newest
+// The matching itself is NOT tested here (the mock's is a toy): that is tests/test_gpu_*.py against the oracle.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gpu_match_plugin.hpp"
+
+extern "C" {
+const char* pm_mock_calls(void);
+void pm_mock_reset_calls(void);
+void pm_mock_set_delay_us(int us);
+}
+
+using namespace orchestrator;
+
+static int g_failed = 0;
+#define CHECK(cond)                                                                 \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      std::fprintf(stderr, "  CHECK failed at %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      ++g_failed;                                                                   \
+    }                                                                               \
+  } while (0)
+#define CHECK_EQ(a, b)                                                                                        \
+  do {                                                                                                        \
+    const auto va_ = (a);                                                                                     \
+    const auto vb_ = (b);                                                                                     \
+    if (!(va_ == vb_)) {                                                                                      \
+      std::ostringstream os_;                                                                                 \
+      os_ << "  CHECK_EQ failed at " << __FILE__ << ":" << __LINE__ << ": " #a " = [" << va_ << "], " #b " = [" << vb_ << "]"; \
+      std::fprintf(stderr, "%s\n", os_.str().c_str());                                                        \
+      ++g_failed;                                                                                             \
+    }                                                                                                         \
+  } while (0)
+
+static std::vector<std::string> calls() {
+  std::vector<std::string> out;
+  std::istringstream is(pm_mock_calls());
+  for (std::string line; std::getline(is, line);) out.push_back(line);
+  return out;
+}
+static bool starts_with(const std::string& s, const std::string& p) { return s.compare(0, p.size(), p) == 0; }
+static std::vector<std::string> calls_named(const std::string& name) {
+  std::vector<std::string> out;
+  for (const std::string& c : calls())
+    if (starts_with(c, name + " ") || c == name) out.push_back(c);
+  return out;
+}
+
+static Address addr(int k) {  // address strings whose byte order is NOT the order of k
+  static const char* hex = "0123456789abcdef";
+  std::string s = "0x";
+  const unsigned v = unsigned(k) * 2654435761u;
+  for (int i = 0; i < 40; ++i) s += hex[(v >> ((i % 8) * 4)) & 15u];
+  s[2] = hex[(k * 7) % 16];
+  s[3] = hex[k % 16];
+  return Address(s);
+}
+static OrchestratorNode node(int k, NodeStatus st = NodeStatus::Healthy, const char* model = nullptr) {
+  OrchestratorNode n;
+  n.address = addr(k);
+  n.status = st;
+  n.p2p_id = "p2p-" + std::to_string(k);
+  ComputeSpecs cs;
+  GpuSpecs g;
+  g.count = 8;
+  g.memory_mb = 80000;
+  if (model) g.model = std::string(model);
+  cs.gpu = g;
+  cs.cpu = CpuSpecs{std::optional<uint32_t>(32)};
+  cs.ram_mb = 1024;
+  cs.storage_gb = 100;
+  n.compute_specs = cs;
+  n.location = NodeLocation{10.0 + k, 20.0 - k};
+  return n;
+}
+static Task task(int k, int64_t created, std::optional<std::vector<std::string>> topologies) {
+  Task t;
+  char id[40];
+  std::snprintf(id, sizeof(id), "00000000-0000-4000-8000-%012x", 0x1000 + k);
+  t.id = id;
+  t.name = "task-" + std::to_string(k);
+  t.image = "image";
+  t.created_at = created;
+  t.allowed_topologies = std::move(topologies);
+  return t;
+}
+
+struct Recorder : WebhookPlugin {
+  std::mutex mu;
+  std::vector<std::string> lines;
+  void push(const char* what, const std::string& id, const std::string& name, const std::vector<std::string>& nodes) {
+    std::string s = std::string(what) + " " + id + " " + name;
+    for (const std::string& n : nodes) s += " " + n;
+    std::lock_guard<std::mutex> lk(mu);
+    lines.push_back(s);
+  }
+  void send_group_created(const std::string& id, const std::string& name, const std::vector<std::string>& nodes) override {
+    push("created", id, name, nodes);
+  }
+  void send_group_destroyed(const std::string& id, const std::string& name, const std::vector<std::string>& nodes) override {
+    push("destroyed", id, name, nodes);
+  }
+};
+
+struct Store : TaskStore {
+  std::vector<Task> tasks;
+  std::atomic<int> loads{0};
+  std::vector<Task> get_all_tasks() override {
+    ++loads;
+    return tasks;
+  }
+};
+
+static std::vector<NodeGroupConfiguration> two_configs() {
+  NodeGroupConfiguration a{"pair", 2, 2, std::string("gpu:count=8;gpu:model=H100")};
+  NodeGroupConfiguration b{"solo", 1, 1, std::nullopt};
+  return {a, b};
+}
+
+// ------------------------------------------------------------------------------------------------
+
+static void constructor_contract() {
+  pm_mock_reset_calls();
+  auto expect_invalid = [](std::vector<NodeGroupConfiguration> t, const std::string& msg) {
+    try {
+      GpuMatchPlugin p(std::move(t), 0, nullptr);
+      CHECK(!"no exception");
+    } catch (const std::invalid_argument& e) {
+      CHECK(std::string(e.what()).find(msg) != std::string::npos);
+    }
+  };
+  expect_invalid({{"a", 1, 2, std::nullopt}, {"a", 2, 3, std::nullopt}}, "Configuration names must be unique");  // mod.rs:142-144
+  expect_invalid({{"a", 3, 2, std::nullopt}}, "Plugin configuration is invalid");                                // mod.rs:145-147
+  expect_invalid({{"a", 0, 2, std::nullopt}}, "Plugin configuration is invalid");
+  expect_invalid({{"a", 1, 2, std::string("gpu:count=eight")}}, "compute_requirements of 'a'");
+  pm_mock_reset_calls();
+  {
+    NodeGroupConfiguration c0{"h100", 2, 4, std::string("gpu:count=8;gpu:model=H100")};
+    NodeGroupConfiguration c1{"any", 1, 1, std::nullopt};
+    NodeGroupConfiguration c2{"two-alts", 1, 8, std::string("gpu:count=4;gpu:model=a100;gpu:count=1;gpu:model=rtx4090;ram_mb=64")};
+    GpuMatchPlugin p({c0, c1, c2}, 3, nullptr);
+    const std::vector<std::string> c = calls();
+    CHECK_EQ(c.size(), size_t(6));
+    if (c.size() == 6) {
+      CHECK_EQ(c[0], std::string("create device=3"));
+      CHECK(starts_with(c[1], "set_configs n=3 alts=3 sizes=2-4 1-1 1-8 model_row=0 model_row=1 model_row=2"));
+      CHECK(starts_with(c[2], "set_model_table rows=3 classes=0"));
+      CHECK_EQ(c[3], std::string("upload_workers n=0 keep=0"));
+      CHECK_EQ(c[4], std::string("enable_group_events 1"));
+      CHECK_EQ(c[5], std::string("upload_tasks n=0"));
+    }
+  }
+  CHECK_EQ(calls().back(), std::string("destroy"));
+}
+
+static void sync_nodes_keeps_rows_stable() {
+  GpuMatchPlugin p(two_configs(), 0, nullptr);
+  pm_mock_reset_calls();
+  // ---- snapshot A: five nodes, in an order of the day
+  p.sync_nodes({node(3), node(1), node(4), node(0, NodeStatus::Healthy, "NVIDIA H100 80GB"), node(2)});
+  CHECK_EQ(p.known_nodes(), size_t(5));
+  CHECK_EQ(*p.row_of(addr(3)), 0u);
+  CHECK_EQ(*p.row_of(addr(2)), 4u);
+  std::vector<std::string> c = calls();
+  // a new spec model first (the table it indexes), then the rows, then everybody's rank
+  CHECK_EQ(c.size(), size_t(3));
+  if (c.size() == 3) {
+    CHECK(starts_with(c[0], "set_model_table rows=1 classes=1 bits=1"));   // "H100" is a substring of the spec model
+    CHECK(starts_with(c[1], "append_workers n=5 first=0"));
+    // ranks = order of the address strings
+    std::vector<int> ks = {3, 1, 4, 0, 2};
+    std::vector<uint32_t> want(5);
+    for (int i = 0; i < 5; ++i) {
+      uint32_t r = 0;
+      for (int j = 0; j < 5; ++j) r += addr(ks[j]).text < addr(ks[i]).text;
+      want[i] = r;
+    }
+    std::string s = "set_addr_ranks [";
+    for (int i = 0; i < 5; ++i) s += (i ? "," : "") + std::to_string(want[i]);
+    CHECK_EQ(c[2], s + "]");
+  }
+  // ---- snapshot B: another order; node 1 changed its specs, node 4 left, node 7 is new, the others are as they were
+  pm_mock_reset_calls();
+  OrchestratorNode n1 = node(1);
+  n1.compute_specs->ram_mb = 2048;
+  p.sync_nodes({node(2), node(7, NodeStatus::Healthy, "A100"), n1, node(0, NodeStatus::Healthy, "NVIDIA H100 80GB"), node(3)});
+  CHECK_EQ(p.known_nodes(), size_t(6));
+  CHECK_EQ(*p.row_of(addr(3)), 0u);   // rows never move
+  CHECK_EQ(*p.row_of(addr(7)), 5u);
+  c = calls();
+  CHECK_EQ(c.size(), size_t(5));
+  if (c.size() == 5) {
+    CHECK(starts_with(c[0], "set_model_table rows=1 classes=2"));            // "A100": a second interned spec model
+    CHECK(starts_with(c[1], "on_worker_status_many w=[2]"));                 // node 4 (row 2) tombstoned: not healthy, dead
+    CHECK(starts_with(c[2], "update_workers idx=[1]"));                      // node 1 (row 1) rewritten in place
+    CHECK(starts_with(c[3], "append_workers n=1 first=5"));
+    CHECK(c[3].find("gpu_class=[1]") != std::string::npos);                  // interned in first-seen order
+    CHECK(starts_with(c[4], "set_addr_ranks ["));
+  }
+  // ---- snapshot C: nothing changed -> nothing is sent
+  pm_mock_reset_calls();
+  p.sync_nodes({node(3), n1, node(0, NodeStatus::Healthy, "NVIDIA H100 80GB"), node(2), node(7, NodeStatus::Healthy, "A100")});
+  CHECK_EQ(calls().size(), size_t(0));
+  // ---- snapshot D: node 4 is back (same row, rewritten), node 2 went unhealthy (a rewrite, not a death)
+  pm_mock_reset_calls();
+  p.sync_nodes({node(4), node(3), n1, node(0, NodeStatus::Healthy, "NVIDIA H100 80GB"), node(2, NodeStatus::Unhealthy),
+                node(7, NodeStatus::Healthy, "A100")});
+  c = calls();
+  CHECK_EQ(c.size(), size_t(1));
+  if (c.size() == 1) CHECK(starts_with(c[0], "update_workers idx=[2,4]"));
+  CHECK_EQ(*p.row_of(addr(4)), 2u);
+}
+
+static void tick_lookup_templating_and_webhooks() {
+  auto rec = std::make_shared<Recorder>();
+  std::atomic<int> counted{0};
+  auto p = std::make_shared<GpuMatchPlugin>(two_configs(), 0,
+                                            [&](const Address&, const std::string&) { ++counted; return size_t(7); },
+                                            std::vector<std::shared_ptr<WebhookPlugin>>{rec});
+  p->sync_nodes({node(0), node(1), node(2)});
+  Task t = task(1, 100, std::vector<std::string>{"pair"});
+  t.env_vars = std::map<std::string, std::string>{{"IDX", "${GROUP_INDEX}/${GROUP_SIZE}"}, {"NEXT", "${NEXT_P2P_ADDRESS}"},
+                                                 {"WHO", "${TASK_ID}@${NODE_ADDRESS}"}};
+  t.cmd = std::vector<std::string>{"--group=${GROUP_ID}", "--uploads=${TOTAL_UPLOAD_COUNT}", "--last=${LAST_FILE_IDX}"};
+  t.volume_mounts = std::vector<VolumeMount>{{"/data/${GROUP_ID}/${TASK_ID}", "/mnt/${TIMESTAMP}"}};
+  p->sync_tasks({t});
+  CHECK_EQ(calls_named("set_enabled_mask").back(), std::string("set_enabled_mask 1"));   // "pair" is configuration 0
+  const pm_stats s = p->tick();
+  CHECK_EQ(s.n_formed, 1u);   // three healthy nodes: one pair (the toy's cut), the third stays free ("solo" is not enabled)
+  {
+    std::lock_guard<std::mutex> lk(rec->mu);
+    CHECK_EQ(rec->lines.size(), size_t(1));
+    if (!rec->lines.empty()) {
+      // members in address-string order, as address strings
+      const std::string a0 = addr(0).text, a1 = addr(1).text;
+      const std::string want_nodes = a0 < a1 ? a0 + " " + a1 : a1 + " " + a0;
+      CHECK(starts_with(rec->lines[0], "created "));
+      CHECK(rec->lines[0].find(" pair " + want_nodes) != std::string::npos);
+    }
+  }
+  // the heartbeat of the first member by rank
+  const bool zero_first = addr(0).text < addr(1).text;
+  const Address first = zero_first ? addr(0) : addr(1), second = zero_first ? addr(1) : addr(0);
+  const std::vector<Task> got = p->filter_tasks({}, first);
+  CHECK_EQ(got.size(), size_t(1));
+  if (got.size() == 1) {
+    const Task& g = got[0];
+    CHECK_EQ(g.id, t.id);
+    CHECK_EQ(g.env_vars->at("GROUP_INDEX"), std::string("0"));                               // scheduler_impl.rs:161
+    CHECK_EQ(g.env_vars->at("IDX"), std::string("0/2"));
+    CHECK_EQ(g.env_vars->at("NEXT"), std::string(zero_first ? "p2p-1" : "p2p-0"));            // the next member's p2p id
+    CHECK_EQ(g.env_vars->at("WHO"), std::string("${TASK_ID}@${NODE_ADDRESS}"));              // the scheduler's variables: not here
+    const std::string gid = g.cmd->at(0).substr(8);
+    CHECK(!gid.empty() && gid.find_first_not_of("0123456789abcdef") == std::string::npos);   // format!("{:x}")
+    CHECK_EQ(g.cmd->at(1), std::string("--uploads=7"));
+    CHECK_EQ(g.cmd->at(2), std::string("--last=6"));                                         // saturating_sub(1)
+    CHECK_EQ(g.volume_mounts->at(0).host_path, "/data/" + gid + "/${TASK_ID}");
+    CHECK_EQ(counted.load(), 1);
+  }
+  // through the scheduler: the chain's head serves from its own list, the store is never asked; then TASK_ID / NODE_ADDRESS
+  auto store = std::make_shared<Store>();
+  Scheduler sched(store, {p});
+  const std::optional<Task> st = sched.get_task_for_node(second, 1234);
+  CHECK(st.has_value());
+  if (st) {
+    CHECK_EQ(st->env_vars->at("GROUP_INDEX"), std::string("1"));
+    CHECK_EQ(st->env_vars->at("WHO"), t.id + "@" + second.text);
+    CHECK_EQ(st->volume_mounts->at(0).container_path, std::string("/mnt/1234"));
+    CHECK(st->volume_mounts->at(0).host_path.find("/" + t.id) != std::string::npos);
+  }
+  CHECK_EQ(store->loads.load(), 0);
+  CHECK(!sched.get_task_for_node(addr(2)).has_value());    // in no group
+  CHECK(!sched.get_task_for_node(addr(99)).has_value());   // not a node of the pool
+}
+
+static void task_observers_follow_deltas() {
+  auto rec = std::make_shared<Recorder>();
+  GpuMatchPlugin p(two_configs(), 0, nullptr, {rec});
+  p.sync_nodes({node(0), node(1), node(2), node(3), node(4)});
+  const Task t_pair = task(1, 100, std::vector<std::string>{"pair"}), t_solo = task(2, 90, std::vector<std::string>{"solo"});
+  p.sync_tasks({t_pair, t_solo});
+  CHECK_EQ(calls_named("set_enabled_mask").back(), std::string("set_enabled_mask 3"));
+  p.tick();
+  auto served = [&](int k) {
+    const std::vector<Task> g = p.filter_tasks({}, addr(k));
+    return g.empty() ? std::string("-") : g[0].name;
+  };
+  std::vector<std::string> before;
+  for (int k = 0; k < 5; ++k) before.push_back(served(k));
+  int n_pair = 0, n_solo = 0;
+  for (const std::string& s : before) {
+    n_pair += s == "task-1";
+    n_solo += s == "task-2";
+  }
+  CHECK(n_pair >= 2 && n_solo >= 1);
+  // ---- a newer task for nobody (no configuration of that name): one row travels, every position moves, nobody notices
+  pm_mock_reset_calls();
+  std::vector<Task> all = {t_pair, t_solo};
+  const Task t_other = task(3, 200, std::vector<std::string>{"no-such-topology"});
+  all.insert(all.begin(), t_other);
+  p.on_task_created(t_other, [&] { return all; });
+  CHECK(starts_with(calls()[0], "tasks_insert_front n=1 republish=0"));
+  CHECK_EQ(calls_named("upload_tasks").size(), size_t(0));
+  for (int k = 0; k < 5; ++k) CHECK_EQ(served(k), before[size_t(k)]);
+  // ---- an OLDER task: the delta does not apply, the snapshot goes up instead (the observer's fallback)
+  pm_mock_reset_calls();
+  const Task t_old = task(4, 50, std::vector<std::string>{"solo"});
+  all.push_back(t_old);
+  p.on_task_created(t_old, [&] { return all; });
+  CHECK_EQ(calls_named("upload_tasks").size(), size_t(1));
+  for (int k = 0; k < 5; ++k) CHECK_EQ(served(k), before[size_t(k)]);
+  // ---- the pair's task is deleted: its groups dissolve (destroyed webhooks), their members are served nothing
+  pm_mock_reset_calls();
+  { std::lock_guard<std::mutex> lk(rec->mu); rec->lines.clear(); }
+  p.on_task_deleted(t_pair);
+  CHECK(starts_with(calls()[0], "tasks_delete n=1 deleted=1"));
+  for (int k = 0; k < 5; ++k) CHECK_EQ(served(k), before[size_t(k)] == "task-1" ? std::string("-") : before[size_t(k)]);
+  {
+    std::lock_guard<std::mutex> lk(rec->mu);
+    CHECK(!rec->lines.empty());
+    for (const std::string& l : rec->lines) CHECK(starts_with(l, "destroyed ") && l.find(" pair ") != std::string::npos);
+  }
+  // ---- a new task for the solo configuration: a standing group that holds a task keeps it; with republish_on_insert an
+  // idle group is served at once, without it only after the next tick
+  p.tick();   // (the freed pair members: "pair" is no longer enabled, they form solo groups; every solo group takes task-2)
+  std::vector<std::string> mid;
+  for (int k = 0; k < 5; ++k) mid.push_back(served(k));
+  for (const std::string& s : mid) CHECK_EQ(s, std::string("task-2"));
+  p.on_task_deleted(t_solo);
+  p.on_task_deleted(t_old);
+  p.tick();   // groups without a task now (nothing names a topology any more: nothing forms, nothing is served)
+  for (int k = 0; k < 5; ++k) CHECK_EQ(served(k), std::string("-"));
+  const Task t_new = task(5, 300, std::vector<std::string>{"solo"});
+  p.on_task_created(t_new, [&] { return std::vector<Task>{t_new, t_other}; });
+  p.tick();
+  for (int k = 0; k < 5; ++k) CHECK_EQ(served(k), std::string("task-5"));
+  p.republish_on_insert = true;
+  pm_mock_reset_calls();
+  const Task t_newer = task(6, 400, std::vector<std::string>{"solo"});
+  p.on_task_created(t_newer, [&] { return std::vector<Task>{t_newer, t_new, t_other}; });
+  CHECK(starts_with(calls()[0], "tasks_insert_front n=1 republish=1"));
+  for (int k = 0; k < 5; ++k) CHECK_EQ(served(k), std::string("task-5"));   // they hold task-5: a group keeps its task
+}
+
+static void status_changes() {
+  auto rec = std::make_shared<Recorder>();
+  GpuMatchPlugin p(two_configs(), 0, nullptr, {rec});
+  p.sync_nodes({node(0), node(1), node(2)});
+  p.sync_tasks({task(1, 100, std::vector<std::string>{"pair"})});
+  p.tick();
+  CHECK(!p.filter_tasks({}, addr(0)).empty());
+  pm_mock_reset_calls();
+  p.handle_status_change(node(99, NodeStatus::Dead));   // unknown: ignored
+  CHECK_EQ(calls().size(), size_t(0));
+  p.handle_status_change(node(0, NodeStatus::Unhealthy));
+  CHECK(starts_with(calls().back(), "on_worker_status w=0 ") && calls().back().find("dead=0") != std::string::npos);
+  CHECK(!p.filter_tasks({}, addr(1)).empty());           // unhealthy is not dead: the group stands (status_update_impl.rs:17-29)
+  { std::lock_guard<std::mutex> lk(rec->mu); rec->lines.clear(); }
+  p.handle_status_change(node(1, NodeStatus::LowBalance));
+  CHECK(calls().back().find("dead=1") != std::string::npos);
+  CHECK(p.filter_tasks({}, addr(0)).empty() && p.filter_tasks({}, addr(1)).empty());
+  {
+    std::lock_guard<std::mutex> lk(rec->mu);
+    CHECK_EQ(rec->lines.size(), size_t(1));
+    if (!rec->lines.empty()) CHECK(starts_with(rec->lines[0], "destroyed "));
+  }
+}
+
+// scheduler/mod.rs:87-104
+static void scheduler_returns_the_stores_task() {
+  auto store = std::make_shared<Store>();
+  Scheduler scheduler(store, {});
+  Task t = task(1, 1, std::nullopt);
+  store->tasks.push_back(t);
+  const std::optional<Task> got = scheduler.get_task_for_node(Address::zero());
+  CHECK(got.has_value() && *got == t);
+  CHECK_EQ(store->loads.load(), 1);
+}
+
+// scheduler/mod.rs:106-160
+static void scheduler_replaces_task_and_node_variables() {
+  auto store = std::make_shared<Store>();
+  Scheduler scheduler(store, {});
+  const Address node_address("0x0101010101010101010101010101010101010101");
+  Task t = task(1, 1, std::nullopt);
+  t.env_vars = std::map<std::string, std::string>{{"TASK_ID_VAR", "task-${TASK_ID}"}, {"NODE_VAR", "node-${NODE_ADDRESS}"}};
+  t.cmd = std::vector<std::string>{"--task=${TASK_ID}", "--node=${NODE_ADDRESS}"};
+  store->tasks.push_back(t);
+  const std::optional<Task> r = scheduler.get_task_for_node(node_address);
+  CHECK(r.has_value());
+  if (!r) return;
+  CHECK_EQ(r->env_vars->at("TASK_ID_VAR"), "task-" + t.id);
+  CHECK_EQ(r->env_vars->at("NODE_VAR"), "node-" + node_address.text);
+  CHECK_EQ(r->cmd->at(0), "--task=" + t.id);
+  CHECK_EQ(r->cmd->at(1), "--node=" + node_address.text);
+}
+
+// newest_task/mod.rs:27-60
+static void newest_task_plugin_picks_the_newest() {
+  NewestTaskPlugin plugin;
+  const std::vector<Task> tasks = {task(1, 1, std::nullopt), task(2, 2, std::nullopt)};
+  const std::vector<Task> f = plugin.filter_tasks(tasks, Address::zero());
+  CHECK_EQ(f.size(), size_t(1));
+  if (!f.empty()) CHECK_EQ(f[0].id, tasks[1].id);
+  CHECK(plugin.filter_tasks({}, Address::zero()).empty());
+}
+
+static void task_uid_is_the_uuids_low_half() {
+  Task t;
+  t.id = "123e4567-e89b-42d3-a456-426614174000";
+  CHECK_EQ(task_uid(t), 0xa456426614174000ull);
+  t.id = "FFFFFFFF-FFFF-4FFF-8000-000000000001";
+  CHECK_EQ(task_uid(t), 0x8000000000000001ull);
+}
+
+// Heartbeats from several threads while the task observers insert and delete at the front of the list: a member of a
+// group that holds task K must be served task K or (never) another one.  The mock pauses at the end of every
+// task-table call — INSIDE the plugin's write lock, between the engine's new positions and the list's change — so a
+// heartbeat that did not wait there would index the old list with a new position and get the neighbour.
+static void heartbeats_race_the_task_observers() {
+  std::vector<NodeGroupConfiguration> cfgs;
+  for (int c = 0; c < 4; ++c) cfgs.push_back({"cfg" + std::to_string(c), 2, 2, std::nullopt});
+  GpuMatchPlugin p(cfgs, 0, nullptr);
+  std::vector<OrchestratorNode> nodes;
+  for (int k = 0; k < 8; ++k) nodes.push_back(node(k));
+  p.sync_nodes(nodes);
+  std::vector<Task> all;
+  for (int c = 0; c < 4; ++c) all.push_back(task(10 + c, 100 - c, std::vector<std::string>{"cfg" + std::to_string(c)}));
+  p.sync_tasks(all);
+  p.tick();
+  std::vector<std::string> want(8);
+  for (int k = 0; k < 8; ++k) {
+    const std::vector<Task> g = p.filter_tasks({}, addr(k));
+    CHECK_EQ(g.size(), size_t(1));
+    want[size_t(k)] = g.empty() ? "?" : g[0].id;
+  }
+  pm_mock_set_delay_us(200);
+  std::atomic<bool> stop{false};
+  std::atomic<long> served{0}, wrong{0};
+  std::vector<std::thread> hb;
+  for (int th = 0; th < 4; ++th)
+    hb.emplace_back([&, th] {
+      for (int k = th; !stop.load(); k = (k + 1) % 8) {
+        const std::vector<Task> g = p.filter_tasks({}, addr(k));
+        if (g.size() != 1 || g[0].id != want[size_t(k)]) ++wrong;
+        ++served;
+      }
+    });
+  std::thread observer([&] {
+    for (int i = 0; i < 60; ++i) {
+      const Task t = task(100 + i, 1000 + i, std::vector<std::string>{"no-such-topology"});
+      all.insert(all.begin(), t);
+      p.on_task_created(t, [&] { return all; });
+      if (i % 3 == 2) {  // ... and the one before it goes again
+        const Task gone = all[1];
+        all.erase(all.begin() + 1);
+        p.on_task_deleted(gone);
+      }
+    }
+  });
+  std::thread loop([&] {  // the management loop beside them
+    for (int i = 0; i < 20; ++i) {
+      p.sync_nodes(nodes);
+      p.tick();
+    }
+  });
+  observer.join();
+  loop.join();
+  stop = true;
+  for (std::thread& t : hb) t.join();
+  pm_mock_set_delay_us(0);
+  CHECK(served.load() > 100);
+  CHECK_EQ(wrong.load(), 0l);
+}
+
+int main(int argc, char** argv) {
+  struct { const char* name; void (*fn)(); } tests[] = {
+      {"constructor_contract", constructor_contract},
+      {"sync_nodes_keeps_rows_stable", sync_nodes_keeps_rows_stable},
+      {"tick_lookup_templating_and_webhooks", tick_lookup_templating_and_webhooks},
+      {"task_observers_follow_deltas", task_observers_follow_deltas},
+      {"status_changes", status_changes},
+      {"scheduler_returns_the_stores_task", scheduler_returns_the_stores_task},
+      {"scheduler_replaces_task_and_node_variables", scheduler_replaces_task_and_node_variables},
+      {"newest_task_plugin_picks_the_newest", newest_task_plugin_picks_the_newest},
+      {"task_uid_is_the_uuids_low_half", task_uid_is_the_uuids_low_half},
+      {"heartbeats_race_the_task_observers", heartbeats_race_the_task_observers},
+  };
+  int ran = 0;
+  for (const auto& t : tests) {
+    if (argc > 1 && std::string(argv[1]) != t.name) continue;
+    const int before = g_failed;
+    t.fn();
+    std::printf("%s %s\n", g_failed == before ? "ok  " : "FAIL", t.name);
+    ++ran;
+  }
+  std::printf("%d tests, %d failed checks\n", ran, g_failed);
+  return g_failed ? 1 : (ran ? 0 : 2);
+}

@@ -1,0 +1,104 @@
+"""The compiled host side (protocol_amd/plugin: GpuMatchPlugin, Scheduler, NewestTaskPlugin — the C++ twin of
+rust/gpu_match_plugin.rs, which this image cannot compile) on the CPU: tests/cpp/plugin_test.cpp against
+tests/cpp/mock_engine.cpp, a stand-in for libpm_engine.so behind the same C ABI.  Plain build, ThreadSanitizer build,
+address + UB sanitizer build — and a build with the lock order the round-3 review found in the Rust shim, which the
+race test must catch.  The product library libpm_plugin.so (the same source linked against the real libpm_engine.so)
+is built and its undefined symbols are checked against the header; it needs a GPU to run."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = [os.path.join(ROOT, "include"), os.path.join(ROOT, "protocol_amd", "plugin"), os.path.join(ROOT, "protocol_amd", "csrc")]
+SRC = [os.path.join(ROOT, "tests", "cpp", "plugin_test.cpp"), os.path.join(ROOT, "protocol_amd", "plugin", "gpu_match_plugin.cpp"),
+       os.path.join(ROOT, "tests", "cpp", "mock_engine.cpp"), os.path.join(ROOT, "protocol_amd", "csrc", "pm_host.cpp")]
+
+
+def _build(tmp_path, name, extra):
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = str(tmp_path / name)
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-Werror", *extra, *[f"-I{d}" for d in INC], *SRC, "-lpthread", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return (exe if r.returncode == 0 else None), r.stderr
+
+
+def _run(exe, *args, env=None):
+    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_plugin_against_the_mock_engine(tmp_path):
+    exe, err = _build(tmp_path, "plugin_test", [])
+    assert exe, err
+    out = _run(exe)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "10 tests, 0 failed checks" in out.stdout
+    assert out.stdout.count("ok  ") == 10
+
+
+def test_plugin_under_thread_sanitizer(tmp_path):
+    """heartbeats from four threads, the task observers and the management loop beside them: no data race, no lock-order
+    inversion (nodes, tasks, engine), and never a task other than the group's own"""
+    exe, err = _build(tmp_path, "plugin_test_tsan", ["-fsanitize=thread", "-fno-omit-frame-pointer"])
+    if not exe:
+        pytest.skip("ThreadSanitizer does not link here: " + err[-300:])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 exitcode=66")
+    out = _run(exe, env=env)
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-4000:]
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_plugin_under_address_and_ub_sanitizers(tmp_path):
+    exe, err = _build(tmp_path, "plugin_test_asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"])
+    if not exe:
+        pytest.skip("the sanitizers do not link here: " + err[-300:])
+    out = _run(exe)
+    assert out.returncode == 0 and "0 failed checks" in out.stdout, out.stdout + out.stderr[-4000:]
+
+
+def test_the_race_test_sees_the_round3_lock_order(tmp_path):
+    """PM_PLUGIN_TEST_ROUND3_LOCK_ORDER builds on_task_created the way the round-3 review found the Rust shim (engine
+    call first, `tasks` lock second): heartbeats between the two are served the neighbouring task, and the race test
+    says so.  (What "nothing can test here" meant for the Rust source; the twin can be raced.)"""
+    exe, err = _build(tmp_path, "plugin_test_r3", ["-DPM_PLUGIN_TEST_ROUND3_LOCK_ORDER"])
+    assert exe, err
+    out = _run(exe, "heartbeats_race_the_task_observers")
+    assert out.returncode == 1, out.stdout + out.stderr
+    assert "FAIL heartbeats_race_the_task_observers" in out.stdout and "wrong.load()" in out.stderr
+    # ... and only that: everything single-threaded is indifferent to the order
+    for name in ("task_observers_follow_deltas", "tick_lookup_templating_and_webhooks"):
+        assert _run(exe, name).returncode == 0
+
+
+def test_product_plugin_library_binds_the_header():
+    """libpm_plugin.so (g++, linked against libpm_engine.so): every pm_* symbol it leaves undefined is declared in
+    include/pm_engine.h and exported by the engine library; the C++ surface (the reference's names) is exported."""
+    from protocol_amd import build as B
+    lib = B.build_plugin()
+    nm = subprocess.run(["nm", "-D", "-C", lib], capture_output=True, text=True, check=True).stdout
+    undefined = set(re.findall(r"^\s+U (pm_[a-z_0-9]+)$", nm, flags=re.M))
+    assert len(undefined) >= 20
+    hdr = open(os.path.join(ROOT, "include", "pm_engine.h")).read()
+    declared = set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", hdr))
+    assert undefined <= declared, sorted(undefined - declared)
+    eng = subprocess.run(["nm", "-D", B.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (pm_[a-z_0-9]+)$", eng, flags=re.M))
+    assert undefined <= exported, sorted(undefined - exported)
+    for sym in ("orchestrator::GpuMatchPlugin::filter_tasks", "orchestrator::GpuMatchPlugin::sync_nodes", "orchestrator::GpuMatchPlugin::tick()",
+                "orchestrator::GpuMatchPlugin::on_task_created", "orchestrator::GpuMatchPlugin::on_task_deleted",
+                "orchestrator::GpuMatchPlugin::handle_status_change", "orchestrator::Scheduler::get_task_for_node",
+                "orchestrator::NewestTaskPlugin::filter_tasks"):
+        assert re.search(r" T " + re.escape(sym), nm), sym
+    # the twin follows the Rust source: every pm_* call of rust/gpu_match_plugin.rs's plugin body is made here too
+    rs = open(os.path.join(ROOT, "rust", "gpu_match_plugin.rs")).read()
+    body = rs[rs.index("\n}\n", rs.index('extern "C" {')):]
+    rust_calls = set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", body)) - {"pm_engine_config", "pm_worker_soa", "pm_task_soa", "pm_stats",
+                                                                    "pm_group_event", "pm_assignment", "pm_group_vars", "pm_config_row",
+                                                                    "pm_gpu_alt_row"}
+    # (the C++ parses the requirement STRING with the library's parser where the Rust projects serde's parsed struct)
+    assert rust_calls <= undefined | {"pm_host_parse_requirements"}, sorted(rust_calls - undefined)
+    assert undefined - rust_calls <= {"pm_host_parse_requirements"}, sorted(undefined - rust_calls)
