@@ -49,8 +49,8 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
 # rust/gpu_match_plugin.rs).  Plain C++17, no HIP: g++, linked against libpm_engine.so next to it.
 PLUGIN_DIR = os.path.join(HERE, "plugin")
 PLUGIN_LIB = os.path.join(HERE, "libpm_plugin.so")
-PLUGIN_SOURCES = ["gpu_match_plugin.cpp"]
-PLUGIN_HEADERS = ["gpu_match_plugin.hpp"]
+PLUGIN_SOURCES = ["gpu_match_plugin.cpp", "pm_plugin_c.cpp"]
+PLUGIN_HEADERS = ["gpu_match_plugin.hpp", "pm_plugin_c.h"]
 
 
 def _cxx() -> str:

@@ -149,8 +149,8 @@ int32_t pm_set_configs(pm_engine* e, const pm_config_row* cfgs, uint32_t n, cons
   return PM_OK;
 }
 int32_t pm_set_model_table(pm_engine* e, const uint32_t* bits, uint32_t n_rows, uint32_t n_classes) {
-  if (!e || !bits) return pm::set_error(PM_EINVAL, "null argument");
   const uint32_t words = (n_classes + 31u) / 32u;
+  if (!e || (!bits && n_rows * words)) return pm::set_error(PM_EINVAL, "null argument");
   std::string s = "set_model_table rows=" + std::to_string(n_rows) + " classes=" + std::to_string(n_classes) + " bits=";
   for (uint32_t i = 0; i < n_rows * words; ++i) s += std::to_string(bits[i]) + " ";
   logf(s);
@@ -183,8 +183,11 @@ int32_t pm_append_workers(pm_engine* e, const pm_worker_soa* rows, uint32_t* fir
   e->flags.insert(e->flags.end(), rows->flags, rows->flags + rows->n);
   e->addr_rank.insert(e->addr_rank.end(), rows->addr_rank, rows->addr_rank + rows->n);
   e->group_of.resize(e->flags.size(), -1);
+  std::string cls = "[";  // (the class only where the row says it has a model: what the engine reads)
+  for (uint32_t i = 0; i < rows->n; ++i)
+    cls += (i ? "," : "") + ((rows->flags[i] & PM_W_GPU_MODEL) ? std::to_string(rows->gpu_model_class[i]) : std::string("-"));
   logf("append_workers n=" + std::to_string(rows->n) + " first=" + std::to_string(*first_index) + " flags=" + list(rows->flags, rows->n) +
-       " gpu_class=" + list(rows->gpu_model_class, rows->n));
+       " gpu_class=" + cls + "]");
   return PM_OK;
 }
 int32_t pm_update_workers(pm_engine* e, const uint32_t* idx, const pm_worker_soa* rows) {

@@ -1,0 +1,149 @@
+"""Differential run of the two transcriptions of rust/gpu_match_plugin.rs — tests/shim_replay.py (Python, statement for
+statement) and protocol_amd/plugin (C++, compiled) — over tests/cpp/mock_engine.cpp, which logs every C-ABI call with its
+arguments: the same store schedule must produce the same calls in the same order, the same answer to every heartbeat and
+the same webhook feed.  Run as a script (tests/test_plugin_cpp.py starts it in a process of its own, because it points
+protocol_amd.engine at the mock library):
+
+    python tests/plugin_diff_driver.py <library with the mock engine, pm_host.cpp, the plugin and its C face>
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main(lib_path: str) -> int:
+    from protocol_amd import build as B
+    from protocol_amd import engine as E
+    B.LIB_PATH = lib_path                 # (this process only: the engine library IS the mock here)
+    B.needs_build = lambda: False
+    E._lib = None
+    from protocol_amd import host
+    from protocol_amd.swarm import make_swarm
+    import plugin_cxx
+    import shim_replay
+    L = E.lib()
+    plugin_cxx.plugin_lib(lib_path)
+    L.pm_mock_calls.restype = C.c_char_p
+    L.pm_mock_reset_calls.restype = None
+
+    ALL = 0xFFFFFFFFFFFFFFFF
+    W_store = 160
+    rng = np.random.default_rng(11)
+
+    def run(kind: str):
+        """the whole schedule on one of the two; returns [(step, calls, heartbeats, events)]"""
+        sw = make_swarm(7, 60, W_store)
+        L.pm_mock_reset_calls()
+        shim = shim_replay.ShimReplay(sw) if kind == "py" else plugin_cxx.PluginCxx(sw)
+        r = np.random.default_rng(3)
+        trace = []
+        masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
+        cur = [(int(m), int(c), int(u)) for m, c, u in zip(masks, created, uid)]
+
+        def enabled():
+            e = 0
+            for m, _c, _u in cur:
+                if m != ALL:
+                    e |= m
+            return e
+
+        def step(name, heartbeat_nodes=()):
+            calls = L.pm_mock_calls().decode().splitlines()
+            L.pm_mock_reset_calls()
+            beats = [shim.filter_tasks(int(n)) for n in heartbeat_nodes]
+            L.pm_mock_reset_calls()      # (look-ups are not logged; keep the log per step clean anyway)
+            ev = list(shim.events)
+            shim.events.clear()
+            trace.append((name, calls, beats, ev))
+
+        step("new")
+        shim.sync_tasks(masks, created, uid, enabled())
+        step("sync_tasks")
+        status = sw.status.copy()
+        healthy = {n for n in range(W_store) if status[n] == 2}
+        present = list(range(100))
+        snap = np.array(present)
+        r.shuffle(snap)
+        shim.sync_nodes(snap, healthy)
+        step("sync_nodes A")
+        shim.tick()
+        step("tick 1", present)
+        t_max = int(created.max())
+        for k in range(3):
+            src = int(r.integers(0, len(masks)))
+            t_max += 1
+            new = (int(masks[src]), t_max, (1 << 40) + k)
+            cur.insert(0, new)
+            shim.on_task_created(new[0], new[1], new[2], enabled())
+            step(f"on_task_created {k}", present[:20])
+        # the task most heartbeats were answered with goes
+        answered = [b for b in trace[3][2] if b is not None]
+        victim = max(set(answered), key=answered.count)
+        cur = [t for t in cur if t[2] != victim]
+        shim.on_task_deleted(victim, enabled())
+        step("on_task_deleted", present)
+        for n in (present[3], present[17], present[40]):
+            healthy.discard(n)
+            shim.handle_status_change(n, healthy=False, dead=True)
+        shim.handle_status_change(present[5], healthy=False, dead=False)
+        healthy.discard(present[5])
+        step("status changes", present)
+        # discovery rewrote a few rows; some nodes left; new ones came
+        rewritten = [n for n in present[50:] if sw.has_specs[n] and sw.ram_some[n]][:6]
+        for n in rewritten:
+            sw.ram_mb[n] += 1
+        shim.packed_all = host.pack_workers(sw)
+        gone = present[60:66]
+        present = [n for n in present if n not in gone] + list(range(100, 140))
+        snap = np.array(present)
+        r.shuffle(snap)
+        shim.sync_nodes(snap, healthy)
+        step("sync_nodes B", present)
+        shim.tick()
+        step("tick 2", present)
+        shim.sync_nodes(snap, healthy)   # nothing changed
+        step("sync_nodes B again")
+        n_rows = len(shim.rows)
+        shim.close()
+        return trace, n_rows
+
+    py, rows_py = run("py")
+    cxx, rows_cxx = run("cxx")
+    bad = 0
+    if rows_py != rows_cxx:
+        print("known rows differ:", rows_py, rows_cxx)
+        bad += 1
+    for (name, c1, b1, e1), (_n, c2, b2, e2) in zip(py, cxx):
+        if c1 != c2:
+            bad += 1
+            print(f"[{name}] C-ABI calls differ")
+            for i in range(max(len(c1), len(c2))):
+                a = c1[i] if i < len(c1) else "<none>"
+                b = c2[i] if i < len(c2) else "<none>"
+                if a != b:
+                    print("   py :", a[:300])
+                    print("   c++:", b[:300])
+                    break
+        if b1 != b2:
+            bad += 1
+            print(f"[{name}] heartbeats differ:", [(i, x, y) for i, (x, y) in enumerate(zip(b1, b2)) if x != y][:5])
+        if e1 != e2:
+            bad += 1
+            print(f"[{name}] webhook feeds differ: {len(e1)} vs {len(e2)} events; first:", next(((x, y) for x, y in zip(e1, e2) if x != y), None))
+    n_calls = sum(len(c) for _n, c, _b, _e in py)
+    n_beats = sum(len(b) for _n, _c, b, _e in py)
+    n_served = sum(x is not None for _n, _c, b, _e in py for x in b)
+    n_events = sum(len(e) for _n, _c, _b, e in py)
+    print(f"steps {len(py)}, C-ABI calls {n_calls}, heartbeats {n_beats} ({n_served} served), webhook events {n_events}")
+    print("DIFF OK" if not bad else f"DIFF FAILED ({bad})")
+    return 0 if not bad else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

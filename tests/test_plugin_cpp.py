@@ -102,3 +102,32 @@ def test_product_plugin_library_binds_the_header():
     # (the C++ parses the requirement STRING with the library's parser where the Rust projects serde's parsed struct)
     assert rust_calls <= undefined | {"pm_host_parse_requirements"}, sorted(rust_calls - undefined)
     assert undefined - rust_calls <= {"pm_host_parse_requirements"}, sorted(undefined - rust_calls)
+
+
+def test_cxx_plugin_and_python_replay_make_the_same_calls(tmp_path):
+    """Two transcriptions of rust/gpu_match_plugin.rs — tests/shim_replay.py (Python, statement for statement) and
+    protocol_amd/plugin (C++, compiled) — driven through the same store schedule over the mock engine, which logs every
+    C-ABI call with its arguments: the same calls in the same order (constructor, task snapshot, two node snapshots with
+    appended / rewritten / departed rows and the rank refresh, created and deleted tasks, status changes, ticks), the same
+    answer to every heartbeat, the same webhook feed.  tests/plugin_diff_driver.py, in a process of its own (it points
+    protocol_amd.engine at the mock library)."""
+    import sys
+    gxx, gcc = shutil.which("g++"), shutil.which("gcc")
+    if not gxx or not gcc:
+        pytest.skip("no g++ / gcc")
+    from protocol_amd import engine as E
+    mock_src = os.path.join(ROOT, "tests", "cpp", "mock_engine.cpp")
+    host_src = os.path.join(ROOT, "protocol_amd", "csrc", "pm_host.cpp")
+    have = set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", open(mock_src).read() + open(host_src).read()))
+    stubs = tmp_path / "stubs.c"   # the exports protocol_amd.engine binds and the plugin never calls: present, never run
+    stubs.write_text("".join(f"int {n}(void) {{ return -4; }}\n" for n in E.EXPORTS if n not in have))
+    subprocess.check_call([gcc, "-c", "-fPIC", str(stubs), "-o", str(tmp_path / "stubs.o")])
+    lib = str(tmp_path / "libpm_mock_all.so")
+    subprocess.check_call([gxx, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", *[f"-I{d}" for d in INC], mock_src, host_src,
+                           os.path.join(ROOT, "protocol_amd", "plugin", "gpu_match_plugin.cpp"),
+                           os.path.join(ROOT, "protocol_amd", "plugin", "pm_plugin_c.cpp"), str(tmp_path / "stubs.o"), "-lpthread", "-o", lib])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "plugin_diff_driver.py"), lib], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "DIFF OK" in out.stdout, out.stdout[-4000:] + out.stderr[-4000:]
+    m = re.search(r"C-ABI calls (\d+), heartbeats (\d+) \((\d+) served\), webhook events (\d+)", out.stdout)
+    assert m and int(m.group(1)) >= 25 and int(m.group(3)) >= 100 and int(m.group(4)) >= 20, out.stdout
