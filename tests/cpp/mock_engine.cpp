@@ -150,7 +150,7 @@ int32_t pm_set_configs(pm_engine* e, const pm_config_row* cfgs, uint32_t n, cons
 }
 int32_t pm_set_model_table(pm_engine* e, const uint32_t* bits, uint32_t n_rows, uint32_t n_classes) {
   const uint32_t words = (n_classes + 31u) / 32u;
-  if (!e || (!bits && n_rows * words)) return pm::set_error(PM_EINVAL, "null argument");
+  if (!e || (!bits && n_rows * words != 0u)) return pm::set_error(PM_EINVAL, "null argument");
   std::string s = "set_model_table rows=" + std::to_string(n_rows) + " classes=" + std::to_string(n_classes) + " bits=";
   for (uint32_t i = 0; i < n_rows * words; ++i) s += std::to_string(bits[i]) + " ";
   logf(s);
