@@ -460,6 +460,16 @@ pm_stats GpuMatchPlugin::tick() {
   return s;
 }
 
+std::vector<pm_stats> GpuMatchPlugin::tick_many(const std::vector<GpuMatchPlugin*>& pools) {
+  std::vector<pm_engine*> engines;
+  for (GpuMatchPlugin* p : pools) engines.push_back(p->engine_);
+  std::vector<pm_stats> stats(pools.size());
+  if (pools.empty()) return stats;
+  pools[0]->check(pm_tick_many(engines.data(), uint32_t(engines.size()), stats.data(), 0));
+  for (GpuMatchPlugin* p : pools) p->emit_group_webhooks();  // each pool drains its own life-cycle feed
+  return stats;
+}
+
 // Drains the engine's group life-cycle feed into send_group_created / send_group_destroyed, in the order the
 // reference emits them.  Runs after everything that can create or dissolve groups.
 void GpuMatchPlugin::emit_group_webhooks() {

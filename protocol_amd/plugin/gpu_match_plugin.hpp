@@ -175,6 +175,10 @@ class GpuMatchPlugin : public SchedulerPlugin {
   void on_task_deleted(const Task& task);
   // one body of run_group_management_loop (mod.rs:180-203) + every worker's filter_tasks, then the webhooks
   pm_stats tick();
+  // A process that serves several pools on one GPU (INTEGRATION.md "Several pools on one GPU"): one pm_tick_many call —
+  // every pool's carve started before the first is waited for — then each pool's webhooks.  pools[i]->tick() K times
+  // in a row matches one pool after the other.
+  static std::vector<pm_stats> tick_many(const std::vector<GpuMatchPlugin*>& pools);
   // SchedulerPlugin::filter_tasks: `tasks` is ignored (the plugin serves from its own list)
   std::vector<Task> filter_tasks(const std::vector<Task>& tasks, const Address& node_address) override;
   bool serves_from_own_task_list() const override { return true; }

@@ -361,6 +361,16 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   return PM_OK;
 }
 
+int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uint32_t flags) {
+  if (!engines || n == 0 || flags > 1u) return pm::set_error(PM_EINVAL, "null argument");
+  logf("tick_many n=" + std::to_string(n));
+  for (uint32_t i = 0; i < n; ++i) {
+    const int32_t rc = pm_tick(engines[i], stats ? &stats[i] : nullptr);
+    if (rc) return rc;
+  }
+  return PM_OK;
+}
+
 int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t w, pm_assignment* out) {
   if (!e || !out) return pm::set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);

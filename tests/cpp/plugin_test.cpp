@@ -380,6 +380,28 @@ static void status_changes() {
   }
 }
 
+// several pools in one process: one pm_tick_many call, every pool's own webhooks
+static void pools_tick_in_one_call() {
+  auto r0 = std::make_shared<Recorder>(), r1 = std::make_shared<Recorder>();
+  GpuMatchPlugin a(two_configs(), 0, nullptr, {r0}), b(two_configs(), 0, nullptr, {r1});
+  a.sync_nodes({node(0), node(1)});
+  b.sync_nodes({node(2), node(3), node(4), node(5)});
+  a.sync_tasks({task(1, 10, std::vector<std::string>{"pair"})});
+  b.sync_tasks({task(2, 10, std::vector<std::string>{"pair"})});
+  pm_mock_reset_calls();
+  const std::vector<pm_stats> s = GpuMatchPlugin::tick_many({&a, &b});
+  CHECK_EQ(s.size(), size_t(2));
+  CHECK_EQ(s[0].n_formed, 1u);
+  CHECK_EQ(s[1].n_formed, 2u);
+  CHECK_EQ(calls()[0], std::string("tick_many n=2"));
+  CHECK_EQ(r0->lines.size(), size_t(1));
+  CHECK_EQ(r1->lines.size(), size_t(2));
+  CHECK_EQ(a.filter_tasks({}, addr(0)).at(0).name, std::string("task-1"));
+  CHECK_EQ(b.filter_tasks({}, addr(5)).at(0).name, std::string("task-2"));
+  CHECK(a.filter_tasks({}, addr(5)).empty());   // pool a does not know pool b's nodes
+  CHECK(GpuMatchPlugin::tick_many({}).empty());
+}
+
 // scheduler/mod.rs:87-104
 static void scheduler_returns_the_stores_task() {
   auto store = std::make_shared<Store>();
@@ -494,6 +516,7 @@ int main(int argc, char** argv) {
       {"tick_lookup_templating_and_webhooks", tick_lookup_templating_and_webhooks},
       {"task_observers_follow_deltas", task_observers_follow_deltas},
       {"status_changes", status_changes},
+      {"pools_tick_in_one_call", pools_tick_in_one_call},
       {"scheduler_returns_the_stores_task", scheduler_returns_the_stores_task},
       {"scheduler_replaces_task_and_node_variables", scheduler_replaces_task_and_node_variables},
       {"newest_task_plugin_picks_the_newest", newest_task_plugin_picks_the_newest},
