@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# PM_TEST_HW_QUEUES=<n>: run the suite with that many HIP hardware queues (GPU_MAX_HW_QUEUES; the runtime reads it once,
+# when it starts — i.e. at the torch.cuda call below).  Unset = the runtime's default of 4, which is what the suite
+# has been verified under; the multi-rank and multi-pool tests are worth a run under 16.
+if os.environ.get("PM_TEST_HW_QUEUES"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ["PM_TEST_HW_QUEUES"])
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
