@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(lib_path: str) -> int:
+def main(lib_path: str, seeds=(3, 4, 5)) -> int:
     from protocol_amd import build as B
     from protocol_amd import engine as E
     B.LIB_PATH = lib_path                 # (this process only: the engine library IS the mock here)
@@ -36,12 +36,12 @@ def main(lib_path: str) -> int:
     W_store = 160
     rng = np.random.default_rng(11)
 
-    def run(kind: str):
+    def run(kind: str, seed: int):
         """the whole schedule on one of the two; returns [(step, calls, heartbeats, events)]"""
-        sw = make_swarm(7, 60, W_store)
+        sw = make_swarm(4 + seed, 60, W_store)
         L.pm_mock_reset_calls()
         shim = shim_replay.ShimReplay(sw) if kind == "py" else plugin_cxx.PluginCxx(sw)
-        r = np.random.default_rng(3)
+        r = np.random.default_rng(seed)
         trace = []
         masks, created, uid = sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy()
         cur = [(int(m), int(c), int(u)) for m, c, u in zip(masks, created, uid)]
@@ -113,34 +113,38 @@ def main(lib_path: str) -> int:
         shim.close()
         return trace, n_rows
 
-    py, rows_py = run("py")
-    cxx, rows_cxx = run("cxx")
     bad = 0
-    if rows_py != rows_cxx:
-        print("known rows differ:", rows_py, rows_cxx)
-        bad += 1
-    for (name, c1, b1, e1), (_n, c2, b2, e2) in zip(py, cxx):
-        if c1 != c2:
+    totals = [0, 0, 0, 0, 0]
+    for seed in seeds:
+        py, rows_py = run("py", seed)
+        cxx, rows_cxx = run("cxx", seed)
+        if rows_py != rows_cxx:
+            print(f"seed {seed}: known rows differ:", rows_py, rows_cxx)
             bad += 1
-            print(f"[{name}] C-ABI calls differ")
-            for i in range(max(len(c1), len(c2))):
-                a = c1[i] if i < len(c1) else "<none>"
-                b = c2[i] if i < len(c2) else "<none>"
-                if a != b:
-                    print("   py :", a[:300])
-                    print("   c++:", b[:300])
-                    break
-        if b1 != b2:
-            bad += 1
-            print(f"[{name}] heartbeats differ:", [(i, x, y) for i, (x, y) in enumerate(zip(b1, b2)) if x != y][:5])
-        if e1 != e2:
-            bad += 1
-            print(f"[{name}] webhook feeds differ: {len(e1)} vs {len(e2)} events; first:", next(((x, y) for x, y in zip(e1, e2) if x != y), None))
-    n_calls = sum(len(c) for _n, c, _b, _e in py)
-    n_beats = sum(len(b) for _n, _c, b, _e in py)
-    n_served = sum(x is not None for _n, _c, b, _e in py for x in b)
-    n_events = sum(len(e) for _n, _c, _b, e in py)
-    print(f"steps {len(py)}, C-ABI calls {n_calls}, heartbeats {n_beats} ({n_served} served), webhook events {n_events}")
+        for (name, c1, b1, e1), (_n, c2, b2, e2) in zip(py, cxx):
+            if c1 != c2:
+                bad += 1
+                print(f"seed {seed} [{name}] C-ABI calls differ")
+                for i in range(max(len(c1), len(c2))):
+                    a = c1[i] if i < len(c1) else "<none>"
+                    b = c2[i] if i < len(c2) else "<none>"
+                    if a != b:
+                        print("   py :", a[:300])
+                        print("   c++:", b[:300])
+                        break
+            if b1 != b2:
+                bad += 1
+                print(f"seed {seed} [{name}] heartbeats differ:", [(i, x, y) for i, (x, y) in enumerate(zip(b1, b2)) if x != y][:5])
+            if e1 != e2:
+                bad += 1
+                print(f"seed {seed} [{name}] webhook feeds differ: {len(e1)} vs {len(e2)} events; first:",
+                      next(((x, y) for x, y in zip(e1, e2) if x != y), None))
+        totals[0] += len(py)
+        totals[1] += sum(len(c) for _n, c, _b, _e in py)
+        totals[2] += sum(len(b) for _n, _c, b, _e in py)
+        totals[3] += sum(x is not None for _n, _c, b, _e in py for x in b)
+        totals[4] += sum(len(e) for _n, _c, _b, e in py)
+    print(f"seeds {len(seeds)}, steps {totals[0]}, C-ABI calls {totals[1]}, heartbeats {totals[2]} ({totals[3]} served), webhook events {totals[4]}")
     print("DIFF OK" if not bad else f"DIFF FAILED ({bad})")
     return 0 if not bad else 1
 

@@ -131,4 +131,4 @@ def test_cxx_plugin_and_python_replay_make_the_same_calls(tmp_path):
                          timeout=600)
     assert out.returncode == 0 and "DIFF OK" in out.stdout, out.stdout[-4000:] + out.stderr[-4000:]
     m = re.search(r"C-ABI calls (\d+), heartbeats (\d+) \((\d+) served\), webhook events (\d+)", out.stdout)
-    assert m and int(m.group(1)) >= 25 and int(m.group(3)) >= 100 and int(m.group(4)) >= 20, out.stdout
+    assert m and int(m.group(1)) >= 75 and int(m.group(3)) >= 300 and int(m.group(4)) >= 60, out.stdout   # (three seeds)
