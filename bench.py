@@ -484,8 +484,10 @@ def main() -> int:
     # says otherwise) and runs two streams that share one in turn: with K engines (a carve stream + a side stream each)
     # in one process, K = 4 pools matched one behind the other in pairs (1.4x the one-pool rate; 3.4x with 8 or more
     # queues — `pools_on_one_gpu`).  Read once, when the runtime starts: set before anything touches HIP.  One engine
-    # is indifferent to it (1.31 vs 1.32 ms per match).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", HIP_HW_QUEUES)
+    # is indifferent to it (1.31 vs 1.32 ms per match).  Only the N = 1 line runs several engines in one process; the
+    # N > 1 ranks (one engine each, beside RCCL's own streams) keep the runtime's default, as they were measured.
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", HIP_HW_QUEUES)
     import torch
     import torch.distributed as dist
 
