@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(HERE, "libpm_engine.so")
 SOURCES = ["pm_kernels.hip", "pm_engine.cpp", "pm_host.cpp"]
-HEADERS = ["pm_device.h", "pm_internal.h", "pm_members.h", "pm_stream.inc"]
+HEADERS = ["pm_device.h", "pm_internal.h", "pm_members.h", "pm_validate.inc", "pm_propose.inc", "pm_prep.inc",
+           "pm_carve_kernel.inc", "pm_stream.inc", "pm_launch.inc"]
 
 
 def _hipcc() -> str:

@@ -1,4 +1,4 @@
-"""CPU model of the proposer's walk over the spatial index (cell_walk / cell_bound_key in pm_kernels.hip), statement by
+"""CPU model of the proposer's walk over the spatial index (cell_walk / cell_bound_key in pm_propose.inc), statement by
 statement: the enumeration of a ring's runs covers the shell of cells exactly once, the lower bounds are lower bounds,
 and a walk that stops by the kernel's rule has seen every candidate below the row's window — so the 64 smallest keys it
 holds are the 64 smallest keys of the whole list.  (The GPU tests compare the carves; this pins the geometry.)"""

@@ -1,4 +1,4 @@
-"""The proposer's spatial index (cell_*_kernel, cell_walk in pm_kernels.hip): a seed that walks the grid cells around it
+"""The proposer's spatial index (cell_*_kernel, cell_walk in pm_propose.inc / pm_prep.inc): a seed that walks the grid cells around it
 must produce the row the whole-list sweep produces — entries, certificate flags and all — so every carve comes out the
 same whichever way its proposals were made.  Modes (pm_debug_prune_mode): 0 never walk, 1 walk when it pays (the
 default), 2 walk whenever there is an index (and build one for any swarm), 3 = 2 with every seed sent through the

@@ -1,6 +1,6 @@
 """The proposer's selection and its tail certificate, restated in plain Python and checked against brute force.
 
-`carve_propose_kernel` (protocol_amd/csrc/pm_kernels.hip: NearRow, near_window, near_track, near_row_offer) keeps a
+`carve_propose_kernel` (protocol_amd/csrc/pm_propose.inc: NearRow, near_window, near_track, near_row_offer) keeps a
 wave's 64 nearest keys sorted across its lanes, lets a candidate in only if it beats lane 63, and summarises the
 candidates that came close without getting (or staying) in — smallest key + its site, smallest key at another site —
 so that `tail_ok` ("every unlisted candidate within the band of the row's last entry sits at that entry's site") needs
