@@ -1897,6 +1897,10 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
       e->n_cus = uint32_t(cus);
   }
+#ifdef PM_EXP_ONE_STREAM  // experiment: the side stream only for its one user, the pipelined batch carve —
+  // an engine then owns ONE stream, and K engines in a process own K of the runtime's hardware queues instead of 2 K
+  if (e->cfg.carve_variant == 4)
+#endif
   (void)hipStreamCreateWithFlags(&e->stream_p, hipStreamNonBlocking);  // (without it the carve is not pipelined)
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     delete e;
@@ -3118,8 +3122,19 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
     rcs[i] = rc;
     msgs[i] = g_last_error;
   };
+#ifdef PM_EXP_TICKMANY_CHUNK  // experiment: at most PM_EXP_TICKMANY_CHUNK carves resident at a time —
+  // the three walks below run over engines [c0, c1), chunk after chunk (the GPU's ceiling for configs[1]-sized pools is
+  // reached at eight)
+  static_assert(PM_EXP_TICKMANY_CHUNK >= 1, "a chunk holds at least one engine");
+  const uint32_t n_all = n;
+  for (uint32_t c0 = 0; c0 < n_all; c0 += uint32_t(PM_EXP_TICKMANY_CHUNK)) {
+  const uint32_t i_lo = c0, i_hi = std::min<uint32_t>(n_all, c0 + uint32_t(PM_EXP_TICKMANY_CHUNK));
+#else
+  const uint32_t i_lo = 0, i_hi = n;
+  {
+#endif
   // ---- 1: compatibility masks, the eligible list, the carve's launch(es) — nothing here waits for a carve
-  for (uint32_t i = 0; i < n; ++i) {
+  for (uint32_t i = i_lo; i < i_hi; ++i) {
     pm_engine* e = engines[i];
     auto stage = [&]() -> int32_t {
       HIPCHK(hipSetDevice(e->cfg.device));
@@ -3138,7 +3153,54 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
   }
   // ---- 2: in launch order (the first carve started is the first to end): the carve's result, the merge pass, the
   // pair sweep and the claim, queued behind it on the engine's stream
-  for (uint32_t i = 0; i < n; ++i) {
+#ifdef PM_EXP_TICKMANY_POLL  // experiment: serve whichever engine's stream has drained first — the walk's
+  // host work for one pool (~0.1 ms) otherwise stands between the other pools' finished carves and their sweeps
+  std::vector<uint32_t> order2;
+  {
+    std::vector<uint32_t> pending;
+    for (uint32_t i = i_lo; i < i_hi; ++i)
+      if (!rcs[i]) pending.push_back(i);
+    while (!pending.empty()) {
+      size_t pick = pending.size();
+      for (size_t k = 0; k < pending.size() && pick == pending.size(); ++k) {
+        (void)hipSetDevice(engines[pending[k]]->cfg.device);
+        if (hipStreamQuery(engines[pending[k]]->stream) == hipSuccess) pick = k;
+      }
+      (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error: do not leave it for the next check)
+      if (pick == pending.size()) {
+        if (pending.size() == 1) pick = 0;  // the last one: its own wait is the wait
+        else {
+          std::this_thread::yield();
+          continue;
+        }
+      }
+      order2.push_back(pending[pick]);
+      pending.erase(pending.begin() + ptrdiff_t(pick));
+      // (served right away, below: the order is decided one engine at a time)
+      const uint32_t i = order2.back();
+      pm_engine* e = engines[i];
+      auto stage = [&]() -> int32_t {
+        HIPCHK(hipSetDevice(e->cfg.device));
+        int32_t rc = run_form_rest(e, *runs[i], &n_formed[i], /*defer_absorb=*/true);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(e->ev[2], e->stream));
+        rc = run_merge(e, &n_merged[i]);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(e->ev[3], e->stream));
+        rc = run_match(e, false, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(e->ev[4], e->stream));
+        return publish_begin(e, &pubs[i], e->d_n_groups);
+      };
+      const int32_t rc = stage();
+      runs[i].reset();
+      if (rc) failed(i, rc);
+    }
+  }
+  for (uint32_t i = i_hi; i < i_hi; ++i) {  // (the in-order walk below is this experiment's off switch: never entered)
+#else
+  for (uint32_t i = i_lo; i < i_hi; ++i) {
+#endif
     if (rcs[i]) continue;
     pm_engine* e = engines[i];
     auto stage = [&]() -> int32_t {
@@ -3159,7 +3221,7 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
     if (rc) failed(i, rc);
   }
   // ---- 3: the host copy of the new groups, the published table
-  for (uint32_t i = 0; i < n; ++i) {
+  for (uint32_t i = i_lo; i < i_hi; ++i) {
     if (rcs[i]) continue;
     pm_engine* e = engines[i];
     auto stage = [&]() -> int32_t {
@@ -3176,6 +3238,7 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
     const int32_t rc = stage();
     if (rc) failed(i, rc);
   }
+  }  // (the chunk, or the one block that holds all three walks)
   for (uint32_t i = 0; i < n; ++i)
     if (rcs[i]) return set_error(rcs[i], msgs[i]);
   return PM_OK;

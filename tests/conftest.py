@@ -14,6 +14,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# PM_EXP_DEFINES=A=1,B: the whole suite against a VARIANT build of the engine library (extra -D flags; the mechanism of
+# tools/variant_bench.py) — how an experiment behind an #ifdef is put through the parity tests before it becomes the
+# default.  Unset = the product library.
+if os.environ.get("PM_EXP_DEFINES"):
+    from protocol_amd import build as _B
+    _alt = os.path.join(os.path.dirname(_B.LIB_PATH), "libpm_engine_exp.so")
+    _B.build(force=True, defines=[d for d in os.environ["PM_EXP_DEFINES"].split(",") if d], out=_alt)
+    _B.LIB_PATH = _alt
+    _B.needs_build = lambda: False
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -26,6 +26,12 @@ def main() -> int:
     args = ap.parse_args()
     if args.queues != "default":
         os.environ["GPU_MAX_HW_QUEUES"] = args.queues    # before anything touches HIP
+    if os.environ.get("PM_EXP_DEFINES"):  # a variant build of the library (extra -D flags), as tools/variant_bench.py
+        from protocol_amd import build as B
+        alt = os.path.join(os.path.dirname(B.LIB_PATH), "libpm_engine_exp.so")
+        B.build(force=True, defines=[d for d in os.environ["PM_EXP_DEFINES"].split(",") if d], out=alt)
+        B.LIB_PATH = alt
+        B.needs_build = lambda: False
     import bench
     from protocol_amd import engine as E
     from protocol_amd import host
