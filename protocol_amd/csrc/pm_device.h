@@ -57,7 +57,10 @@ static constexpr uint32_t PM_STREAM_RQ = 8192;      // row ring: rows of tickets
 static constexpr uint32_t PM_STREAM_TP = 4096;      // tickets whose seed position the validator remembers (LDS)
 static constexpr uint32_t PM_STREAM_LA_MAX = 3072;  // look-ahead: tickets issued and not yet handed to the chain
 static constexpr uint32_t PM_STREAM_CTL_WORDS = 64; // control block (u32): see the SC_* indices
-static constexpr uint32_t PM_STREAM_PROP_WAVES = 4; // waves of a proposer workgroup that build rows (one per SIMD)
+#ifndef PM_STREAM_PROP_WAVES_N  // (settable in a variant build: with few row-making workgroups per pool — K pools on one
+#define PM_STREAM_PROP_WAVES_N 4  // GPU — eight waves a workgroup trade a row's latency for rows per second)
+#endif
+static constexpr uint32_t PM_STREAM_PROP_WAVES = PM_STREAM_PROP_WAVES_N; // waves of a proposer workgroup that build rows (one per SIMD)
 static constexpr uint32_t PM_STREAM_SLW_TREQ = PM_STREAM_TP;      // words of the validator's ticket state that
 static constexpr uint32_t PM_STREAM_SLW_PAY = PM_STREAM_TP + 1;   // carve_fast_steps<STREAM> reads (pm_stream.inc: SLW_*)
 static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 128;
