@@ -115,6 +115,21 @@ def main(lib_path: str, seeds=(3, 4, 5)) -> int:
 
     bad = 0
     totals = [0, 0, 0, 0, 0]
+    # the C face reports the constructor's refusals (the reference's two panics) instead of letting them cross the ABI
+    import copy
+    sw_bad = make_swarm(1, 4, 8)
+    for mutate, want in ((lambda c: c.__setitem__(1, (c[0][0],) + tuple(c[1][1:])), "Configuration names must be unique"),
+                         (lambda c: c.__setitem__(0, (c[0][0], 5, 2, c[0][3])), "Plugin configuration is invalid")):
+        sw_b = copy.deepcopy(sw_bad)
+        mutate(sw_b.configs)
+        try:
+            plugin_cxx.PluginCxx(sw_b)
+            print("no refusal for", want)
+            bad += 1
+        except RuntimeError as ex:
+            if want not in str(ex):
+                print("refusal says", ex, "instead of", want)
+                bad += 1
     for seed in seeds:
         py, rows_py = run("py", seed)
         cxx, rows_cxx = run("cxx", seed)
