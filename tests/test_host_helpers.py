@@ -378,3 +378,37 @@ def test_member_list_of_a_group_record(tmp_path):
         subprocess.check_call(base)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "members_test ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_library_is_the_build_the_gpu_suite_ran_on():
+    """profiles/r*_verified_binary.txt (the newest) holds the sha256 of the six sections of libpm_engine.so that carry
+    code and data — the gfx950 code object's .text / .rodata / .note, the host's .text / .rodata / .data — as they were
+    in the build the last full `pytest -m gpu` run was made on.  They are deterministic from build to build (unlike the
+    library as a whole), so this says: what is in the tree compiles to what was verified.  A change that is meant to leave
+    the product alone (moving code between files, experiments behind #ifdef, comments) passes as it is; a change to the
+    product fails here until the GPU suite has been run on it and the file refreshed (python tools/section_hashes.py)."""
+    import glob
+    import importlib.util
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_verified_binary.txt")))
+    assert files, "no verified-binary record under profiles/"
+    want = dict(re.findall(r"^\s*((?:gfx950|host) \.\w+)\s+([0-9a-f]{16})\b", open(files[-1]).read(), flags=re.M))
+    assert len(want) == 6, want
+    spec = importlib.util.spec_from_file_location("section_hashes", os.path.join(ROOT, "tools", "section_hashes.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    if not os.path.exists(os.path.join(sh.LLVM, "llvm-objcopy")):
+        pytest.skip("no llvm-objcopy / clang-offload-bundler here")
+    from protocol_amd import build as B
+    got = sh.hashes(B.build())
+    assert got == want, ("the product library differs from the build the GPU suite ran on (" + os.path.basename(files[-1]) +
+                         "): run the GPU suite on it, then refresh that file", got, want)
+
+
+def test_experiment_flags_compile_together(tmp_path):
+    """the untried experiments of DESIGN section 9 sit behind #ifdefs (PM_EXP_*): all of them switched on at once still
+    compile for gfx950 — what a new round starts from"""
+    from protocol_amd import build as B
+    flags = ["PM_EXP_ONE_STREAM", "PM_EXP_TICKMANY_CHUNK=8", "PM_EXP_TICKMANY_POLL", "PM_EXP_SMALL_CTZ", "PM_EXP_PRE_SKIP_SMALL",
+             "PM_EXP_COLD_WALK=32", "PM_STREAM_PROP_WAVES_N=8", "STREAM_PRE_EARLY=256u"]
+    out = B.build(force=True, defines=flags, out=str(tmp_path / "libpm_engine_exp.so"))
+    assert os.path.getsize(out) > 500_000
