@@ -28,6 +28,12 @@ int32_t pm_debug_stream_trace(pm_engine* e, unsigned long long* out, uint32_t ca
  * needs more than 262,144 candidates of one configuration; 0 = off. */
 int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n);
 
+/* Test hook: the streaming carve (carve_variant 0) gives its launch up — CARVE_STATE_ABORTED, what a lost hand-shake
+ * inside the validator workgroup ends in — as soon as n steps of the carve are committed (and the chain's budget runs
+ * out there); the engine then continues the carve on the batch pipeline from the configuration it stopped in
+ * (pm_stats / debug_carve_counters: stream_aborts).  0 = off. */
+int32_t pm_debug_stream_abort_after(pm_engine* e, uint32_t n);
+
 /* Test hook / experiment: when the proposers walk the spatial index instead of sweeping the whole candidate list —
  * 0 never, 1 when it pays (default), 2 whenever the carve has an index, 3 = 2 with every seed forced through the
  * whole-list fallback.  (PM_PRUNE_MODE in the environment sets the default of new engines.) */

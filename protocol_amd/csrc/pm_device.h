@@ -262,7 +262,9 @@ struct CarveArgs {
   unsigned long long* stream_row_hi;  // [PM_STREAM_RQ][64]       {tag, high half}
   uint32_t* stream_ctl;               // [PM_STREAM_CTL_WORDS] SC_*
   uint32_t stream_la, stream_row_spins;  // look-ahead cap (0 = default); polls before the validator gives a row up
-  uint32_t stream_la_div, _pad_s;        // look-ahead = candidates / (la_div x (max_group_size - 1)) (0 = default)
+  uint32_t stream_la_div;                // look-ahead = candidates / (la_div x (max_group_size - 1)) (0 = default)
+  uint32_t debug_abort_after;            // test hook (pm_debug_stream_abort_after): the chain gives the launch up — CARVE_STATE_ABORTED —
+                                         // once this many steps of the carve are committed (0 = off)
   unsigned long long* stream_trace;      // PM_CARVE_PROF builds: [PM_STREAM_TRACE_CAP][2] {s_memtime, type | a << 8 | b << 32}
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
@@ -318,6 +320,7 @@ void launch_task_compact(const uint32_t* first_u, const uint32_t* count_u, uint3
 void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_begin, uint32_t t_end,
                    uint32_t* idx_by_block, long long* val_by_block, uint32_t n_blocks, hipStream_t s);
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
+hipError_t carve_kernels_init();  // per device: the carve kernels' dynamic LDS sizes (pm_engine_create)
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
 uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, bool speculative, hipStream_t s);  // [plan +] count + place
 uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound, uint32_t index_min, uint32_t start_ci,

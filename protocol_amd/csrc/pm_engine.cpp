@@ -139,6 +139,7 @@ struct pm_engine {
   unsigned long long carve_why[24]{};  // CarveStatus::why of the last carve, its batches and void launches, the spatial
                                        // index, the streaming carve's counters
   uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above
+  uint32_t debug_abort_after = 0;  // pm_debug_stream_abort_after
   uint32_t prune_mode = 1;       // pm_debug_prune_mode / PM_PRUNE_MODE: CarveArgs::prune_mode
   uint32_t prune_factor = 512;   // PM_PRUNE_FACTOR: CarveArgs::prune_factor (measured crossover)
   uint32_t walk_cap_div = 0;     // PM_WALK_CAP_DIV: CarveArgs::walk_cap_div (0 = the kernels' default)
@@ -682,6 +683,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     a->stream_la = e->stream_la_env;
     a->stream_la_div = e->stream_la_div_env;
     a->stream_row_spins = e->stream_row_spins_env;
+    a->debug_abort_after = e->debug_abort_after;
   }
   return PM_OK;
 }
@@ -1861,6 +1863,7 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return set_error(PM_ENODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  HIPCHK(carve_kernels_init());  // (per device; idempotent)
   pm_engine* e = new (std::nothrow) pm_engine();
   if (!e) return set_error(PM_ENOMEM, "out of host memory");
   e->cfg = *cfg;
@@ -2757,6 +2760,7 @@ int32_t pm_form_groups(pm_engine* e, uint32_t* n_formed) {
   HIPCHK(hipSetDevice(e->cfg.device));
   e->tick_host_resolved = e->tick_carve_launches = e->tick_carve_steps = 0;
   e->tick_fast_steps = 0;
+  e->tick_stream_aborts = 0;
   int32_t rc = run_form(e, n_formed);
   e->last_stats.carve_fast_steps = e->tick_fast_steps;
   e->last_stats.host_resolved_steps = e->tick_host_resolved;
@@ -3513,6 +3517,16 @@ int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   e->debug_mem_above = n;
+  return PM_OK;
+}
+
+// debug (include/pm_engine_debug.h): the streaming carve's chain gives its launch up (CARVE_STATE_ABORTED, as a lost
+// hand-shake inside the validator would) once n steps of the carve are committed; the engine continues on the batch
+// pipeline from there (form_poll).  0 = off
+int32_t pm_debug_stream_abort_after(pm_engine* e, uint32_t n) {
+  if (!e) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->debug_abort_after = n;
   return PM_OK;
 }
 

@@ -491,6 +491,14 @@ class Engine:
         L.pm_debug_mem_lists_above.restype = C.c_int32
         check(L.pm_debug_mem_lists_above(self._h, n))
 
+    def debug_stream_abort_after(self, n: int):
+        """test hook (include/pm_engine_debug.h): the streaming carve gives its launch up (CARVE_STATE_ABORTED) once n
+        steps are committed, and the engine continues on the batch pipeline; 0 = off"""
+        L = lib()
+        L.pm_debug_stream_abort_after.argtypes = [C.c_void_p, C.c_uint32]
+        L.pm_debug_stream_abort_after.restype = C.c_int32
+        check(L.pm_debug_stream_abort_after(self._h, n))
+
     def debug_carve_counters(self) -> dict:
         """how the last carve went (pm_internal.h, pm_debug_carve_prof words 32..45): how its validation launches ended,
         and what the proposer's spatial index did"""

@@ -143,9 +143,13 @@ void GpuMatchPlugin::check(int32_t rc) const {
 GpuMatchPlugin::GpuMatchPlugin(std::vector<NodeGroupConfiguration> templates, int32_t device, UploadCounter upload_counter,
                                std::vector<std::shared_ptr<WebhookPlugin>> webhook_plugins)
     : upload_counter_(std::move(upload_counter)), webhook_plugins_(std::move(webhook_plugins)) {
-  // Hardware queues for the HIP runtime: read once, at the first HIP call of the process (the pm_engine_create
-  // below).  See rust/gpu_match_plugin.rs GpuMatchPlugin::new and include/pm_engine.h (pm_set_carve_workgroups).
-  setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0);
+  // Hardware queues for the HIP runtime (GPU_MAX_HW_QUEUES, read once at the first HIP call of the process): the
+  // PROCESS ENTRY POINT sets it, before any thread exists — a library constructor that writes the environment races
+  // with every getenv in a threaded host ("main.rs").  Here it is only looked at: one pool is
+  // indifferent to the value, several pools in one process want >= 2 per pool (include/pm_engine.h, pm_set_carve_workgroups).
+  if (const char* q = getenv("GPU_MAX_HW_QUEUES"); !q || atoi(q) < 8)
+    fprintf(stderr, "GpuMatchPlugin: GPU_MAX_HW_QUEUES is %s; set it to 16 in the launcher before the first HIP call if this "
+                    "process serves more than one pool on the GPU\n", q ? q : "unset (runtime default 4)");
   {
     std::set<std::string> seen;
     for (const NodeGroupConfiguration& t : templates)
@@ -319,6 +323,27 @@ void GpuMatchPlugin::sync_nodes(const std::vector<OrchestratorNode>& snapshot) {
         appended.push(row, i);
       }
     }
+    // The row map above is the plugin's truth from here on; the engine calls below bring the engine's worker table to
+    // it.  If one of them fails the two have diverged (tombstones recorded here and never sent, rows appended here the
+    // engine does not have): the next interval then re-sends the whole table instead of deltas.
+    if (engine_rows_stale_) {
+      RowColumns all;
+      const std::vector<uint32_t> ranks = address_ranks(t.by_address, t.rows.size());
+      for (size_t i = 0; i < seen.size(); ++i)
+        if (!seen[i]) t.present[i] = false;
+      for (size_t i = 0; i < t.rows.size(); ++i) {
+        if (!t.present[i]) t.rows[i].flags &= ~uint32_t(PM_W_HEALTHY);
+        all.push(t.rows[i], ranks[i]);
+      }
+      push_model_table(t);
+      const pm_worker_soa w = all.soa();
+      check(pm_upload_workers(engine_, &w, 0));  // (groups are dissolved: which rows they held is no longer known)
+      engine_rows_stale_ = false;
+      lk.unlock();
+      emit_group_webhooks();
+      return;
+    }
+    engine_rows_stale_ = true;  // (cleared behind the last engine call below)
     if (new_model) push_model_table(t);
     // nodes that left the store: tombstone (their group dissolves, like a death; status_update_impl.rs:17-29)
     std::vector<uint32_t> gone, gone_flags;
@@ -363,6 +388,7 @@ void GpuMatchPlugin::sync_nodes(const std::vector<OrchestratorNode>& snapshot) {
       const std::vector<uint32_t> ranks = address_ranks(t.by_address, t.rows.size());
       check(pm_set_addr_ranks(engine_, ranks.data(), uint32_t(ranks.size())));
     }
+    engine_rows_stale_ = false;
   }
   emit_group_webhooks();  // tombstoned nodes dissolved their groups
 }
@@ -491,13 +517,20 @@ void GpuMatchPlugin::emit_group_webhooks() {
   }
   if (!drained) return;
   if (webhook_plugins_.empty()) return;
-  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  // (the address strings are copied under the lock and the deliveries made without it: a slow webhook endpoint must not
+  // hold handle_status_change and sync_nodes up)
+  std::vector<std::vector<std::string>> nodes_of(ne);
+  {
+    std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+    for (uint32_t k = 0; k < ne; ++k)
+      for (uint32_t j = 0; j < events[k].n_members; ++j)
+        nodes_of[k].push_back(nodes_.address_strings[members[events[k].member_begin + j]]);  // group.nodes order
+  }
   for (uint32_t k = 0; k < ne; ++k) {
     const pm_group_event& ev = events[k];
     const std::string id = hex_lower(ev.group_id);
     const std::string& name = config_names_[ev.config];
-    std::vector<std::string> nodes;
-    for (uint32_t j = 0; j < ev.n_members; ++j) nodes.push_back(nodes_.address_strings[members[ev.member_begin + j]]);  // group.nodes order
+    const std::vector<std::string>& nodes = nodes_of[k];
     for (const auto& p : webhook_plugins_) {
       try {
         if (ev.kind == PM_GROUP_CREATED) p->send_group_created(id, name, nodes);

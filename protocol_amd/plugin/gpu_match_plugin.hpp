@@ -232,6 +232,7 @@ class GpuMatchPlugin : public SchedulerPlugin {
   std::vector<std::string> req_models_;   // requirement model strings, one per pm_gpu_alt_row.model_row
   mutable std::shared_mutex nodes_mu_;
   NodeTable nodes_;
+  bool engine_rows_stale_ = false;   // an engine call of sync_nodes failed half-way: the next one re-sends every row
   mutable std::shared_mutex tasks_mu_;
   std::vector<Task> tasks_;               // get_all_tasks order: the engine reports positions in this list
   UploadCounter upload_counter_;

@@ -277,13 +277,17 @@ impl GpuMatchPlugin {
     pub fn new(templates: Vec<NodeGroupConfiguration>, device: i32,
                upload_counter: Box<dyn Fn(&Address, &str) -> usize + Send + Sync>,
                webhook_plugins: Option<Vec<WebhookPlugin>>) -> Self {
-        // Hardware queues for the HIP runtime (read once, at the first HIP call of the process — which is the
-        // pm_engine_create below, the orchestrator uses HIP for nothing else): it maps a process's streams onto 4 of
-        // them by default and runs two streams that share one in turn; an engine owns two streams, so a process that
-        // serves several pools on one GPU needs >= 2 per pool (include/pm_engine.h, pm_set_carve_workgroups).  One
-        // pool is indifferent to the value.  Left alone if the operator has set it.
-        if std::env::var_os("GPU_MAX_HW_QUEUES").is_none() {
-            std::env::set_var("GPU_MAX_HW_QUEUES", "16");
+        // Hardware queues for the HIP runtime (GPU_MAX_HW_QUEUES, read once at the first HIP call of the process — the
+        // pm_engine_create below; the orchestrator uses HIP for nothing else): the runtime maps a process's streams
+        // onto 4 of them by default and runs two streams that share one in turn; an engine owns two streams, so a
+        // process that serves several pools on one GPU needs >= 2 per pool (include/pm_engine.h,
+        // pm_set_carve_workgroups).  `main()` sets it BEFORE the tokio runtime starts: writing the
+        // environment from here would race with every getenv of a threaded process (and is `unsafe` in Rust 2024).
+        // One pool is indifferent to the value; here it is only looked at.
+        match std::env::var("GPU_MAX_HW_QUEUES").ok().and_then(|v| v.parse::<u32>().ok()) {
+            Some(q) if q >= 8 => {}
+            other => log::warn!("GPU_MAX_HW_QUEUES is {:?}: set it to 16 in main() before the runtime starts if this \
+                                 process serves more than one pool on the GPU", other),
         }
         let mut cfg: pm_engine_config = unsafe { std::mem::zeroed() };
         unsafe { pm_engine_config_default(&mut cfg) };

@@ -17,7 +17,14 @@ if ROOT not in sys.path:
 # PM_EXP_DEFINES=A=1,B: the whole suite against a VARIANT build of the engine library (extra -D flags; the mechanism of
 # tools/variant_bench.py) — how an experiment behind an #ifdef is put through the parity tests before it becomes the
 # default.  Unset = the product library.
-if os.environ.get("PM_EXP_DEFINES"):
+# PM_EXP_LIB=<path>: the same with a variant library built beforehand (tools/build_variants.py builds them where there is
+# no GPU; they travel to the GPU box with the tree, and the box's minutes go into the tests instead of hipcc).
+if os.environ.get("PM_EXP_LIB"):
+    from protocol_amd import build as _B
+    assert os.path.exists(os.environ["PM_EXP_LIB"]), os.environ["PM_EXP_LIB"]
+    _B.LIB_PATH = os.path.abspath(os.environ["PM_EXP_LIB"])
+    _B.needs_build = lambda: False
+elif os.environ.get("PM_EXP_DEFINES"):
     from protocol_amd import build as _B
     _alt = os.path.join(os.path.dirname(_B.LIB_PATH), "libpm_engine_exp.so")
     _B.build(force=True, defines=[d for d in os.environ["PM_EXP_DEFINES"].split(",") if d], out=_alt)

@@ -15,6 +15,7 @@
 // Every call is logged (pm_mock_calls) so a test can check WHAT the plugin sent, in which order.  The pm_host_* helpers
 // are the product's own (pm_host.cpp is compiled into this library unchanged).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -176,9 +177,15 @@ int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_gr
   logf("upload_workers n=" + std::to_string(w->n) + " keep=" + std::to_string(keep_groups));
   return PM_OK;
 }
+static std::atomic<int> g_fail_appends{0};  // pm_mock_fail_appends: that many pm_append_workers calls fail before anything is applied
 int32_t pm_append_workers(pm_engine* e, const pm_worker_soa* rows, uint32_t* first_index) {
   if (!e || !rows || !first_index) return pm::set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (g_fail_appends.load() > 0) {
+    g_fail_appends.fetch_sub(1);
+    logf("append_workers FAILED (injected)");
+    return pm::set_error(PM_ENOMEM, "injected failure");
+  }
   *first_index = uint32_t(e->flags.size());
   e->flags.insert(e->flags.end(), rows->flags, rows->flags + rows->n);
   e->addr_rank.insert(e->addr_rank.end(), rows->addr_rank, rows->addr_rank + rows->n);
@@ -402,6 +409,7 @@ void pm_mock_reset_calls(void) {
   std::lock_guard<std::mutex> lk(g_log_mu);
   g_log.clear();
 }
+void pm_mock_fail_appends(int n) { g_fail_appends.store(n); }
 void pm_mock_set_delay_us(int us) { g_delay_us = us; }  // a pause at the END of every task-table call, behind the mock's own lock (race windows)
 
 }  // extern "C"

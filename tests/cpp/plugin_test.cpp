@@ -22,6 +22,7 @@ extern "C" {
 const char* pm_mock_calls(void);
 void pm_mock_reset_calls(void);
 void pm_mock_set_delay_us(int us);
+void pm_mock_fail_appends(int n);
 }
 
 using namespace orchestrator;
@@ -223,6 +224,40 @@ static void sync_nodes_keeps_rows_stable() {
   CHECK_EQ(c.size(), size_t(1));
   if (c.size() == 1) CHECK(starts_with(c[0], "update_workers idx=[2,4]"));
   CHECK_EQ(*p.row_of(addr(4)), 2u);
+}
+
+static void sync_nodes_resends_everything_after_a_failed_interval() {
+  // An engine call that fails in the middle of sync_nodes leaves the plugin's row map ahead of the engine's worker table
+  // (the tombstone went out, the append did not): the next interval re-sends the whole table instead of deltas.
+  GpuMatchPlugin p(two_configs(), 0, nullptr);
+  p.sync_nodes({node(3), node(1), node(4)});
+  pm_mock_reset_calls();
+  pm_mock_fail_appends(1);
+  bool threw = false;
+  try {
+    p.sync_nodes({node(3), node(1), node(7), node(8)});  // node 4 left, 7 and 8 are new: the append fails
+  } catch (const EngineError&) {
+    threw = true;
+  }
+  CHECK(threw);
+  CHECK_EQ(p.known_nodes(), size_t(5));
+  pm_mock_reset_calls();
+  p.sync_nodes({node(8), node(3), node(1), node(7), node(9)});  // the interval after: one more node, everything re-sent
+  std::vector<std::string> c = calls();
+  CHECK_EQ(p.known_nodes(), size_t(6));
+  CHECK_EQ(*p.row_of(addr(4)), 2u);  // rows never move, not even across a resync
+  CHECK_EQ(*p.row_of(addr(9)), 5u);
+  bool uploaded = false;
+  for (const std::string& x : c) {
+    uploaded = uploaded || x == "upload_workers n=6 keep=0";
+    CHECK(!starts_with(x, "append_workers") && !starts_with(x, "update_workers"));
+  }
+  CHECK(uploaded);
+  // ... and deltas again from then on
+  pm_mock_reset_calls();
+  p.sync_nodes({node(8), node(3), node(1), node(7), node(9), node(10)});
+  c = calls();
+  CHECK(c.size() == 2 && starts_with(c[0], "append_workers n=1 first=6") && starts_with(c[1], "set_addr_ranks ["));
 }
 
 static void tick_lookup_templating_and_webhooks() {
@@ -513,6 +548,7 @@ int main(int argc, char** argv) {
   struct { const char* name; void (*fn)(); } tests[] = {
       {"constructor_contract", constructor_contract},
       {"sync_nodes_keeps_rows_stable", sync_nodes_keeps_rows_stable},
+      {"sync_nodes_resends_everything_after_a_failed_interval", sync_nodes_resends_everything_after_a_failed_interval},
       {"tick_lookup_templating_and_webhooks", tick_lookup_templating_and_webhooks},
       {"task_observers_follow_deltas", task_observers_follow_deltas},
       {"status_changes", status_changes},

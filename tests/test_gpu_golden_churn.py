@@ -96,6 +96,24 @@ def test_churn_stream_against_oracle_digests():
     eng.close()
 
 
+def test_churn_stream_with_aborted_streaming_launches():
+    """every tick's streaming launch is made to give up (CARVE_STATE_ABORTED, include/pm_engine_debug.h) — the cold match after
+    2,000 committed steps, the churn ticks after 25 — and the carve continues on the batch pipeline from the configuration
+    it stopped in: groups, tasks and the life-cycle feed are the oracle's digests tick for tick"""
+    eng = E.Engine(group_id_seed=1)
+    aborts = []
+
+    def tick():
+        eng.debug_stream_abort_after(2000 if not aborts else 25)
+        stats = eng.tick()
+        aborts.append(eng.debug_carve_counters()["stream_aborts"])
+        return stats
+
+    _replay(tick, eng)
+    assert aborts == [1] * (1 + CHURN_TICKS_PINNED), aborts
+    eng.close()
+
+
 def test_churn_stream_on_two_in_process_ranks():
     """the same stream through the stepwise multi-GPU tick: two engines sharing the device, the exchanges as device
     copies (tests/test_gpu_dist.py) — every rank must reproduce the oracle's digests"""

@@ -938,3 +938,36 @@ def test_streaming_carve_under_pressure(env, monkeypatch):
         c = eng.debug_carve_counters()
         assert c["stream"] == 1 and c["stream_aborts"] == 0, c
         eng.close()
+
+
+@pytest.mark.parametrize("after", [1, 40, 300, 1500])
+def test_streaming_carve_abort_falls_back_to_the_batch_pipeline(after):
+    """CARVE_STATE_ABORTED — what a lost hand-shake inside the validator workgroup (proposers that cannot run beside it: a
+    shared GPU) ends a streaming launch in — forced by the debug hook after `after` committed steps, early, in the
+    middle of a large configuration and late.  What was committed stands, and the engine continues from the
+    configuration the launch stopped in on the batch pipeline (pm_engine.cpp form_poll): a different kernel family,
+    a rebuilt eligible list, per-batch candidate lists.  The groups are the oracle's all the same."""
+    for sw in (baseline_config(1, seed=2), make_swarm(31, 2000, 3000), baseline_config(0, seed=3)):
+        st = oracle_state_for(sw, reference_shaped=(sw.W <= 2048), group_id_seed=7)
+        eng = E.Engine(group_id_seed=7)
+        host.load_swarm(eng, sw)
+        eng.debug_stream_abort_after(after)
+        n_want = st.try_form_new_groups()
+        assert n_want == eng.form_groups()
+        assert oracle_groups(st) == engine_groups(eng), (after, sw.W)
+        c = eng.debug_carve_counters()
+        # (a carve with fewer steps through the chain than `after` never reaches the hook)
+        assert c["stream_aborts"] in (0, 1), c
+        if c["stream_aborts"]:
+            assert c["stream"] == 0 and c["batches"] >= 1, c  # the rest of the carve ran as batches
+        elif sw.W >= 10000:
+            assert after >= 1500, c  # configs[1]'s first configuration commits 300 groups through the chain
+        # the engine streams again afterwards: the hook off, the groups dissolved, the same carve once more
+        eng.debug_stream_abort_after(0)
+        eng.reset_groups()
+        st2 = oracle_state_for(sw, reference_shaped=(sw.W <= 2048), group_id_seed=7)
+        assert st2.try_form_new_groups() == eng.form_groups()
+        c2 = eng.debug_carve_counters()
+        assert c2["stream"] == 1 and c2["stream_aborts"] == 0, c2
+        assert [g[1:] for g in oracle_groups(st2)] == [g[1:] for g in engine_groups(eng)]
+        eng.close()

@@ -2,10 +2,8 @@
 against the oracle, with the schedule tests/test_gpu_shim_replay.py drives the Python replay of the Rust shim with
 (tests/plugin_cxx.py gives the C++ objects that interface).
 
-OPT-IN this round (PM_TEST_CXX_PLUGIN=1): the library was written after the round's GPU budget was spent — on the CPU it
-is covered by tests/test_plugin_cpp.py (mock engine, sanitizers, and call for call against the Python replay, which IS
-verified against the oracle on the GPU) — and a test that has never met the GPU does not belong in the default `-m gpu`
-run.  First thing next round: run it, then drop the gate."""
+Part of the default `-m gpu` run since round 5 (it was opt-in for the one round in which it had been written after
+the GPU budget was spent)."""
 import os
 
 import numpy as np
@@ -19,9 +17,7 @@ from helpers import engine_groups, oracle_groups
 from plugin_cxx import PluginCxx
 from test_gpu_ingest import _WORKER_FIELDS
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("PM_TEST_CXX_PLUGIN") != "1",
-                                 reason="the C++ plugin's GPU leg is opt-in until it has been run once (PM_TEST_CXX_PLUGIN=1)")]
+pytestmark = pytest.mark.gpu
 NONE = 0xFFFFFFFF
 
 

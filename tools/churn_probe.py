@@ -9,6 +9,10 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from protocol_amd import build as B
+if os.environ.get("PM_EXP_LIB"):  # a variant built beforehand (tools/build_variants.py)
+    B.LIB_PATH = os.path.abspath(os.environ["PM_EXP_LIB"])
+    B.needs_build = lambda: False
 from protocol_amd import engine as E, host
 from protocol_amd.churn import ChurnStream
 

@@ -38,6 +38,17 @@ def hashes(lib: str) -> dict:
     return out
 
 
+def toolchain() -> str:
+    """the compiler the hashes belong to: hipcc's HIP and clang version lines"""
+    try:
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception:
+        return "unknown"
+    hip = [l.split(":", 1)[1].strip() for l in out.splitlines() if l.startswith("HIP version")]
+    clang = [l.strip() for l in out.splitlines() if "clang version" in l]
+    return "; ".join((hip[:1] or ["?"]) + [c.split("(")[0].strip() for c in clang[:1]])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         lib = sys.argv[1]
@@ -45,4 +56,5 @@ if __name__ == "__main__":
         from protocol_amd import build as B
         lib = B.build()
     for k, v in hashes(lib).items():
-        print(f"{k:16s} {v}")
+        print(f"  {k:16s} {v}")
+    print(f"  toolchain        {toolchain()}")

@@ -6,7 +6,10 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from protocol_amd import build as B
-if os.environ.get("PM_EXP_DEFINES"):
+if os.environ.get("PM_EXP_LIB"):  # a variant built beforehand (tools/build_variants.py)
+    B.LIB_PATH = os.path.abspath(os.environ["PM_EXP_LIB"])
+    B.needs_build = lambda: False
+elif os.environ.get("PM_EXP_DEFINES"):
     alt = os.path.join(os.path.dirname(B.LIB_PATH), "libpm_engine_exp.so")
     B.build(force=True, defines=os.environ["PM_EXP_DEFINES"].split(","), out=alt)
     B.LIB_PATH = alt
@@ -38,5 +41,5 @@ out = (C.c_ulonglong * 42)()
 E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
 E.lib().pm_debug_carve_prof(eng._h, out, 42)
 print("  validation launches ended by: chain thin %d, seeds used up %d, exact-step thin %d, config exhausted %d | void: other config %d, too stale %d, not entered %d | batches %d void %d" % tuple(out[32:41]))
-print(f"config {ci} defines {os.environ.get('PM_EXP_DEFINES', '-')}: carve p50 {carve[len(carve) // 2]:.3f} ms, groups {s['n_groups']}, "
+print(f"config {ci} defines {os.environ.get('PM_EXP_LIB') or os.environ.get('PM_EXP_DEFINES', '-')}: carve p50 {carve[len(carve) // 2]:.3f} ms, groups {s['n_groups']}, "
       f"steps {s['carve_steps']} ({s['carve_fast_steps']} fast), launches {s.get('carve_launches', '?')}")
