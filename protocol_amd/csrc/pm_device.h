@@ -63,7 +63,8 @@ static constexpr uint32_t PM_STREAM_CTL_WORDS = 64; // control block (u32): see 
 static constexpr uint32_t PM_STREAM_PROP_WAVES = PM_STREAM_PROP_WAVES_N; // waves of a proposer workgroup that build rows (one per SIMD)
 static constexpr uint32_t PM_STREAM_SLW_TREQ = PM_STREAM_TP;      // words of the validator's ticket state that
 static constexpr uint32_t PM_STREAM_SLW_PAY = PM_STREAM_TP + 1;   // carve_fast_steps<STREAM> reads (pm_stream.inc: SLW_*)
-static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 128;
+static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 128 +
+                                              (PM_MAX_CONFIGS + 8) * 4;  // + candidate counts of the configurations ahead
 // control words in global memory (each hot word on its own 64-byte line)
 enum { SC_CLAIM = 0,    // next ticket a proposer wave takes (atomicAdd)
        SC_QUIT = 16,    // the validator is through: proposers leave
@@ -256,6 +257,11 @@ struct CarveArgs {
   // bits_scratch = {the published `free` bitmap (positions no group holds yet — the proposers' view, a few commits
   // behind), loc_g}, alive_g = the validator's own master copy of it (brought up to date between configurations).
   uint32_t stream, stream_tag0;  // stream: 1 = this argument block drives carve_stream_kernel; tag0: first ticket tag
+  // gather copies of the columns a row maker reads per candidate, 32 bytes a record = ONE memory line per candidate
+  // instead of five (unit vector x 3, site, located bit): {ux, uy, uz, site | located << 32} — a row is a chain of
+  // gathers, and its latency is what the chain waits for at every cold start
+  double* c_pack;                // [n][4] by position (carve_elig_place_kernel)
+  double* cs_pack;               // [n_indexed][4] by entry of the spatial index (cell_place_kernel)
   uint64_t* cfgbits;             // [n_avail][bits_stride] per configuration (carve order): compatible positions
   unsigned long long* stream_sq;      // [PM_STREAM_SQ] seed tickets: {tag, position | ci << 18 | mode << 24}
   unsigned long long* stream_row_lo;  // [PM_STREAM_RQ][64] rows: {tag, flags word | low half of the packed key of entry g - 1}

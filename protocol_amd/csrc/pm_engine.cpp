@@ -244,6 +244,7 @@ struct pm_engine {
   // spatial index of a carve's located positions (cell_*_kernel)
   DevBuf<uint32_t> d_cell_cnt, d_cell_start, d_pos_cell, d_pos_rank, d_cs_of_pos, d_cs_slot, d_cs_site;
   DevBuf<double> d_cs_u[3];
+  DevBuf<double> d_c_pack, d_cs_pack;  // streaming carve: 32-byte gather records by position / by index entry
   // streaming carve (carve_stream_kernel): per-configuration bitmaps, ticket and row rings, control block, candidate list
   DevBuf<uint64_t> d_cfgbits, d_stream_sq, d_stream_row_lo, d_stream_row_hi, d_stream_trace;
   DevBuf<uint32_t> d_stream_ctl;
@@ -560,6 +561,8 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   HIPCHK(e->d_bits.ensure(size_t(stride) * 4));
   HIPCHK(e->d_snap.ensure(size_t(stride) * 2));
   if (stream) {
+    HIPCHK(e->d_c_pack.ensure(cap * 4));
+    HIPCHK(e->d_cs_pack.ensure(cap * 4));
     HIPCHK(e->d_cfgbits.ensure(size_t(stride) * PM_MAX_CONFIGS));
     HIPCHK(e->d_stream_ctl.ensure(PM_STREAM_CTL_WORDS));
     if (!e->d_stream_sq.p) {  // (tags never repeat within 127 launches; the rings are cleared when the counter wraps)
@@ -672,6 +675,8 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     a->loc_g = e->d_bits.p + stride;
     a->alive_g = e->d_bits.p + size_t(stride) * 2;
     a->cfgbits = e->d_cfgbits.p;
+    a->c_pack = e->d_c_pack.p;
+    a->cs_pack = e->d_cs_pack.p;
     a->stream_sq = (unsigned long long*)e->d_stream_sq.p;
     a->stream_row_lo = (unsigned long long*)e->d_stream_row_lo.p;
     a->stream_row_hi = (unsigned long long*)e->d_stream_row_hi.p;
@@ -1971,6 +1976,8 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_cell_cnt.release(); e->d_cell_start.release(); e->d_pos_cell.release(); e->d_pos_rank.release();
   e->d_cs_of_pos.release(); e->d_cs_slot.release(); e->d_cs_site.release();
   for (auto& u : e->d_cs_u) u.release();
+  e->d_c_pack.release();
+  e->d_cs_pack.release();
   e->set2.release(); e->d_desc.release(); e->d_snap.release(); e->d_ikeys.release(); e->d_umask.release(); e->d_ivals.release();
   delete e->form;
   delete e;

@@ -420,7 +420,7 @@ def test_experiment_flags_compile_together(tmp_path):
     """the untried experiments of DESIGN section 9 sit behind #ifdefs (PM_EXP_*): all of them switched on at once still
     compile for gfx950 — what a new round starts from"""
     from protocol_amd import build as B
-    flags = ["PM_EXP_ONE_STREAM", "PM_EXP_TICKMANY_CHUNK=8", "PM_EXP_TICKMANY_POLL", "PM_EXP_SMALL_CTZ", "PM_EXP_PRE_SKIP_SMALL",
-             "PM_EXP_COLD_WALK=32", "PM_STREAM_PROP_WAVES_N=8", "STREAM_PRE_EARLY=256u"]
+    flags = ["PM_EXP_ONE_STREAM", "PM_EXP_TICKMANY_CHUNK=8", "PM_EXP_TICKMANY_POLL", "PM_STREAM_PROP_WAVES_N=8",
+             "STREAM_PRE_EARLY=256u"]
     out = B.build(force=True, defines=flags, out=str(tmp_path / "libpm_engine_exp.so"))
     assert os.path.getsize(out) > 500_000
