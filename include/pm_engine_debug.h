@@ -14,10 +14,10 @@
 extern "C" {
 #endif
 
-/* Counters of the last carve.  out[0..32) and out[56..72): s_memtime phase counters (all zero unless the library was
+/* Counters of the last carve.  out[0..32) and out[56..88): s_memtime phase counters (all zero unless the library was
  * built with -DPM_CARVE_PROF: tools/stream_prof.py, tools/carve_prof.py); out[32..56): how the carve went — reasons
  * its launches ended, index geometry, streaming-carve tickets / timeouts / switches (protocol_amd/engine.py
- * debug_carve_counters names them).  Copies min(cap, 72) words. */
+ * debug_carve_counters names them).  Copies min(cap, 88) words (out[72..88): the row makers' anatomy, tools/stream_prof.py). */
 int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap);
 
 /* Timeline of the last streaming carve launch (PM_CARVE_PROF builds; otherwise *n = 0): up to cap events of two words

@@ -71,6 +71,7 @@ enum { SC_CLAIM = 0,    // next ticket a proposer wave takes (atomicAdd)
        SC_ROWS = 48,    // rows the proposers delivered (statistics)
        SC_GAVE_UP = 49, // proposer waves that left because nothing was asked of them for too long
        SC_FINISH = 50,  // the carve launch ran (carve_finish_kernel has records to finish)
+       SC_FINISH_TICKET = 52,  // carve_finish_kernel: blocks through (the last one mirrors the status to the host)
        SC_TRACE = 51    // PM_CARVE_PROF builds: events written to the trace buffer
 };
 static constexpr uint32_t PM_STREAM_TRACE_CAP = 1u << 17;  // events (two u64 each) of a PM_CARVE_PROF build's timeline
@@ -169,7 +170,7 @@ struct CarveStatus {
   uint32_t blog[3 * 512];   // per preparation: list length (0 = none), seeds, grid of the walk (0 = whole-list sweep)
 #endif
   unsigned long long prop_keys;  // keys (Haversine terms) those sweeps evaluated
-  unsigned long long prof[48];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
+  unsigned long long prof[64];  // PM_CARVE_PROF builds: accumulated s_memtime ticks per phase
 };
 
 // A proposal batch as its preparation describes it (carve_plan_kernel + carve_prep_*_kernel write it, the proposer
@@ -271,6 +272,17 @@ struct CarveArgs {
   uint32_t stream_la_div;                // look-ahead = candidates / (la_div x (max_group_size - 1)) (0 = default)
   uint32_t debug_abort_after;            // test hook (pm_debug_stream_abort_after): the chain gives the launch up — CARVE_STATE_ABORTED —
                                          // once this many steps of the carve are committed (0 = off)
+  // behind the streaming carve, carve_finish_kernel completes the records of the groups the launch appended — worker ids for
+  // positions, group_of, and: their ids (generate_group_id's stream: output k + 1 of id_state for group id_g0 + k), an
+  // empty task word, and a copy of the records and of the status in pinned HOST memory (stage_*, h_status: written by the
+  // kernel over PCIe) — so that nothing has to be copied, and no launch queued, between the carve and the pair sweep
+  unsigned long long id_state;
+  uint32_t id_g0, stage_m0;              // first group / member slot of this carve (the staging arrays start there)
+  uint32_t stage_cap_g, stage_cap_m;     // entries the staging arrays hold
+  uint32_t *stage_cfg, *stage_n, *stage_off, *stage_mem;  // pinned host memory (null: no host copy)
+  unsigned long long* g_id_out;          // [cap_groups] ids (null: none written)
+  uint32_t* g_task_out;                  // [cap_groups] task words
+  CarveStatus* h_status;                 // pinned host memory (null: no mirror)
   unsigned long long* stream_trace;      // PM_CARVE_PROF builds: [PM_STREAM_TRACE_CAP][2] {s_memtime, type | a << 8 | b << 32}
   // configurations in carve order (get_available_configurations, mod.rs:399-418)
   uint32_t n_avail, start_ci;
@@ -329,11 +341,13 @@ void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng
 hipError_t carve_kernels_init();  // per device: the carve kernels' dynamic LDS sizes (pm_engine_create)
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
 uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, bool speculative, hipStream_t s);  // [plan +] count + place
+// eligible list [+ spatial index]; returns the launches.  fresh: the status block is initialised by the first kernel
+// (state RUNNING, n_groups0 groups, n_members0 member slots, everything else zero) instead of by a copy in front of it
 uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound, uint32_t index_min, uint32_t start_ci,
-                           hipStream_t s);  // eligible list [+ spatial index]; returns the launches
+                           bool fresh, uint32_t n_groups0, uint32_t n_members0, hipStream_t s);
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
-hipError_t launch_carve_stream(const CarveArgs* d_args, uint32_t start_ci, uint32_t n_prop_wgs, uint32_t* ctl, hipStream_t s);
+hipError_t launch_carve_stream(const CarveArgs* d_args, uint32_t start_ci, uint32_t n_prop_wgs, hipStream_t s);
 
 }  // namespace pm
 #endif

@@ -135,7 +135,7 @@ struct pm_engine {
   float k_ms_compat = 0, k_ms_carve = 0, k_ms_sweep = 0;
   bool k_sweep_recorded = false, k_compat_recorded = false;
   uint64_t tick_cand_sum = 0;
-  unsigned long long carve_prof[48]{};
+  unsigned long long carve_prof[64]{};
   unsigned long long carve_why[24]{};  // CarveStatus::why of the last carve, its batches and void launches, the spatial
                                        // index, the streaming carve's counters
   uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above
@@ -229,6 +229,8 @@ struct pm_engine {
   // ---- carve scratch
   DevBuf<uint32_t> d_order;
   uint32_t form_rounds_hint = 0;  // validation rounds the last proposal-driven carve needed (0 = unknown)
+  bool tick_needs_merge = false;  // the last pm_tick found two or more single-node groups (the merge pass ran): the next one does
+                                  // not queue its pair sweep before it has seen the carve's result
   // group life-cycle feed (pm_enable_group_events / pm_drain_group_events)
   bool events_on = false;
   std::vector<pm_group_event> ev_log;
@@ -286,6 +288,8 @@ struct pm_engine {
   // pinned staging for the group records a carve appended (absorbed into the host list by absorb_groups)
   uint32_t* h_gstage = nullptr;
   size_t h_gstage_cap = 0;
+  const uint32_t *ab_cfg_p = nullptr, *ab_n_p = nullptr, *ab_off_p = nullptr, *ab_mem_p = nullptr;  // the staged records absorb_groups reads
+  CarveStatus* h_status = nullptr;  // pinned: carve_finish_kernel mirrors the status block here (streaming carve)
   hipEvent_t ev_groups = nullptr;
   bool absorb_pending = false;
   uint32_t ab_g0 = 0, ab_g1 = 0, ab_m0 = 0, ab_m1 = 0, ab_solo = 0;
@@ -802,8 +806,7 @@ static int32_t absorb_groups(pm_engine* e) {
   if (!e->absorb_pending) return PM_OK;
   HIPCHK(hipEventSynchronize(e->ev_groups));
   const uint32_t g0 = e->ab_g0, ng = e->ab_g1 - e->ab_g0, m0 = e->ab_m0;
-  const uint32_t *g_cfg = e->h_gstage, *g_n = g_cfg + ng, *g_off = g_cfg + 2 * size_t(ng),
-                 *members = g_cfg + 3 * size_t(ng);
+  const uint32_t *g_cfg = e->ab_cfg_p, *g_n = e->ab_n_p, *g_off = e->ab_off_p, *members = e->ab_mem_p;
   e->groups.reserve(e->groups.size() + ng);
   for (uint32_t k = 0; k < ng; ++k) {
     Group gr;
@@ -857,6 +860,8 @@ struct FormRun {
   bool stream = false;       // one streaming launch (carve_stream_kernel) instead of the batch pipeline
   bool single_call = true;   // run_form drives the whole carve (the stepwise multi-GPU tick exchanges rows per batch)
   uint32_t stream_wgs = 0;   // proposer workgroups of the streaming launch
+  bool rearmed = false;      // the carve took more than its first launch sequence (host-resolved step, aborted streaming launch)
+  uint32_t stage_cap = 0;    // streaming carve: entries of each staging array carve_finish_kernel fills in pinned host memory
 };
 
 static int32_t launch_propose_timed(pm_engine* e, const CarveArgs* d_args, uint32_t n_bound, hipStream_t s);
@@ -911,15 +916,16 @@ static int32_t pipe_queue_validate(pm_engine* e, FormRun* r) {
 
 static int32_t form_setup_args(pm_engine* e, FormRun* r);
 
-static int32_t form_queue_init(pm_engine* e, FormRun* r) {
-  HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
+// fresh: the first launch sequence of a carve — the status block (RUNNING, the group and member counts so far, zero
+// otherwise) is initialised by the first kernel of the sequence instead of by a copy in front of it
+static int32_t form_queue_init(pm_engine* e, FormRun* r, bool fresh = false) {
+  fresh = fresh && r->use_props;  // (the proposal-free carve's one launch reads the status it is handed)
+  if (!fresh) HIPCHK(hipMemcpyAsync(e->d_status.p, &r->st, sizeof(r->st), hipMemcpyHostToDevice, e->stream));
   if (r->use_props) {
-    HIPCHK(hipMemsetAsync(e->d_desc.p, 0, 2 * sizeof(BatchDesc), e->stream));
+    if (!r->stream) HIPCHK(hipMemsetAsync(e->d_desc.p, 0, 2 * sizeof(BatchDesc), e->stream));  // (the batch pipeline's descriptors)
     // the ordered eligible list, and the spatial index of its positions when there are enough of them to matter
     const uint32_t index_min = !r->a.prune_mode ? 0u : r->a.prune_mode >= 2u ? 1u : PM_CELL_MIN_N;
-    e->tick_carve_launches += launch_carve_elig(e->d_carve_args.p, e->W, r->n_bound, r->n_elig_hint >= index_min ? index_min : 0u,
-                                                r->start_ci, e->stream);
-    if (r->stream) {  // everything else in one launch (+ the pass that turns positions into worker ids)
+    if (r->stream) {
       // every launch tags its tickets and rows from a range of its own (a launch re-armed behind a host-resolved step
       // must not take the rows of the one before it for its own); the rings are cleared when the counter wraps
       if (e->stream_seq == 0 || e->stream_seq >= 127) {
@@ -929,9 +935,16 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r) {
         e->stream_seq = 0;
       }
       e->stream_seq += 1;
-      r->a.stream_tag0 = e->stream_seq << 25;
-      HIPCHK(hipMemcpyAsync(&e->d_carve_args.p->stream_tag0, &r->a.stream_tag0, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-      HIPCHK(launch_carve_stream(e->d_carve_args.p, r->start_ci, r->stream_wgs, e->d_stream_ctl.p, e->stream));
+      const uint32_t tag0 = e->stream_seq << 25;
+      if (r->a.stream_tag0 != tag0) {  // (the first sequence of a carve carries its tag in the argument block it uploads)
+        r->a.stream_tag0 = tag0;
+        HIPCHK(hipMemcpyAsync(&e->d_carve_args.p->stream_tag0, &r->a.stream_tag0, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+      }
+    }
+    e->tick_carve_launches += launch_carve_elig(e->d_carve_args.p, e->W, r->n_bound, r->n_elig_hint >= index_min ? index_min : 0u,
+                                                r->start_ci, fresh, r->st.n_groups, r->st.n_members, e->stream);
+    if (r->stream) {  // everything else in one launch (+ the pass that turns positions into worker ids)
+      HIPCHK(launch_carve_stream(e->d_carve_args.p, r->start_ci, r->stream_wgs, e->stream));
       e->tick_carve_launches += 2;
       return PM_OK;
     }
@@ -993,10 +1006,12 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
   // stepwise multi-GPU tick, swarms beyond 262,144 unassigned rows) goes through the batch pipeline.
   r->stream = r->single_call && r->use_props && e->cfg.carve_variant == 0 && e->dist_world == 1 && r->n_bound <= PM_CARVE_BIG_SLOTS &&
               !e->debug_mem_above;  // (the test hook for the all-in-HBM lists is the batch pipeline's)
+  host_mark("form: begin (host mirrors counted)");
   rc = form_setup_args(e, r);
   if (rc) return rc;
+  host_mark("form: arguments queued");
   HIPCHK(hipEventRecord(e->kev[2], e->stream));
-  return form_queue_init(e, r);  // prepares the first candidate list (all of it when there are no proposals)
+  return form_queue_init(e, r, /*fresh=*/true);  // prepares the first candidate list (all of it when there are no proposals)
 }
 
 // The argument block(s) of a carve, filled and uploaded (again, when a streaming launch gave up and the batch
@@ -1011,6 +1026,33 @@ static int32_t form_setup_args(pm_engine* e, FormRun* r) {
     uint32_t wgs = e->stream_wgs_env ? e->stream_wgs_env : r->n_elig_hint / 64u + 48u;
     const uint32_t max_wgs = e->n_cus > 8u ? e->n_cus - 4u : 4u;
     r->stream_wgs = std::max(1u, std::min(wgs, max_wgs));
+    // the tag of the launch sequence form_queue_init is about to queue (it advances the counter: see there)
+    a.stream_tag0 = ((e->stream_seq == 0 || e->stream_seq >= 127) ? 1u : e->stream_seq + 1u) << 25;
+    // carve_finish_kernel: group ids, empty task words, and the host's copy of records and status
+    a.id_state = e->id_rng;
+    a.id_g0 = r->g0;
+    a.stage_m0 = r->m0;
+    a.g_id_out = (unsigned long long*)e->d_g_id.p;
+    a.g_task_out = e->d_g_task.p;
+    r->stage_cap = std::max<uint32_t>(r->n_bound, 1u);  // (a group holds at least one of the rows no group holds yet)
+    const size_t need = size_t(4) * r->stage_cap;
+    if (e->h_gstage_cap < need) {
+      HIPCHK(hipStreamSynchronize(e->stream));  // (nothing in flight may still write the old buffer)
+      if (e->h_gstage) (void)hipHostFree(e->h_gstage);
+      e->h_gstage = nullptr;
+      e->h_gstage_cap = 0;
+      const size_t cap = std::max<size_t>(need, size_t(4) * std::max<uint32_t>(e->W, 1));
+      HIPCHK(hipHostMalloc((void**)&e->h_gstage, cap * sizeof(uint32_t)));
+      e->h_gstage_cap = cap;
+    }
+    if (!e->h_status) HIPCHK(hipHostMalloc((void**)&e->h_status, sizeof(CarveStatus)));
+    a.stage_cap_g = a.stage_cap_m = r->stage_cap;
+    a.stage_cfg = e->h_gstage;
+    a.stage_n = e->h_gstage + r->stage_cap;
+    a.stage_off = e->h_gstage + size_t(2) * r->stage_cap;
+    a.stage_mem = e->h_gstage + size_t(3) * r->stage_cap;
+    a.h_status = e->h_status;
+    e->h_status->state = 0xFFFFFFFFu;  // (not yet written by this carve)
   }
   a.n_avail = uint32_t(r->avail.size());
   for (size_t i = 0; i < r->avail.size(); ++i) {
@@ -1116,6 +1158,7 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
       // continues from there on the batch pipeline, whose launches depend on nothing running beside them.
       if (!r->stream) return set_error(PM_ENODEV, "carve: a hand-shake inside the validator timed out");
       e->tick_stream_aborts++;
+      r->rearmed = true;
       r->stream = false;
       int32_t rca = form_setup_args(e, r);
       if (rca) return rca;
@@ -1129,6 +1172,7 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
     int32_t rc = host_resolve_form_step(e, r->avail[r->st.stop_ci], &r->st);
     if (rc) return rc;
     e->tick_host_resolved++;
+    r->rearmed = true;
     r->start_ci = r->st.stop_ci;
     r->st.state = CARVE_STATE_RUNNING;
     rc = form_queue_init(e, r);
@@ -1138,7 +1182,8 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
   }
 }
 
-static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool defer_absorb) {
+// have_event: ev_groups has been recorded behind the carve already (and waited for)
+static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool defer_absorb, bool have_event = false) {
   if (n_formed) *n_formed = 0;
   if (r->nothing) return PM_OK;
   const CarveStatus& st = r->st;
@@ -1176,24 +1221,40 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
   const uint32_t g0 = r->g0, m0 = r->m0, g1 = st.n_groups, m1 = st.n_members;
   if (g1 > g0) {
     const uint32_t ng = g1 - g0, nm = m1 - m0;
-    const size_t need = size_t(3) * ng + nm;
-    if (e->h_gstage_cap < need) {
-      if (e->h_gstage) (void)hipHostFree(e->h_gstage);
-      e->h_gstage = nullptr;
-      e->h_gstage_cap = 0;
-      const size_t cap = std::max<size_t>(need, size_t(4) * std::max<uint32_t>(e->W, 1));
-      HIPCHK(hipHostMalloc((void**)&e->h_gstage, cap * sizeof(uint32_t)));
-      e->h_gstage_cap = cap;
+    // One streaming launch sequence did the whole carve: carve_finish_kernel has written the records' host copy, the
+    // ids and the empty task words already (the caller waited for the stream since).  Otherwise — a re-armed carve, the
+    // batch pipeline — they are copied and filled in here.
+    const bool staged = r->stream && !r->rearmed && ng <= r->stage_cap && nm <= r->stage_cap;
+    if (staged) {
+      e->ab_cfg_p = e->h_gstage;
+      e->ab_n_p = e->h_gstage + r->stage_cap;
+      e->ab_off_p = e->h_gstage + size_t(2) * r->stage_cap;
+      e->ab_mem_p = e->h_gstage + size_t(3) * r->stage_cap;
+      if (!have_event) HIPCHK(hipEventRecord(e->ev_groups, e->stream));
+    } else {
+      const size_t need = size_t(3) * ng + nm;
+      if (e->h_gstage_cap < need) {
+        if (e->h_gstage) (void)hipHostFree(e->h_gstage);
+        e->h_gstage = nullptr;
+        e->h_gstage_cap = 0;
+        const size_t cap = std::max<size_t>(need, size_t(4) * std::max<uint32_t>(e->W, 1));
+        HIPCHK(hipHostMalloc((void**)&e->h_gstage, cap * sizeof(uint32_t)));
+        e->h_gstage_cap = cap;
+      }
+      uint32_t* st_cfg = e->h_gstage;
+      HIPCHK(hipMemcpyAsync(st_cfg, e->d_g_cfg.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(st_cfg + ng, e->d_g_n.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(st_cfg + 2 * size_t(ng), e->d_g_off.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(st_cfg + 3 * size_t(ng), e->d_members.p + m0, size_t(nm) * 4, hipMemcpyDeviceToHost, e->stream));
+      e->ab_cfg_p = st_cfg;
+      e->ab_n_p = st_cfg + ng;
+      e->ab_off_p = st_cfg + 2 * size_t(ng);
+      e->ab_mem_p = st_cfg + 3 * size_t(ng);
+      HIPCHK(hipEventRecord(e->ev_groups, e->stream));
+      host_mark("form: group copies queued");
+      launch_group_ids(e->d_g_id.p + g0, e->d_g_task.p + g0, ng, e->id_rng, e->stream);
+      HIPCHK(hipGetLastError());
     }
-    uint32_t* st_cfg = e->h_gstage;
-    HIPCHK(hipMemcpyAsync(st_cfg, e->d_g_cfg.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(st_cfg + ng, e->d_g_n.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(st_cfg + 2 * size_t(ng), e->d_g_off.p + g0, size_t(ng) * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(st_cfg + 3 * size_t(ng), e->d_members.p + m0, size_t(nm) * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipEventRecord(e->ev_groups, e->stream));
-    host_mark("form: group copies queued");
-    launch_group_ids(e->d_g_id.p + g0, e->d_g_task.p + g0, ng, e->id_rng, e->stream);
-    HIPCHK(hipGetLastError());
     e->absorb_pending = true;
     e->ab_g0 = g0;
     e->ab_g1 = g1;
@@ -1335,7 +1396,9 @@ static int32_t pick_task_for_config(pm_engine* e, uint32_t cfg, uint64_t group_i
 
 // The pair sweep + chooser + claim for every worker — or, in a multi-GPU tick (`dist`), for the workers this
 // rank owns, whose rows go packed into this rank's segment of the exchange buffer (pm_dist_match_begin).
-static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* count_out, bool dist = false) {
+// G_ub: the task words of that many groups are carried over (0 = the device's group count: every caller but the tick that
+// queues the match before it knows how many groups the carve in front of it formed)
+static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* count_out, bool dist = false, size_t G_ub = 0) {
   if (!e->have_cfgs || !e->have_workers || !e->have_tasks)
     return set_error(PM_ESTATE, "configs, workers and tasks must be uploaded first");
   int32_t rc = push_groups(e);
@@ -1371,7 +1434,7 @@ static int32_t run_match(pm_engine* e, bool want_count, std::vector<uint32_t>* c
   }
   launch_group_rank(e->d_group_of.p, e->d_g_n.p, e->d_g_off.p, e->d_members.p, e->d_addr_rank.p, e->W,
                     e->d_rank_in_group.p, e->d_by_rank.p, e->stream);
-  const size_t G = e->d_n_groups;  // == groups.size() once the last carve is absorbed
+  const size_t G = G_ub ? G_ub : e->d_n_groups;  // == groups.size() once the last carve is absorbed
   if (G) HIPCHK(hipMemcpyAsync(e->d_g_task_next.p, e->d_g_task.p, G * 4, hipMemcpyDeviceToDevice, e->stream));
   ClaimArgs c{};
   c.R = R;
@@ -1685,6 +1748,7 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
   if (!e->have_cfgs || !e->have_workers) return set_error(PM_ESTATE, "configs and workers must be uploaded first");
   size_t solo = e->absorb_pending ? e->ab_solo : 0;  // single-node groups of the carve not yet absorbed
   for (const Group& g : e->groups) solo += g.members.size() == 1;
+  e->tick_needs_merge = solo >= 2;  // (pm_tick: whether the next tick may queue its pair sweep behind the carve unseen)
   if (solo < 2) return PM_OK;  // mod.rs:641-644
   {
     int32_t rc0 = absorb_groups(e);
@@ -1960,6 +2024,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_table.release(); e->d_task_col.release(); e->d_shard.release(); e->d_own_rows.release(); e->d_xrow.release();
   e->d_sel_own.release(); e->d_table_x.release(); e->d_row_stage.release(); e->d_nb_idx.release(); e->d_nb_val.release();
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
+  if (e->h_status) (void)hipHostFree(e->h_status);
   if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
   if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
   for (PubTable& t : e->pub)
@@ -3046,31 +3111,90 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   // The host copy of the new groups is built while the pair sweep runs, unless the merge pass needs it.
   host_mark("tick: compat queued");
-  rc = run_form(e, &n_formed, /*defer_absorb=*/true);
+  FormRun r;
+  rc = form_begin(e, &r, /*allow_pipeline=*/true);
   if (rc) return rc;
-  host_mark("tick: form done");
-  HIPCHK(hipEventRecord(e->ev[2], e->stream));
-  rc = run_merge(e, &n_merged);
-  if (rc) return rc;
-  host_mark("tick: merge done");
-  HIPCHK(hipEventRecord(e->ev[3], e->stream));
-  rc = run_match(e, false, nullptr);
-  if (rc) return rc;
-  host_mark("tick: match queued");
-  HIPCHK(hipEventRecord(e->ev[4], e->stream));
-  // the table's copies travel while the host builds its copy of the new groups
-  PubRun pr;
-  rc = publish_begin(e, &pr, e->d_n_groups);
-  if (rc) return rc;
-  rc = absorb_groups(e);
-  if (rc) {
-    publish_abandon(e, pr);
-    return rc;
+  // ---- the streaming carve: everything behind it is queued BEFORE the host waits for any of it.  The carve's last
+  // kernel has completed the group records on the device (ids, empty task words) and written their host copy and the
+  // status into pinned memory itself, so behind it come — without a copy or a host round trip in between — the pair
+  // sweep, the claim, and the copies of the table: ONE wait per match instead of two, and nothing on the stream while the
+  // host sleeps and wakes (30 us each way) or walks through a dozen enqueue calls.  The bet is that the carve ends DONE in
+  // its one launch and leaves fewer than two single-node groups (no merge pass): if not, the queued work was for nothing
+  // — it changes no state the engine keeps — and the general path below takes over from the status the launch left.
+  bool done = false;
+  if (r.stream && !r.nothing && !e->tick_needs_merge) {
+    PubRun pr;
+    HIPCHK(hipEventRecord(e->kev[3], e->stream));
+    HIPCHK(hipEventRecord(e->ev_groups, e->stream));  // the carve is through: records and status are in host memory
+    HIPCHK(hipEventRecord(e->ev[2], e->stream));
+    HIPCHK(hipEventRecord(e->ev[3], e->stream));
+    const size_t G_ub = std::min<size_t>(size_t(r.g0) + r.stage_cap, std::min(e->d_g_task.cap, e->d_g_task_next.cap));
+    rc = run_match(e, false, nullptr, false, G_ub);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev[4], e->stream));
+    rc = publish_begin(e, &pr, G_ub);
+    if (rc) return rc;
+    host_mark("tick: everything queued");
+    // the host's copy of the new groups is built while the pair sweep and the claim run
+    if (hipEventSynchronize(e->ev_groups) != hipSuccess) {
+      publish_abandon(e, pr);
+      return set_error(PM_ENODEV, "tick: the stream failed");
+    }
+    host_mark("tick: carve through");
+    const CarveStatus& hs = *e->h_status;
+    size_t solo = hs.n_solo;
+    for (const Group& g : e->groups) solo += g.members.size() == 1 && !g.dead;
+    const bool fits = hs.n_groups >= r.g0 && hs.n_groups - r.g0 <= r.stage_cap && hs.n_members >= r.m0 &&
+                      hs.n_members - r.m0 <= r.stage_cap && hs.n_groups <= G_ub;
+    if (hs.state == CARVE_STATE_DONE && fits && solo < 2) {
+      r.st = hs;
+      rc = form_finish(e, &r, &n_formed, /*defer_absorb=*/false, /*have_event=*/true);
+      if (rc) {
+        publish_abandon(e, pr);
+        return rc;
+      }
+      host_mark("tick: groups absorbed");
+      pr.G = e->groups.size();
+      rc = publish_end(e, pr);  // (waits for the stream: the table's copies)
+      host_mark("tick: published");
+      if (rc) return rc;
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
+      e->k_ms_carve += ms;
+      done = true;
+    } else {
+      publish_abandon(e, pr);
+      e->tick_needs_merge = solo >= 2;
+    }
   }
-  host_mark("tick: groups absorbed");
-  rc = publish_end(e, pr);
-  host_mark("tick: published");
-  if (rc) return rc;
+  if (!done) {
+    rc = run_form_rest(e, r, &n_formed, /*defer_absorb=*/true);
+    if (rc) return rc;
+    host_mark("tick: form done");
+    HIPCHK(hipEventRecord(e->ev[2], e->stream));
+    rc = run_merge(e, &n_merged);
+    if (rc) return rc;
+    host_mark("tick: merge done");
+    HIPCHK(hipEventRecord(e->ev[3], e->stream));
+    rc = run_match(e, false, nullptr);
+    if (rc) return rc;
+    host_mark("tick: match queued");
+    HIPCHK(hipEventRecord(e->ev[4], e->stream));
+    // the table's copies travel while the host builds its copy of the new groups
+    PubRun pr;
+    rc = publish_begin(e, &pr, e->d_n_groups);
+    if (rc) return rc;
+    host_mark("tick: table copies queued");
+    rc = absorb_groups(e);
+    if (rc) {
+      publish_abandon(e, pr);
+      return rc;
+    }
+    host_mark("tick: groups absorbed");
+    rc = publish_end(e, pr);
+    host_mark("tick: published");
+    if (rc) return rc;
+  }
   return tick_stats(e, stats, n_formed, n_merged);
 }
 
@@ -3499,7 +3623,7 @@ int32_t pm_debug_carve_prof(pm_engine* e, unsigned long long* out, uint32_t cap)
   const uint32_t n = std::min<uint32_t>(cap, 32u);
   std::memcpy(out, e->carve_prof, size_t(n) * sizeof(unsigned long long));
   for (uint32_t k = 32; k < cap && k < 56; ++k) out[k] = e->carve_why[k - 32];
-  for (uint32_t k = 56; k < cap && k < 72; ++k) out[k] = e->carve_prof[k - 56 + 32];  // (phase counters 32..47)  // (how the validation launches ended; the index)
+  for (uint32_t k = 56; k < cap && k < 88; ++k) out[k] = e->carve_prof[k - 56 + 32];  // (phase counters 32..47)  // (how the validation launches ended; the index)
   return PM_OK;
 }
 

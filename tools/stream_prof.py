@@ -30,9 +30,9 @@ host.load_swarm(eng, sw)
 for it in range(3):
     eng.reset_groups()
     s = eng.tick()
-out = (C.c_ulonglong * 72)()
+out = (C.c_ulonglong * 88)()
 E.lib().pm_debug_carve_prof.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
-E.lib().pm_debug_carve_prof(eng._h, out, 72)
+E.lib().pm_debug_carve_prof(eng._h, out, 88)
 o = [int(v) for v in out]
 info = eng.debug_carve_counters()
 steps = max(s["carve_steps"], 1)
@@ -59,6 +59,11 @@ print(f"  proposer rows: bitmap sweep {row(o[10], o[12])}; index walk {row(o[13]
 print(f"  a row on average: ticket seen -> candidates swept {us(o[59]) / max(o[12] + o[14] + o[29], 1):.2f} us, finished and written "
       f"{us(o[60]) / max(o[12] + o[14] + o[29], 1):.2f} us, {o[61] / max(o[12] + o[14] + o[29], 1):.0f} candidates evaluated")
 print(f"  bitmap sweeps: {o[62 + 2]} passes {us(o[62]) / max(o[62 + 2], 1):.2f} us each, {o[62 + 3]} batches of 256 {us(o[62 + 1]) / max(o[62 + 3], 1):.2f} us each")
+n_rows = max(o[12] + o[14] + o[29], 1)
+print(f"  a row's compute (us, count per row): sorted insertions {us(o[72]) / n_rows:.2f} ({o[73] / n_rows:.0f}), near-miss tracker "
+      f"{us(o[74]) / n_rows:.2f} ({o[75] / n_rows:.0f}), sine-form keys {us(o[76]) / n_rows:.2f} ({o[77] / n_rows:.1f} strides), evictions with a site "
+      f"look-up {o[78] / n_rows:.1f}, strides offered {o[79] / n_rows:.1f}; bitmap-sweep batches: waiting for the gathers "
+      f"{us(o[80]) / max(o[12], 1):.2f}, evaluating {us(o[81]) / max(o[12], 1):.2f} per swept row")
 print(f"  stream_small: {o[66 + 5]} groups; per group (us): seed {us(o[66]) / max(o[71], 1):.2f}, keys {us(o[67]) / max(o[71], 1):.2f}, "
       f"selection {us(o[68]) / max(o[71], 1):.2f}, certificate {us(o[69]) / max(o[71], 1):.2f}, commit {us(o[70]) / max(o[71], 1):.2f}")
 print(f"  exact-sweep reasons: no row {o[20]}, debug hook {o[21]}, row exhausted {o[25]}, certificate {o[31]}")
