@@ -55,8 +55,6 @@ static constexpr size_t PM_CARVE_LDS_BYTES = size_t(16) * PM_CARVE_PART * 8 + si
 static constexpr uint32_t PM_STREAM_SQ = 8192;      // seed-ticket ring (8-byte granules): > waves that can hold a claim
 static constexpr uint32_t PM_STREAM_RQ = 8192;      // row ring: rows of tickets t, t + RQ share a slot
 static constexpr uint32_t PM_STREAM_TP = 4096;      // tickets whose seed position the validator remembers (LDS)
-static constexpr uint32_t PM_STREAM_PARTS = 4;       // sub-tickets of a row made in parts (bits 26..27 of the payload; bit 28 = in parts)
-static constexpr uint32_t PM_STREAM_PART_WORDS = 68; // 64 keys + m1, m2, s1 of the near-miss tracker
 static constexpr uint32_t PM_STREAM_LA_MAX = 3072;  // look-ahead: tickets issued and not yet handed to the chain
 static constexpr uint32_t PM_STREAM_CTL_WORDS = 64; // control block (u32): see the SC_* indices
 #ifndef PM_STREAM_PROP_WAVES_N  // (settable in a variant build: with few row-making workgroups per pool — K pools on one
@@ -255,8 +253,7 @@ struct CarveArgs {
   uint32_t prune_mode;           // 0 never, 1 when it pays (list length vs live fraction), 2 whenever there is an index,
                                  // 3 = 2 with every seed forced through the whole-list fallback (test hooks)
   uint32_t prune_factor;         // mode 1: walk when n_list^2 >= prune_factor x (indexed positions)
-  uint32_t walk_cap_div;         // seeds of a batch that walks the index: n_list / walk_cap_div
-  uint32_t stream_cold_n;        // streaming carve: first tickets of a run that starts cold whose rows are made in parts (0 = none)
+  uint32_t walk_cap_div, _pad_w; // seeds of a batch that walks the index: n_list / walk_cap_div
   // ---- streaming carve (carve_stream_kernel).  Slot == position: cc_* alias c_*, slot_wid aliases order,
   // bits_scratch = {the published `free` bitmap (positions no group holds yet — the proposers' view, a few commits
   // behind), loc_g}, alive_g = the validator's own master copy of it (brought up to date between configurations).
@@ -270,11 +267,6 @@ struct CarveArgs {
   unsigned long long* stream_sq;      // [PM_STREAM_SQ] seed tickets: {tag, position | ci << 18 | mode << 24}
   unsigned long long* stream_row_lo;  // [PM_STREAM_RQ][64] rows: {tag, flags word | low half of the packed key of entry g - 1}
   unsigned long long* stream_row_hi;  // [PM_STREAM_RQ][64]       {tag, high half}
-  // rows made in parts (a run that starts cold: the chain is waiting for exactly these rows, and a row is a chain of
-  // dependent instructions on ONE wave): a ticket handed out as PM_STREAM_PARTS sub-tickets, each wave sweeps its share
-  // of the candidate bitmap into a partial row, the last one through merges them
-  unsigned long long* stream_part;    // [PM_STREAM_RQ][PM_STREAM_PARTS][PM_STREAM_PART_WORDS] keys of a partial row + its tracker
-  unsigned long long* stream_part_cnt; // [PM_STREAM_RQ] {ticket tag << 3 | parts through}
   uint32_t* stream_ctl;               // [PM_STREAM_CTL_WORDS] SC_*
   uint32_t stream_la, stream_row_spins;  // look-ahead cap (0 = default); polls before the validator gives a row up
   uint32_t stream_la_div;                // look-ahead = candidates / (la_div x (max_group_size - 1)) (0 = default)

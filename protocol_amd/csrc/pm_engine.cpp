@@ -248,12 +248,11 @@ struct pm_engine {
   DevBuf<double> d_cs_u[3];
   DevBuf<double> d_c_pack, d_cs_pack;  // streaming carve: 32-byte gather records by position / by index entry
   // streaming carve (carve_stream_kernel): per-configuration bitmaps, ticket and row rings, control block, candidate list
-  DevBuf<uint64_t> d_cfgbits, d_stream_sq, d_stream_row_lo, d_stream_row_hi, d_stream_trace, d_stream_part, d_stream_part_cnt;
+  DevBuf<uint64_t> d_cfgbits, d_stream_sq, d_stream_row_lo, d_stream_row_hi, d_stream_trace;
   DevBuf<uint32_t> d_stream_ctl;
   uint32_t stream_seq = 0;       // launches so far: the tags of a launch's tickets start at stream_seq << 25
   uint32_t stream_wgs_env = 0;   // PM_STREAM_WGS: proposer workgroups (0 = by the size of the eligible list)
   uint32_t stream_la_env = 0;    // PM_STREAM_LA: look-ahead cap (0 = the kernel's default)
-  uint32_t stream_cold_n = 96;   // PM_STREAM_COLD: tickets of a cold run whose rows are made in parts (0 = none)
   uint32_t stream_la_div_env = 0;  // PM_STREAM_LA_DIV: look-ahead divisor (0 = the kernel's default)
   uint32_t stream_row_spins_env = 0;  // PM_STREAM_ROW_SPINS: polls before the validator gives a row up (0 = default)
   uint32_t n_cus = 256;
@@ -574,8 +573,6 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
       HIPCHK(e->d_stream_sq.ensure(PM_STREAM_SQ));
       HIPCHK(e->d_stream_row_lo.ensure(size_t(PM_STREAM_RQ) * 64));
       HIPCHK(e->d_stream_row_hi.ensure(size_t(PM_STREAM_RQ) * 64));
-      HIPCHK(e->d_stream_part.ensure(size_t(PM_STREAM_RQ) * PM_STREAM_PARTS * PM_STREAM_PART_WORDS));
-      HIPCHK(e->d_stream_part_cnt.ensure(PM_STREAM_RQ));
       e->stream_seq = 0;
     }
   }
@@ -688,9 +685,6 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     a->stream_row_lo = (unsigned long long*)e->d_stream_row_lo.p;
     a->stream_row_hi = (unsigned long long*)e->d_stream_row_hi.p;
     a->stream_ctl = e->d_stream_ctl.p;
-    a->stream_part = (unsigned long long*)e->d_stream_part.p;
-    a->stream_part_cnt = (unsigned long long*)e->d_stream_part_cnt.p;
-    a->stream_cold_n = e->stream_cold_n;
 #ifdef PM_CARVE_PROF
     HIPCHK(e->d_stream_trace.ensure(size_t(PM_STREAM_TRACE_CAP) * 2));
     a->stream_trace = (unsigned long long*)e->d_stream_trace.p;
@@ -938,7 +932,6 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r, bool fresh = false) {
         HIPCHK(hipMemsetAsync(e->d_stream_sq.p, 0, size_t(PM_STREAM_SQ) * 8, e->stream));
         HIPCHK(hipMemsetAsync(e->d_stream_row_lo.p, 0, size_t(PM_STREAM_RQ) * 64 * 8, e->stream));
         HIPCHK(hipMemsetAsync(e->d_stream_row_hi.p, 0, size_t(PM_STREAM_RQ) * 64 * 8, e->stream));
-        HIPCHK(hipMemsetAsync(e->d_stream_part_cnt.p, 0, size_t(PM_STREAM_RQ) * 8, e->stream));
         e->stream_seq = 0;
       }
       e->stream_seq += 1;
@@ -1967,10 +1960,6 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
     const long f = atol(v);
     if (f > 0 && f < 4096) e->stream_la_div_env = uint32_t(f);
   }
-  if (const char* v = getenv("PM_STREAM_COLD")) {
-    const long f = atol(v);
-    if (f >= 0 && f <= 512) e->stream_cold_n = uint32_t(f);
-  }
   if (const char* v = getenv("PM_STREAM_LA")) {
     const long f = atol(v);
     if (f > 0 && f <= long(PM_STREAM_LA_MAX)) e->stream_la_env = uint32_t(f);
@@ -2029,7 +2018,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_c_compat.release(); e->d_keys.release(); e->d_bits.release(); e->d_status.release(); e->d_carve_args.release();
   e->d_m_cfg.release(); e->d_m_n.release(); e->d_m_off.release(); e->d_m_members.release();
   e->d_cfgbits.release(); e->d_stream_sq.release(); e->d_stream_row_lo.release(); e->d_stream_row_hi.release();
-  e->d_stream_ctl.release(); e->d_stream_trace.release(); e->d_stream_part.release(); e->d_stream_part_cnt.release();
+  e->d_stream_ctl.release(); e->d_stream_trace.release();
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
   e->d_table.release(); e->d_task_col.release(); e->d_shard.release(); e->d_own_rows.release(); e->d_xrow.release();

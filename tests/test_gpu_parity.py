@@ -922,11 +922,7 @@ def test_task_deltas_equal_a_fresh_upload():
 
 
 @pytest.mark.parametrize("env", [{"PM_STREAM_LA": "24"}, {"PM_STREAM_WGS": "1"}, {"PM_STREAM_ROW_SPINS": "1", "PM_STREAM_WGS": "2"},
-                                 {"PM_STREAM_LA": "1024", "PM_STREAM_LA_DIV": "16"},
-                                 # rows made in parts (a cold run's first tickets): none, every ticket a window holds, and
-                                 # the parts of every row on the four waves of ONE workgroup
-                                 {"PM_STREAM_COLD": "0"}, {"PM_STREAM_COLD": "512"}, {"PM_STREAM_COLD": "512", "PM_STREAM_WGS": "1"},
-                                 {"PM_STREAM_COLD": "512", "PM_STREAM_LA": "24"}])
+                                 {"PM_STREAM_LA": "1024", "PM_STREAM_LA_DIV": "16"}])
 def test_streaming_carve_under_pressure(env, monkeypatch):
     """The streaming carve (carve_variant 0) with its knobs turned the wrong way: a look-ahead of two dozen tickets, a
     single proposer workgroup, a validator that gives a row up after one poll (every such seed is a step for the exact
