@@ -34,6 +34,11 @@ int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n);
  * (pm_stats / debug_carve_counters: stream_aborts).  0 = off. */
 int32_t pm_debug_stream_abort_after(pm_engine* e, uint32_t n);
 
+/* Counter: merge configurations (try_merge_groups_for_config, mod.rs:676-709) whose selections went through the streaming
+ * carve (lists of PM_MERGE_STREAM_MIN = 512 compatible solo groups or more; the environment variable lowers it for tests)
+ * since the engine was created. */
+int32_t pm_debug_merge_streamed(pm_engine* e, uint32_t* n);
+
 /* Test hook / experiment: when the proposers walk the spatial index instead of sweeping the whole candidate list —
  * 0 never, 1 when it pays (default), 2 whenever the carve has an index, 3 = 2 with every seed forced through the
  * whole-list fallback.  (PM_PRUNE_MODE in the environment sets the default of new engines.) */

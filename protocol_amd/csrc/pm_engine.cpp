@@ -140,6 +140,8 @@ struct pm_engine {
                                        // index, the streaming carve's counters
   uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above
   uint32_t debug_abort_after = 0;  // pm_debug_stream_abort_after
+  uint32_t merge_streamed = 0;     // merge configurations whose selections went through the streaming carve (since creation)
+  uint32_t merge_stream_min = 512; // PM_MERGE_STREAM_MIN: compatible solo groups from which a merge configuration does (tests: 8)
   uint32_t prune_mode = 1;       // pm_debug_prune_mode / PM_PRUNE_MODE: CarveArgs::prune_mode
   uint32_t prune_factor = 512;   // PM_PRUNE_FACTOR: CarveArgs::prune_factor (measured crossover)
   uint32_t walk_cap_div = 0;     // PM_WALK_CAP_DIV: CarveArgs::walk_cap_div (0 = the kernels' default)
@@ -1802,8 +1804,17 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
       HIPCHK(e->d_m_n.ensure(cap));
       HIPCHK(e->d_m_off.ensure(cap));
       HIPCHK(e->d_m_members.ensure(cap));
+      // The selections of a long list go through the streaming carve first (carve_stream_kernel in MERGE mode: the chain
+      // commits the groups of a seed and its max - 1 nearest located candidates at 0.3 us each where the single-workgroup
+      // kernel below sweeps the whole list for every one of them, 17 us at 5,000 candidates); whatever that launch leaves —
+      // nothing, as a rule: it ends with exact steps of its own — is the old kernel's.
+      bool try_stream = e->cfg.carve_variant == 0 && e->cfg.proximity_enabled && e->dist_world == 1 && !e->debug_mem_above &&
+                        order.size() >= e->merge_stream_min && order.size() <= PM_CARVE_BIG_SLOTS && c.max_group_size > 1 &&
+                        c.max_group_size - 1u < PM_PROP_KMAX && c.min_group_size >= 1;
       for (;;) {
-        rc = fill_carve_args(e, &a, CARVE_MODE_MERGE, uint32_t(order.size()));
+        const bool stream_now = try_stream;
+        try_stream = false;
+        rc = fill_carve_args(e, &a, CARVE_MODE_MERGE, uint32_t(order.size()), stream_now);
         if (rc) return rc;
         a.n_avail = 1;
         a.avail_cfg[0] = cfg;
@@ -1827,9 +1838,26 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
         b_off.resize(nb_max);
         mem.resize(std::max<size_t>(n_o, 1));
         if (n_o) HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), n_o * 4, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->d_status.p, &st_in, sizeof(st_in), hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
-        HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, 0, lds, e->stream));
+        if (stream_now) {
+          if (e->stream_seq == 0 || e->stream_seq >= 127) {  // (see form_queue_init: the rings are cleared when the tags wrap)
+            HIPCHK(hipMemsetAsync(e->d_stream_sq.p, 0, size_t(PM_STREAM_SQ) * 8, e->stream));
+            HIPCHK(hipMemsetAsync(e->d_stream_row_lo.p, 0, size_t(PM_STREAM_RQ) * 64 * 8, e->stream));
+            HIPCHK(hipMemsetAsync(e->d_stream_row_hi.p, 0, size_t(PM_STREAM_RQ) * 64 * 8, e->stream));
+            e->stream_seq = 0;
+          }
+          e->stream_seq += 1;
+          a.stream_tag0 = e->stream_seq << 25;
+          const uint32_t wgs_want = e->stream_wgs_env ? e->stream_wgs_env : uint32_t(n_o) / 64u + 48u;
+          const uint32_t wgs = std::max(1u, std::min(wgs_want, e->n_cus > 8u ? e->n_cus - 4u : 4u));
+          HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
+          launch_merge_place(e->d_carve_args.p, uint32_t(n_o), 0u, 0u, e->tick_carve_steps, e->stream);
+          HIPCHK(launch_carve_stream(e->d_carve_args.p, 0u, wgs, e->stream));
+          e->tick_carve_launches += 2;
+        } else {
+          HIPCHK(hipMemcpyAsync(e->d_status.p, &st_in, sizeof(st_in), hipMemcpyHostToDevice, e->stream));
+          HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
+          HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, 0, lds, e->stream));
+        }
         HIPCHK(hipMemcpyAsync(&st, e->d_status.p, sizeof(st), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipMemcpyAsync(b_n.data(), e->d_m_n.p, nb_max * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipMemcpyAsync(b_off.data(), e->d_m_off.p, nb_max * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1837,7 +1865,10 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
         HIPCHK(hipStreamSynchronize(e->stream));
         e->tick_carve_launches++;
         if (st.state == CARVE_STATE_OVERFLOW) return set_error(PM_ENOMEM, "merge: batch arrays overflow");
-        if (st.state != CARVE_STATE_DONE && st.state != CARVE_STATE_UNCERTAIN)
+        const bool stream_gave_up = stream_now && st.state == CARVE_STATE_ABORTED;  // (what it committed stands)
+        if (stream_gave_up) e->tick_stream_aborts++;
+        if (stream_now) e->merge_streamed++;
+        if (st.state != CARVE_STATE_DONE && st.state != CARVE_STATE_UNCERTAIN && !stream_gave_up)
           return set_error(PM_ENODEV, "merge kernel did not complete");
         const uint32_t nb = st.n_groups;
         if (nb > nb_max || st.n_members > mem.size()) return set_error(PM_ENODEV, "merge: more batches than candidates");
@@ -1848,6 +1879,7 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
         e->tick_carve_steps = st.steps_total;
         drop_used();
         if (st.state == CARVE_STATE_DONE) break;
+        if (stream_gave_up) continue;  // the single-workgroup kernel takes the rest of the list
         // UNCERTAIN: settle exactly this selection on the host, then let the kernel continue
         if (order.size() < c.min_group_size) break;
         std::vector<uint32_t> b;
@@ -1959,6 +1991,10 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
   if (const char* v = getenv("PM_STREAM_LA_DIV")) {
     const long f = atol(v);
     if (f > 0 && f < 4096) e->stream_la_div_env = uint32_t(f);
+  }
+  if (const char* v = getenv("PM_MERGE_STREAM_MIN")) {
+    const long f = atol(v);
+    if (f >= 2 && f <= (1l << 30)) e->merge_stream_min = uint32_t(f);
   }
   if (const char* v = getenv("PM_STREAM_LA")) {
     const long f = atol(v);
@@ -3658,6 +3694,15 @@ int32_t pm_debug_stream_abort_after(pm_engine* e, uint32_t n) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   e->debug_abort_after = n;
+  return PM_OK;
+}
+
+// debug (include/pm_engine_debug.h): merge configurations (pm_merge_solo_groups, pm_tick) whose selections went through the
+// streaming carve since the engine was created
+int32_t pm_debug_merge_streamed(pm_engine* e, uint32_t* n) {
+  if (!e || !n) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  *n = e->merge_streamed;
   return PM_OK;
 }
 

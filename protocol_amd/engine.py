@@ -499,6 +499,15 @@ class Engine:
         L.pm_debug_stream_abort_after.restype = C.c_int32
         check(L.pm_debug_stream_abort_after(self._h, n))
 
+    def debug_merge_streamed(self) -> int:
+        """merge configurations whose selections went through the streaming carve since the engine was created"""
+        L = lib()
+        L.pm_debug_merge_streamed.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.pm_debug_merge_streamed.restype = C.c_int32
+        n = C.c_uint32(0)
+        check(L.pm_debug_merge_streamed(self._h, C.byref(n)))
+        return n.value
+
     def debug_carve_counters(self) -> dict:
         """how the last carve went (pm_internal.h, pm_debug_carve_prof words 32..45): how its validation launches ended,
         and what the proposer's spatial index did"""

@@ -221,8 +221,14 @@ def _solo_scenario(seed, tasks_only_for=None, **kw):
     return sw, st, eng
 
 
+@pytest.mark.parametrize("stream_min", [None, "8"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_merge_solo_groups_bit_exact(seed):
+def test_merge_solo_groups_bit_exact(seed, stream_min, monkeypatch):
+    """stream_min: from how many compatible solo groups a merge configuration's selections go through the streaming carve
+    (512 in production; 8 sends these small lists — location-less nodes, lists shorter than a group, configurations of
+    every size — down that path too)"""
+    if stream_min:
+        monkeypatch.setenv("PM_MERGE_STREAM_MIN", stream_min)
     sw, st, eng = _solo_scenario(seed)
     assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
     assert sum(len(g[2]) == 1 for g in engine_groups(eng)) > 10
@@ -241,7 +247,10 @@ def test_merge_solo_groups_bit_exact(seed):
     eng.close()
 
 
-def test_merge_policies_and_host_resolve():
+@pytest.mark.parametrize("stream_min", [None, "8"])
+def test_merge_policies_and_host_resolve(stream_min, monkeypatch):
+    if stream_min:
+        monkeypatch.setenv("PM_MERGE_STREAM_MIN", stream_min)
     sw, st, eng = _solo_scenario(2, switching=False)
     assert st.try_merge_solo_groups() == eng.merge_solo_groups() == 0
     eng.close()

@@ -287,6 +287,38 @@ def test_solo_merge_of_the_bench_workload():
     ev = eng.drain_group_events()
     assert events_digest(ev) == events_digest(st.drain_events())
     assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    assert eng.debug_merge_streamed() == 1   # (the selections went through the streaming carve: one configuration)
+    eng.close()
+
+
+@pytest.mark.parametrize("how", ["plain", "abort", "uncertain", "one_workgroup"])
+def test_solo_merge_through_the_streaming_carve(how, monkeypatch):
+    """The merge pass of the bench workload's swarm through carve_stream_kernel in MERGE mode (pm_engine.cpp run_merge): as it
+    runs; with the launch made to give up after 40 selections (CARVE_STATE_ABORTED: the single-workgroup kernel takes the
+    rest of the list); with every third step sent to the host (glibc distances); with one row-making workgroup."""
+    from protocol_amd.swarm import events_digest, solo_merge_swarm
+    if how == "one_workgroup":
+        monkeypatch.setenv("PM_STREAM_WGS", "1")
+    sw = solo_merge_swarm(2)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=np.array([1, 0], dtype=np.uint8), tasks=tasks, reference_shaped=False, group_id_seed=1)
+    eng = E.Engine(group_id_seed=1, debug_uncertain_every=3 if how == "uncertain" else 0)
+    host.load_swarm(eng, sw, enabled=0b01)
+    eng.enable_group_events()
+    assert eng.form_groups() == st.try_form_new_groups() > 4500
+    eng.drain_group_events()
+    st.drain_events()
+    st.set_enabled(np.array([1, 1], dtype=np.uint8))
+    eng.set_enabled_mask(0b11)
+    if how == "abort":
+        eng.debug_stream_abort_after(40)
+    n_merged = eng.merge_solo_groups()
+    assert st.try_merge_solo_groups() == n_merged > 550
+    assert events_digest(eng.drain_group_events()) == events_digest(st.drain_events())
+    assert sorted(oracle_groups(st)) == sorted(engine_groups(eng))
+    assert eng.debug_merge_streamed() == 1
+    if how == "uncertain":
+        assert eng.last_stats()["host_resolved_steps"] > 0
     eng.close()
 
 
