@@ -523,8 +523,7 @@ def main() -> int:
     workload = names.get(cfg_index, f"BASELINE configs[{cfg_index}]")
 
     eng = E.Engine(device=local_rank, sweep_variant=args.sweep_variant, carve_variant=args.carve_variant,
-                   group_id_seed=args.seed, time_proposer=world > 1)  # (N > 1: the stepwise tick waits for every batch
-                                                                       # anyway, so timing its proposer costs nothing)
+                   group_id_seed=args.seed)
     host.load_swarm(eng, sw)
     sharded = None
     if world > 1:
@@ -612,18 +611,18 @@ def main() -> int:
         out["ranks_seen"] = ranks_seen
         n_ticks = args.steps + args.warmup
         exch_ms = sharded.exchange_ms / n_ticks
-        # what the N GPUs share out (proposal sweeps: the summed proposer launches of this rank; pair sweep: owned rows)
-        # against what every rank repeats (validation chain + list preparation) — the Amdahl split of this design
-        prop_ms = med(stats, "ms_propose_kernel")
-        sharded_ms = prop_ms + med(stats, "ms_sweep")
+        # what the N GPUs share out (the pair sweep + claim: owned rows) against what every rank repeats (the carve: a
+        # chain of dependent steps, replicated — one streaming launch per rank) — the Amdahl split of this design
+        sharded_ms = med(stats, "ms_sweep")
         out["dist"] = {"workers_owned_by_rank0": own, "exchanges_per_tick": sharded.exchanges / n_ticks,
                        "backend": backend, "identical_groups_on_all_ranks": True,
                        "exchange_ms": exch_ms, "sharded_ms": sharded_ms,
                        "replicated_ms": max(1e3 * elapsed / args.steps - sharded_ms - exch_ms, 0.0),
-                       "split_note": ("per tick on rank 0: exchange = device time inside the all-gathers (events around "
-                                      "each); sharded = this rank's proposer launches (timed individually) + its pair "
-                                      "sweep; replicated = the rest of the tick (validation chain, list preparation, "
-                                      "publish) — the part N GPUs do not divide")}
+                       "split_note": ("per tick on rank 0: exchange = device time inside the ONE all-gather of a tick (the "
+                                      "published rows of the owned workers; events around it); sharded = this rank's pair "
+                                      "sweep + claim over the workers it owns; replicated = the rest of the tick — compat "
+                                      "sweep, the carve (one streaming launch, the same on every rank: a chain of "
+                                      "dependent steps that N GPUs do not divide), publish")}
         if rank == 0:
             # the SAME swarm on one GPU, unsharded (a second engine on rank 0's device, after the timed region): the
             # N = 1 line of the default command is a different workload (configs[1]), so the honest one-GPU

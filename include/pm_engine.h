@@ -407,11 +407,15 @@ int32_t pm_set_stream(pm_engine*, void* hip_stream);
 /* After pm_upload_workers (and again whenever the row count changes).  world == 1 switches back. */
 int32_t pm_dist_configure(pm_engine*, uint32_t rank, uint32_t world, const uint8_t* shard_of_worker);
 /* The tick in steps:
- *   pm_dist_tick_begin                      compat sweep, first candidate list
- *   loop: pm_dist_carve_next(&x, &more)     waits for the carve, settles near-ties on the host (replicated);
- *                                           more == 1: this rank's proposals are queued -> all-gather x ->
- *         pm_dist_carve_validate            validation of the batch + preparation of the next one
- *   pm_dist_match_begin(&x)                 solo merge, pair sweep + claim of the owned workers -> all-gather x ->
+ *   pm_dist_tick_begin                      compat sweep; the carve is started — the WHOLE carve, on every rank (the
+ *                                           reference carves from one pool, node_groups/mod.rs:492-503, and the chain of
+ *                                           dependent steps that forms the groups does not shard: it is replicated, one
+ *                                           streaming launch per rank, and ends on the identical groups and ids everywhere)
+ *   loop: pm_dist_carve_next(&x, &more)     waits for the carve, settles near-ties on the host (replicated); more == 0
+ *                                           always since ABI v2 round 5 (nothing is exchanged for the carve; the call and
+ *         pm_dist_carve_validate            its partner stay for drivers written against a local compute that deals rows)
+ *   pm_dist_match_begin(&x)                 solo merge, pair sweep + claim of the OWNED workers -> all-gather x (the one
+ *                                           exchange of a tick) ->
  *   pm_dist_tick_end(&stats)                scatter into the full table, publish (pm_lookup_* serve every worker) */
 int32_t pm_dist_tick_begin(pm_engine*);
 int32_t pm_dist_carve_next(pm_engine*, pm_dist_xfer* x, uint32_t* more);

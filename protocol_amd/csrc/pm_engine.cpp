@@ -862,6 +862,7 @@ struct FormRun {
   bool stream = false;       // one streaming launch (carve_stream_kernel) instead of the batch pipeline
   bool single_call = true;   // run_form drives the whole carve (the stepwise multi-GPU tick exchanges rows per batch)
   uint32_t stream_wgs = 0;   // proposer workgroups of the streaming launch
+  bool local_carve = false;  // the multi-GPU tick: this rank carves the whole pool itself (every rank does, and ends with the same groups)
   bool rearmed = false;      // the carve took more than its first launch sequence (host-resolved step, aborted streaming launch)
   uint32_t stage_cap = 0;    // streaming carve: entries of each staging array carve_finish_kernel fills in pinned host memory
 };
@@ -970,7 +971,9 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r, bool fresh = false) {
   return PM_OK;
 }
 
-static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
+// local_carve: a rank of the multi-GPU tick — the carve is replicated, not exchanged (see pm_dist_tick_begin): the launches
+// are those of one GPU whatever dist_world says
+static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline, bool local_carve = false) {
   int32_t rc = absorb_groups(e);  // a match that failed half-way may have left the last carve unabsorbed
   if (rc) return rc;
   rc = ensure_compat(e);
@@ -1003,10 +1006,12 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline) {
   r->st.n_groups = r->g0;
   r->st.n_members = r->m0;
   r->single_call = allow_pipeline;
+  r->local_carve = local_carve;
   r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
   // The streaming carve: one engine, one call, positions that fit the validator's LDS bitmaps.  Everything else (the
   // stepwise multi-GPU tick, swarms beyond 262,144 unassigned rows) goes through the batch pipeline.
-  r->stream = r->single_call && r->use_props && e->cfg.carve_variant == 0 && e->dist_world == 1 && r->n_bound <= PM_CARVE_BIG_SLOTS &&
+  r->stream = r->single_call && r->use_props && e->cfg.carve_variant == 0 && (e->dist_world == 1 || r->local_carve) &&
+              r->n_bound <= PM_CARVE_BIG_SLOTS &&
               !e->debug_mem_above;  // (the test hook for the all-in-HBM lists is the batch pipeline's)
   host_mark("form: begin (host mirrors counted)");
   rc = form_setup_args(e, r);
@@ -1055,6 +1060,11 @@ static int32_t form_setup_args(pm_engine* e, FormRun* r) {
     a.stage_mem = e->h_gstage + size_t(3) * r->stage_cap;
     a.h_status = e->h_status;
     e->h_status->state = 0xFFFFFFFFu;  // (not yet written by this carve)
+  }
+  if (r->local_carve) {  // (rows are made here for every seed: no segment of another rank's to wait for)
+    a.dist_rank = 0;
+    a.dist_world = 1;
+    a.prop_send = a.prop;
   }
   a.n_avail = uint32_t(r->avail.size());
   for (size_t i = 0; i < r->avail.size(); ++i) {
@@ -1277,7 +1287,7 @@ static int32_t form_finish(pm_engine* e, FormRun* r, uint32_t* n_formed, bool de
 // The part of a single-call carve behind form_begin: wait for what was queued, queue more rounds if the carve needs
 // them, take the result in.  (Split from the beginning so that pm_tick_many can start the carves of several engines
 // before it waits for the first.)
-static int32_t run_form_rest(pm_engine* e, FormRun& r, uint32_t* n_formed, bool defer_absorb) {
+static int32_t run_form_wait(pm_engine* e, FormRun& r) {
   int32_t rc = PM_OK;
   if (!r.nothing) {
     // (propose, validate, prepare) rounds are queued blindly and the ones behind a finished carve return at once —
@@ -1303,6 +1313,11 @@ static int32_t run_form_rest(pm_engine* e, FormRun& r, uint32_t* n_formed, bool 
     }
   }
   if (!r.nothing && r.use_props && !r.stream) e->form_rounds_hint = r.st.n_batches + r.st.n_void;
+  return PM_OK;
+}
+static int32_t run_form_rest(pm_engine* e, FormRun& r, uint32_t* n_formed, bool defer_absorb) {
+  int32_t rc = run_form_wait(e, r);
+  if (rc) return rc;
   return form_finish(e, &r, n_formed, defer_absorb);
 }
 
@@ -1808,7 +1823,7 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
       // commits the groups of a seed and its max - 1 nearest located candidates at 0.3 us each where the single-workgroup
       // kernel below sweeps the whole list for every one of them, 17 us at 5,000 candidates); whatever that launch leaves —
       // nothing, as a rule: it ends with exact steps of its own — is the old kernel's.
-      bool try_stream = e->cfg.carve_variant == 0 && e->cfg.proximity_enabled && e->dist_world == 1 && !e->debug_mem_above &&
+      bool try_stream = e->cfg.carve_variant == 0 && e->cfg.proximity_enabled && !e->debug_mem_above &&
                         order.size() >= e->merge_stream_min && order.size() <= PM_CARVE_BIG_SLOTS && c.max_group_size > 1 &&
                         c.max_group_size - 1u < PM_PROP_KMAX && c.min_group_size >= 1;
       for (;;) {
@@ -3506,7 +3521,10 @@ int32_t pm_dist_tick_begin(pm_engine* e) {
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   e->form = new (std::nothrow) FormRun();
   if (!e->form) return set_error(PM_ENOMEM, "out of host memory");
-  rc = form_begin(e, e->form, /*allow_pipeline=*/false);
+  // The carve is REPLICATED: every rank runs the whole of it — the streaming launch, as on one GPU — and ends with the
+  // identical groups and ids, because the result does not depend on how the launch went (which rows arrived when), only
+  // on the reference's rule: nothing is exchanged until the published table.
+  rc = form_begin(e, e->form, /*allow_pipeline=*/true, /*local_carve=*/true);
   if (rc) {
     dist_abort(e);
     return rc;
@@ -3524,25 +3542,12 @@ int32_t pm_dist_carve_next(pm_engine* e, pm_dist_xfer* x, uint32_t* more) {
   *more = 0;
   std::memset(x, 0, sizeof(*x));
   if (!r->nothing) {
-    int32_t rc = form_poll(e, r);
+    // (kept in the protocol for a local compute that deals a batch's rows over the ranks — tests/dist_model.py does, the
+    // engine did until round 5: *more stays 0, there is nothing to exchange for the carve)
+    int32_t rc = run_form_wait(e, *r);
     if (rc) {
       dist_abort(e);
       return rc;
-    }
-    if (r->st.state == CARVE_STATE_RUNNING && r->use_props) {
-      // a candidate list is prepared: this rank's share of the batch's neighbour lists
-      int32_t rcp = launch_propose_timed(e, e->d_carve_args.p, e->form->n_bound, e->stream);
-      if (rcp) {
-        dist_abort(e);
-        return rcp;
-      }
-      e->tick_carve_launches++;
-      HIPCHK(hipGetLastError());
-      x->send_ptr = uint64_t(reinterpret_cast<uintptr_t>(r->a.prop_send));
-      x->recv_ptr = uint64_t(reinterpret_cast<uintptr_t>(r->a.prop));
-      x->bytes_per_rank = (r->desc[0].valid && r->desc[0].prop_k) ? uint64_t(r->desc[0].rows_pr) * PM_PROP_ROW * 8u : 0u;
-      *more = 1;
-      return PM_OK;
     }
     if (r->st.state != CARVE_STATE_DONE) {
       dist_abort(e);
@@ -3557,10 +3562,8 @@ int32_t pm_dist_carve_validate(pm_engine* e) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(hipSetDevice(e->cfg.device));
-  if (e->dist_phase != 1 || !e->form || e->form->nothing) return set_error(PM_ESTATE, "no proposal batch pending");
-  HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, e->form->lds, e->stream));
-  e->tick_carve_launches += 1u + launch_carve_prep(e->d_carve_args.p, e->form->n_bound, false, e->stream);
-  return PM_OK;
+  (void)e;
+  return set_error(PM_ESTATE, "no proposal batch pending (the carve of the multi-GPU tick is replicated: pm_dist_carve_next reports none)");
 }
 
 int32_t pm_dist_match_begin(pm_engine* e, pm_dist_xfer* x) {

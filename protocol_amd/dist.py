@@ -6,9 +6,12 @@ Every rank holds the WHOLE swarm (100k worker rows are 6 MB) and worker w is own
 The reference carves from one pool (node_groups/mod.rs:492-503), so the carve domain is NOT split — a rank per
 shard carving on its own would form different groups than one orchestrator.  What is split is the parallel work:
 
-  * the neighbour-list proposals of a carve batch (the full-chip sweep that dominates at 100k workers) are dealt
-    round-robin over the ranks and ALL-GATHERED once per batch; the sequential validation chain runs replicated
-    on identical inputs, so every rank commits the identical groups;
+  * the carve itself is REPLICATED: a chain of dependent steps (group g + 1's seed depends on what group g took) that
+    no number of GPUs shortens; every rank runs it whole, as one streaming launch (libpm_engine.so, DESIGN.md
+    section 7), and — the result being the reference's, whatever the timing — ends with the identical groups and
+    ids.  Nothing is exchanged for it.  (The protocol below still knows a local compute that deals a batch's
+    neighbour rows over the ranks and all-gathers them, `carve_next` -> more: tests/dist_model.py can, the engine
+    did until round 5 — 55 host-waited exchanges per tick at 1M x 100k, slower on 8 GPUs than on one);
   * the pair sweep + chooser + claim run for the OWNED workers only; the published rows are ALL-GATHERED once per
     tick and scattered into every rank's full table (any rank can answer any worker's heartbeat);
   * per-task best bids (north_star orientation) are computed over the owned workers and folded across ranks

@@ -33,7 +33,11 @@ F64_MAX = 1.7976931348623157e308
 
 
 class ModelLocal:
-    def __init__(self, sw, *, group_id_seed=1, proximity=True, max_seeds=16384, min_cap=512):
+    def __init__(self, sw, *, group_id_seed=1, proximity=True, max_seeds=16384, min_cap=512, local_carve=False):
+        # local_carve: the engine's protocol since round 5 — every rank carves the whole pool itself (its rows are its own),
+        # carve_next reports no batch; False: a batch's rows are dealt over the ranks and all-gathered (what
+        # ShardedEngine's loop is for)
+        self.local_carve = local_carve
         self.sw = sw
         nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
         self.masks = orc.compat_masks(nodes, cfgs)
@@ -48,12 +52,14 @@ class ModelLocal:
         self.proximity = proximity
         self.max_seeds, self.min_cap = max_seeds, min_cap
         self.rank, self.world = 0, 1
+        self.c_rank, self.c_world = 0, 1
         self.batches = 0
         self.rows_from_others = 0
 
     # ---------------------------------------------------------------- ownership
     def configure(self, rank, world, shard):
         self.rank, self.world = rank, world
+        self.c_rank, self.c_world = (0, 1) if self.local_carve else (rank, world)   # who makes which row of a batch
         self.shard = np.asarray(shard, dtype=np.int64)
         self.own = np.nonzero(self.shard == rank)[0]
         counts = np.bincount(self.shard, minlength=world)
@@ -105,7 +111,7 @@ class ModelLocal:
             self.limit = min(self.limit, n)
             self.seeds = [int(s) for s in located if s < self.limit]
             self.seed_no = {s: i for i, s in enumerate(self.seeds)}
-            self.rows_pr = (len(self.seeds) + self.world - 1) // self.world
+            self.rows_pr = (len(self.seeds) + self.c_world - 1) // self.c_world
 
     def _sorted_others(self, seed):
         """every live candidate but the seed, by (distance to the seed, slot) — sort_nodes_by_proximity
@@ -121,6 +127,16 @@ class ModelLocal:
         return idx[np.argsort(d, kind="stable")]
 
     def carve_next(self):
+        if self.local_carve:   # the whole carve here and now: every batch's rows made and used by this rank
+            while not self.done:
+                more, send, recv = self._carve_next_batch()
+                if send is not None:
+                    recv.copy_(send)
+                self.carve_validate()
+            return False, None, None
+        return self._carve_next_batch()
+
+    def _carve_next_batch(self):
         if self.done:
             return False, None, None
         if not self.prop_k or not self.seeds:
@@ -128,16 +144,16 @@ class ModelLocal:
         self.batches += 1
         send = torch.full((self.rows_pr * ROW,), -1, dtype=torch.int64)
         for i, s in enumerate(self.seeds):
-            if i % self.world != self.rank:
+            if i % self.c_world != self.c_rank:
                 continue
             near = self._sorted_others(s)
             row = np.full(ROW, -1, dtype=np.int64)
             k = min(self.prop_k, len(near))
             row[:k] = near[:k]
             row[ROW - 1] = 1 if len(near) <= self.prop_k else 0     # the row holds every live candidate
-            j = i // self.world
+            j = i // self.c_world
             send[j * ROW:(j + 1) * ROW] = torch.from_numpy(row)
-        self.recv = torch.full((self.world * self.rows_pr * ROW,), -7, dtype=torch.int64)
+        self.recv = torch.full((self.c_world * self.rows_pr * ROW,), -7, dtype=torch.int64)
         return True, send, self.recv
 
     def carve_validate(self):
@@ -156,10 +172,10 @@ class ModelLocal:
                     return
                 if self.prop_k:
                     i = self.seed_no[seed]
-                    r0 = ((i % self.world) * self.rows_pr + i // self.world) * ROW
+                    r0 = ((i % self.c_world) * self.rows_pr + i // self.c_world) * ROW
                     row = recv[r0:r0 + ROW]
                     assert row[ROW - 1] in (0, 1), "the row of another rank never arrived"
-                    if i % self.world != self.rank:
+                    if i % self.c_world != self.c_rank:
                         self.rows_from_others += 1
                     ent = row[:ROW - 1]
                     ent = ent[ent >= 0]
