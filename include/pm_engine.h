@@ -154,18 +154,15 @@ typedef struct {
   uint32_t carve_variant;        /* group formation: 0 = default: the streaming carve — ONE launch per pass; workgroup 0
                                         validates (the in-order chain), every other workgroup computes neighbour rows for
                                         the seeds a bounded look-ahead in front of the chain; slot == position, nothing
-                                        is compacted.  (The stepwise multi-GPU tick and swarms with more than 262,144
-                                        unassigned rows take the batch pipeline, 3.)
+                                        is compacted.  (Swarms with more than 262,144 unassigned rows take the batch
+                                        pipeline, 3.)
                                     1 = single-workgroup sequential exact sweep only (the straightforward kernel),
-                                    2 = batch pipeline with single-wave validation that re-derives every certificate
-                                        from the row's keys,
                                     3 = the batch pipeline: per batch, full-chip preparation of a compact candidate
                                         list, full-chip neighbour-list proposals, validation by the in-order chain
-                                        (the default of rounds 1-3),
-                                    4 = as 3, but the next batch is prepared and proposed (from a snapshot, on a
-                                        second stream) beside the validation of the batch in front of it; measured
-                                        slower than 3 on the BASELINE swarms — the batch behind is stale by what the
-                                        one in front consumes — and kept as a tested alternative */
+                                        (the default of rounds 1-3; what a streaming launch that gives up falls back to).
+                                    Anything else is PM_EINVAL (2: single-wave validation, 4: two batches in flight —
+                                    both measured slower in rounds 2 / 3 and removed in round 5; their numbers are in
+                                    profiles/r03_*) */
   uint32_t time_proposer;        /* bench: hipEvents around every proposer launch (pm_stats.ms_propose_kernel) */
 } pm_engine_config;
 

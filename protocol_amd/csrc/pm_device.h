@@ -194,7 +194,7 @@ struct CarveArgs {
   uint32_t W;
   uint32_t proximity;
   uint32_t debug_uncertain_every;
-  uint32_t rounds_enabled;  // located steps through the three-wave chain (carve_variant 0 and 4; 2 = wave 0 alone)
+  uint32_t _pad_re;
   // worker columns
   const uint32_t* wflags;
   const double *lat, *lon, *coslat;
@@ -238,9 +238,8 @@ struct CarveArgs {
   uint32_t* prep_block_counts;   // [blocks][PM_MAX_CONFIGS] live compatible positions per block and configuration
   uint32_t* prep_counts;         // [PM_MAX_CONFIGS] totals, [PM_MAX_CONFIGS] = finished-blocks ticket
   BatchDesc* desc;               // this argument block's batch (the per-batch scratch above belongs to it)
-  const BatchDesc* desc_prev;    // the batch in front of it (the other argument block's; itself when there is one block)
   uint64_t* alive_snap;          // the position bitmap as the preparation saw it (bits_stride words)
-  uint32_t speculative;          // the preparation may run beside the validation of the batch in front
+  uint32_t _pad_sp;
   uint32_t debug_mem_above;      // test hook: candidate lists longer than this take the all-in-HBM path (0 = off)
   // spatial index over the located positions (built once per carve behind the eligible list, see cell_count_kernel)
   uint32_t* cell_cnt;            // [PM_CELL_TABLE] members per cell while the index is built; zero between builds
@@ -340,7 +339,7 @@ void launch_newest(const int64_t* created_at, const uint64_t* live, uint32_t t_b
 void launch_group_ids(uint64_t* g_id, uint32_t* g_task, uint32_t n, uint64_t rng_state, hipStream_t s);
 hipError_t carve_kernels_init();  // per device: the carve kernels' dynamic LDS sizes (pm_engine_create)
 hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_ci, size_t lds_bytes, hipStream_t s);
-uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, bool speculative, hipStream_t s);  // [plan +] count + place
+uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s);  // count + place
 // eligible list [+ spatial index]; returns the launches.  fresh: the status block is initialised by the first kernel
 // (state RUNNING, n_groups0 groups, n_members0 member slots, everything else zero) instead of by a copy in front of it
 uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound, uint32_t index_min, uint32_t start_ci,

@@ -261,21 +261,6 @@ struct pm_engine {
   uint32_t tick_stream_timeouts = 0, tick_stream_tickets = 0, tick_stream_aborts = 0;
   DevBuf<uint64_t> d_ikeys, d_umask;  // per-task orientation: table of the distinct topology masks, the masks densely
   DevBuf<uint32_t> d_ivals;
-  // per-batch scratch of the SECOND argument block (the first uses the d_cc_* / d_slot_* / d_prop ... members):
-  // with two sets the next batch is prepared and proposed on stream_p while the batch in front is validated
-  struct CarveSet {
-    DevBuf<double> cc_lat, cc_lon, cc_cos, cc_u[3];
-    DevBuf<uint32_t> cc_site, slot_pos, slot_wid, seed_prefix, seed_slots, prep_block_counts, prep_counts;
-    DevBuf<uint64_t> prop, seed_map, bits;
-    void release() {
-      cc_lat.release(); cc_lon.release(); cc_cos.release();
-      for (auto& u : cc_u) u.release();
-      cc_site.release(); slot_pos.release(); slot_wid.release(); seed_prefix.release(); seed_slots.release();
-      prep_block_counts.release(); prep_counts.release(); prop.release(); seed_map.release(); bits.release();
-    }
-  } set2;
-  hipStream_t stream_p = nullptr;   // preparation + proposals of the batch behind the one being validated
-  std::vector<hipEvent_t> pipe_ev;  // [2k] batch k proposed, [2k + 1] batch k validated
   DevBuf<uint32_t> d_m_cfg, d_m_n, d_m_off, d_m_members;  // MERGE batches
 
   // ---- sweep scratch
@@ -599,7 +584,6 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->W = e->W;
   a->proximity = e->cfg.proximity_enabled;
   a->debug_uncertain_every = e->cfg.debug_uncertain_every;
-  a->rounds_enabled = (e->cfg.carve_variant == 0 || e->cfg.carve_variant == 3 || e->cfg.carve_variant == 4) ? 1u : 0u;
   a->wflags = e->d_flags.p;
   a->lat = e->d_lat.p;
   a->lon = e->d_lon.p;
@@ -646,9 +630,7 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
   a->bits_stride = stride;
   a->status = e->d_status.p;
   a->desc = e->d_desc.p;
-  a->desc_prev = e->d_desc.p;  // (one argument block: no batch in front)
   a->alive_snap = e->d_snap.p;
-  a->speculative = 0;
   a->debug_mem_above = e->debug_mem_above;
   if (mode == CARVE_MODE_FORM && e->prune_mode && e->cfg.proximity_enabled) {
     a->prune_mode = e->prune_mode;
@@ -696,48 +678,6 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     a->stream_row_spins = e->stream_row_spins_env;
     a->debug_abort_after = e->debug_abort_after;
   }
-  return PM_OK;
-}
-
-// The second argument block: the same carve, its own per-batch scratch.
-static int32_t fill_carve_args2(pm_engine* e, const CarveArgs& a, CarveArgs* b) {
-  const size_t cap = std::max<size_t>(e->W, 1);
-  auto& s2 = e->set2;
-  HIPCHK(s2.cc_lat.ensure(cap));
-  HIPCHK(s2.cc_lon.ensure(cap));
-  HIPCHK(s2.cc_cos.ensure(cap));
-  for (auto& u : s2.cc_u) HIPCHK(u.ensure(cap));
-  HIPCHK(s2.cc_site.ensure(cap));
-  HIPCHK(s2.slot_pos.ensure(cap));
-  HIPCHK(s2.slot_wid.ensure(cap));
-  HIPCHK(s2.prop.ensure((size_t(PM_PROP_MAX_SEEDS) + 64) * PM_PROP_ROW));
-  HIPCHK(s2.seed_map.ensure((cap + 63) / 64 + 64));
-  HIPCHK(s2.seed_prefix.ensure((cap + 63) / 64 + 64));
-  HIPCHK(s2.seed_slots.ensure(size_t(PM_PROP_MAX_SEEDS) + 128));
-  HIPCHK(s2.prep_block_counts.ensure(((cap + 255) / 256 + 1) * PM_MAX_CONFIGS));
-  HIPCHK(s2.prep_counts.ensure(PM_MAX_CONFIGS + 8));
-  HIPCHK(s2.bits.ensure(size_t(a.bits_stride) * 2));
-  *b = a;
-  b->cc_lat = s2.cc_lat.p;
-  b->cc_lon = s2.cc_lon.p;
-  b->cc_cos = s2.cc_cos.p;
-  b->cc_ux = s2.cc_u[0].p;
-  b->cc_uy = s2.cc_u[1].p;
-  b->cc_uz = s2.cc_u[2].p;
-  b->cc_site = s2.cc_site.p;
-  b->slot_pos = s2.slot_pos.p;
-  b->slot_wid = s2.slot_wid.p;
-  b->prop = s2.prop.p;
-  b->prop_send = s2.prop.p;
-  b->seed_map = s2.seed_map.p;
-  b->seed_prefix = s2.seed_prefix.p;
-  b->seed_slots = s2.seed_slots.p;
-  b->prep_block_counts = s2.prep_block_counts.p;
-  b->prep_counts = s2.prep_counts.p;
-  b->bits_scratch = s2.bits.p;
-  b->desc = e->d_desc.p + 1;
-  b->desc_prev = e->d_desc.p;
-  b->alive_snap = e->d_snap.p + a.bits_stride;
   return PM_OK;
 }
 
@@ -847,10 +787,7 @@ static void host_mark(const char* what) {
 // (one status read per proposal batch, the all-gather of the batch's rows issued by the caller in between).
 struct FormRun {
   CarveArgs a;
-  CarveArgs b;              // the second argument block (pipelined carve)
   BatchDesc desc[2] = {};   // the batch descriptors as of the last poll
-  bool pipelined = false;   // two batches in flight: batch k + 1 prepared and proposed beside the validation of batch k
-  uint32_t kP = 0, kV = 0;  // batches whose preparation / validation has been queued
   CarveStatus st;
   std::vector<uint32_t> avail;
   uint32_t g0 = 0, m0 = 0, start_ci = 0;
@@ -868,54 +805,6 @@ struct FormRun {
 };
 
 static int32_t launch_propose_timed(pm_engine* e, const CarveArgs* d_args, uint32_t n_bound, hipStream_t s);
-
-static int32_t pipe_event(pm_engine* e, size_t i, hipEvent_t* ev) {
-  while (e->pipe_ev.size() <= i) {
-    hipEvent_t x = nullptr;
-    HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-    e->pipe_ev.push_back(x);
-  }
-  *ev = e->pipe_ev[i];
-  return PM_OK;
-}
-
-// Pipelined carve: batch k lives in argument block k & 1.  Its preparation and its proposals go to stream_p —
-// behind the validation of batch k - 2, which used the same block — its validation to the engine's stream, behind
-// its proposals.  So the validation of batch k and the preparation of batch k + 1 run side by side.
-static int32_t pipe_queue_prepare(pm_engine* e, FormRun* r) {
-  const uint32_t k = r->kP;
-  const CarveArgs* blk = e->d_carve_args.p + (k & 1u);
-  hipEvent_t ev = nullptr;
-  if (k >= 2u) {
-    int32_t rc = pipe_event(e, size_t(2) * (k - 2u) + 1u, &ev);
-    if (rc) return rc;
-    HIPCHK(hipStreamWaitEvent(e->stream_p, ev, 0));
-  }
-  e->tick_carve_launches += launch_carve_prep(blk, r->n_bound, true, e->stream_p);
-  int32_t rc = launch_propose_timed(e, blk, r->n_bound, e->stream_p);
-  if (rc) return rc;
-  rc = pipe_event(e, size_t(2) * k, &ev);
-  if (rc) return rc;
-  HIPCHK(hipEventRecord(ev, e->stream_p));
-  e->tick_carve_launches += 1;
-  r->kP = k + 1u;
-  return PM_OK;
-}
-static int32_t pipe_queue_validate(pm_engine* e, FormRun* r) {
-  const uint32_t k = r->kV;
-  const CarveArgs* blk = e->d_carve_args.p + (k & 1u);
-  hipEvent_t ev = nullptr;
-  int32_t rc = pipe_event(e, size_t(2) * k, &ev);
-  if (rc) return rc;
-  HIPCHK(hipStreamWaitEvent(e->stream, ev, 0));
-  HIPCHK(launch_carve(blk, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, r->lds, e->stream));
-  rc = pipe_event(e, size_t(2) * k + 1u, &ev);
-  if (rc) return rc;
-  HIPCHK(hipEventRecord(ev, e->stream));
-  e->tick_carve_launches += 1;
-  r->kV = k + 1u;
-  return PM_OK;
-}
 
 static int32_t form_setup_args(pm_engine* e, FormRun* r);
 
@@ -951,19 +840,7 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r, bool fresh = false) {
       e->tick_carve_launches += 2;
       return PM_OK;
     }
-    if (r->pipelined) {
-      // (both streams are idle here: the first call of a carve, or a poll has just drained them)
-      hipEvent_t ev = nullptr;
-      int32_t rc = pipe_event(e, 0, &ev);  // (re-recorded by the first preparation below)
-      if (rc) return rc;
-      HIPCHK(hipEventRecord(ev, e->stream));
-      HIPCHK(hipStreamWaitEvent(e->stream_p, ev, 0));  // the eligible list first
-      r->kP = r->kV = 0;
-      rc = pipe_queue_prepare(e, r);
-      if (rc) return rc;
-    } else {
-      e->tick_carve_launches += launch_carve_prep(e->d_carve_args.p, r->n_bound, false, e->stream);  // the first candidate list
-    }
+    e->tick_carve_launches += launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);  // the first candidate list
     HIPCHK(hipGetLastError());
   } else
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_INIT | CARVE_F_RUN | CARVE_F_ALL, r->start_ci, r->lds, e->stream));
@@ -1007,7 +884,7 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline, bool lo
   r->st.n_members = r->m0;
   r->single_call = allow_pipeline;
   r->local_carve = local_carve;
-  r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;  // 2 = proposals, sequential validation
+  r->use_props = e->cfg.carve_variant != 1 && e->cfg.proximity_enabled;
   // The streaming carve: one engine, one call, positions that fit the validator's LDS bitmaps.  Everything else (the
   // stepwise multi-GPU tick, swarms beyond 262,144 unassigned rows) goes through the batch pipeline.
   r->stream = r->single_call && r->use_props && e->cfg.carve_variant == 0 && (e->dist_world == 1 || r->local_carve) &&
@@ -1024,7 +901,6 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline, bool lo
 // The argument block(s) of a carve, filled and uploaded (again, when a streaming launch gave up and the batch
 // pipeline takes over).
 static int32_t form_setup_args(pm_engine* e, FormRun* r) {
-  const bool allow_pipeline = r->single_call;
   CarveArgs& a = r->a;
   int32_t rc = fill_carve_args(e, &a, CARVE_MODE_FORM, 0, r->stream);
   if (rc) return rc;
@@ -1080,16 +956,6 @@ static int32_t form_setup_args(pm_engine* e, FormRun* r) {
   a.cap_members = uint32_t(std::min<size_t>(e->d_members.cap, 0xFFFFFFFFu));
   bool in_lds;
   r->lds = carve_lds_bytes(a.bits_stride, &in_lds);
-  // Two batches in flight on one GPU (the stepwise multi-GPU tick exchanges the rows of every batch through its
-  // caller, one batch at a time)
-  r->pipelined = allow_pipeline && r->use_props && e->dist_world == 1 && e->stream_p != nullptr && e->cfg.carve_variant == 4;
-  if (r->pipelined) {
-    a.speculative = 1;
-    a.desc_prev = e->d_desc.p + 1;
-    rc = fill_carve_args2(e, a, &r->b);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(e->d_carve_args.p + 1, &r->b, sizeof(r->b), hipMemcpyHostToDevice, e->stream));
-  }
   HIPCHK(hipMemcpyAsync(e->d_carve_args.p, &a, sizeof(a), hipMemcpyHostToDevice, e->stream));
   return PM_OK;
 }
@@ -1115,20 +981,11 @@ static int32_t launch_propose_timed(pm_engine* e, const CarveArgs* d_args, uint3
 // (propose, validate) pairs: one per configuration plus one per re-proposal round; launches queued behind a
 // finished carve return immediately
 static int32_t form_queue_pairs(pm_engine* e, FormRun* r, uint32_t count) {
-  if (r->pipelined) {
-    for (uint32_t k = 0; k < count; ++k) {
-      int32_t rc = pipe_queue_prepare(e, r);  // the batch behind ...
-      if (rc) return rc;
-      rc = pipe_queue_validate(e, r);         // ... beside the validation of this one
-      if (rc) return rc;
-    }
-    return PM_OK;
-  }
   for (uint32_t k = 0; k < count; ++k) {
     int32_t rc = launch_propose_timed(e, e->d_carve_args.p, r->n_bound, e->stream);
     if (rc) return rc;
     HIPCHK(launch_carve(e->d_carve_args.p, CARVE_F_RUN | CARVE_F_PROPS | CARVE_F_EXTPREP, 0, r->lds, e->stream));
-    e->tick_carve_launches += 2u + launch_carve_prep(e->d_carve_args.p, r->n_bound, false, e->stream);  // the next candidate list
+    e->tick_carve_launches += 2u + launch_carve_prep(e->d_carve_args.p, r->n_bound, e->stream);  // the next candidate list
   }
   return PM_OK;
 }
@@ -1142,16 +999,8 @@ static int32_t form_poll(pm_engine* e, FormRun* r) {
     // (the batch descriptors: on the engine's stream with the status — a blocking copy on the null stream was a second
     // driver round trip per poll; the streaming carve has none)
     const bool want_desc = r->use_props && !r->stream;
-    if (want_desc && !r->pipelined)
-      HIPCHK(hipMemcpyAsync(r->desc, e->d_desc.p, sizeof(r->desc), hipMemcpyDeviceToHost, e->stream));
+    if (want_desc) HIPCHK(hipMemcpyAsync(r->desc, e->d_desc.p, sizeof(r->desc), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (r->pipelined) {
-      HIPCHK(hipStreamSynchronize(e->stream_p));  // (a preparation queued behind the last validation)
-      if (want_desc) {
-        HIPCHK(hipMemcpyAsync(r->desc, e->d_desc.p, sizeof(r->desc), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-      }
-    }
     {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, e->kev[2], e->kev[3]));
@@ -1970,6 +1819,8 @@ void pm_engine_config_default(pm_engine_config* c) {
 int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
   if (!cfg || !out) return set_error(PM_EINVAL, "null argument");
   if (cfg->abi_version != PM_ABI_VERSION) return set_error(PM_EINVAL, "ABI version mismatch");
+  if (cfg->carve_variant != 0 && cfg->carve_variant != 1 && cfg->carve_variant != 3)
+    return set_error(PM_EINVAL, "carve_variant: 0 (streaming carve), 1 (exact sweep only) or 3 (batch pipeline); 2 and 4 were removed");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return set_error(PM_ENODEV, "no HIP device visible: the matching engine needs an MI355X (gfx950); there is no CPU fallback");
@@ -2020,11 +1871,7 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
       e->n_cus = uint32_t(cus);
   }
-#ifdef PM_EXP_ONE_STREAM  // experiment: the side stream only for its one user, the pipelined batch carve —
-  // an engine then owns ONE stream, and K engines in a process own K of the runtime's hardware queues instead of 2 K
-  if (e->cfg.carve_variant == 4)
-#endif
-  (void)hipStreamCreateWithFlags(&e->stream_p, hipStreamNonBlocking);  // (without it the carve is not pipelined)
+  // (an engine owns ONE stream: K engines in a process take K of the HIP runtime's hardware queues)
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     delete e;
     return set_error(PM_ENODEV, "hipStreamCreate failed");
@@ -2087,14 +1934,12 @@ void pm_engine_destroy(pm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t x : e->prop_ev) (void)hipEventDestroy(x);
   if (e->stream_owned) (void)hipStreamDestroy(e->stream_owned);
-  if (e->stream_p) (void)hipStreamDestroy(e->stream_p);
-  for (hipEvent_t x : e->pipe_ev) (void)hipEventDestroy(x);
   e->d_cell_cnt.release(); e->d_cell_start.release(); e->d_pos_cell.release(); e->d_pos_rank.release();
   e->d_cs_of_pos.release(); e->d_cs_slot.release(); e->d_cs_site.release();
   for (auto& u : e->d_cs_u) u.release();
   e->d_c_pack.release();
   e->d_cs_pack.release();
-  e->set2.release(); e->d_desc.release(); e->d_snap.release(); e->d_ikeys.release(); e->d_umask.release(); e->d_ivals.release();
+  e->d_desc.release(); e->d_snap.release(); e->d_ikeys.release(); e->d_umask.release(); e->d_ivals.release();
   delete e->form;
   delete e;
 }
@@ -3308,17 +3153,8 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
     rcs[i] = rc;
     msgs[i] = g_last_error;
   };
-#ifdef PM_EXP_TICKMANY_CHUNK  // experiment: at most PM_EXP_TICKMANY_CHUNK carves resident at a time —
-  // the three walks below run over engines [c0, c1), chunk after chunk (the GPU's ceiling for configs[1]-sized pools is
-  // reached at eight)
-  static_assert(PM_EXP_TICKMANY_CHUNK >= 1, "a chunk holds at least one engine");
-  const uint32_t n_all = n;
-  for (uint32_t c0 = 0; c0 < n_all; c0 += uint32_t(PM_EXP_TICKMANY_CHUNK)) {
-  const uint32_t i_lo = c0, i_hi = std::min<uint32_t>(n_all, c0 + uint32_t(PM_EXP_TICKMANY_CHUNK));
-#else
   const uint32_t i_lo = 0, i_hi = n;
   {
-#endif
   // ---- 1: compatibility masks, the eligible list, the carve's launch(es) — nothing here waits for a carve
   for (uint32_t i = i_lo; i < i_hi; ++i) {
     pm_engine* e = engines[i];
@@ -3339,54 +3175,7 @@ int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uin
   }
   // ---- 2: in launch order (the first carve started is the first to end): the carve's result, the merge pass, the
   // pair sweep and the claim, queued behind it on the engine's stream
-#ifdef PM_EXP_TICKMANY_POLL  // experiment: serve whichever engine's stream has drained first — the walk's
-  // host work for one pool (~0.1 ms) otherwise stands between the other pools' finished carves and their sweeps
-  std::vector<uint32_t> order2;
-  {
-    std::vector<uint32_t> pending;
-    for (uint32_t i = i_lo; i < i_hi; ++i)
-      if (!rcs[i]) pending.push_back(i);
-    while (!pending.empty()) {
-      size_t pick = pending.size();
-      for (size_t k = 0; k < pending.size() && pick == pending.size(); ++k) {
-        (void)hipSetDevice(engines[pending[k]]->cfg.device);
-        if (hipStreamQuery(engines[pending[k]]->stream) == hipSuccess) pick = k;
-      }
-      (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error: do not leave it for the next check)
-      if (pick == pending.size()) {
-        if (pending.size() == 1) pick = 0;  // the last one: its own wait is the wait
-        else {
-          std::this_thread::yield();
-          continue;
-        }
-      }
-      order2.push_back(pending[pick]);
-      pending.erase(pending.begin() + ptrdiff_t(pick));
-      // (served right away, below: the order is decided one engine at a time)
-      const uint32_t i = order2.back();
-      pm_engine* e = engines[i];
-      auto stage = [&]() -> int32_t {
-        HIPCHK(hipSetDevice(e->cfg.device));
-        int32_t rc = run_form_rest(e, *runs[i], &n_formed[i], /*defer_absorb=*/true);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(e->ev[2], e->stream));
-        rc = run_merge(e, &n_merged[i]);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(e->ev[3], e->stream));
-        rc = run_match(e, false, nullptr);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(e->ev[4], e->stream));
-        return publish_begin(e, &pubs[i], e->d_n_groups);
-      };
-      const int32_t rc = stage();
-      runs[i].reset();
-      if (rc) failed(i, rc);
-    }
-  }
-  for (uint32_t i = i_hi; i < i_hi; ++i) {  // (the in-order walk below is this experiment's off switch: never entered)
-#else
   for (uint32_t i = i_lo; i < i_hi; ++i) {
-#endif
     if (rcs[i]) continue;
     pm_engine* e = engines[i];
     auto stage = [&]() -> int32_t {

@@ -89,7 +89,7 @@ def _form_both(sw, **kw):
     return st, eng
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("carve_variant", [0, 1, 3])
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
 def test_form_groups_cfg1_bit_exact(seed, carve_variant):
     sw = baseline_config(0, seed=seed)
@@ -101,7 +101,7 @@ def test_form_groups_cfg1_bit_exact(seed, carve_variant):
     eng.close()
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("carve_variant", [0, 1, 3])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_form_groups_cfg2_bit_exact(seed, carve_variant):
     sw = baseline_config(1, seed=seed)
@@ -111,7 +111,7 @@ def test_form_groups_cfg2_bit_exact(seed, carve_variant):
     assert oracle_groups(st) == engine_groups(eng)
     stats = eng.last_stats()
     assert stats["host_resolved_steps"] == 0
-    if carve_variant in (0, 2, 3, 4):   # most steps must come straight from the neighbour-list proposals
+    if carve_variant in (0, 3):   # most steps must come straight from the neighbour-list proposals
         assert stats["carve_fast_steps"] > 0.5 * stats["carve_steps"]
     eng.close()
 
@@ -123,7 +123,7 @@ def test_form_groups_wide_and_huge_groups():
     sw.topo = (sw.topo.astype(np.int64) % 3).astype(np.int16)
     sw.topo[sw.n_topo[:, None] <= np.arange(3)[None, :]] = -2
     sw.topo[~sw.restricted] = -2
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 3):
         st = oracle_state_for(sw)
         eng = E.Engine(carve_variant=variant)
         host.load_swarm(eng, sw)
@@ -147,7 +147,7 @@ def test_form_groups_without_proximity_and_with_partial_enable():
         eng.close()
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("carve_variant", [0, 1, 3])
 def test_host_resolve_path_gives_identical_groups(carve_variant):
     """debug_uncertain_every forces the exact host path (glibc distances) on every 3rd step."""
     sw = make_swarm(4, 200, 1500)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 NONE = 0xFFFFFFFF
 
 
-@pytest.mark.parametrize("carve_variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("carve_variant", [0, 1, 3])
 def test_form_groups_big_lists_bit_exact(carve_variant):
     """30k workers: several configurations have > 8192 candidates (big-list mode, proposal batches of 16384)."""
     sw = make_swarm(2, 2000, 30000, zipf=True)
@@ -114,7 +114,7 @@ def _check_against_golden(name, carve_variant):
     eng.close()
 
 
-@pytest.mark.parametrize("carve_variant", [0, 2, 3])
+@pytest.mark.parametrize("carve_variant", [0, 3])
 def test_config1_full_size_against_oracle_digest(carve_variant):
     """BASELINE configs[1], every group and every worker's row against the oracle's committed digests
     (tests/golden/scale_digests.json, tools/make_golden_scale.py)."""
@@ -208,7 +208,7 @@ def test_config2_full_size_properties():
 
 
 @pytest.mark.parametrize("seed", [1, 2, 7])
-@pytest.mark.parametrize("carve_variant", [0, 2, 3])
+@pytest.mark.parametrize("carve_variant", [0, 3])
 def test_config1_full_size_groups_bit_exact(seed, carve_variant):
     """BASELINE configs[1] (10k workers, 24 mixed configurations): the groups — ids, configurations, members in
     carve order — equal the oracle's; the oracle's carve needs ~2 s at this size (its pair sweep is not run)."""
