@@ -39,6 +39,12 @@ int32_t pm_debug_stream_abort_after(pm_engine* e, uint32_t n);
  * since the engine was created. */
 int32_t pm_debug_merge_streamed(pm_engine* e, uint32_t* n);
 
+/* Counter: how often the device's copy of the group state was brought up to date by a DELTA — the workers of the groups
+ * dissolved since and the rows appended since, a scatter and a fill — instead of compacting and uploading the whole list
+ * (pm_engine.cpp push_groups: the path of a tick that follows status changes and new workers), since the engine was created.
+ * pm_get_groups, pm_dissolve_group and the merge pass compact the list: the tick after them uploads it whole. */
+int32_t pm_debug_delta_pushes(pm_engine* e, uint32_t* n);
+
 /* Test hook / experiment: when the proposers walk the spatial index instead of sweeping the whole candidate list —
  * 0 never, 1 when it pays (default), 2 whenever the carve has an index, 3 = 2 with every seed forced through the
  * whole-list fallback.  (PM_PRUNE_MODE in the environment sets the default of new engines.) */

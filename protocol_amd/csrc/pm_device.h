@@ -347,6 +347,8 @@ uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 hipError_t launch_carve_stream(const CarveArgs* d_args, uint32_t start_ci, uint32_t n_prop_wgs, hipStream_t s);
+void launch_scatter_const(uint32_t* dst, const uint32_t* idx, uint32_t n, uint32_t v, hipStream_t s);
+void launch_scatter_pairs(uint32_t* dst, const uint32_t* pairs, uint32_t n, hipStream_t s);
 void launch_merge_place(const CarveArgs* d_args, uint32_t n_order, uint32_t n_groups0, uint32_t n_members0, uint32_t steps0,
                         hipStream_t s);
 

@@ -140,6 +140,7 @@ struct pm_engine {
                                        // index, the streaming carve's counters
   uint32_t debug_mem_above = 0;  // pm_debug_mem_lists_above
   uint32_t debug_abort_after = 0;  // pm_debug_stream_abort_after
+  uint32_t delta_pushes = 0;       // push_groups calls that went up as a delta (since creation)
   uint32_t merge_streamed = 0;     // merge configurations whose selections went through the streaming carve (since creation)
   uint32_t merge_stream_min = 512; // PM_MERGE_STREAM_MIN: compatible solo groups from which a merge configuration does (tests: 8)
   uint32_t prune_mode = 1;       // pm_debug_prune_mode / PM_PRUNE_MODE: CarveArgs::prune_mode
@@ -223,6 +224,20 @@ struct pm_engine {
   std::vector<int32_t> h_group_of;
   uint64_t id_rng = 0;
   bool groups_dirty = true;
+  // Delta sync of the device's group state (the churn path: a tick's status changes and new rows touch a few thousand
+  // entries of tables that hold a hundred thousand).  While groups_delta_ok the device arrays are the host list as of the
+  // last full push_groups / carve, except for what these record: workers whose group was dissolved since (group_of -> -1;
+  // the dissolved group stays in both lists as a tombstone — no slot moves), rows appended since (group_of -> -1 for the
+  // tail).  Anything else that changes the list clears the flag, and the next push_groups compacts and uploads it whole.
+  bool groups_delta_ok = false;
+  std::vector<uint32_t> delta_free;
+  uint32_t delta_tail_from = PM_NONE;
+  // ... and of the flags column: rows whose flags changed since the last upload, while flags_delta_ok
+  bool flags_delta_ok = false;
+  std::vector<uint32_t> delta_flags;
+  uint32_t* h_delta_pin[2] = {nullptr, nullptr};  // pinned staging: [0] freed workers (indices), [1] flags ({index, value} pairs)
+  size_t h_delta_cap[2] = {0, 0};
+  DevBuf<uint32_t> d_delta[2];
   DevBuf<int32_t> d_group_of;
   DevBuf<uint32_t> d_g_cfg, d_g_n, d_g_off, d_g_task, d_g_task_next, d_members, d_by_rank, d_rank_in_group;
   DevBuf<uint64_t> d_g_id;
@@ -328,7 +343,7 @@ static void reset_groups_locked(pm_engine* e) {
   e->absorb_pending = false;  // records of a carve that was never absorbed belong to the old list
   e->h_group_of.assign(e->W, -1);
   e->id_rng = e->cfg.group_id_seed;
-  e->groups_dirty = true;
+  e->groups_dirty = true, e->groups_delta_ok = false;
   // The published rows name slots and ids of the list that just went (and the id stream restarts: the same ids will
   // name other groups): a heartbeat before the next publish is told "no group", and pub_patch resolves nothing
   // against the new list.
@@ -367,9 +382,10 @@ static void dissolve_locked(pm_engine* e, uint32_t slot) {
   if (slot >= e->groups.size() || e->groups[slot].dead) return;
   log_group_event(e, PM_GROUP_DESTROYED, e->groups[slot]);  // mod.rs:1469-1481
   for (uint32_t w : e->groups[slot].members) e->h_group_of[w] = -1;
+  if (e->groups_delta_ok) e->delta_free.insert(e->delta_free.end(), e->groups[slot].members.begin(), e->groups[slot].members.end());
   e->groups[slot].dead = true;
   e->n_dead_groups++;
-  e->groups_dirty = true;
+  e->groups_dirty = true;  // (a delta while groups_delta_ok: see push_groups)
 }
 
 static void compact_groups(pm_engine* e) {
@@ -381,11 +397,55 @@ static void compact_groups(pm_engine* e) {
   for (size_t g = 0; g < e->groups.size(); ++g)
     for (uint32_t w : e->groups[g].members) e->h_group_of[w] = int32_t(g);
   e->n_dead_groups = 0;
-  e->groups_dirty = true;
+  e->groups_dirty = true, e->groups_delta_ok = false;
 }
 
 // Mirror the host group list into HBM (packed member pool, slot = index).
+// n u32 words of pinned staging + device scratch for a delta (the stream has drained since the last use: a delta goes
+// up once per tick, in front of it)
+static int32_t delta_stage(pm_engine* e, int which, size_t n) {
+  HIPCHK(hipStreamSynchronize(e->stream));  // (nothing in flight may still read the staging: an idle stream answers at once)
+  if (e->h_delta_cap[which] < n) {
+    if (e->h_delta_pin[which]) (void)hipHostFree(e->h_delta_pin[which]);
+    e->h_delta_pin[which] = nullptr;
+    e->h_delta_cap[which] = 0;
+    const size_t cap = n + n / 2 + 4096;
+    HIPCHK(hipHostMalloc((void**)&e->h_delta_pin[which], cap * sizeof(uint32_t)));
+    e->h_delta_cap[which] = cap;
+  }
+  HIPCHK(e->d_delta[which].ensure(n));
+  return PM_OK;
+}
+
 static int32_t push_groups(pm_engine* e) {
+  if (!e->groups_dirty) return PM_OK;
+  // ---- the churn path: only dissolutions and new rows since the device last held the list.  The dissolved groups stay
+  // where they are, in both lists, as tombstones (no worker names them any more; a slot number — what group_of and the
+  // published rows hold — keeps its meaning); their workers and the new rows read "no group" on the device after one
+  // scatter and one fill.  Compaction waits until a good part of the list is dead or the arrays run short of room for
+  // what the next carve may append.
+  const size_t room_g = std::min(e->d_g_cfg.cap, std::min(e->d_g_task.cap, std::min(e->d_g_task_next.cap, e->d_g_id.cap)));
+  const size_t room_m = std::min(e->d_members.cap, std::min(e->d_by_rank.cap, e->d_rank_in_group.cap));
+  if (e->groups_delta_ok && e->n_dead_groups * 4 <= e->groups.size() + 256 && size_t(e->d_n_groups) + e->W <= room_g &&
+      size_t(e->d_n_members) + e->W <= room_m && e->d_n_groups == e->groups.size()) {
+    HIPCHK(e->d_group_of.grow_keep(std::max<size_t>(e->W, 1), e->delta_tail_from == PM_NONE ? e->W : e->delta_tail_from, e->stream));
+    if (e->delta_tail_from != PM_NONE && e->delta_tail_from < e->W)
+      HIPCHK(hipMemsetAsync(e->d_group_of.p + e->delta_tail_from, 0xFF, size_t(e->W - e->delta_tail_from) * 4, e->stream));
+    if (!e->delta_free.empty()) {
+      const size_t n = e->delta_free.size();
+      int32_t rc = delta_stage(e, 0, n);
+      if (rc) return rc;
+      std::memcpy(e->h_delta_pin[0], e->delta_free.data(), n * 4);
+      HIPCHK(hipMemcpyAsync(e->d_delta[0].p, e->h_delta_pin[0], n * 4, hipMemcpyHostToDevice, e->stream));
+      launch_scatter_const(reinterpret_cast<uint32_t*>(e->d_group_of.p), e->d_delta[0].p, uint32_t(n), 0xFFFFFFFFu, e->stream);
+      HIPCHK(hipGetLastError());
+    }
+    e->delta_free.clear();
+    e->delta_tail_from = PM_NONE;
+    e->groups_dirty = false;
+    e->delta_pushes++;
+    return PM_OK;
+  }
   compact_groups(e);
   if (!e->groups_dirty) return PM_OK;
   const size_t G = e->groups.size();
@@ -401,7 +461,8 @@ static int32_t push_groups(pm_engine* e) {
     g_id[g] = gr.id;
     members.insert(members.end(), gr.members.begin(), gr.members.end());
   }
-  const size_t capG = std::max<size_t>(e->W, 1), capM = std::max<size_t>(e->W, 1);
+  // (twice the table: room for a carve's appends on top of a list that carries tombstones — see the delta path above)
+  const size_t capG = std::max<size_t>(size_t(2) * e->W, 1), capM = std::max<size_t>(size_t(2) * e->W, 1);
   HIPCHK(e->d_g_cfg.ensure(capG));
   HIPCHK(e->d_g_n.ensure(capG));
   HIPCHK(e->d_g_off.ensure(capG));
@@ -431,14 +492,34 @@ static int32_t push_groups(pm_engine* e) {
   e->d_n_groups = uint32_t(G);
   e->d_n_members = uint32_t(members.size());
   e->groups_dirty = false;
+  e->groups_delta_ok = true;  // the device holds the list: dissolutions and new rows from here on are deltas
+  e->delta_free.clear();
+  e->delta_tail_from = PM_NONE;
   return PM_OK;
 }
 
 // status changes only touch the host copy of the flags column; the column goes up once before its next use
 static int32_t sync_flags(pm_engine* e) {
   if (!e->flags_dirty || !e->have_workers) return PM_OK;
-  HIPCHK(hipMemcpyAsync(e->d_flags.p, e->h_flags.data(), size_t(e->W) * 4, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));  // pageable source
+  if (e->flags_delta_ok && e->delta_flags.size() * 8 <= size_t(e->W)) {  // a few rows: {index, value} pairs and one scatter
+    const size_t n = e->delta_flags.size();
+    if (n) {
+      int32_t rc = delta_stage(e, 1, 2 * n);
+      if (rc) return rc;
+      for (size_t k = 0; k < n; ++k) {
+        e->h_delta_pin[1][2 * k] = e->delta_flags[k];
+        e->h_delta_pin[1][2 * k + 1] = e->h_flags[e->delta_flags[k]];
+      }
+      HIPCHK(hipMemcpyAsync(e->d_delta[1].p, e->h_delta_pin[1], n * 8, hipMemcpyHostToDevice, e->stream));
+      launch_scatter_pairs(e->d_flags.p, e->d_delta[1].p, uint32_t(n), e->stream);
+      HIPCHK(hipGetLastError());
+    }
+  } else {
+    HIPCHK(hipMemcpyAsync(e->d_flags.p, e->h_flags.data(), size_t(e->W) * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // pageable source
+  }
+  e->delta_flags.clear();
+  e->flags_delta_ok = true;
   e->flags_dirty = false;
   return PM_OK;
 }
@@ -1535,6 +1616,7 @@ static int32_t publish_end(pm_engine* e, const PubRun& pr) {
   e->h_table = reinterpret_cast<const pm_assignment*>(pr.words);
   e->pub_groups_epoch = e->groups_epoch;
   for (size_t g = 0; g < G; ++g) {
+    if (e->groups[g].dead) continue;  // (a tombstone: its device record is stale)
     e->groups[g].task = g_task[g];
     e->groups[g].task_uid = g_task[g] == PM_NONE ? 0 : (e->tasks_have_uid ? e->h_tuid[g_task[g]] : task_position(e, g_task[g]));
   }
@@ -1786,7 +1868,7 @@ static int32_t run_merge(pm_engine* e, uint32_t* n_merged) {
         e->h_group_of[w] = slot_new;
       }
       e->groups.push_back(std::move(gr));  // mod.rs:924-942
-      e->groups_dirty = true;
+      e->groups_dirty = true, e->groups_delta_ok = false;
       ++merged;
     }
   }
@@ -1923,6 +2005,10 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_sel_own.release(); e->d_table_x.release(); e->d_row_stage.release(); e->d_nb_idx.release(); e->d_nb_val.release();
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
   if (e->h_status) (void)hipHostFree(e->h_status);
+  for (int k = 0; k < 2; ++k) {
+    if (e->h_delta_pin[k]) (void)hipHostFree(e->h_delta_pin[k]);
+    e->d_delta[k].release();
+  }
   if (e->h_gtask_pinned) (void)hipHostFree(e->h_gtask_pinned);
   if (e->ev_groups) (void)hipEventDestroy(e->ev_groups);
   for (PubTable& t : e->pub)
@@ -2050,6 +2136,8 @@ static int32_t upload_worker_columns(pm_engine* e) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->stream));
   e->flags_dirty = false;
+  e->flags_delta_ok = true;  // (the whole column has just gone up)
+  e->delta_flags.clear();
   e->price_dirty = true;
   e->compat_dirty = true;
   return PM_OK;
@@ -2110,7 +2198,7 @@ int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_gr
   if (rc) return rc;
   e->have_workers = true;
   if (!keep_groups || e->h_group_of.size() != n) reset_groups_locked(e);
-  e->groups_dirty = true;
+  e->groups_dirty = true, e->groups_delta_ok = false;
   return PM_OK;
 }
 
@@ -2277,7 +2365,8 @@ int32_t pm_append_workers(pm_engine* e, const pm_worker_soa* rows, uint32_t* fir
     e->h_own_rows.clear();
   }
   e->price_dirty = true;
-  e->groups_dirty = true;  // group_of and the group arrays are sized by W
+  if (e->groups_delta_ok && e->delta_tail_from == PM_NONE) e->delta_tail_from = w0;
+  e->groups_dirty = true;  // group_of is sized by W (a delta while groups_delta_ok: see push_groups)
   return PM_OK;
 }
 
@@ -2350,7 +2439,7 @@ static int32_t tasks_grow(pm_engine* e, uint32_t cap) {
   e->t_dead = dead;
   for (Group& g : e->groups)
     if (g.task != PM_NONE) g.task += shift;
-  e->groups_dirty = true;
+  e->groups_dirty = true, e->groups_delta_ok = false;
   if (e->uid_map_valid)
     for (auto& kv : e->uid_to_u) kv.second += shift;
   rc = tasks_push_range(e, new_lo, cap);
@@ -2442,7 +2531,7 @@ int32_t pm_upload_tasks(pm_engine* e, const pm_task_soa* t) {
         dissolve_locked(e, uint32_t(g));
       } else if (e->t_lo + ni != gr.task) {
         gr.task = e->t_lo + ni;
-        e->groups_dirty = true;
+        e->groups_dirty = true, e->groups_delta_ok = false;
       }
     }
   }
@@ -2619,6 +2708,7 @@ int32_t pm_on_worker_status(pm_engine* e, uint32_t worker, uint32_t flags_new, u
   HIPCHK(hipSetDevice(e->cfg.device));
   ABSORB_PENDING(e);
   e->h_flags[worker] = flags_new;
+  if (e->flags_delta_ok) e->delta_flags.push_back(worker);
   e->flags_dirty = true;   // uploaded once before the next kernel that reads the column (sync_flags)
   e->compat_dirty = true;  // HAS_SPECS etc. may have changed with the row
   if (dead && e->h_group_of[worker] >= 0) {  // status_update_impl.rs:17-29
@@ -2645,6 +2735,7 @@ int32_t pm_on_worker_status_many(pm_engine* e, const uint32_t* workers, const ui
   for (uint32_t k = 0; k < n; ++k) {
     const uint32_t w = workers[k];
     e->h_flags[w] = flags_new[k];
+    if (e->flags_delta_ok) e->delta_flags.push_back(w);
     if (dead && dead[k] && e->h_group_of[w] >= 0) {  // status_update_impl.rs:17-29
       const uint32_t slot = uint32_t(e->h_group_of[w]);
       freed.insert(freed.end(), e->groups[slot].members.begin(), e->groups[slot].members.end());
@@ -2976,7 +3067,7 @@ static int32_t tick_stats(pm_engine* e, pm_stats* stats, uint32_t n_formed, uint
   s.ms_propose_kernel = e->k_ms_propose;
   s.proposals = e->tick_props;
   s.propose_keys = e->tick_prop_keys;
-  s.n_groups = uint32_t(e->groups.size());
+  s.n_groups = uint32_t(e->groups.size() - e->n_dead_groups);
   s.n_formed = n_formed;
   s.n_merged = n_merged;
   s.carve_steps = e->tick_carve_steps;
@@ -3495,6 +3586,15 @@ int32_t pm_debug_merge_streamed(pm_engine* e, uint32_t* n) {
   if (!e || !n) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   *n = e->merge_streamed;
+  return PM_OK;
+}
+
+// debug (include/pm_engine_debug.h): times the device's group state was brought up to date by a delta (dissolved groups'
+// workers + new rows) instead of the whole list, since the engine was created
+int32_t pm_debug_delta_pushes(pm_engine* e, uint32_t* n) {
+  if (!e || !n) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  *n = e->delta_pushes;
   return PM_OK;
 }
 

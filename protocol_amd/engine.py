@@ -508,6 +508,15 @@ class Engine:
         check(L.pm_debug_merge_streamed(self._h, C.byref(n)))
         return n.value
 
+    def debug_delta_pushes(self) -> int:
+        """times the device's group state went up as a delta instead of the whole list since the engine was created"""
+        L = lib()
+        L.pm_debug_delta_pushes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.pm_debug_delta_pushes.restype = C.c_int32
+        n = C.c_uint32(0)
+        check(L.pm_debug_delta_pushes(self._h, C.byref(n)))
+        return n.value
+
     def debug_carve_counters(self) -> dict:
         """how the last carve went (pm_internal.h, pm_debug_carve_prof words 32..45): how its validation launches ended,
         and what the proposer's spatial index did"""

@@ -96,6 +96,48 @@ def test_churn_stream_against_oracle_digests():
     eng.close()
 
 
+def test_churn_stream_with_delta_sync_of_the_group_state():
+    """the same stream as a deployment runs it: nobody asks for the group list between the ticks (pm_get_groups compacts it,
+    and the tick behind a compaction uploads it whole), so a tick's 1,000 dissolved groups and 1,000 new rows reach the
+    device as a delta — their workers' group_of, a fill for the new rows, the changed flags — and the dissolved groups
+    stay in the list as tombstones until a quarter of it is dead.  Every tick: each worker's task and the life-cycle
+    feed against the oracle's digests; after the last one the groups themselves."""
+    gold = GOLD["churn"]
+    eng = E.Engine(group_id_seed=1)
+    cs = ChurnStream(CHURN_SEED, CHURN_TICKS_PLANNED)
+    sw_all = cs.sw_all
+    packed = host.pack_workers(sw_all)
+    rows = lambda idx: {k: np.ascontiguousarray(v[idx]) for k, v in packed.items()}
+    cfg_rows, alt_rows, req_models = host.pack_configs(sw_all.configs)
+    eng.set_configs(cfg_rows, alt_rows)
+    eng.set_model_table(host.build_model_table(req_models, sw_all.model_names), len(req_models), len(sw_all.model_names))
+    eng.upload_workers(rows(np.arange(cs.W0)))
+    eng.upload_tasks(cs.masks, cs.created, cs.uid)
+    eng.set_enabled_mask(sw_all.enabled_mask())
+    eng.enable_group_events()
+    flags = packed["flags"].astype(np.int64)
+
+    def check(W, g, stats, tag):
+        assert stats["n_formed"] == g["n_formed"] and stats["n_groups"] == g["n_groups"], (tag, stats)
+        assert sha(_task_column(eng, W)) == g["task_sha256"], f"{tag}: per-worker tasks differ from the oracle"
+        ev = eng.drain_group_events()
+        assert len(ev) == g["n_events"] and events_digest(ev) == g["events_sha256"], f"{tag}: life-cycle feed differs"
+
+    check(cs.W0, gold["cold"], eng.tick(), "cold")
+    for k in range(CHURN_TICKS_PINNED):
+        leave, idx_new, new_tasks = cs.step()
+        eng.on_worker_status_many(leave, flags[leave] & ~E.W_HEALTHY, np.ones(len(leave), dtype=np.uint32))
+        eng.append_workers(rows(idx_new))
+        eng.tasks_insert_front(*new_tasks[:3])
+        check(cs.W, gold["ticks"][k], eng.tick(), f"tick {k}")
+    # (every tick behind the cold match but the one or two at which a quarter of the list was dead and it was compacted)
+    assert CHURN_TICKS_PINNED - 2 <= eng.debug_delta_pushes() <= CHURN_TICKS_PINNED
+    last = gold["ticks"][CHURN_TICKS_PINNED - 1]
+    groups = [(g[0], g[1], g[2]) for g in engine_groups(eng)]
+    assert len(groups) == last["n_groups"] and groups_digest(groups) == last["groups_sha256"]
+    eng.close()
+
+
 def test_churn_stream_with_aborted_streaming_launches():
     """every tick's streaming launch is made to give up (CARVE_STATE_ABORTED, include/pm_engine_debug.h) — the cold match after
     2,000 committed steps, the churn ticks after 25 — and the carve continues on the batch pipeline from the configuration
