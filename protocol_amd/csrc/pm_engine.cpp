@@ -830,7 +830,8 @@ static int32_t absorb_groups(pm_engine* e) {
   HIPCHK(hipEventSynchronize(e->ev_groups));
   const uint32_t g0 = e->ab_g0, ng = e->ab_g1 - e->ab_g0, m0 = e->ab_m0;
   const uint32_t *g_cfg = e->ab_cfg_p, *g_n = e->ab_n_p, *g_off = e->ab_off_p, *members = e->ab_mem_p;
-  e->groups.reserve(e->groups.size() + ng);
+  // (geometric: an exact reserve moves the whole list — 30,000 records — at every tick that appends to a full vector)
+  if (e->groups.capacity() < e->groups.size() + ng) e->groups.reserve(std::max(e->groups.size() + ng, e->groups.capacity() * 2));
   for (uint32_t k = 0; k < ng; ++k) {
     Group gr;
     gr.id = splitmix64_next(&e->id_rng);
