@@ -299,7 +299,11 @@ def run_extra_pools(E, host, seed, ks=(2, 4, 8), steps=8):
     one = statistics.median(t1)
     one_rate = float(engines[0][1].T) * float(engines[0][1].W) / one
     out = {"workload": "K x BASELINE configs[1] (one swarm per pool, seeds differ), concurrent cold matches on one GPU",
-           "steps_per_pool": steps, "one_pool": {"match_ms_p50": 1e3 * one, "pair_evals_per_s": one_rate}, "by_k": {},
+           "steps_per_pool": steps, "one_pool": {"match_ms_p50": 1e3 * one, "pair_evals_per_s": one_rate},
+           "supported_way": ("tick_many (pm_tick_many: ONE call for the K pools — include/pm_engine.h); by_k_python_threads is K "
+                             "Python threads each calling pm_tick: what that leg reaches is the harness's thread scheduling "
+                             "(single matches of 7 - 9 ms among medians of 1.5), kept for the record"),
+           "by_k_python_threads": {},
            "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
            "note": ("K engines in ONE process, one host thread and one HIP stream each; every engine takes (CUs - K) / K "
                     "row-making workgroups for its carve (pm_set_carve_workgroups).  x_one_pool = aggregate rate / the rate "
@@ -332,7 +336,7 @@ def run_extra_pools(E, host, seed, ks=(2, 4, 8), steps=8):
         el = time.perf_counter() - t0
         pairs = sum(float(engines[i][1].T) * float(engines[i][1].W) for i in range(K)) * steps
         allm = sorted(x for l in lat for x in l)
-        out["by_k"][str(K)] = {"carve_workgroups_per_pool": share, "pair_evals_per_s": pairs / el, "x_one_pool": pairs / el / one_rate,
+        out["by_k_python_threads"][str(K)] = {"carve_workgroups_per_pool": share, "pair_evals_per_s": pairs / el, "x_one_pool": pairs / el / one_rate,
                                "match_ms_p50": allm[len(allm) // 2], "match_ms_max": allm[-1], "wall_ms": 1e3 * el}
     # ---- the same pools through pm_tick_many: ONE call per round of K matches — from one host thread (the carves are
     # started before the first is waited for), and with the library's thread-per-engine variant (K threads inside the
@@ -481,7 +485,7 @@ def main() -> int:
     args = ap.parse_args()
 
     # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
-    # says otherwise) and runs two streams that share one in turn: with K engines (a carve stream + a side stream each)
+    # says otherwise) and runs two streams that share one in turn: with K engines (one stream each; two until round 5)
     # in one process, K = 4 pools matched one behind the other in pairs (1.4x the one-pool rate; 3.4x with 8 or more
     # queues — `pools_on_one_gpu`).  Read once, when the runtime starts: set before anything touches HIP.  One engine
     # is indifferent to it (1.31 vs 1.32 ms per match).  Only the N = 1 line runs several engines in one process; the

@@ -380,10 +380,11 @@ typedef struct {
  * (test_pools_share_one_gpu), bench.py `pools_on_one_gpu`.
  *   The process must also give the HIP runtime enough hardware queues: it multiplexes a process's streams onto
  * GPU_MAX_HW_QUEUES of them (environment, read once when the runtime starts; 4 by default) and two streams on one queue
- * run in turn.  An engine owns two streams, so with the default the third engine's carve already waits behind another
- * engine's: K = 4 pools reach 1.4x the one-pool rate with 4 queues, 3.3x with 8 or more (profiles/r04_pools_hw_queues.json).
- * Set GPU_MAX_HW_QUEUES >= 2 K (16 is a good value up to K = 8; 32 oversubscribes the device's queue slots) before the
- * first HIP call of the process — INTEGRATION.md "Several pools on one GPU". */
+ * run in turn.  An engine owns one stream (two until round 5), so with the default the fifth engine's carve already waits
+ * behind another engine's (round 4, two streams an engine: K = 4 pools 1.4x the one-pool rate with 4 queues, 3.3x with 8
+ * or more — profiles/r04_pools_hw_queues.json).  Set GPU_MAX_HW_QUEUES >= K (16 is a good value up to K = 8; 32
+ * oversubscribes the device's queue slots) before the first HIP call of the process, from the process entry point —
+ * INTEGRATION.md "Several pools on one GPU". */
 int32_t pm_set_carve_workgroups(pm_engine*, uint32_t n);
 /* pm_tick for n engines (pools) in ONE call from ONE host thread: every engine's carve is started on its own stream
  * before the first is waited for, so the launches are resident side by side (pm_set_carve_workgroups first) and the
@@ -393,9 +394,12 @@ int32_t pm_set_carve_workgroups(pm_engine*, uint32_t n);
  * fails leaves the batch (in the state a failed pm_tick leaves it in), the others finish; the call returns the first
  * failure.  The reference runs one pool per orchestrator process (run_group_management_loop, mod.rs:180-203): this is
  * the entry point for a process that serves several.
- *   flags: 0, or PM_TICK_MANY_THREADS = one host thread per engine, each calling pm_tick (for comparison: with
- *   enough hardware queues the two are within 10 % of each other up to K = 4; at K = 8 the one-thread walk keeps its
- *   3.1x where the threads fall to 2.4x — bench.py `pools_on_one_gpu.tick_many`). */
+ * THIS is the supported way to match several pools of one process (K = 4: 3.0x the one-pool rate, every pool's match
+ * within 1.1x of the median; K = 8: 3.8x — profiles/r05*_bench.json `pools_on_one_gpu.tick_many`); K application threads
+ * that each call pm_tick work too, but what they reach depends on the caller's threads (a Python harness: 1.8x at K = 4
+ * with single matches of 7 ms; threads inside the library, below: 3.1x).
+ *   flags: 0, or PM_TICK_MANY_THREADS = one host thread per engine inside the library, each calling pm_tick (K = 4: 3.1x,
+ *   K = 8: 4.1x, K = 16: 2.5x where the one-thread walk keeps 3.1x). */
 #define PM_TICK_MANY_THREADS 1u
 int32_t pm_tick_many(pm_engine* const* engines, uint32_t n, pm_stats* stats, uint32_t flags);
 /* All work of this engine goes to the caller's HIP stream (hipStream_t), e.g. the stream its RCCL calls use, so

@@ -146,7 +146,7 @@ GpuMatchPlugin::GpuMatchPlugin(std::vector<NodeGroupConfiguration> templates, in
   // Hardware queues for the HIP runtime (GPU_MAX_HW_QUEUES, read once at the first HIP call of the process): the
   // PROCESS ENTRY POINT sets it, before any thread exists — a library constructor that writes the environment races
   // with every getenv in a threaded host ("main.rs").  Here it is only looked at: one pool is
-  // indifferent to the value, several pools in one process want >= 2 per pool (include/pm_engine.h, pm_set_carve_workgroups).
+  // indifferent to the value, several pools in one process want >= 1 per pool (include/pm_engine.h, pm_set_carve_workgroups).
   if (const char* q = getenv("GPU_MAX_HW_QUEUES"); !q || atoi(q) < 8)
     fprintf(stderr, "GpuMatchPlugin: GPU_MAX_HW_QUEUES is %s; set it to 16 in the launcher before the first HIP call if this "
                     "process serves more than one pool on the GPU\n", q ? q : "unset (runtime default 4)");

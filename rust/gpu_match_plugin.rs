@@ -279,8 +279,8 @@ impl GpuMatchPlugin {
                webhook_plugins: Option<Vec<WebhookPlugin>>) -> Self {
         // Hardware queues for the HIP runtime (GPU_MAX_HW_QUEUES, read once at the first HIP call of the process — the
         // pm_engine_create below; the orchestrator uses HIP for nothing else): the runtime maps a process's streams
-        // onto 4 of them by default and runs two streams that share one in turn; an engine owns two streams, so a
-        // process that serves several pools on one GPU needs >= 2 per pool (include/pm_engine.h,
+        // onto 4 of them by default and runs two streams that share one in turn; an engine owns one stream, so a
+        // process that serves several pools on one GPU needs >= 1 per pool (include/pm_engine.h,
         // pm_set_carve_workgroups).  `main()` sets it BEFORE the tokio runtime starts: writing the
         // environment from here would race with every getenv of a threaded process (and is `unsafe` in Rust 2024).
         // One pool is indifferent to the value; here it is only looked at.
