@@ -63,8 +63,7 @@ static constexpr uint32_t PM_STREAM_CTL_WORDS = 64; // control block (u32): see 
 static constexpr uint32_t PM_STREAM_PROP_WAVES = PM_STREAM_PROP_WAVES_N; // waves of a proposer workgroup that build rows (one per SIMD)
 static constexpr uint32_t PM_STREAM_SLW_TREQ = PM_STREAM_TP;      // words of the validator's ticket state that
 static constexpr uint32_t PM_STREAM_SLW_PAY = PM_STREAM_TP + 1;   // carve_fast_steps<STREAM> reads (pm_stream.inc: SLW_*)
-static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 128 +
-                                              (PM_MAX_CONFIGS + 8) * 4;  // + candidate counts of the configurations ahead
+static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STREAM_TP) * 4 + 128;
 // control words in global memory (each hot word on its own 64-byte line)
 enum { SC_CLAIM = 0,    // next ticket a proposer wave takes (atomicAdd)
        SC_QUIT = 16,    // the validator is through: proposers leave
