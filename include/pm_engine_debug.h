@@ -54,6 +54,19 @@ int32_t pm_debug_prune_mode(pm_engine* e, uint32_t mode);
  * bench.py cites beside the roofline's 8 TB/s. */
 int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s);
 
+/* A measuring build's (-DPM_ROW_REC) record of the last streaming launch's rows: eight words per ticket — s_memtime when the
+ * ticket was seen, when the first pass of the sweep was packed, when the first batch's keys were there, when the candidates
+ * were through, when the row was finished, when it was stored; candidates evaluated | mode << 32; hardware id.  n_rows = 0 from
+ * a product build. */
+int32_t pm_debug_row_records(pm_engine* e, unsigned long long* out, uint32_t cap_rows, uint32_t* n_rows);
+
+/* Neighbour rows two ways from the same keys (keys[n_waves * n_per_wave], ~0 = no candidate; the low slot_bits of a key index
+ * sites[1 << slot_bits]; n_waves a multiple of four): the serial insertion, and four strides at a time through the sorting networks for the first `upto`
+ * keys of a row (what the streaming carve's rows do).  Compared on the device: mismatches[0] = 1 a register differs | 2 a
+ * threshold | 4 what a tracker answers, mismatches[1] = rows that differ; rows_out[n_waves * 64] = the networks' rows. */
+int32_t pm_debug_row_networks(pm_engine* e, const uint64_t* keys, const uint32_t* sites, uint32_t n_waves, uint32_t n_per_wave,
+                              uint32_t slot_bits, uint64_t ulps, uint32_t upto, uint64_t* rows_out, uint32_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,7 +67,10 @@ static constexpr size_t PM_STREAM_LDS_BYTES = PM_CARVE_LDS_BYTES + size_t(PM_STR
 // control words in global memory (each hot word on its own 64-byte line)
 enum { SC_CLAIM = 0,    // next ticket a proposer wave takes (atomicAdd)
        SC_QUIT = 16,    // the validator is through: proposers leave
+       SC_DROP = 32,    // configuration << 26 | ticket: that configuration's tickets below this one are not wanted any more (its
+                        // tickets were issued afresh, or it is over) — a row maker that holds one lets it be
        SC_ROWS = 48,    // rows the proposers delivered (statistics)
+       SC_LET_BE = 53,  // rows given up half-made because their ticket was dropped (statistics)
        SC_GAVE_UP = 49, // proposer waves that left because nothing was asked of them for too long
        SC_FINISH = 50,  // the carve launch ran (carve_finish_kernel has records to finish)
        SC_FINISH_TICKET = 52,  // carve_finish_kernel: blocks through (the last one mirrors the status to the host)
@@ -297,6 +300,8 @@ void launch_compat(const CompatArgs& a, hipStream_t s);
 void launch_geo(const double* lat, const double* lon, double* coslat, double* ux, double* uy, double* uz, uint32_t W,
                 hipStream_t s);
 void launch_triad(const double* b, const double* c, double* a, size_t n, hipStream_t s);
+void launch_row_network_test(const uint64_t* keys, const uint32_t* sites, uint32_t n_waves, uint32_t n_per_wave, uint32_t slot_bits,
+                             uint64_t ulps, uint32_t upto, uint64_t* rows_out, uint32_t* mismatches, hipStream_t s);
 void launch_update_rows(const RowUpdateArgs& a, hipStream_t s);
 void launch_worker_selector(const int32_t* group_of, const uint32_t* g_cfg, uint32_t R, const uint32_t* rows,
                             uint64_t* sel, hipStream_t s);

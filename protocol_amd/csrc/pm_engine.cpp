@@ -750,9 +750,12 @@ static int32_t fill_carve_args(pm_engine* e, CarveArgs* a, uint32_t mode, uint32
     a->stream_row_lo = (unsigned long long*)e->d_stream_row_lo.p;
     a->stream_row_hi = (unsigned long long*)e->d_stream_row_hi.p;
     a->stream_ctl = e->d_stream_ctl.p;
-#ifdef PM_CARVE_PROF
+#if defined(PM_CARVE_PROF) || defined(PM_ROW_REC)
     HIPCHK(e->d_stream_trace.ensure(size_t(PM_STREAM_TRACE_CAP) * 2));
     a->stream_trace = (unsigned long long*)e->d_stream_trace.p;
+#endif
+#ifdef PM_ROW_REC  // (a measuring build: one record of time stamps per ticket, pm_debug_row_records)
+    HIPCHK(hipMemsetAsync(e->d_stream_trace.p, 0, size_t(PM_STREAM_TRACE_CAP) * 16, e->stream));
 #endif
     a->stream_la = e->stream_la_env;
     a->stream_la_div = e->stream_la_div_env;
@@ -3556,14 +3559,33 @@ int32_t pm_debug_stream_trace(pm_engine* e, unsigned long long* out, uint32_t ca
   if (!e->d_stream_trace.p || !e->d_stream_ctl.p) return PM_OK;
   uint32_t cnt = 0;
   HIPCHK(hipMemcpy(&cnt, e->d_stream_ctl.p + SC_TRACE, 4, hipMemcpyDeviceToHost));
+#ifdef PM_ROW_REC  // (the validator's events live in the second half of the buffer there)
+  cnt = std::min<uint32_t>(cnt, std::min<uint32_t>(cap, PM_STREAM_TRACE_CAP / 2u));
+  if (cnt) HIPCHK(hipMemcpy(out, e->d_stream_trace.p + PM_STREAM_TRACE_CAP, size_t(cnt) * 16, hipMemcpyDeviceToHost));
+#else
   cnt = std::min<uint32_t>(cnt, std::min<uint32_t>(cap, PM_STREAM_TRACE_CAP));
   if (cnt) HIPCHK(hipMemcpy(out, e->d_stream_trace.p, size_t(cnt) * 16, hipMemcpyDeviceToHost));
+#endif
   *n = cnt;
   return PM_OK;
 }
 
 // debug (include/pm_engine_debug.h): candidate lists longer than `n` slots take the all-in-HBM carve path (carve_step_mem), which
 // otherwise needs more than 262,144 candidates for one configuration; 0 = off
+// debug (PM_ROW_REC builds, tools/row_rec.py): the time stamps the row makers of the last streaming launch left, eight words
+// per ticket (see stream_proposer); 0 rows from any other build
+int32_t pm_debug_row_records(pm_engine* e, unsigned long long* out, uint32_t cap_rows, uint32_t* n_rows) {
+  if (!e || !out || !n_rows) return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  *n_rows = 0;
+#ifdef PM_ROW_REC
+  if (!e->d_stream_trace.p) return PM_OK;
+  const uint32_t n = std::min<uint32_t>(cap_rows, PM_STREAM_TRACE_CAP / 8u);
+  HIPCHK(hipMemcpy(out, e->d_stream_trace.p, size_t(n) * 64, hipMemcpyDeviceToHost));
+  *n_rows = n;
+#endif
+  return PM_OK;
+}
 int32_t pm_debug_mem_lists_above(pm_engine* e, uint32_t n) {
   if (!e) return set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
@@ -3648,6 +3670,38 @@ int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, doub
   (void)hipFree(c);
   *gb_per_s = double(n_doubles) * 24.0 / (double(best) * 1e-3) / 1e9;
   return PM_OK;
+}
+
+// debug (include/pm_engine_debug.h): rows built by the insertion and by the networks from the same keys, compared on the
+// device (mismatches[0]: 1 = a register differs, 2 = a threshold, 4 = what a tracker answers; [1] = rows that differ); the
+// networks' rows come back for the caller's own sort
+int32_t pm_debug_row_networks(pm_engine* e, const uint64_t* keys, const uint32_t* sites, uint32_t n_waves, uint32_t n_per_wave,
+                              uint32_t slot_bits, uint64_t ulps, uint32_t upto, uint64_t* rows_out, uint32_t* mismatches) {
+  if (!e || !keys || !sites || !rows_out || !mismatches || !n_waves || (n_waves & 3u) || !n_per_wave || slot_bits == 0 || slot_bits > 24)
+    return set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const size_t nk = size_t(n_waves) * n_per_wave, ns = size_t(1) << slot_bits;
+  uint64_t *d_k = nullptr, *d_rows = nullptr;
+  uint32_t *d_s = nullptr, *d_m = nullptr;
+  int32_t rc = PM_OK;
+  if (hipMalloc((void**)&d_k, nk * 8) != hipSuccess || hipMalloc((void**)&d_rows, size_t(n_waves) * 64 * 8) != hipSuccess ||
+      hipMalloc((void**)&d_s, ns * 4) != hipSuccess || hipMalloc((void**)&d_m, 8) != hipSuccess) {
+    rc = set_error(PM_ENOMEM, "row network test buffers");
+  } else {
+    (void)hipMemcpyAsync(d_k, keys, nk * 8, hipMemcpyHostToDevice, e->stream);
+    (void)hipMemcpyAsync(d_s, sites, ns * 4, hipMemcpyHostToDevice, e->stream);
+    (void)hipMemsetAsync(d_m, 0, 8, e->stream);
+    launch_row_network_test(d_k, d_s, n_waves, n_per_wave, slot_bits, ulps, upto, d_rows, d_m, e->stream);
+    (void)hipMemcpyAsync(rows_out, d_rows, size_t(n_waves) * 64 * 8, hipMemcpyDeviceToHost, e->stream);
+    (void)hipMemcpyAsync(mismatches, d_m, 8, hipMemcpyDeviceToHost, e->stream);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) rc = set_error(PM_ENODEV, "row network test");
+  }
+  if (d_k) (void)hipFree(d_k);
+  if (d_rows) (void)hipFree(d_rows);
+  if (d_s) (void)hipFree(d_s);
+  if (d_m) (void)hipFree(d_m);
+  return rc;
 }
 
 int32_t pm_last_stats(pm_engine* e, pm_stats* stats) {

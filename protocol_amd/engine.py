@@ -517,6 +517,24 @@ class Engine:
         check(L.pm_debug_delta_pushes(self._h, C.byref(n)))
         return n.value
 
+    def debug_row_networks(self, keys, sites, n_per_wave: int, slot_bits: int, ulps: int, upto: int):
+        """test hook (include/pm_engine_debug.h): rows from keys[n_waves * n_per_wave] by the insertion and by the sorting
+        networks, compared on the device -> (mismatch bits, rows that differ, the networks' rows as u64[n_waves, 64])"""
+        import numpy as np
+        L = lib()
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        sites = np.ascontiguousarray(sites, dtype=np.uint32)
+        assert keys.size % n_per_wave == 0 and sites.size == 1 << slot_bits
+        n_waves = keys.size // n_per_wave
+        rows = np.zeros((n_waves, 64), dtype=np.uint64)
+        mism = (C.c_uint32 * 2)()
+        L.pm_debug_row_networks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                            C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.pm_debug_row_networks.restype = C.c_int32
+        check(L.pm_debug_row_networks(self._h, keys.ctypes.data, sites.ctypes.data, n_waves, n_per_wave, slot_bits, ulps, upto,
+                                      rows.ctypes.data, mism))
+        return int(mism[0]), int(mism[1]), rows
+
     def debug_carve_counters(self) -> dict:
         """how the last carve went (pm_internal.h, pm_debug_carve_prof words 32..45): how its validation launches ended,
         and what the proposer's spatial index did"""

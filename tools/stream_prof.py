@@ -63,7 +63,10 @@ n_rows = max(o[12] + o[14] + o[29], 1)
 print(f"  a row's compute (us, count per row): sorted insertions {us(o[72]) / n_rows:.2f} ({o[73] / n_rows:.0f}), near-miss tracker "
       f"{us(o[74]) / n_rows:.2f} ({o[75] / n_rows:.0f}), sine-form keys {us(o[76]) / n_rows:.2f} ({o[77] / n_rows:.1f} strides), evictions with a site "
       f"look-up {o[78] / n_rows:.1f}, strides offered {o[79] / n_rows:.1f}; bitmap-sweep batches: waiting for the gathers "
-      f"{us(o[80]) / max(o[12], 1):.2f}, evaluating {us(o[81]) / max(o[12], 1):.2f} per swept row")
+      f"{us(o[80]) / max(o[12], 1):.2f}, evaluating {us(o[81]) / max(o[12], 1):.2f} per swept row (the keys {us(o[82]) / max(o[12], 1):.2f}, "
+      f"the row {us(o[83]) / max(o[12], 1):.2f})")
+print(f"  the networks' calls: {us(o[87]) / n_rows:.2f} us per row in all; inside: counting + packing {us(o[84]) / n_rows:.2f}, "
+      f"threshold + evictions {us(o[85]) / n_rows:.2f}, near misses {us(o[86]) / n_rows:.2f} (the networks themselves: the sorted insertions above)")
 print(f"  stream_small: {o[66 + 5]} groups; per group (us): seed {us(o[66]) / max(o[71], 1):.2f}, keys {us(o[67]) / max(o[71], 1):.2f}, "
       f"selection {us(o[68]) / max(o[71], 1):.2f}, certificate {us(o[69]) / max(o[71], 1):.2f}, commit {us(o[70]) / max(o[71], 1):.2f}")
 print(f"  exact-sweep reasons: no row {o[20]}, debug hook {o[21]}, row exhausted {o[25]}, certificate {o[31]}")

@@ -69,7 +69,8 @@ ev = sorted((int(buf[2 * i]), int(buf[2 * i + 1]) & 0xFF, (int(buf[2 * i + 1]) >
 if not ev:
     raise SystemExit("no events (not a PM_CARVE_PROF build, or the carve did not stream)")
 rows_ev = [e for e in ev if e[1] == 8]   # (written by other CUs: their clocks are not the validator's)
-ev = [e for e in ev if e[1] != 8]
+seg_ev = [e for e in ev if 20 <= e[1] <= 25]  # (a swept row's segments: see carve_stream_kernel's row makers)
+ev = [e for e in ev if e[1] != 8 and not 20 <= e[1] <= 25]
 t0 = ev[0][0]
 span = ev[-1][0] - t0
 tpu = span / max(1e3 * s["ms_carve_kernel"] - 45.0, 1.0)
@@ -80,6 +81,12 @@ if dump:
     with open(dump, "w") as f:
         for t, ty, a, b in ev:
             f.write(f"{us(t):10.2f} {str(names.get(ty, ty)):8s} {a:8d} {b:10d}\n")
+    with open(dump + ".segs", "w") as f:   # per swept row: ticket, us: seed columns, passes, gather waits, evaluation, rest of the batches, finish
+        segs = {}
+        for t, ty, a, b in seg_ev:
+            segs.setdefault(a, [0.0] * 6)[ty - 20] = b / tpu
+        for a in sorted(segs):
+            f.write(f"{a:8d} " + " ".join(f"{v:8.2f}" for v in segs[a]) + "\n")
     with open(dump + ".rows", "w") as f:   # (other CUs' clocks: ticket, ticks the row took its wave)
         for t, ty, a, b in rows_ev:
             f.write(f"{a:8d} {b / tpu:10.2f}\n")
