@@ -44,7 +44,12 @@ static constexpr uint32_t PM_PROP_MAX_SEEDS = 16384;   // located slots that get
 // x fastest, so a run of cells along x is one contiguous range of the cell-sorted entries
 static constexpr uint32_t PM_CELL_G_MAX = 64;
 static constexpr uint32_t PM_CELL_TABLE = PM_CELL_G_MAX * PM_CELL_G_MAX * PM_CELL_G_MAX + 2;  // starts of every cell + the end
-static constexpr uint32_t PM_CELL_MIN_N = 6000;        // eligible positions below which no index is built
+static constexpr uint32_t PM_CELL_MIN_N = 6000;        // eligible positions below which the grid is 32^3 whatever is asked for (forced modes)
+// eligible positions from which a carve builds the index of its own accord (prune_mode 1).  Measured with the streaming
+// carve (profiles/r05_index_crossover.txt, tools/index_crossover.py): with and without the index a cold match costs
+// the same within +-3 % from 6,000 to 30,000 workers (10,000: 1.074 against 1.047 ms — the four cell_* launches are
+// not paid back), and the index wins from 50,000 on (3.88 against 3.99 ms; 100,000: 6.9 against 9.1)
+static constexpr uint32_t PM_CELL_AUTO_N = 40000;
 static constexpr uint32_t PM_CELL_BIG_N = 40000;       // ... from which the grid is 64^3 instead of 32^3
 static constexpr uint32_t PM_CELL_RMAX = 14;           // rings of cells a seed walks before it falls back to the whole list
 // part | alive, loc bitmaps | wid | site | key | sel_out | BlockRed + s_n

@@ -901,7 +901,7 @@ static int32_t form_queue_init(pm_engine* e, FormRun* r, bool fresh = false) {
   if (r->use_props) {
     if (!r->stream) HIPCHK(hipMemsetAsync(e->d_desc.p, 0, 2 * sizeof(BatchDesc), e->stream));  // (the batch pipeline's descriptors)
     // the ordered eligible list, and the spatial index of its positions when there are enough of them to matter
-    const uint32_t index_min = !r->a.prune_mode ? 0u : r->a.prune_mode >= 2u ? 1u : PM_CELL_MIN_N;
+    const uint32_t index_min = !r->a.prune_mode ? 0u : r->a.prune_mode >= 2u ? 1u : PM_CELL_AUTO_N;
     if (r->stream) {
       // every launch tags its tickets and rows from a range of its own (a launch re-armed behind a host-resolved step
       // must not take the rows of the one before it for its own); the rings are cleared when the counter wraps

@@ -32,10 +32,32 @@ namespace pm {
 // ------------------------------------------------------------------------------------------------
 // wave / block reduction helpers (64-lane butterflies; results valid in every lane)
 
+// wave-wide inclusive prefix sum in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16, then the row ends carried
+// over with row_bcast 15 / 31): no LDS traffic.  (Six __shfl_up are six ds_bpermute round trips, ~130 cycles each — a
+// third of a pass of the bitmap sweep and of the ticketer's look.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_step(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v = dpp_add_step<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add_step<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add_step<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add_step<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// the wave's sum: the scan's last lane, read into a scalar register (a __shfl_xor butterfly is three to six
+// ds_bpermute round trips; every count at a configuration boundary of the streaming carve ends in one of these)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#ifdef PM_WAVE_SUM_SHFL
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#else
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
+#endif
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
 #pragma unroll
@@ -385,23 +407,6 @@ __global__ __launch_bounds__(256) void pair_select_planes_kernel(const uint64_t*
     }
   }
   out[r] = res;
-}
-
-// wave-wide inclusive prefix sum in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16, then the row ends carried
-// over with row_bcast 15 / 31): no LDS traffic.  (Six __shfl_up are six ds_bpermute round trips, ~130 cycles each — a
-// third of a pass of the bitmap sweep and of the ticketer's look.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add_step(uint32_t v) {
-  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-  v = dpp_add_step<0x111, 0xF>(v);  // row_shr:1
-  v = dpp_add_step<0x112, 0xF>(v);  // row_shr:2
-  v = dpp_add_step<0x114, 0xF>(v);  // row_shr:4
-  v = dpp_add_step<0x118, 0xF>(v);  // row_shr:8
-  v = dpp_add_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
-  v = dpp_add_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
-  return v;
 }
 
 // ---- task table deltas (the table grows downwards: new tasks sit in front of the old ones)

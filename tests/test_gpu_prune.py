@@ -37,8 +37,11 @@ def test_config1_same_groups_whichever_way_the_rows_were_made(seed):
     for mode in (1, 2, 3):
         n, g, c, stats = _carve(sw, mode)
         assert (n, g) == (n0, g0), mode
+        if mode == 1:  # (the default policy builds no index below PM_CELL_AUTO_N eligible positions: it does not pay there)
+            assert c["cell_g"] == 0 and c["pruned_batches"] == 0, c
+            continue
         assert c["cell_g"] == 32 and 0 < c["n_indexed"] <= sw.W, c
-        assert mode == 1 or c["pruned_batches"] > 0, (mode, c)   # (the default policy may find no list long enough here)
+        assert c["pruned_batches"] > 0, (mode, c)
         if mode == 2:
             assert c["pruned_batches"] >= c["batches"] // 2, c
         if mode == 3:
