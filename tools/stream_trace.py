@@ -77,7 +77,7 @@ tpu = span / max(1e3 * s["ms_carve_kernel"] - 45.0, 1.0)
 us = lambda t: (t - t0) / tpu
 print(f"T={T} W={W}: carve {s['ms_carve_kernel']:.3f} ms, {n.value} events over {span} ticks ({tpu:.0f} ticks per us)")
 if dump:
-    names = {1: "config", 2: "wait", 3: "go", 4: "tickets", 5: "parked", 6: "run", 7: "end", 8: "row", 9: "exact", 10: "fast", 11: "probe", 12: "tail", 13: "tiny", 14: "ranout", 15: "small", 16: "rowwait", 17: "slots_in", 18: "slots_out", 19: "slot_at"}
+    names = {1: "config", 2: "wait", 3: "go", 4: "tickets", 5: "parked", 6: "run", 7: "end", 8: "row", 9: "exact", 10: "fast", 11: "probe", 12: "tail", 13: "tiny", 14: "ranout", 15: "small", 16: "rowwait", 17: "slots_in", 18: "slots_out", 19: "slot_at", 26: "ack"}
     with open(dump, "w") as f:
         for t, ty, a, b in ev:
             f.write(f"{us(t):10.2f} {str(names.get(ty, ty)):8s} {a:8d} {b:10d}\n")
