@@ -133,6 +133,33 @@ def test_form_groups_wide_and_huge_groups():
         eng.close()
 
 
+@pytest.mark.parametrize("W", [300, 900, 2500])
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_configurations_that_end_or_start_in_registers(seed, W):
+    """Configurations of a wave's worth of located candidates or fewer are carved on sorted rows made by helper waves
+    (stream_small_rows), 65..128 start two a lane and finish there, groups of ONE node are written in one go
+    (stream_first_come in two parts: located first) — small swarms where every configuration is such a one, the
+    co-located workers of the 32 cities in them (ties: the certificate's second look), with and without every second
+    step forced through the host."""
+    sw = make_swarm(seed, 400, W)
+    sw.configs = [("quad8", 4, 4, "gpu:count=8"), ("pairs4", 2, 2, "gpu:count=4"), ("wide2", 3, 7, "gpu:count=2"),
+                  ("singles-h100", 1, 1, "gpu:count=1;gpu:model=h100"), ("rest1", 2, 6, "gpu:count=1"), ("solo-any", 1, 1, None)]
+    sw.topo = (sw.topo.astype(np.int64) % len(sw.configs)).astype(np.int16)
+    sw.topo[sw.n_topo[:, None] <= np.arange(3)[None, :]] = -2
+    sw.topo[~sw.restricted] = -2
+    for every in (0, 2):
+        st = oracle_state_for(sw)
+        st.try_form_new_groups()
+        eng = E.Engine(debug_uncertain_every=every)
+        host.load_swarm(eng, sw)
+        eng.form_groups()
+        stats = eng.last_stats()
+        assert oracle_groups(st) == engine_groups(eng), (seed, W, every)
+        assert (stats["host_resolved_steps"] > 0) == (every != 0)
+        assert eng.debug_carve_counters()["stream_aborts"] == 0
+        eng.close()
+
+
 def test_form_groups_without_proximity_and_with_partial_enable():
     sw = make_swarm(11, 500, 3000)
     for kw, enabled in ((dict(proximity=False), None), (dict(), 0b1010_1010_0110_0101_0011_0001)):
