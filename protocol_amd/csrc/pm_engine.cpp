@@ -156,6 +156,7 @@ struct pm_engine {
   std::vector<pm_gpu_alt_row> alts;
   std::vector<uint32_t> model_bits;
   uint32_t model_rows = 0, model_classes = 0;
+  bool cls_check_dirty = true;  // gpu_model_class of some row, or the model table, changed since ensure_compat last checked the column
   uint64_t enabled = ~0ull;
   DevBuf<pm_config_row> d_cfgs;
   DevBuf<pm_gpu_alt_row> d_alts;
@@ -534,10 +535,13 @@ static int32_t ensure_compat(pm_engine* e) {
   for (const pm_gpu_alt_row& a : e->alts)
     if ((a.flags & PM_G_MODEL) && a.model_row >= e->model_rows)
       return set_error(PM_ESTATE, "a GPU alternative names a model row but pm_set_model_table was not called");
-  if (e->model_rows)
+  // (once per change of the column or the table, not once per tick: a pass over every row on the host is 100 us at
+  // 100,000 workers, a tenth of a churn tick's match)
+  if (e->model_rows && e->cls_check_dirty)
     for (uint32_t w = 0; w < e->W; ++w)
       if ((e->h_flags[w] & PM_W_GPU_MODEL) && e->h_gpu_cls[w] >= e->model_classes)
         return set_error(PM_ERANGE, "worker gpu_model_class outside the model table");
+  e->cls_check_dirty = false;
   HIPCHK(e->d_compat.ensure(std::max<size_t>(e->W, 1)));
   CompatArgs a{};
   a.W = e->W;
@@ -951,15 +955,25 @@ static int32_t form_begin(pm_engine* e, FormRun* r, bool allow_pipeline, bool lo
   // the eligible list is a subset of the rows no group holds (host mirror, current after absorb_groups): the
   // per-round preparation kernels are sized by that, not by the table (an incremental tick on a standing swarm
   // prepares lists of a few thousand positions out of a hundred thousand rows)
-  r->n_bound = uint32_t(std::count_if(e->h_group_of.begin(), e->h_group_of.end(), [](int32_t g) { return g < 0; }));
   // ... and how many of those the kernels will find eligible (mod.rs:492-497), as far as the host mirror knows: only
-  // used to decide whether the spatial index is worth its four launches (a standing swarm's tick: a few thousand)
-  r->n_elig_hint = r->n_bound;
+  // used to decide whether the spatial index is worth its four launches (a standing swarm's tick: a few thousand).
+  // (Both counts in ONE branch-free pass the compiler vectorises: at 100,000 workers two passes with branches were
+  // 150 - 250 us of a churn tick's 1.3 ms.)
   if (e->h_group_of.size() == e->W && e->h_flags.size() == e->W) {
-    uint32_t n = 0;
-    for (uint32_t w = 0; w < e->W; ++w)
-      n += (e->h_group_of[w] < 0 && (e->h_flags[w] & PM_W_HEALTHY) && (e->h_flags[w] & PM_W_HAS_P2P)) ? 1u : 0u;
-    r->n_elig_hint = n;
+    const int32_t* const gof = e->h_group_of.data();
+    const uint32_t* const fl = e->h_flags.data();
+    const uint32_t need = PM_W_HEALTHY | PM_W_HAS_P2P;
+    uint32_t nb = 0, ne = 0;
+    for (uint32_t w = 0; w < e->W; ++w) {
+      const uint32_t un = uint32_t(gof[w]) >> 31;  // 1 where no group holds the row
+      nb += un;
+      ne += un & uint32_t((fl[w] & need) == need);
+    }
+    r->n_bound = nb;
+    r->n_elig_hint = ne;
+  } else {
+    r->n_bound = uint32_t(std::count_if(e->h_group_of.begin(), e->h_group_of.end(), [](int32_t g) { return g < 0; }));
+    r->n_elig_hint = r->n_bound;
   }
   if (e->h_group_of.size() != e->W) r->n_bound = r->n_elig_hint = e->W;
   if (r->n_bound == 0) r->n_bound = 1;
@@ -2071,6 +2085,7 @@ int32_t pm_set_model_table(pm_engine* e, const uint32_t* bits, uint32_t n_rows, 
   e->model_bits.assign(bits, bits + words);
   e->model_rows = n_rows;
   e->model_classes = n_classes;
+  e->cls_check_dirty = true;
   int32_t rc = upload(e->d_model_bits, e->model_bits.data(), words, e->stream);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -2186,6 +2201,7 @@ int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_gr
   e->h_gpu_count.assign(w->gpu_count, w->gpu_count + n);
   e->h_gpu_mem.assign(w->gpu_mem_mb, w->gpu_mem_mb + n);
   e->h_gpu_cls.assign(w->gpu_model_class, w->gpu_model_class + n);
+  e->cls_check_dirty = true;
   e->h_cpu_cores.assign(w->cpu_cores, w->cpu_cores + n);
   e->h_ram.assign(w->ram_mb, w->ram_mb + n);
   e->h_storage.assign(w->storage_gb, w->storage_gb + n);
@@ -2224,6 +2240,7 @@ static int32_t scatter_rows(pm_engine* e, const uint32_t* idx, const pm_worker_s
     e->h_gpu_count[w] = rows->gpu_count[k];
     e->h_gpu_mem[w] = rows->gpu_mem_mb[k];
     e->h_gpu_cls[w] = rows->gpu_model_class[k];
+    e->cls_check_dirty = true;
     e->h_cpu_cores[w] = rows->cpu_cores[k];
     e->h_ram[w] = rows->ram_mb[k];
     e->h_storage[w] = rows->storage_gb[k];
@@ -3097,7 +3114,13 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   uint32_t n_formed = 0, n_merged = 0;
   HIPCHK(hipEventRecord(e->ev[0], e->stream));
   e->compat_dirty = true;  // a full-swarm match re-evaluates the W x C predicate, like mod.rs:511-515
-  int32_t rc = ensure_compat(e);
+  // (the group deltas of a churn tick first: their staging waits for the stream to drain — an idle stream answers at
+  // once, one that has just been handed the compat sweep of 100,000 rows answers 100 us later)
+  int32_t rc = absorb_groups(e);  // (form_begin's order: a carve left unabsorbed first, then the list goes up)
+  if (rc) return rc;
+  rc = push_groups(e);
+  if (rc) return rc;
+  rc = ensure_compat(e);
   if (rc) return rc;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   // The host copy of the new groups is built while the pair sweep runs, unless the merge pass needs it.
