@@ -116,6 +116,10 @@ struct PubTable {
   size_t cap_rows = 0;
 };
 static_assert(sizeof(pm_assignment) == 32, "published rows are copied as four 64-bit words");
+static_assert(offsetof(pm_assignment, task) == 0 && offsetof(pm_assignment, group_slot) == 4 && offsetof(pm_assignment, group_index) == 8 &&
+                  offsetof(pm_assignment, group_size) == 12 && offsetof(pm_assignment, next_worker) == 16 &&
+                  offsetof(pm_assignment, group_id) == 24,
+              "the words pub_patch clears in place");
 
 }  // namespace pm
 
@@ -1532,10 +1536,22 @@ static void pub_patch(pm_engine* e, const std::vector<uint32_t>* only) {
   const uint64_t s0 = t.seq.load(std::memory_order_relaxed);
   t.seq.store(s0 + 1, std::memory_order_relaxed);  // odd: being written
   std::atomic_thread_fence(std::memory_order_release);
-  if (only) {  // a dissolved group's members: a handful of rows, in place
-    const uint32_t keep_shift = t.task_shift.load(std::memory_order_relaxed);
-    for (uint32_t w : *only)
-      if (w < n) store_row(&rows[w], patched(rows[w], keep_shift));
+  if (only) {  // the members of groups dissolved just now: rows in place
+    // A worker is in one group at a time, and `only` holds members of groups that are gone: a row of theirs that names a
+    // group at all names one that is gone (the one just dissolved, or an older one the table still carried) — it reads "no
+    // group" from now on, whatever it named.  No look at the group list (by slot, or by id through a hash map once the
+    // list has been compacted): for the 5,000 workers a status sweep of a thousand deaths frees, those look-ups — two
+    // cache misses a row — were 260 of the call's 300 us (PM_HOST_MARKS_STATUS build, tools/churn_probe.py).
+    for (uint32_t w : *only) {
+      if (w >= n) continue;
+      uint64_t* d = reinterpret_cast<uint64_t*>(&rows[w]);
+      if (uint32_t(__atomic_load_n(&d[0], __ATOMIC_RELAXED) >> 32) == PM_NONE) continue;  // (no group: as it is)
+      const uint64_t w2 = __atomic_load_n(&d[2], __ATOMIC_RELAXED);                        // next_worker | padding
+      __atomic_store_n(&d[0], (uint64_t(PM_NONE) << 32) | PM_NONE, __ATOMIC_RELAXED);      // task, group_slot
+      __atomic_store_n(&d[1], 0ull, __ATOMIC_RELAXED);                                      // group_index, group_size
+      __atomic_store_n(&d[2], (w2 & 0xFFFFFFFF00000000ull) | PM_NONE, __ATOMIC_RELAXED);
+      __atomic_store_n(&d[3], 0ull, __ATOMIC_RELAXED);                                      // group_id
+    }
   } else {
     for (uint32_t w = 0; w < n; ++w) store_row(&rows[w], patched(rows[w], 0u));
     t.task_shift.store(0, std::memory_order_relaxed);  // (the rows hold current positions again)
@@ -2751,7 +2767,13 @@ int32_t pm_on_worker_status_many(pm_engine* e, const uint32_t* workers, const ui
     if (workers[k] >= e->W) return set_error(PM_ERANGE, "worker index out of range");
   if (!n) return PM_OK;
   HIPCHK(hipSetDevice(e->cfg.device));
+#ifdef PM_HOST_MARKS_STATUS  // (a measuring build: where a status sweep's time goes)
+  host_mark("status: begin");
+#endif
   ABSORB_PENDING(e);
+#ifdef PM_HOST_MARKS_STATUS
+  host_mark("status: pending groups absorbed");
+#endif
   std::vector<uint32_t> freed;  // members of the groups this sweep dissolves
   for (uint32_t k = 0; k < n; ++k) {
     const uint32_t w = workers[k];
@@ -2763,9 +2785,15 @@ int32_t pm_on_worker_status_many(pm_engine* e, const uint32_t* workers, const ui
       dissolve_locked(e, slot);
     }
   }
+#ifdef PM_HOST_MARKS_STATUS
+  host_mark("status: groups dissolved");
+#endif
   e->flags_dirty = true;
   e->compat_dirty = true;
   if (!freed.empty()) pub_patch(e, &freed);
+#ifdef PM_HOST_MARKS_STATUS
+  host_mark("status: published rows patched");
+#endif
   return PM_OK;
 }
 
