@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 2
+#define PM_ABI_VERSION 3 /* 3 (round 6): + the by-id / by-worker group calls of the plugin's read surface; the stepwise tick's
+                            carve_next / carve_validate pair became pm_dist_carve_wait; pm_upload_workers(keep_groups = 1)
+                            accepts new rows behind the known ones; carve_variant 2 / 4 are PM_EINVAL (since round 5) */
 
 enum {
   PM_OK = 0,
@@ -186,8 +188,10 @@ int32_t pm_set_model_table(pm_engine*, const uint32_t* bits, uint32_t n_rows, ui
 int32_t pm_set_enabled_mask(pm_engine*, uint64_t enabled);
 
 /* NodeStore::get_nodes snapshot (order significant). Resets group state iff keep_groups == 0.
- * keep_groups == 1 keeps the groups and their claimed tasks and therefore needs the SAME rows in the same order
- * (groups are keyed by row index); anything else is a delta: */
+ * keep_groups == 1 keeps the groups and their claimed tasks (groups are keyed by row index): the rows the engine already
+ * has must come first, in the same order; rows behind them are new ones, exactly as pm_append_workers would have added
+ * them (in no group).  It is the re-synchronisation call of a host whose delta calls failed half-way: every row again,
+ * nothing dissolved, the id stream not restarted — followed by pm_on_worker_status_many for the rows that died meanwhile. */
 int32_t pm_upload_workers(pm_engine*, const pm_worker_soa* workers, uint32_t keep_groups);
 /* A node the discovery monitor sees for the first time (orchestrator/src/discovery/monitor.rs:236-420 ->
  * NodeStore::add_node): rows are appended behind the existing ones (*first_index = index of the first new row),
@@ -264,6 +268,12 @@ int32_t pm_drain_group_events(pm_engine*, pm_group_event* events, uint32_t cap_e
                               uint32_t cap_members, uint32_t* n_events, uint32_t* n_members);
 /* dissolve_group (mod.rs:1423-1487) by group slot. */
 int32_t pm_dissolve_group(pm_engine*, uint32_t group_slot);
+/* dissolve_group(&group_id) as the API routes call it (mod.rs:1002-1004 -> :1423-1487; DELETE /groups/{id} and
+ * force-regroup, api/routes/groups.rs:126, :349): by the group's id (the generate_group_id value whose "{:x}" text the
+ * route carries).  An id that names no group is not an error — the reference logs "No group found" and returns Ok(()):
+ * PM_OK with *dissolved = 0.  The group's rows in the published table read "no group" before the call returns; the
+ * life-cycle feed gets its PM_GROUP_DESTROYED.  dissolved may be NULL. */
+int32_t pm_dissolve_group_by_id(pm_engine*, uint64_t group_id, uint32_t* dissolved);
 /* Drop all groups (bench: cold start of a full-swarm match). */
 int32_t pm_reset_groups(pm_engine*);
 
@@ -285,9 +295,24 @@ typedef struct {
 
 /* get_all_groups (mod.rs:1006-1044) in slot (creation) order.  group_of_worker (W entries, slot in
  * the returned array or -1), groups (cap_groups) and members (cap_members, BTreeSet order) may be
- * NULL to query counts only. */
+ * NULL to query counts only.  (The reference sorts the list by id text, mod.rs:1040: the caller's step — the ids are
+ * numbers here and "{:x}" strings there.) */
 int32_t pm_get_groups(pm_engine*, int32_t* group_of_worker, pm_group* groups, uint32_t cap_groups,
                       uint32_t* n_groups, uint32_t* members, uint32_t cap_members, uint32_t* n_members);
+/* ONE group, for the read surface the API routes use between ticks:
+ *   pm_get_group_by_id      get_group_by_id (mod.rs:1046-1055; GET /groups/{id}/logs, api/routes/groups.rs:160)
+ *   pm_get_group_of_worker  get_node_group (mod.rs:324-337; the storage route's upload name, api/routes/storage.rs:150,
+ *                           and per node get_node_groups_batch, mod.rs:339-397, api/routes/nodes.rs:74) — worker = the
+ *                           row index of the node's address
+ * *slot = the group's slot (as pm_get_groups numbers them NOW) or PM_NONE: no such group / the worker is in none
+ * (Ok(None) in the reference) — PM_OK either way.  out->member_begin is 0; members (cap_members entries, BTreeSet order:
+ * the position of a worker in it is get_idx_in_group, mod.rs:424-434) may be NULL; with a members buffer that is too small
+ * the call returns PM_ERANGE after filling *out (out->n_members says what is needed).  Host-side state only: no HIP call,
+ * but the engine's mutex (a tick in flight finishes first). */
+int32_t pm_get_group_by_id(pm_engine*, uint64_t group_id, pm_group* out, uint32_t* members, uint32_t cap_members,
+                           uint32_t* slot);
+int32_t pm_get_group_of_worker(pm_engine*, uint32_t worker, pm_group* out, uint32_t* members, uint32_t cap_members,
+                               uint32_t* slot);
 
 /* Phase B, reference orientation — NodeGroupsPlugin::filter_tasks (scheduler_impl.rs:11-110) for
  * EVERY worker at once: the T x W topology sweep, the chooser and the per-group claim (SETNX :74).
@@ -356,9 +381,9 @@ int32_t pm_device_task_column(pm_engine*, uint64_t* device_ptr, uint32_t* n);
  * worker w is owned by rank shard_of_worker[w] (the caller's hash of the address, e.g. splitmix64(address) %
  * world).  The reference carves from ONE pool (node_groups/mod.rs:492-503), so the carve domain is not split:
  * what is split is the parallel work, and every rank ends a tick with bit-identical groups and tables.
- *   - the sequential validation chain of try_form_new_groups runs replicated (identical inputs, deterministic);
- *   - the neighbour-list proposals of a batch — the full-chip sweep that dominates at 100k workers — are dealt
- *     round-robin over the ranks (seed i of the batch -> rank i % world) and all-gathered once per batch;
+ *   - the carve — try_form_new_groups' chain of dependent steps — runs REPLICATED: every rank runs the whole streaming
+ *     launch on identical inputs and ends on the identical groups and ids; nothing is exchanged for it (rounds 2-4 dealt a
+ *     batch's neighbour-list proposals over the ranks and all-gathered them ~55 times a tick: slower on 8 GPUs than on one);
  *   - the pair sweep + chooser + claim run for the OWNED workers only; the published rows are all-gathered once
  *     per tick and scattered into every rank's full table (the "cross-shard conflict-resolution all-gather");
  *   - pm_match_per_task bids with the owned workers only; the caller folds the per-task bests (min index / sum).
@@ -408,19 +433,19 @@ int32_t pm_set_stream(pm_engine*, void* hip_stream);
 /* After pm_upload_workers (and again whenever the row count changes).  world == 1 switches back. */
 int32_t pm_dist_configure(pm_engine*, uint32_t rank, uint32_t world, const uint8_t* shard_of_worker);
 /* The tick in steps:
- *   pm_dist_tick_begin                      compat sweep; the carve is started — the WHOLE carve, on every rank (the
- *                                           reference carves from one pool, node_groups/mod.rs:492-503, and the chain of
- *                                           dependent steps that forms the groups does not shard: it is replicated, one
- *                                           streaming launch per rank, and ends on the identical groups and ids everywhere)
- *   loop: pm_dist_carve_next(&x, &more)     waits for the carve, settles near-ties on the host (replicated); more == 0
- *                                           always since ABI v2 round 5 (nothing is exchanged for the carve; the call and
- *         pm_dist_carve_validate            its partner stay for drivers written against a local compute that deals rows)
- *   pm_dist_match_begin(&x)                 solo merge, pair sweep + claim of the OWNED workers -> all-gather x (the one
- *                                           exchange of a tick) ->
- *   pm_dist_tick_end(&stats)                scatter into the full table, publish (pm_lookup_* serve every worker) */
+ *   pm_dist_tick_begin         compat sweep; the carve is started — the WHOLE carve, on every rank (the reference carves
+ *                              from one pool, node_groups/mod.rs:492-503, and the chain of dependent steps that forms the
+ *                              groups does not shard: it is replicated, one streaming launch per rank, and ends on the
+ *                              identical groups and ids everywhere)
+ *   pm_dist_carve_wait         waits for the carve and settles near-ties on the host (replicated, deterministic)
+ *   pm_dist_match_begin(&x)    solo merge, pair sweep + claim of the OWNED workers -> all-gather x (the ONE exchange of a
+ *                              tick) ->
+ *   pm_dist_tick_end(&stats)   scatter into the full table, publish (pm_lookup_* serve every worker)
+ * (ABI 2 had a carve_next(&x, &more) + carve_validate pair in the place of pm_dist_carve_wait: a loop that
+ * exchanged nothing since round 5.  Removed with the version bump, so that a driver written as that loop fails at the
+ * version check and not at run time.) */
 int32_t pm_dist_tick_begin(pm_engine*);
-int32_t pm_dist_carve_next(pm_engine*, pm_dist_xfer* x, uint32_t* more);
-int32_t pm_dist_carve_validate(pm_engine*);
+int32_t pm_dist_carve_wait(pm_engine*);
 int32_t pm_dist_match_begin(pm_engine*, pm_dist_xfer* x);
 int32_t pm_dist_tick_end(pm_engine*, pm_stats* stats);
 /* pm_match_per_task with the results left on the device (u32[T] each, worker indices are global) for a

@@ -9,9 +9,8 @@ shard carving on its own would form different groups than one orchestrator.  Wha
   * the carve itself is REPLICATED: a chain of dependent steps (group g + 1's seed depends on what group g took) that
     no number of GPUs shortens; every rank runs it whole, as one streaming launch (libpm_engine.so, DESIGN.md
     section 7), and — the result being the reference's, whatever the timing — ends with the identical groups and
-    ids.  Nothing is exchanged for it.  (The protocol below still knows a local compute that deals a batch's
-    neighbour rows over the ranks and all-gathers them, `carve_next` -> more: tests/dist_model.py can, the engine
-    did until round 5 — 55 host-waited exchanges per tick at 1M x 100k, slower on 8 GPUs than on one);
+    ids.  Nothing is exchanged for it.  (Until round 5 a batch's neighbour rows were dealt over the ranks and
+    all-gathered: 55 host-waited exchanges per tick at 1M x 100k, slower on 8 GPUs than on one.  Gone with ABI 3.)
   * the pair sweep + chooser + claim run for the OWNED workers only; the published rows are ALL-GATHERED once per
     tick and scattered into every rank's full table (any rank can answer any worker's heartbeat);
   * per-task best bids (north_star orientation) are computed over the owned workers and folded across ranks
@@ -99,13 +98,8 @@ class EngineLocal:
     def tick_begin(self):
         self.eng.dist_tick_begin()
 
-    def carve_next(self):
-        x, more = self.eng.dist_carve_next()
-        send, recv = self._tensors(x, self.world)
-        return more, send, recv
-
-    def carve_validate(self):
-        self.eng.dist_carve_validate()
+    def carve_wait(self):
+        self.eng.dist_carve_wait()
 
     def match_begin(self):
         return self._tensors(self.eng.dist_match_begin(), self.world)
@@ -122,7 +116,7 @@ class EngineLocal:
 class ShardedEngine:
     """One rank of the multi-GPU matcher.
 
-    local      the local compute: tick_begin / carve_next / carve_validate / match_begin / tick_end /
+    local      the local compute: tick_begin / carve_wait / match_begin / tick_end /
                match_per_task_device (+ configure, stream_ctx) — EngineLocal in production
     address    uint64[W]: the worker addresses (the same table on every rank); ownership = shard_of(address)
     exchanger  object with all_gather(recv, send), world, rank — TorchExchanger by default
@@ -160,15 +154,7 @@ class ShardedEngine:
         L = self.local
         with self._ctx():
             L.tick_begin()
-            for _batch in range(1 << 20):        # (bounded: a stuck carve must fail, not hang the job)
-                more, send, recv = L.carve_next()
-                if not more:
-                    break
-                if send is not None:            # the batch's neighbour lists: every rank contributes its share
-                    self._gather(recv, send)
-                L.carve_validate()
-            else:
-                raise RuntimeError("the carve did not finish")
+            L.carve_wait()                      # the whole carve, replicated: nothing to exchange
             send, recv = L.match_begin()
             if send is not None:                # the published rows of the owned workers
                 self._gather(recv, send)

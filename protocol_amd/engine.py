@@ -96,8 +96,9 @@ EXPORTS = [
     "pm_last_stats", "pm_lookup_task_for_worker", "pm_device_task_column", "pm_host_parse_requirements", "pm_host_model_matches",
     "pm_host_build_model_table", "pm_host_config_order", "pm_host_group_vars", "pm_host_volume_vars",
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
-    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_set_carve_workgroups", "pm_tick_many", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_next", "pm_dist_carve_validate",
+    "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_set_carve_workgroups", "pm_tick_many", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_wait",
     "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
+    "pm_dissolve_group_by_id", "pm_get_group_by_id", "pm_get_group_of_worker",
 ]
 
 _lib = None
@@ -157,8 +158,10 @@ def lib() -> C.CDLL:
         L.pm_set_stream.argtypes = [vp, vp]
         L.pm_dist_configure.argtypes = [vp, u32, u32, vp]
         L.pm_dist_tick_begin.argtypes = [vp]
-        L.pm_dist_carve_next.argtypes = [vp, C.POINTER(DistXfer), C.POINTER(u32)]
-        L.pm_dist_carve_validate.argtypes = [vp]
+        L.pm_dist_carve_wait.argtypes = [vp]
+        L.pm_dissolve_group_by_id.argtypes = [vp, u64, C.POINTER(u32)]
+        L.pm_get_group_by_id.argtypes = [vp, u64, vp, vp, u32, C.POINTER(u32)]
+        L.pm_get_group_of_worker.argtypes = [vp, u32, vp, vp, u32, C.POINTER(u32)]
         L.pm_dist_match_begin.argtypes = [vp, C.POINTER(DistXfer)]
         L.pm_dist_tick_end.argtypes = [vp, C.POINTER(Stats)]
         L.pm_match_per_task_device.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
@@ -372,6 +375,35 @@ class Engine:
     def dissolve_group(self, slot: int):
         check(lib().pm_dissolve_group(self._h, slot))
 
+    def dissolve_group_by_id(self, group_id: int) -> bool:
+        """dissolve_group(&group_id) (mod.rs:1002-1004): False = no group has this id (not an error)"""
+        n = C.c_uint32(0)
+        check(lib().pm_dissolve_group_by_id(self._h, int(group_id), C.byref(n)))
+        return bool(n.value)
+
+    def _one_group(self, call):
+        g = np.zeros(1, dtype=group_dt)
+        slot = C.c_uint32(0)
+        members = np.zeros(64, dtype=np.uint32)
+        rc = call(g.ctypes.data, members.ctypes.data, len(members), C.byref(slot))
+        if rc == PM_ERANGE and slot.value != PM_NONE:            # a group of more than 64: its size is in the record
+            members = np.zeros(int(g[0]["n_members"]), dtype=np.uint32)
+            rc = call(g.ctypes.data, members.ctypes.data, len(members), C.byref(slot))
+        check(rc)
+        if slot.value == PM_NONE:
+            return None
+        n = int(g[0]["n_members"])
+        return {"slot": slot.value, "id": int(g[0]["id"]), "config": int(g[0]["config"]), "task": int(g[0]["task"]),
+                "members": members[:n].tolist()}
+
+    def get_group_by_id(self, group_id: int):
+        """get_group_by_id (mod.rs:1046-1055) -> None or {slot, id, config, task, members (BTreeSet order)}"""
+        return self._one_group(lambda g, m, cap, s: lib().pm_get_group_by_id(self._h, int(group_id), g, m, cap, s))
+
+    def get_group_of_worker(self, worker: int):
+        """get_node_group (mod.rs:324-337) by row index -> None or the same record"""
+        return self._one_group(lambda g, m, cap, s: lib().pm_get_group_of_worker(self._h, int(worker), g, m, cap, s))
+
     def reset_groups(self):
         check(lib().pm_reset_groups(self._h))
 
@@ -450,14 +482,8 @@ class Engine:
     def dist_tick_begin(self):
         check(lib().pm_dist_tick_begin(self._h))
 
-    def dist_carve_next(self):
-        """-> (DistXfer, more): more == False: the carve is done"""
-        x, more = DistXfer(), C.c_uint32(0)
-        check(lib().pm_dist_carve_next(self._h, C.byref(x), C.byref(more)))
-        return x, bool(more.value)
-
-    def dist_carve_validate(self):
-        check(lib().pm_dist_carve_validate(self._h))
+    def dist_carve_wait(self):
+        check(lib().pm_dist_carve_wait(self._h))
 
     def dist_match_begin(self) -> DistXfer:
         x = DistXfer()

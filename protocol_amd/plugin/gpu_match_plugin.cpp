@@ -30,6 +30,22 @@ std::string hex_lower(uint64_t v) {  // format!("{:x}", v): generate_group_id, m
   return buf;
 }
 
+// the inverse of format!("{:x}", u64): lower-case hex digits, no sign, no prefix, no leading zero (but "0"), <= 16 of them.
+// Anything else is the text of no group id (a Redis key that does not exist in the reference).
+bool parse_group_id(const std::string& s, uint64_t* out) {
+  if (s.empty() || s.size() > 16 || (s.size() > 1 && s[0] == '0')) return false;
+  uint64_t v = 0;
+  for (char c : s) {
+    uint64_t d;
+    if (c >= '0' && c <= '9') d = uint64_t(c - '0');
+    else if (c >= 'a' && c <= 'f') d = uint64_t(c - 'a' + 10);
+    else return false;
+    v = (v << 4) | d;
+  }
+  *out = v;
+  return true;
+}
+
 // the two-call convention of the pm_host_* string helpers: size, then fill
 template <typename F>
 std::string render(F&& f, const std::function<void(int32_t)>& check) {
@@ -98,6 +114,11 @@ std::vector<Task> NewestTaskPlugin::filter_tasks(const std::vector<Task>& tasks,
 
 // ------------------------------------------------------------------------------------------------ the plugin
 
+static std::atomic<int>& pools_in_process() {  // live GpuMatchPlugin objects
+  static std::atomic<int> n{0};
+  return n;
+}
+
 bool GpuMatchPlugin::Row::operator==(const Row& o) const {
   // (f64 compared like Rust's derived PartialEq: by value)
   return flags == o.flags && gpu_count == o.gpu_count && gpu_mem == o.gpu_mem && gpu_class == o.gpu_class &&
@@ -147,9 +168,6 @@ GpuMatchPlugin::GpuMatchPlugin(std::vector<NodeGroupConfiguration> templates, in
   // PROCESS ENTRY POINT sets it, before any thread exists — a library constructor that writes the environment races
   // with every getenv in a threaded host ("main.rs").  Here it is only looked at: one pool is
   // indifferent to the value, several pools in one process want >= 1 per pool (include/pm_engine.h, pm_set_carve_workgroups).
-  if (const char* q = getenv("GPU_MAX_HW_QUEUES"); !q || atoi(q) < 8)
-    fprintf(stderr, "GpuMatchPlugin: GPU_MAX_HW_QUEUES is %s; set it to 16 in the launcher before the first HIP call if this "
-                    "process serves more than one pool on the GPU\n", q ? q : "unset (runtime default 4)");
   {
     std::set<std::string> seen;
     for (const NodeGroupConfiguration& t : templates)
@@ -162,6 +180,7 @@ GpuMatchPlugin::GpuMatchPlugin(std::vector<NodeGroupConfiguration> templates, in
   try {
     for (const NodeGroupConfiguration& t : templates) config_names_.push_back(t.name);
     set_configs(templates);
+    templates_ = std::move(templates);
     // an empty worker / task table, so that the delta calls have something to extend
     RowColumns empty;
     const pm_worker_soa w = empty.soa();
@@ -177,9 +196,14 @@ GpuMatchPlugin::GpuMatchPlugin(std::vector<NodeGroupConfiguration> templates, in
     engine_ = nullptr;
     throw;
   }
+  if (pools_in_process().fetch_add(1) == 1)  // (a SECOND live pool in the process: one pool is indifferent to the value)
+    if (const char* q = getenv("GPU_MAX_HW_QUEUES"); !q || atoi(q) < 8)
+      fprintf(stderr, "GpuMatchPlugin: a second pool in this process and GPU_MAX_HW_QUEUES is %s; set it to 16 in the launcher "
+                      "before the first HIP call\n", q ? q : "unset (runtime default 4)");
 }
 
 GpuMatchPlugin::~GpuMatchPlugin() {
+  pools_in_process().fetch_sub(1);
   if (engine_) pm_engine_destroy(engine_);
 }
 
@@ -222,6 +246,7 @@ void GpuMatchPlugin::set_configs(const std::vector<NodeGroupConfiguration>& temp
   const int32_t rc = pm_set_configs(engine_, rows.data(), uint32_t(rows.size()), alts.data(), uint32_t(alts.size()));
   if (rc == PM_EINVAL) throw std::invalid_argument("Plugin configuration is invalid");  // mod.rs:145-147
   check(rc);
+  config_rows_ = rows;
   push_model_table(NodeTable{});
 }
 
@@ -327,17 +352,31 @@ void GpuMatchPlugin::sync_nodes(const std::vector<OrchestratorNode>& snapshot) {
     // it.  If one of them fails the two have diverged (tombstones recorded here and never sent, rows appended here the
     // engine does not have): the next interval then re-sends the whole table instead of deltas.
     if (engine_rows_stale_) {
+      // Every row again, in row order — which is the order the engine has its own in, with the rows it never received
+      // behind them: pm_upload_workers(keep_groups = 1) keeps the standing groups, their claims and the id stream (rows
+      // never move, so a group's row indices are as valid as before).  Then the deaths the engine may have missed: every
+      // row that is not in the store, as dead — a no-op for a row in no group, the reference's dissolution (and its
+      // send_group_destroyed) for the others.
       RowColumns all;
       const std::vector<uint32_t> ranks = address_ranks(t.by_address, t.rows.size());
       for (size_t i = 0; i < seen.size(); ++i)
         if (!seen[i]) t.present[i] = false;
+      std::vector<uint32_t> gone, gone_flags;
       for (size_t i = 0; i < t.rows.size(); ++i) {
-        if (!t.present[i]) t.rows[i].flags &= ~uint32_t(PM_W_HEALTHY);
+        if (!t.present[i]) {
+          t.rows[i].flags &= ~uint32_t(PM_W_HEALTHY);
+          gone.push_back(uint32_t(i));
+          gone_flags.push_back(t.rows[i].flags);
+        }
         all.push(t.rows[i], ranks[i]);
       }
       push_model_table(t);
       const pm_worker_soa w = all.soa();
-      check(pm_upload_workers(engine_, &w, 0));  // (groups are dissolved: which rows they held is no longer known)
+      check(pm_upload_workers(engine_, &w, 1));
+      if (!gone.empty()) {
+        const std::vector<uint32_t> dead(gone.size(), 1u);
+        check(pm_on_worker_status_many(engine_, gone.data(), gone_flags.data(), dead.data(), uint32_t(gone.size())));
+      }
       engine_rows_stale_ = false;
       lk.unlock();
       emit_group_webhooks();
@@ -404,7 +443,7 @@ uint64_t GpuMatchPlugin::topology_mask(const Task& t) const {
   return m;
 }
 
-void GpuMatchPlugin::push_enabled(const std::vector<Task>& tasks) const {
+void GpuMatchPlugin::push_enabled(const std::vector<Task>& tasks) {
   // available_node_group_configs: every topology some task names (on_task_created, mod.rs:1224-1243)
   uint64_t enabled = 0;
   for (const Task& t : tasks) {
@@ -412,6 +451,7 @@ void GpuMatchPlugin::push_enabled(const std::vector<Task>& tasks) const {
     if (m != ~0ull) enabled |= m;
   }
   check(pm_set_enabled_mask(engine_, enabled));
+  enabled_mask_.store(enabled);
 }
 
 // The engine reports a task as a POSITION in `tasks_`, and it re-derives the published positions inside
@@ -516,6 +556,14 @@ void GpuMatchPlugin::emit_group_webhooks() {
     else if (rc != PM_ERANGE) return;
   }
   if (!drained) return;
+  {  // NodeGroup.created_at (mod.rs:575: Utc::now() when the group is formed) — the clock at the report of the creation
+    const int64_t now = clock ? clock() : 0;
+    std::lock_guard<std::mutex> lk(group_meta_mu_);
+    for (uint32_t k = 0; k < ne; ++k) {
+      if (events[k].kind == PM_GROUP_CREATED) group_created_at_[events[k].group_id] = now;
+      else group_created_at_.erase(events[k].group_id);
+    }
+  }
   if (webhook_plugins_.empty()) return;
   // (the address strings are copied under the lock and the deliveries made without it: a slow webhook endpoint must not
   // hold handle_status_change and sync_nodes up)
@@ -580,6 +628,188 @@ std::vector<Task> GpuMatchPlugin::filter_tasks(const std::vector<Task>&, const A
       for (std::string* path : {&m.host_path, &m.container_path})
         *path = render([&](char* o, size_t c, size_t* n) { return pm_host_volume_vars(path->c_str(), group_id.c_str(), o, c, n); }, chk);
   return {task};
+}
+
+// ------------------------------------------------------------------------------------------------ the read surface
+// What the API routes call on AppState.node_groups_plugin (node_groups/mod.rs:324-434, :1002-1065).  The reference reads
+// Redis; here the engine's host-side group list is the store (pm_get_groups / pm_get_group_by_id / pm_get_group_of_worker /
+// pm_dissolve_group_by_id) and the plugin's node table turns row indices back into address strings.
+
+GpuMatchPlugin::GroupSnapshot GpuMatchPlugin::snapshot_groups(bool want_group_of) const {
+  GroupSnapshot snap;
+  for (int attempt = 0; attempt < 8; ++attempt) {  // (a tick between the size query and the copy: ask again)
+    uint32_t ng = 0, nm = 0;
+    check(pm_get_groups(engine_, nullptr, nullptr, 0, &ng, nullptr, 0, &nm));
+    snap.groups.resize(ng);
+    snap.members.resize(nm);
+    // (group_of_worker gets W entries, W the ENGINE's row count: never more than the plugin's, whose lock the caller holds)
+    if (want_group_of) snap.group_of.assign(nodes_.rows.size(), -1);
+    const int32_t rc = pm_get_groups(engine_, want_group_of && !snap.group_of.empty() ? snap.group_of.data() : nullptr,
+                                     ng ? snap.groups.data() : nullptr, ng, &ng, nm ? snap.members.data() : nullptr, nm, &nm);
+    if (rc == PM_OK) {
+      snap.groups.resize(ng);
+      snap.members.resize(nm);
+      return snap;
+    }
+    if (rc != PM_ERANGE) check(rc);
+  }
+  throw EngineError(PM_ESTATE, "the group list kept changing under pm_get_groups");
+}
+
+NodeGroup GpuMatchPlugin::make_group(const NodeTable& t, const pm_group& g, const uint32_t* members) const {
+  NodeGroup out;
+  out.id = hex_lower(g.id);
+  for (uint32_t j = 0; j < g.n_members; ++j) out.nodes.push_back(t.address_strings[members[j]]);  // BTreeSet order already
+  out.configuration_name = config_names_[g.config];
+  {
+    std::lock_guard<std::mutex> lk(group_meta_mu_);
+    const auto it = group_created_at_.find(g.id);
+    out.created_at = it != group_created_at_.end() ? it->second : (clock ? clock() : 0);  // (formed, creation not reported yet)
+  }
+  return out;
+}
+
+// the reference keys node_to_group by address TEXT: exact string match (binary search in the address-ordered row list)
+std::optional<uint32_t> GpuMatchPlugin::row_of_address_text(const NodeTable& t, const std::string& text) const {
+  const auto at = std::partition_point(t.by_address.begin(), t.by_address.end(), [&](uint32_t j) { return t.address_strings[j] < text; });
+  if (at == t.by_address.end() || t.address_strings[*at] != text) return std::nullopt;
+  return *at;
+}
+
+std::vector<NodeGroup> GpuMatchPlugin::get_all_groups() const {
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  const GroupSnapshot snap = snapshot_groups(false);
+  std::vector<NodeGroup> out;
+  out.reserve(snap.groups.size());
+  for (const pm_group& g : snap.groups) out.push_back(make_group(nodes_, g, snap.members.data() + g.member_begin));
+  std::sort(out.begin(), out.end(), [](const NodeGroup& a, const NodeGroup& b) { return a.id < b.id; });  // mod.rs:1040
+  return out;
+}
+
+std::optional<NodeGroup> GpuMatchPlugin::get_group_by_id(const std::string& group_id) const {
+  uint64_t id = 0;
+  if (!parse_group_id(group_id, &id)) return std::nullopt;
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  pm_group g{};
+  uint32_t slot = PM_NONE;
+  std::vector<uint32_t> members(64);
+  int32_t rc = pm_get_group_by_id(engine_, id, &g, members.data(), uint32_t(members.size()), &slot);
+  if (rc == PM_ERANGE && slot != PM_NONE) {  // (a group of more than 64 nodes)
+    members.resize(g.n_members);
+    rc = pm_get_group_by_id(engine_, id, &g, members.data(), uint32_t(members.size()), &slot);
+  }
+  check(rc);
+  if (slot == PM_NONE) return std::nullopt;
+  return make_group(nodes_, g, members.data());
+}
+
+std::unordered_map<std::string, std::string> GpuMatchPlugin::get_all_node_group_mappings() const {
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  const GroupSnapshot snap = snapshot_groups(false);
+  std::unordered_map<std::string, std::string> out;
+  for (const pm_group& g : snap.groups) {
+    const std::string id = hex_lower(g.id);
+    for (uint32_t j = 0; j < g.n_members; ++j) out.emplace(nodes_.address_strings[snap.members[g.member_begin + j]], id);
+  }
+  return out;
+}
+
+std::optional<NodeGroup> GpuMatchPlugin::get_node_group(const std::string& node_addr) const {
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  const std::optional<uint32_t> row = row_of_address_text(nodes_, node_addr);
+  if (!row) return std::nullopt;
+  pm_group g{};
+  uint32_t slot = PM_NONE;
+  std::vector<uint32_t> members(64);
+  int32_t rc = pm_get_group_of_worker(engine_, *row, &g, members.data(), uint32_t(members.size()), &slot);
+  if (rc == PM_ERANGE && slot != PM_NONE) {
+    members.resize(g.n_members);
+    rc = pm_get_group_of_worker(engine_, *row, &g, members.data(), uint32_t(members.size()), &slot);
+  }
+  if (rc == PM_ERANGE && slot == PM_NONE) return std::nullopt;  // (a row the engine has not been sent yet: in no group)
+  check(rc);
+  if (slot == PM_NONE) return std::nullopt;
+  return make_group(nodes_, g, members.data());
+}
+
+std::unordered_map<std::string, std::optional<NodeGroup>> GpuMatchPlugin::get_node_groups_batch(
+    const std::vector<std::string>& node_addresses) const {
+  std::unordered_map<std::string, std::optional<NodeGroup>> out;
+  if (node_addresses.empty()) return out;  // mod.rs:346-348
+  std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+  const GroupSnapshot snap = snapshot_groups(true);
+  std::unordered_map<int32_t, NodeGroup> made;  // (every group is built once, like the reference's MGET of the unique ids)
+  for (const std::string& a : node_addresses) {
+    std::optional<NodeGroup> group;
+    const std::optional<uint32_t> row = row_of_address_text(nodes_, a);
+    if (row && *row < snap.group_of.size() && snap.group_of[*row] >= 0) {
+      const int32_t gi = snap.group_of[*row];
+      auto it = made.find(gi);
+      if (it == made.end()) it = made.emplace(gi, make_group(nodes_, snap.groups[size_t(gi)], snap.members.data() + snap.groups[size_t(gi)].member_begin)).first;
+      group = it->second;
+    }
+    out[a] = group;
+  }
+  return out;
+}
+
+size_t GpuMatchPlugin::get_idx_in_group(const NodeGroup& node_group, const std::string& node_addr) const {
+  const auto it = std::find(node_group.nodes.begin(), node_group.nodes.end(), node_addr);
+  if (it == node_group.nodes.end()) throw std::out_of_range("Node " + node_addr + " not found in group");
+  return size_t(it - node_group.nodes.begin());
+}
+
+std::vector<NodeGroupConfiguration> GpuMatchPlugin::get_available_configurations() const {
+  std::vector<uint32_t> order(config_rows_.size() + 1);
+  uint32_t n = 0;
+  check(pm_host_config_order(config_rows_.data(), uint32_t(config_rows_.size()), enabled_mask_.load(), order.data(), &n));
+  std::vector<NodeGroupConfiguration> out;
+  for (uint32_t k = 0; k < n; ++k) out.push_back(templates_[order[k]]);
+  return out;
+}
+
+std::vector<NodeGroupConfiguration> GpuMatchPlugin::get_all_configuration_templates() const {
+  // every template, in the order the constructor's sort leaves them in (mod.rs:150-164): the carve order with nothing disabled
+  const size_t C = config_rows_.size();
+  std::vector<uint32_t> order(C + 1);
+  uint32_t n = 0;
+  check(pm_host_config_order(config_rows_.data(), uint32_t(C), C >= 64 ? ~0ull : ((1ull << C) - 1ull), order.data(), &n));
+  std::vector<NodeGroupConfiguration> out;
+  for (uint32_t k = 0; k < n; ++k) out.push_back(templates_[order[k]]);
+  return out;
+}
+
+void GpuMatchPlugin::dissolve_group(const std::string& group_id) {
+  uint64_t id = 0;
+  if (!parse_group_id(group_id, &id)) return;  // "No group found with ID" (mod.rs:1483-1484): Ok(())
+  uint32_t dissolved = 0;
+  check(pm_dissolve_group_by_id(engine_, id, &dissolved));
+  if (dissolved) emit_group_webhooks();  // send_group_destroyed, mod.rs:1469-1481
+}
+
+std::vector<std::string> get_task_topologies(const Task& task) {
+  return task.allowed_topologies ? *task.allowed_topologies : std::vector<std::string>{};
+}
+
+std::string upload_file_name(const GpuMatchPlugin& plugin, const std::string& file_name_in, const std::string& address,
+                             const std::function<uint64_t(const std::string&, const std::string&)>& count_uploads,
+                             std::string* group_id_out) {
+  // storage.rs:147-166: the group variables only when the node is in a group ...
+  const std::optional<NodeGroup> group = plugin.get_node_group(address);
+  size_t idx = 0;
+  if (group) idx = plugin.get_idx_in_group(*group, address);
+  if (group_id_out) *group_id_out = group ? group->id : std::string();
+  // ... :170-199: the count of this node's uploads under the group's key (or "no-group"), :202-207 the two count variables
+  const uint64_t count = count_uploads ? count_uploads(address, group ? group->id : std::string("no-group")) : 0;
+  const auto chk = [](int32_t rc) {
+    if (rc != PM_OK) throw EngineError(rc, std::string("pm_host_upload_name_vars: ") + (pm_last_error() ? pm_last_error() : ""));
+  };
+  return render(
+      [&](char* o, size_t c, size_t* n) {
+        return pm_host_upload_name_vars(file_name_in.c_str(), group ? group->id.c_str() : nullptr, group ? uint32_t(group->nodes.size()) : 0u,
+                                        uint32_t(idx), count, o, c, n);
+      },
+      chk);
 }
 
 void GpuMatchPlugin::handle_status_change(const OrchestratorNode& node) {

@@ -19,6 +19,14 @@
 //                                         filter_tasks (scheduler_impl.rs:11-205), handle_status_change
 //                                         (status_update_impl.rs:8-39), the task observers (mod.rs:1224-1325)
 //   WebhookPlugin                         orchestrator/src/plugins/webhook/mod.rs:240-266 (the two calls the path makes)
+//   NodeGroup + the plugin's READ SURFACE  node_groups/mod.rs:63-69; get_node_group :324-337, get_node_groups_batch
+//                                         :339-397, get_available_configurations :399-418,
+//                                         get_all_configuration_templates :420-422, get_idx_in_group :424-434,
+//                                         dissolve_group :1002-1004 (-> :1423-1487), get_all_groups :1006-1044,
+//                                         get_group_by_id :1046-1055, get_all_node_group_mappings :1057-1065 — what the
+//                                         API routes call on AppState.node_groups_plugin (api/routes/groups.rs:34-160,
+//                                         :319-360, nodes.rs:68-90, storage.rs:147-156, metrics/sync_service.rs:57-75,
+//                                         :273-274); get_task_topologies :1407-1421 (api/routes/task.rs:68-72)
 //
 // Errors: the Rust returns anyhow::Result and panics in the constructor; here every failed engine call throws
 // EngineError (code + pm_last_error text) and the constructor's panics are std::invalid_argument with the reference's
@@ -27,10 +35,12 @@
 #define PM_GPU_MATCH_PLUGIN_HPP
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <shared_mutex>
 #include <stdexcept>
@@ -113,6 +123,18 @@ struct NodeGroupConfiguration {
   std::optional<std::string> compute_requirements;
 };
 
+// NodeGroup (node_groups/mod.rs:63-69)
+struct NodeGroup {
+  std::string id;                  // generate_group_id: format!("{:x}", u64) (mod.rs:1489-1493)
+  std::vector<std::string> nodes;  // BTreeSet<String>: address.to_string() in byte order
+  int64_t created_at = 0;          // chrono::DateTime<Utc>, as milliseconds since the epoch: the plugin's clock when the
+                                   // creation was reported to it (the reference stamps Utc::now() in the same loop pass, mod.rs:575)
+  std::string configuration_name;
+  bool operator==(const NodeGroup& o) const {
+    return id == o.id && nodes == o.nodes && created_at == o.created_at && configuration_name == o.configuration_name;
+  }
+};
+
 // the two calls of webhook/mod.rs the path makes; `nodes` in group.nodes (BTreeSet<String>) order
 class WebhookPlugin {
  public:
@@ -185,6 +207,32 @@ class GpuMatchPlugin : public SchedulerPlugin {
   // StatusUpdatePlugin::handle_status_change (status_update_impl.rs:8-39)
   void handle_status_change(const OrchestratorNode& node);
 
+  // ---- the read surface the API routes use (AppState.node_groups_plugin in the reference; INTEGRATION.md "The routes").
+  // Host-side state of the engine only: no GPU work, any thread, also while a tick runs (it then waits for the tick).
+  // get_all_groups (mod.rs:1006-1044): every group, sorted by id text (:1040)
+  std::vector<NodeGroup> get_all_groups() const;
+  // get_group_by_id (mod.rs:1046-1055): an id that is not the "{:x}" text of a live group's id is nullopt
+  std::optional<NodeGroup> get_group_by_id(const std::string& group_id) const;
+  // get_all_node_group_mappings (mod.rs:1057-1065): node address text -> group id text (HGETALL node_to_group)
+  std::unordered_map<std::string, std::string> get_all_node_group_mappings() const;
+  // get_node_group (mod.rs:324-337): the group of the node with this address TEXT (the key of the reference's hash)
+  std::optional<NodeGroup> get_node_group(const std::string& node_addr) const;
+  // get_node_groups_batch (mod.rs:339-397): every asked address is a key of the result; one snapshot of the engine's list
+  std::unordered_map<std::string, std::optional<NodeGroup>> get_node_groups_batch(const std::vector<std::string>& node_addresses) const;
+  // get_idx_in_group (mod.rs:424-434): position in group.nodes; "Node {} not found in group" -> std::out_of_range
+  size_t get_idx_in_group(const NodeGroup& node_group, const std::string& node_addr) const;
+  // get_available_configurations (mod.rs:399-418): the templates some task names, min_group_size descending (stable)
+  std::vector<NodeGroupConfiguration> get_available_configurations() const;
+  // get_all_configuration_templates (mod.rs:420-422): in the constructor's order (mod.rs:150-164)
+  std::vector<NodeGroupConfiguration> get_all_configuration_templates() const;
+  // dissolve_group (mod.rs:1002-1004 -> :1423-1487): by id text; an unknown id is not an error; sends the webhook
+  void dissolve_group(const std::string& group_id);
+
+  // chrono::Utc::now() for NodeGroup.created_at, milliseconds since the epoch (tests inject their own)
+  std::function<int64_t()> clock = [] {
+    return int64_t(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count());
+  };
+
   // on_task_created also re-matches the standing groups (pm_tasks_insert_front_ex, republish = 1)
   std::atomic<bool> republish_on_insert{false};
 
@@ -223,11 +271,24 @@ class GpuMatchPlugin : public SchedulerPlugin {
   static Row project(const OrchestratorNode& node, NodeTable& table, bool* new_model);
   static std::vector<uint32_t> address_ranks(const std::vector<uint32_t>& by_address, size_t known);
   uint64_t topology_mask(const Task& t) const;
-  void push_enabled(const std::vector<Task>& tasks) const;
+  void push_enabled(const std::vector<Task>& tasks);
   void sync_tasks_locked(std::vector<Task>& guard, std::vector<Task> tasks);
   void emit_group_webhooks();
+  struct GroupSnapshot {
+    std::vector<int32_t> group_of;   // per row: index into `groups` or -1
+    std::vector<pm_group> groups;
+    std::vector<uint32_t> members;
+  };
+  GroupSnapshot snapshot_groups(bool want_group_of) const;
+  NodeGroup make_group(const NodeTable& t, const pm_group& g, const uint32_t* members) const;
+  std::optional<uint32_t> row_of_address_text(const NodeTable& t, const std::string& text) const;
 
   pm_engine* engine_ = nullptr;
+  std::vector<NodeGroupConfiguration> templates_;   // caller order: the engine's configuration index
+  std::vector<pm_config_row> config_rows_;          // what pm_set_configs was given (pm_host_config_order reads sizes + PM_R_HAS_REQ)
+  std::atomic<uint64_t> enabled_mask_{0};           // "available_node_group_configs" as last pushed (push_enabled)
+  mutable std::mutex group_meta_mu_;                // LEAF lock: never held across an engine call or another lock
+  mutable std::unordered_map<uint64_t, int64_t> group_created_at_;
   std::vector<std::string> config_names_;
   std::vector<std::string> req_models_;   // requirement model strings, one per pm_gpu_alt_row.model_row
   mutable std::shared_mutex nodes_mu_;
@@ -245,6 +306,20 @@ class TaskStore {
   virtual ~TaskStore() = default;
   virtual std::vector<Task> get_all_tasks() = 0;
 };
+
+// get_task_topologies (node_groups/mod.rs:1407-1421): what create_task checks when the grouping plugin is active
+// ("No topology found for task but grouping plugin is active", api/routes/task.rs:68-75): the task's allowed_topologies,
+// empty when any Option on the way is None
+std::vector<std::string> get_task_topologies(const Task& task);
+
+// The storage route's file name (api/routes/storage.rs:147-185, after generate_file_name): ${NODE_GROUP_ID},
+// ${NODE_GROUP_SIZE}, ${NODE_GROUP_INDEX} through get_node_group + get_idx_in_group when the node is in a group, then
+// ${TOTAL_UPLOAD_COUNT_AFTER} / ${CURRENT_FILE_INDEX} from count_uploads(address, group id or "no-group") — the number of
+// `upload:<address>:<group|no-group>:*` keys, which stays with the store (storage.rs:170-199).
+// *group_id_out (may be null) = the group id the route keys its upload counter by, empty when the node is in no group.
+std::string upload_file_name(const GpuMatchPlugin& plugin, const std::string& file_name, const std::string& address,
+                             const std::function<uint64_t(const std::string& address, const std::string& group_or_no_group)>& count_uploads,
+                             std::string* group_id_out = nullptr);
 
 class Scheduler {
  public:

@@ -121,9 +121,16 @@ OrchestratorNode to_node(const pmx_node& n) {
   return r;
 }
 
+std::string group_line(const NodeGroup& g) {
+  std::string s = esc(g.id) + "\t" + esc(g.configuration_name) + "\t" + std::to_string(g.created_at);
+  for (const std::string& n : g.nodes) s += "\t" + esc(n);
+  return s;
+}
+
 }  // namespace
 
 struct pmx_plugin {
+  std::atomic<int64_t> now_ms{0};
   std::shared_ptr<RecordingWebhook> hook = std::make_shared<RecordingWebhook>();
   std::shared_ptr<ListStore> store = std::make_shared<ListStore>();
   std::shared_ptr<GpuMatchPlugin> plugin;
@@ -162,6 +169,7 @@ int32_t pmx_create(const pmx_config* cfgs, uint32_t n, int32_t device, pmx_plugi
         std::move(t), device, [raw](const Address&, const std::string&) { return size_t(raw->upload_count.load()); },
         std::vector<std::shared_ptr<WebhookPlugin>>{p->hook});
     p->scheduler.reset(new Scheduler(p->store, {p->plugin}));
+    p->plugin->clock = [raw] { return raw->now_ms.load(); };
     *out = p.release();
   })
 }
@@ -266,6 +274,86 @@ int32_t pmx_get_task_for_node(pmx_plugin* p, const char* address, int64_t now, c
     g_error = e.what();
     return -1;
   }
+}
+
+#define PMX_TEXT(...)                 \
+  try {                               \
+    std::string text;                 \
+    __VA_ARGS__;                      \
+    return give(text, out, cap, needed); \
+  } catch (const std::exception& e) { \
+    g_error = e.what();               \
+    return -1;                        \
+  }
+
+void pmx_set_clock(pmx_plugin* p, int64_t now_ms) { p->now_ms = now_ms; }
+
+int32_t pmx_get_all_groups(pmx_plugin* p, char* out, size_t cap, size_t* needed) {
+  PMX_TEXT({
+    for (const NodeGroup& g : p->plugin->get_all_groups()) text += group_line(g) + "\n";
+  })
+}
+
+int32_t pmx_get_group_by_id(pmx_plugin* p, const char* group_id, char* out, size_t cap, size_t* needed) {
+  PMX_TEXT({
+    const std::optional<NodeGroup> g = p->plugin->get_group_by_id(group_id ? group_id : "");
+    if (g) text = group_line(*g) + "\n";
+  })
+}
+
+int32_t pmx_get_node_group(pmx_plugin* p, const char* address, char* out, size_t cap, size_t* needed) {
+  PMX_TEXT({
+    const std::string a = address ? address : "";
+    const std::optional<NodeGroup> g = p->plugin->get_node_group(a);
+    if (g) text = std::to_string(p->plugin->get_idx_in_group(*g, a)) + "\t" + group_line(*g) + "\n";
+  })
+}
+
+int32_t pmx_get_node_groups_batch(pmx_plugin* p, const char* const* addresses, uint32_t n, char* out, size_t cap, size_t* needed) {
+  PMX_TEXT({
+    std::vector<std::string> asked;
+    for (uint32_t i = 0; i < n; ++i) asked.push_back(addresses[i]);
+    const auto got = p->plugin->get_node_groups_batch(asked);
+    for (const std::string& a : asked) {
+      const auto it = got.find(a);
+      if (it == got.end()) throw std::logic_error("an asked address is missing from the batch result");
+      text += esc(a) + "\t" + (it->second ? group_line(*it->second) : std::string("-")) + "\n";
+    }
+  })
+}
+
+int32_t pmx_get_all_node_group_mappings(pmx_plugin* p, char* out, size_t cap, size_t* needed) {
+  PMX_TEXT({
+    const auto m = p->plugin->get_all_node_group_mappings();
+    std::vector<std::pair<std::string, std::string>> v(m.begin(), m.end());
+    std::sort(v.begin(), v.end());
+    for (const auto& kv : v) text += esc(kv.first) + "\t" + esc(kv.second) + "\n";
+  })
+}
+
+int32_t pmx_get_configurations(pmx_plugin* p, uint32_t available_only, char* out, size_t cap, size_t* needed) {
+  PMX_TEXT({
+    const std::vector<NodeGroupConfiguration> v =
+        available_only ? p->plugin->get_available_configurations() : p->plugin->get_all_configuration_templates();
+    for (const NodeGroupConfiguration& c : v)
+      text += esc(c.name) + "\t" + std::to_string(c.min_group_size) + "\t" + std::to_string(c.max_group_size) + "\t" +
+              (c.compute_requirements ? esc(*c.compute_requirements) : std::string("-")) + "\n";
+  })
+}
+
+int32_t pmx_dissolve_group(pmx_plugin* p, const char* group_id) { PMX_TRY(p->plugin->dissolve_group(group_id ? group_id : "")) }
+
+int32_t pmx_upload_file_name(pmx_plugin* p, const char* file_name, const char* address, char* out, size_t cap, size_t* needed) {
+  PMX_TEXT({
+    std::string key_group;
+    const std::string name = upload_file_name(
+        *p->plugin, file_name ? file_name : "", address ? address : "",
+        [&](const std::string&, const std::string& g) {
+          key_group = g;
+          return uint64_t(p->upload_count.load());
+        });
+    text = esc(name) + "\n" + esc(key_group) + "\n";
+  })
 }
 
 int32_t pmx_take_webhooks(pmx_plugin* p, char* out, size_t cap, size_t* needed) {

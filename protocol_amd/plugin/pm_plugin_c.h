@@ -85,6 +85,23 @@ int32_t pmx_get_task_for_node(pmx_plugin*, const char* address, int64_t now, cha
  * name>\t<node>\t<node>..." */
 int32_t pmx_take_webhooks(pmx_plugin*, char* out, size_t cap, size_t* needed);
 
+/* ---- the plugin's read surface (node_groups/mod.rs:324-434, :1002-1065: what the API routes call).  A group is one line
+ * "<id>\t<configuration name>\t<created_at ms>\t<node>\t<node>..." (nodes in BTreeSet<String> order). */
+void pmx_set_clock(pmx_plugin*, int64_t now_ms); /* what the plugin's clock answers from now on (NodeGroup.created_at) */
+int32_t pmx_get_all_groups(pmx_plugin*, char* out, size_t cap, size_t* needed);               /* sorted by id text */
+int32_t pmx_get_group_by_id(pmx_plugin*, const char* group_id, char* out, size_t cap, size_t* needed); /* empty = None */
+/* get_node_group + get_idx_in_group: empty = None, else "<idx>\t" in front of the group line */
+int32_t pmx_get_node_group(pmx_plugin*, const char* address, char* out, size_t cap, size_t* needed);
+/* one line per asked address, in the order asked: "<address>\t-" (None) or "<address>\t" + the group line */
+int32_t pmx_get_node_groups_batch(pmx_plugin*, const char* const* addresses, uint32_t n, char* out, size_t cap, size_t* needed);
+int32_t pmx_get_all_node_group_mappings(pmx_plugin*, char* out, size_t cap, size_t* needed); /* "<address>\t<group id>", by address */
+/* get_all_configuration_templates (available_only = 0) / get_available_configurations (1): "<name>\t<min>\t<max>\t<requirements or ->" */
+int32_t pmx_get_configurations(pmx_plugin*, uint32_t available_only, char* out, size_t cap, size_t* needed);
+int32_t pmx_dissolve_group(pmx_plugin*, const char* group_id);
+/* the storage route's file name (api/routes/storage.rs:147-207) through get_node_group + get_idx_in_group; the key count is
+ * pmx_set_upload_count's value.  Two lines: the name, then the group id the route keys its counter by ("no-group" if none). */
+int32_t pmx_upload_file_name(pmx_plugin*, const char* file_name, const char* address, char* out, size_t cap, size_t* needed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-//! GpuMatchPlugin — the third `SchedulerPlugin` variant: binds libpm_engine.so (include/pm_engine.h, ABI v2).
+//! GpuMatchPlugin — the third `SchedulerPlugin` variant: binds libpm_engine.so (include/pm_engine.h, ABI v3).
 //!
 //! SOURCE ONLY: this image has no cargo/rustc, so this file has never been compiled.  It is the binding a
 //! maintainer adds under crates/orchestrator/src/plugins/gpu_match/mod.rs, next to
@@ -7,6 +7,13 @@
 //! The plugin owns an opaque `pm_engine*`.  The group-management loop calls `tick()` instead of
 //! `try_form_new_groups` + `try_merge_solo_groups` (node_groups/mod.rs:180-203); `filter_tasks` becomes a
 //! lock-free lookup of the table published by the last tick (scheduler_impl.rs:11-110).
+//!
+//! The READ SURFACE the API routes call on `AppState.node_groups_plugin` (node_groups/mod.rs:324-434, :1002-1065) is
+//! here with the reference's names, signatures and result types, so the routes compile unchanged against
+//! `Option<Arc<GpuMatchPlugin>>` (INTEGRATION.md "The routes"): get_all_groups, get_group_by_id,
+//! get_all_node_group_mappings, get_node_group, get_node_groups_batch, get_idx_in_group,
+//! get_available_configurations, get_all_configuration_templates, dissolve_group.  The engine's host-side group list
+//! is the store behind them (the reference reads Redis).
 //!
 //! Row identity.  The engine keys workers, groups and claims by ROW INDEX.  `NodeStore::get_nodes` is Redis
 //! SMEMBERS order followed by a status sort (node_store.rs:195-206), so the position of a node in that Vec moves
@@ -17,22 +24,24 @@
 //! unspecified SMEMBERS order).
 #![allow(non_camel_case_types, dead_code)]
 
-use std::collections::HashMap;
+use std::collections::{BTreeSet, HashMap};
 use std::ffi::{c_char, CStr, CString};
 use std::os::raw::c_void;
+use std::sync::atomic::{AtomicU64, Ordering};
 
 use alloy::primitives::Address;
-use anyhow::{anyhow, Result};
+use anyhow::{anyhow, Error, Result};
 use shared::models::node::{ComputeRequirements, ComputeSpecs};
 use shared::models::task::Task;
 
 use crate::models::node::{NodeStatus, OrchestratorNode};
-use crate::plugins::node_groups::NodeGroupConfiguration;
+use crate::plugins::node_groups::{NodeGroup, NodeGroupConfiguration};
 use crate::plugins::webhook::WebhookPlugin;
 
 pub const PM_NONE: u32 = 0xFFFF_FFFF;
-pub const PM_ABI_VERSION: u32 = 2;
+pub const PM_ABI_VERSION: u32 = 3;
 const PM_EINVAL: i32 = -1;
+const PM_ESTATE: i32 = -4;
 const PM_ERANGE: i32 = -5;
 
 #[repr(C)]
@@ -112,6 +121,17 @@ pub struct pm_group_event {
     pub n_members: u32,
 }
 
+/// include/pm_engine.h: one group of pm_get_groups / pm_get_group_by_id / pm_get_group_of_worker
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct pm_group {
+    pub id: u64,
+    pub config: u32,
+    pub n_members: u32,
+    pub member_begin: u32,
+    pub task: u32,
+}
+
 #[repr(C)]
 #[derive(Default)]
 pub struct pm_assignment {
@@ -173,6 +193,13 @@ extern "C" {
     fn pm_enable_group_events(e: *mut c_void, on: u32) -> i32;
     fn pm_drain_group_events(e: *mut c_void, events: *mut pm_group_event, cap_events: u32, members: *mut u32,
                              cap_members: u32, n_events: *mut u32, n_members: *mut u32) -> i32;
+    fn pm_dissolve_group(e: *mut c_void, group_slot: u32) -> i32;
+    fn pm_dissolve_group_by_id(e: *mut c_void, group_id: u64, dissolved: *mut u32) -> i32;
+    fn pm_get_groups(e: *mut c_void, group_of_worker: *mut i32, groups: *mut pm_group, cap_groups: u32, n_groups: *mut u32,
+                     members: *mut u32, cap_members: u32, n_members: *mut u32) -> i32;
+    fn pm_get_group_by_id(e: *mut c_void, group_id: u64, out: *mut pm_group, members: *mut u32, cap_members: u32, slot: *mut u32) -> i32;
+    fn pm_get_group_of_worker(e: *mut c_void, worker: u32, out: *mut pm_group, members: *mut u32, cap_members: u32, slot: *mut u32) -> i32;
+    fn pm_host_config_order(cfgs: *const pm_config_row, n_cfgs: u32, enabled: u64, order_out: *mut u32, n_out: *mut u32) -> i32;
     fn pm_tick(e: *mut c_void, stats: *mut pm_stats) -> i32;
     fn pm_lookup_task_for_worker(e: *mut c_void, worker: u32, out: *mut pm_assignment) -> i32;
     fn pm_host_group_vars(input: *const c_char, v: *const pm_group_vars, out: *mut c_char, cap: usize, needed: *mut usize) -> i32;
@@ -186,8 +213,7 @@ extern "C" {
     fn pm_tick_many(engines: *const *mut c_void, n: u32, stats: *mut pm_stats, flags: u32) -> i32;
     fn pm_dist_configure(e: *mut c_void, rank: u32, world: u32, shard_of_worker: *const u8) -> i32;
     fn pm_dist_tick_begin(e: *mut c_void) -> i32;
-    fn pm_dist_carve_next(e: *mut c_void, x: *mut pm_dist_xfer, more: *mut u32) -> i32;
-    fn pm_dist_carve_validate(e: *mut c_void) -> i32;
+    fn pm_dist_carve_wait(e: *mut c_void) -> i32;
     fn pm_dist_match_begin(e: *mut c_void, x: *mut pm_dist_xfer) -> i32;
     fn pm_dist_tick_end(e: *mut c_void, stats: *mut pm_stats) -> i32;
 }
@@ -248,10 +274,19 @@ struct NodeTable {
     by_address: Vec<u32>,           // rows in address-string order (kept sorted: a new node is one binary search)
     spec_models: Vec<String>,       // interned gpu.model strings; the index is gpu_model_class
     spec_model_index: HashMap<String, u32>,
+    /// an engine call of sync_nodes failed half-way: the row map above is ahead of the engine's worker table (tombstones
+    /// recorded here and never sent, rows appended here the engine does not have) — the next interval re-sends every row
+    engine_rows_stale: bool,
 }
 
 pub struct GpuMatchPlugin {
     engine: *mut c_void,
+    templates: Vec<NodeGroupConfiguration>,     // caller order: the engine's configuration index
+    config_rows: Vec<pm_config_row>,            // what pm_set_configs was given (pm_host_config_order reads sizes + R_HAS_REQ)
+    enabled_mask: AtomicU64,                    // "available_node_group_configs" as last pushed (push_enabled)
+    /// NodeGroup.created_at (mod.rs:575: Utc::now() when the group forms): stamped when the creation is reported by the
+    /// life-cycle feed, dropped with the group.  A LEAF lock: never held across an engine call or another lock.
+    group_created_at: parking_lot::Mutex<HashMap<u64, chrono::DateTime<chrono::Utc>>>,
     config_names: Vec<String>,
     req_models: Vec<CString>,       // requirement model strings, one per pm_gpu_alt_row.model_row
     nodes: parking_lot::RwLock<NodeTable>,
@@ -298,7 +333,9 @@ impl GpuMatchPlugin {
         for t in &templates {
             if !seen.insert(t.name.clone()) { panic!("Configuration names must be unique"); }   // mod.rs:142-144
         }
-        let mut this = Self { engine, config_names: templates.iter().map(|t| t.name.clone()).collect(),
+        let mut this = Self { engine, templates: templates.clone(), config_rows: Vec::new(), enabled_mask: AtomicU64::new(0),
+                              group_created_at: Default::default(),
+                              config_names: templates.iter().map(|t| t.name.clone()).collect(),
                               req_models: Vec::new(), nodes: Default::default(), tasks: Default::default(),
                               upload_counter, webhook_plugins, republish_on_insert: false };
         this.set_configs(&templates);
@@ -352,6 +389,7 @@ impl GpuMatchPlugin {
         let rc = unsafe { pm_set_configs(self.engine, rows.as_ptr(), rows.len() as u32, alts.as_ptr(), alts.len() as u32) };
         if rc == PM_EINVAL { panic!("Plugin configuration is invalid"); }                                   // mod.rs:145-147
         check(rc).expect("pm_set_configs");
+        self.config_rows = rows;
         self.push_model_table(&NodeTable::default());
     }
 
@@ -414,13 +452,15 @@ impl GpuMatchPlugin {
             match t.index.get(&node.address).copied() {
                 Some(i) => {
                     let i = i as usize;
-                    seen[i] = true;
+                    if i < seen.len() { seen[i] = true; }   // (an address twice in one snapshot: the second one finds the row just appended)
                     t.p2p_ids[i] = node.p2p_id.clone().unwrap_or_default();
                     if t.rows[i] != row || !t.present[i] {
                         t.rows[i] = row.clone();
                         t.present[i] = true;
-                        upd_idx.push(i as u32);
-                        updated.push(&row, 0);          // ranks are replaced wholesale below when they change
+                        if i < seen.len() {
+                            upd_idx.push(i as u32);
+                            updated.push(&row, 0);      // ranks are replaced wholesale below when they change
+                        }
                     }
                 }
                 None => {
@@ -438,6 +478,38 @@ impl GpuMatchPlugin {
                 }
             }
         }
+        // The row map above is the plugin's truth from here on; the engine calls below bring the engine's worker table
+        // to it.  If one of them fails the two have diverged: the next interval then re-sends the whole table.
+        if t.engine_rows_stale {
+            // Every row again, in row order — the order the engine has its own in, with the rows it never received
+            // behind them: pm_upload_workers(keep_groups = 1) keeps the standing groups, their claims and the id stream
+            // (rows never move, so a group's row indices are as valid as before).  Then the deaths the engine may have
+            // missed: every row that is not in the store, as dead — a no-op for a row in no group, the reference's
+            // dissolution (and its send_group_destroyed) for the others.
+            let ranks = Self::address_ranks(&t.by_address, t.rows.len());
+            for i in 0..seen.len() { if !seen[i] { t.present[i] = false; } }
+            let mut all = RowColumns::default();
+            let (mut gone, mut gone_flags) = (Vec::<u32>::new(), Vec::<u32>::new());
+            for i in 0..t.rows.len() {
+                if !t.present[i] {
+                    t.rows[i].flags &= !W_HEALTHY;
+                    gone.push(i as u32);
+                    gone_flags.push(t.rows[i].flags);
+                }
+                let row = t.rows[i].clone();
+                all.push(&row, ranks[i]);
+            }
+            self.push_model_table(&t);
+            check(unsafe { pm_upload_workers(self.engine, &all.soa(), 1) })?;
+            if !gone.is_empty() {
+                let dead = vec![1u32; gone.len()];
+                check(unsafe { pm_on_worker_status_many(self.engine, gone.as_ptr(), gone_flags.as_ptr(), dead.as_ptr(), gone.len() as u32) })?;
+            }
+            t.engine_rows_stale = false;
+            drop(t);
+            return self.emit_group_webhooks();
+        }
+        t.engine_rows_stale = true;     // (cleared behind the last engine call below: every `?` in between leaves it set)
         if new_model { self.push_model_table(&t); }
         // nodes that left the store: tombstone (their group dissolves, like a death; status_update_impl.rs:17-29)
         let (mut gone, mut gone_flags) = (Vec::<u32>::new(), Vec::<u32>::new());
@@ -461,13 +533,23 @@ impl GpuMatchPlugin {
             check(unsafe { pm_update_workers(self.engine, upd_idx.as_ptr(), &updated.soa()) })?;
         }
         if !appended.flags.is_empty() {
+            // (a row appended by this very snapshot may have been rewritten by a later entry of it: send what it is now)
+            for k in 0..appended.flags.len() {
+                let r = t.rows[seen.len() + k].clone();
+                appended.flags[k] = r.flags; appended.gpu_count[k] = r.gpu_count; appended.gpu_mem[k] = r.gpu_mem;
+                appended.gpu_class[k] = r.gpu_class; appended.cpu_cores[k] = r.cpu_cores; appended.ram[k] = r.ram;
+                appended.storage[k] = r.storage; appended.lat[k] = r.lat; appended.lon[k] = r.lon;
+            }
             let mut first = 0u32;
             check(unsafe { pm_append_workers(self.engine, &appended.soa(), &mut first) })?;
-            debug_assert_eq!(first as usize, seen.len());
+            if first as usize != seen.len() {
+                return Err(anyhow!("pm_engine error {PM_ESTATE}: the engine's worker table and the plugin's row map disagree"));
+            }
             // a new address shifts the global ranks of the others: GROUP_INDEX only needs the relative order
             let ranks = Self::address_ranks(&t.by_address, t.rows.len());
             check(unsafe { pm_set_addr_ranks(self.engine, ranks.as_ptr(), ranks.len() as u32) })?;
         }
+        t.engine_rows_stale = false;
         drop(t);
         self.emit_group_webhooks()      // tombstoned nodes dissolved their groups
     }
@@ -493,7 +575,9 @@ impl GpuMatchPlugin {
     fn push_enabled(&self, tasks: &[Task]) -> Result<()> {
         // available_node_group_configs: every topology some task names (on_task_created, mod.rs:1224-1243)
         let enabled = tasks.iter().map(|t| self.topology_mask(t)).filter(|m| *m != u64::MAX).fold(0u64, |a, m| a | m);
-        check(unsafe { pm_set_enabled_mask(self.engine, enabled) })
+        check(unsafe { pm_set_enabled_mask(self.engine, enabled) })?;
+        self.enabled_mask.store(enabled, Ordering::Release);
+        Ok(())
     }
 
     // LOCK ORDER: `nodes`, then `tasks`, then the engine's own mutex (taken inside every pm_* call but the look-up).
@@ -575,6 +659,13 @@ impl GpuMatchPlugin {
             if rc != PM_ERANGE { log::error!("pm_drain_group_events: {rc}"); return Ok(()); }
         }
         if events.len() < ne as usize { log::error!("group events kept for the next drain"); return Ok(()); }
+        {   // NodeGroup.created_at (mod.rs:575): the clock at the report of the creation
+            let now = chrono::Utc::now();
+            let mut stamps = self.group_created_at.lock();
+            for ev in &events[..ne as usize] {
+                if ev.kind == 1 { stamps.insert(ev.group_id, now); } else { stamps.remove(&ev.group_id); }
+            }
+        }
         let Some(plugins) = &self.webhook_plugins else { return Ok(()) };
         let t = self.nodes.read();
         for ev in &events[..ne as usize] {
@@ -641,6 +732,160 @@ impl GpuMatchPlugin {
             }
         }
         Ok(vec![task])
+    }
+
+    // ------------------------------------------------------------------------------------------------ the read surface
+    // What the API routes call on AppState.node_groups_plugin, with the reference's names and result types
+    // (node_groups/mod.rs:324-434, :1002-1065).  `async` only because the reference's are (the routes `.await` them):
+    // nothing here waits for anything but the engine's mutex.
+
+    /// one snapshot of the engine's group list: (group_of per row or empty, groups, members)
+    fn snapshot_groups(&self, rows: usize, want_group_of: bool) -> Result<(Vec<i32>, Vec<pm_group>, Vec<u32>)> {
+        for _ in 0..8 {      // (a tick between the size query and the copy: ask again)
+            let (mut ng, mut nm) = (0u32, 0u32);
+            check(unsafe { pm_get_groups(self.engine, std::ptr::null_mut(), std::ptr::null_mut(), 0, &mut ng, std::ptr::null_mut(), 0, &mut nm) })?;
+            let mut groups = vec![pm_group::default(); ng as usize];
+            let mut members = vec![0u32; nm as usize];
+            // (group_of_worker gets W entries, W the ENGINE's row count: never more than the plugin's, whose lock the caller holds)
+            let mut group_of = if want_group_of { vec![-1i32; rows] } else { Vec::new() };
+            let gp = if want_group_of && rows > 0 { group_of.as_mut_ptr() } else { std::ptr::null_mut() };
+            let rc = unsafe { pm_get_groups(self.engine, gp, groups.as_mut_ptr(), ng, &mut ng, members.as_mut_ptr(), nm, &mut nm) };
+            if rc == 0 {
+                groups.truncate(ng as usize);
+                members.truncate(nm as usize);
+                return Ok((group_of, groups, members));
+            }
+            if rc != PM_ERANGE { check(rc)?; }
+        }
+        Err(anyhow!("the group list kept changing under pm_get_groups"))
+    }
+
+    fn make_group(&self, t: &NodeTable, g: &pm_group, members: &[u32]) -> NodeGroup {
+        let created_at = self.group_created_at.lock().get(&g.id).copied().unwrap_or_else(chrono::Utc::now);
+        NodeGroup {
+            id: format!("{:x}", g.id),                                                  // generate_group_id, mod.rs:1489-1493
+            nodes: members.iter().map(|&w| t.address_strings[w as usize].clone()).collect::<BTreeSet<String>>(),
+            created_at,
+            configuration_name: self.config_names[g.config as usize].clone(),
+        }
+    }
+
+    /// the inverse of format!("{:x}", u64): lower-case hex, no sign / prefix / leading zero (but "0"), <= 16 digits.
+    /// Anything else is the text of no group id (a Redis key that does not exist in the reference).
+    fn parse_group_id(s: &str) -> Option<u64> {
+        if s.is_empty() || s.len() > 16 || (s.len() > 1 && s.starts_with('0')) { return None; }
+        if !s.bytes().all(|c| c.is_ascii_digit() || (b'a'..=b'f').contains(&c)) { return None; }
+        u64::from_str_radix(s, 16).ok()
+    }
+
+    /// the reference keys node_to_group by address TEXT: exact string match (binary search in the address-ordered rows)
+    fn row_of_address_text(t: &NodeTable, text: &str) -> Option<u32> {
+        let at = t.by_address.partition_point(|&j| t.address_strings[j as usize].as_str() < text);
+        t.by_address.get(at).copied().filter(|&j| t.address_strings[j as usize] == text)
+    }
+
+    fn one_group(&self, t: &NodeTable, call: impl Fn(*mut pm_group, *mut u32, u32, *mut u32) -> i32) -> Result<Option<NodeGroup>> {
+        let (mut g, mut slot) = (pm_group::default(), PM_NONE);
+        let mut members = vec![0u32; 64];
+        let mut rc = call(&mut g, members.as_mut_ptr(), members.len() as u32, &mut slot);
+        if rc == PM_ERANGE && slot != PM_NONE {          // a group of more than 64 nodes: its size is in the record
+            members.resize(g.n_members as usize, 0);
+            rc = call(&mut g, members.as_mut_ptr(), members.len() as u32, &mut slot);
+        }
+        if rc == PM_ERANGE && slot == PM_NONE { return Ok(None); }   // (a row the engine has not been sent yet: in no group)
+        check(rc)?;
+        if slot == PM_NONE { return Ok(None); }
+        Ok(Some(self.make_group(t, &g, &members[..g.n_members as usize])))
+    }
+
+    /// get_all_groups (mod.rs:1006-1044): every group, sorted by id text (:1040)
+    pub(crate) async fn get_all_groups(&self) -> Result<Vec<NodeGroup>, Error> {
+        let t = self.nodes.read();
+        let (_, groups, members) = self.snapshot_groups(t.rows.len(), false)?;
+        let mut out: Vec<NodeGroup> = groups.iter()
+            .map(|g| self.make_group(&t, g, &members[g.member_begin as usize..(g.member_begin + g.n_members) as usize])).collect();
+        out.sort_by(|a, b| a.id.cmp(&b.id));
+        Ok(out)
+    }
+
+    /// get_group_by_id (mod.rs:1046-1055)
+    pub(crate) async fn get_group_by_id(&self, group_id: &str) -> Result<Option<NodeGroup>, Error> {
+        let Some(id) = Self::parse_group_id(group_id) else { return Ok(None) };
+        let t = self.nodes.read();
+        self.one_group(&t, |g, m, cap, slot| unsafe { pm_get_group_by_id(self.engine, id, g, m, cap, slot) })
+    }
+
+    /// get_all_node_group_mappings (mod.rs:1057-1065): node address text -> group id text
+    pub(crate) async fn get_all_node_group_mappings(&self) -> Result<HashMap<String, String>, Error> {
+        let t = self.nodes.read();
+        let (_, groups, members) = self.snapshot_groups(t.rows.len(), false)?;
+        let mut out = HashMap::new();
+        for g in &groups {
+            let id = format!("{:x}", g.id);
+            for &w in &members[g.member_begin as usize..(g.member_begin + g.n_members) as usize] {
+                out.insert(t.address_strings[w as usize].clone(), id.clone());
+            }
+        }
+        Ok(out)
+    }
+
+    /// get_node_group (mod.rs:324-337)
+    pub async fn get_node_group(&self, node_addr: &str) -> Result<Option<NodeGroup>, Error> {
+        let t = self.nodes.read();
+        let Some(row) = Self::row_of_address_text(&t, node_addr) else { return Ok(None) };
+        self.one_group(&t, |g, m, cap, slot| unsafe { pm_get_group_of_worker(self.engine, row, g, m, cap, slot) })
+    }
+
+    /// get_node_groups_batch (mod.rs:339-397): every asked address is a key of the result; one snapshot of the list
+    pub async fn get_node_groups_batch(&self, node_addresses: &[String]) -> Result<HashMap<String, Option<NodeGroup>>, Error> {
+        let mut result = HashMap::new();
+        if node_addresses.is_empty() { return Ok(result); }                             // mod.rs:346-348
+        let t = self.nodes.read();
+        let (group_of, groups, members) = self.snapshot_groups(t.rows.len(), true)?;
+        let mut made: HashMap<i32, NodeGroup> = HashMap::new();      // every group is built once (the reference MGETs the unique ids)
+        for a in node_addresses {
+            let gi = Self::row_of_address_text(&t, a).and_then(|r| group_of.get(r as usize).copied()).filter(|&g| g >= 0);
+            let group = gi.map(|gi| made.entry(gi).or_insert_with(|| {
+                let g = &groups[gi as usize];
+                self.make_group(&t, g, &members[g.member_begin as usize..(g.member_begin + g.n_members) as usize])
+            }).clone());
+            result.insert(a.clone(), group);
+        }
+        Ok(result)
+    }
+
+    /// get_idx_in_group (mod.rs:424-434)
+    pub fn get_idx_in_group(&self, node_group: &NodeGroup, node_addr: &str) -> Result<usize, Error> {
+        node_group.nodes.iter().position(|n| n == node_addr).ok_or_else(|| anyhow!("Node {} not found in group", node_addr))
+    }
+
+    fn ordered_templates(&self, enabled: u64) -> Vec<NodeGroupConfiguration> {
+        let mut order = vec![0u32; self.config_rows.len() + 1];
+        let mut n = 0u32;
+        let rc = unsafe { pm_host_config_order(self.config_rows.as_ptr(), self.config_rows.len() as u32, enabled, order.as_mut_ptr(), &mut n) };
+        if rc != 0 { return vec![]; }                                                   // (the reference answers vec![] on a store error, mod.rs:400-402)
+        order[..n as usize].iter().map(|&c| self.templates[c as usize].clone()).collect()
+    }
+
+    /// get_available_configurations (mod.rs:399-418): the templates some task names, min_group_size descending (stable)
+    pub async fn get_available_configurations(&self) -> Vec<NodeGroupConfiguration> {
+        self.ordered_templates(self.enabled_mask.load(Ordering::Acquire))
+    }
+
+    /// get_all_configuration_templates (mod.rs:420-422): in the constructor's order (mod.rs:150-164) = the carve order
+    /// with nothing disabled
+    pub fn get_all_configuration_templates(&self) -> Vec<NodeGroupConfiguration> {
+        let c = self.config_rows.len();
+        self.ordered_templates(if c >= 64 { u64::MAX } else { (1u64 << c) - 1 })
+    }
+
+    /// dissolve_group (mod.rs:1002-1004 -> :1423-1487): by id text; an id that names no group is Ok(()) ("No group found")
+    pub(crate) async fn dissolve_group(&self, group_id: &str) -> Result<(), Error> {
+        let Some(id) = Self::parse_group_id(group_id) else { return Ok(()) };
+        let mut dissolved = 0u32;
+        check(unsafe { pm_dissolve_group_by_id(self.engine, id, &mut dissolved) })?;
+        if dissolved != 0 { self.emit_group_webhooks()?; }                              // send_group_destroyed, mod.rs:1469-1481
+        Ok(())
     }
 
     /// StatusUpdatePlugin::handle_status_change (status_update_impl.rs:8-39).

@@ -51,7 +51,7 @@ struct pm_engine {
   std::vector<MockGroup> groups;
   std::vector<int32_t> group_of;
   bool published = false;
-  uint64_t id_rng = 1;
+  uint64_t id_rng = 1, id_seed = 1;
   bool events_on = false;
   std::vector<pm_group_event> ev;
   std::vector<uint32_t> ev_members;
@@ -123,7 +123,7 @@ int32_t pm_engine_create(const pm_engine_config* cfg, pm_engine** out) {
   if (!cfg || !out) return pm::set_error(PM_EINVAL, "null argument");
   if (cfg->abi_version != PM_ABI_VERSION) return pm::set_error(PM_EINVAL, "ABI version mismatch");
   pm_engine* e = new pm_engine();
-  e->id_rng = cfg->group_id_seed;
+  e->id_rng = e->id_seed = cfg->group_id_seed;
   *out = e;
   logf("create device=" + std::to_string(cfg->device));
   return PM_OK;
@@ -168,11 +168,15 @@ int32_t pm_set_enabled_mask(pm_engine* e, uint64_t enabled) {
 int32_t pm_upload_workers(pm_engine* e, const pm_worker_soa* w, uint32_t keep_groups) {
   if (!e || !w) return pm::set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (keep_groups && w->n < e->flags.size()) return pm::set_error(PM_EINVAL, "keep_groups requires the rows the engine has in front");
   e->flags.assign(w->flags, w->flags + w->n);
   e->addr_rank.assign(w->addr_rank, w->addr_rank + w->n);
   if (!keep_groups) {
     e->groups.clear();
     e->group_of.assign(w->n, -1);
+    e->id_rng = e->id_seed;  // (the real engine restarts its id stream with the groups)
+  } else {
+    e->group_of.resize(w->n, -1);
   }
   logf("upload_workers n=" + std::to_string(w->n) + " keep=" + std::to_string(keep_groups));
   return PM_OK;
@@ -323,6 +327,81 @@ int32_t pm_drain_group_events(pm_engine* e, pm_group_event* events, uint32_t cap
   std::copy(e->ev_members.begin(), e->ev_members.end(), members);
   e->ev.clear();
   e->ev_members.clear();
+  return PM_OK;
+}
+
+static void fill_group(const MockGroup& g, pm_group* out, const pm_engine* e) {
+  out->id = g.id;
+  out->config = g.cfg;
+  out->n_members = uint32_t(g.members.size());
+  out->member_begin = 0;
+  out->task = PM_NONE;
+  if (g.task_uid)
+    for (size_t i = 0; i < e->tasks.size(); ++i)
+      if (e->tasks[i].uid == g.task_uid) out->task = uint32_t(i);
+}
+int32_t pm_get_groups(pm_engine* e, int32_t* group_of_worker, pm_group* groups, uint32_t cap_groups, uint32_t* n_groups,
+                      uint32_t* members, uint32_t cap_members, uint32_t* n_members) {
+  if (!e) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  uint32_t M = 0;
+  for (const MockGroup& g : e->groups) M += uint32_t(g.members.size());
+  if (n_groups) *n_groups = uint32_t(e->groups.size());
+  if (n_members) *n_members = M;
+  if (group_of_worker) std::copy(e->group_of.begin(), e->group_of.end(), group_of_worker);
+  if (groups && cap_groups < e->groups.size()) return pm::set_error(PM_ERANGE, "groups buffer too small");
+  if (members && cap_members < M) return pm::set_error(PM_ERANGE, "members buffer too small");
+  uint32_t off = 0;
+  for (size_t g = 0; g < e->groups.size(); ++g) {
+    if (groups) {
+      fill_group(e->groups[g], &groups[g], e);
+      groups[g].member_begin = off;
+    }
+    if (members) std::copy(e->groups[g].members.begin(), e->groups[g].members.end(), members + off);
+    off += uint32_t(e->groups[g].members.size());
+  }
+  return PM_OK;
+}
+static int32_t give_one(pm_engine* e, size_t g, pm_group* out, uint32_t* members, uint32_t cap) {
+  fill_group(e->groups[g], out, e);
+  if (!members) return PM_OK;
+  if (cap < e->groups[g].members.size()) return pm::set_error(PM_ERANGE, "members buffer too small");
+  std::copy(e->groups[g].members.begin(), e->groups[g].members.end(), members);
+  return PM_OK;
+}
+int32_t pm_get_group_by_id(pm_engine* e, uint64_t id, pm_group* out, uint32_t* members, uint32_t cap, uint32_t* slot) {
+  if (!e || !out || !slot) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  std::memset(out, 0, sizeof(*out));
+  *slot = PM_NONE;
+  for (size_t g = 0; g < e->groups.size(); ++g)
+    if (e->groups[g].id == id) {
+      *slot = uint32_t(g);
+      return give_one(e, g, out, members, cap);
+    }
+  return PM_OK;
+}
+int32_t pm_get_group_of_worker(pm_engine* e, uint32_t w, pm_group* out, uint32_t* members, uint32_t cap, uint32_t* slot) {
+  if (!e || !out || !slot) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (w >= e->flags.size()) return pm::set_error(PM_ERANGE, "worker index out of range");
+  std::memset(out, 0, sizeof(*out));
+  *slot = e->group_of[w] < 0 ? PM_NONE : uint32_t(e->group_of[w]);
+  if (e->group_of[w] < 0) return PM_OK;
+  return give_one(e, size_t(e->group_of[w]), out, members, cap);
+}
+int32_t pm_dissolve_group_by_id(pm_engine* e, uint64_t id, uint32_t* dissolved) {
+  if (!e) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (dissolved) *dissolved = 0;
+  for (size_t g = 0; g < e->groups.size(); ++g)
+    if (e->groups[g].id == id) {
+      dissolve(e, g);
+      if (dissolved) *dissolved = 1;
+      logf("dissolve_group_by_id found");
+      return PM_OK;
+    }
+  logf("dissolve_group_by_id unknown");
   return PM_OK;
 }
 

@@ -7,10 +7,15 @@
 //   scheduler/mod.rs:87-104  test_get_task_for_node        -> scheduler_returns_the_stores_task
 //   scheduler/mod.rs:106-160 test_variable_replacement     -> scheduler_replaces_task_and_node_variables
 //   newest_task/mod.rs:27-60 test_filter_tasks             -> newest_task_plugin_picks_the_newest
+//   node_groups/tests.rs:1381-1446 test_get_idx_in_group, :1448-1465 ..._not_found -> read_surface_idx_in_group
+//   api/routes/storage.rs:534-716 test_with_node_and_group, :718-.. test_upload_counter_without_node_group
+//                                                           -> storage_route_file_name_through_the_read_surface
 // The matching itself is NOT tested here (the mock's is a toy): that is tests/test_gpu_*.py against the oracle.
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -249,10 +254,13 @@ static void sync_nodes_resends_everything_after_a_failed_interval() {
   CHECK_EQ(*p.row_of(addr(9)), 5u);
   bool uploaded = false;
   for (const std::string& x : c) {
-    uploaded = uploaded || x == "upload_workers n=6 keep=0";
+    uploaded = uploaded || x == "upload_workers n=6 keep=1";   // the groups and the id stream survive a resync
     CHECK(!starts_with(x, "append_workers") && !starts_with(x, "update_workers"));
   }
   CHECK(uploaded);
+  // the departed node (row 2) goes out as dead behind the upload: whatever group it was in dissolves WITH its webhook
+  CHECK_EQ(calls_named("on_worker_status_many").size(), size_t(1));
+  if (!calls_named("on_worker_status_many").empty()) CHECK(starts_with(calls_named("on_worker_status_many")[0], "on_worker_status_many w=[2]"));
   // ... and deltas again from then on
   pm_mock_reset_calls();
   p.sync_nodes({node(8), node(3), node(1), node(7), node(9), node(10)});
@@ -544,6 +552,208 @@ static void heartbeats_race_the_task_observers() {
   CHECK_EQ(wrong.load(), 0l);
 }
 
+
+// ------------------------------------------------------------------------------------------------ the read surface
+
+static void read_surface_idx_in_group() {
+  GpuMatchPlugin p({}, 0, nullptr);
+  NodeGroup g;
+  g.id = "test-group";
+  g.nodes = {"0x1234567890123456789012345678901234567890", "0x2234567890123456789012345678901234567890",
+             "0x3234567890123456789012345678901234567890"};
+  g.configuration_name = "test-config";
+  CHECK_EQ(p.get_idx_in_group(g, "0x1234567890123456789012345678901234567890"), size_t(0));
+  CHECK_EQ(p.get_idx_in_group(g, "0x2234567890123456789012345678901234567890"), size_t(1));
+  CHECK_EQ(p.get_idx_in_group(g, "0x3234567890123456789012345678901234567890"), size_t(2));
+  bool threw = false;
+  try {
+    p.get_idx_in_group(g, "0x4234567890123456789012345678901234567890");
+  } catch (const std::out_of_range& e) {
+    threw = std::string(e.what()) == "Node 0x4234567890123456789012345678901234567890 not found in group";
+  }
+  CHECK(threw);
+}
+
+static void read_surface_groups_and_mappings() {
+  auto rec = std::make_shared<Recorder>();
+  GpuMatchPlugin p(two_configs(), 0, nullptr, {rec});
+  int64_t now = 1000;
+  p.clock = [&] { return now; };
+  CHECK(p.get_all_groups().empty());
+  CHECK(p.get_all_node_group_mappings().empty());
+  CHECK(p.get_node_groups_batch({}).empty());                                       // mod.rs:346-348
+  p.sync_nodes({node(0), node(1), node(2), node(3), node(4)});
+  p.sync_tasks({task(1, 100, std::vector<std::string>{"pair"}), task(2, 90, std::vector<std::string>{"solo"})});
+  p.tick();   // the toy's cut: pair(rows 0,1), solo(2), pair(3,4)
+  std::vector<NodeGroup> all = p.get_all_groups();
+  CHECK_EQ(all.size(), size_t(3));
+  for (size_t i = 1; i < all.size(); ++i) CHECK(all[i - 1].id < all[i].id);        // sorted by id TEXT (mod.rs:1040)
+  size_t pairs = 0, solos = 0, nodes_in_groups = 0;
+  for (const NodeGroup& g : all) {
+    CHECK_EQ(g.created_at, int64_t(1000));
+    CHECK(!g.id.empty() && g.id.find_first_not_of("0123456789abcdef") == std::string::npos);
+    for (size_t i = 1; i < g.nodes.size(); ++i) CHECK(g.nodes[i - 1] < g.nodes[i]);   // BTreeSet<String> order
+    pairs += g.configuration_name == "pair";
+    solos += g.configuration_name == "solo";
+    nodes_in_groups += g.nodes.size();
+    // get_group_by_id gives the same record
+    const std::optional<NodeGroup> again = p.get_group_by_id(g.id);
+    CHECK(again.has_value() && *again == g);
+    // every member's get_node_group is this group, its index the position in the set
+    for (size_t i = 0; i < g.nodes.size(); ++i) {
+      const std::optional<NodeGroup> mine = p.get_node_group(g.nodes[i]);
+      CHECK(mine.has_value() && *mine == g);
+      if (mine) CHECK_EQ(p.get_idx_in_group(*mine, g.nodes[i]), i);
+    }
+  }
+  CHECK_EQ(pairs, size_t(2));
+  CHECK_EQ(solos, size_t(1));
+  CHECK_EQ(nodes_in_groups, size_t(5));
+  // ids that are no group's: unknown number, not the "{:x}" form (upper case, leading zero, prefix, too long, empty)
+  for (const char* bad : {"1234567", "ABCDEF", "0abc", "0x12", "12345678901234567", "", "g1"}) CHECK(!p.get_group_by_id(bad).has_value());
+  // the mapping: every grouped node -> its group's id
+  const auto map = p.get_all_node_group_mappings();
+  CHECK_EQ(map.size(), size_t(5));
+  for (const NodeGroup& g : all)
+    for (const std::string& n : g.nodes) CHECK(map.count(n) == 1 && map.at(n) == g.id);
+  // the batch: every asked address is a key; unknown addresses and nodes in no group map to None
+  p.sync_nodes({node(0), node(1), node(2), node(3), node(4), node(5, NodeStatus::Unhealthy)});
+  const auto batch = p.get_node_groups_batch({addr(0).text, addr(5).text, "0xnot-a-node", addr(4).text});
+  CHECK_EQ(batch.size(), size_t(4));
+  CHECK(batch.at(addr(0).text).has_value() && batch.at(addr(4).text).has_value());
+  CHECK(!batch.at(addr(5).text).has_value() && !batch.at("0xnot-a-node").has_value());
+  if (batch.at(addr(0).text)) CHECK(*batch.at(addr(0).text) == *p.get_node_group(addr(0).text));
+  CHECK(!p.get_node_group(addr(5).text).has_value());
+  CHECK(!p.get_node_group("0xnot-a-node").has_value());
+  // dissolve_group by id: the webhook goes out, the group and its mappings are gone, an unknown id is not an error
+  const NodeGroup victim = all[0];
+  {
+    std::lock_guard<std::mutex> lk(rec->mu);
+    rec->lines.clear();
+  }
+  pm_mock_reset_calls();
+  p.dissolve_group(victim.id);
+  {
+    std::lock_guard<std::mutex> lk(rec->mu);
+    CHECK_EQ(rec->lines.size(), size_t(1));
+    if (!rec->lines.empty()) CHECK(starts_with(rec->lines[0], "destroyed " + victim.id + " " + victim.configuration_name + " " + victim.nodes[0]));
+  }
+  CHECK(!p.get_group_by_id(victim.id).has_value());
+  CHECK(!p.get_node_group(victim.nodes[0]).has_value());
+  CHECK_EQ(p.get_all_groups().size(), size_t(2));
+  CHECK_EQ(p.get_all_node_group_mappings().size(), 5 - victim.nodes.size());
+  p.dissolve_group(victim.id);        // again: "No group found with ID" -> Ok(())
+  p.dissolve_group("not-hex");        // not the text of any id: nothing reaches the engine
+  CHECK_EQ(calls_named("dissolve_group_by_id").size(), size_t(2));
+  // a group formed later carries the later clock; the survivors keep theirs
+  now = 2000;
+  p.tick();
+  for (const NodeGroup& g : p.get_all_groups()) {
+    const bool old = std::any_of(all.begin(), all.end(), [&](const NodeGroup& o) { return o.id == g.id; });
+    CHECK_EQ(g.created_at, int64_t(old ? 1000 : 2000));
+  }
+}
+
+static void read_surface_configurations() {
+  // templates in the constructor's order (mod.rs:150-164): min_group_size descending, with-requirements first among equals;
+  // available = the ones some task names, min_group_size descending (mod.rs:399-418)
+  NodeGroupConfiguration a{"any-two", 2, 4, std::nullopt};
+  NodeGroupConfiguration b{"solo", 1, 1, std::nullopt};
+  NodeGroupConfiguration c{"gpu-two", 2, 2, std::string("gpu:count=8")};
+  NodeGroupConfiguration d{"big", 8, 8, std::nullopt};
+  GpuMatchPlugin p({a, b, c, d}, 0, nullptr);
+  const auto names = [](const std::vector<NodeGroupConfiguration>& v) {
+    std::string s;
+    for (const auto& x : v) s += x.name + " ";
+    return s;
+  };
+  CHECK_EQ(names(p.get_all_configuration_templates()), std::string("big gpu-two any-two solo "));
+  CHECK_EQ(names(p.get_available_configurations()), std::string(""));               // nothing enabled yet
+  const std::vector<NodeGroupConfiguration> all = p.get_all_configuration_templates();
+  CHECK(all[1].compute_requirements.has_value() && *all[1].compute_requirements == "gpu:count=8" && all[1].max_group_size == 2);
+  const Task t1 = task(1, 100, std::vector<std::string>{"solo", "any-two"}), t2 = task(2, 200, std::vector<std::string>{"big"});
+  p.sync_tasks({t1});
+  CHECK_EQ(names(p.get_available_configurations()), std::string("any-two solo "));
+  p.on_task_created(t2, [&] { return std::vector<Task>{t2, t1}; });
+  CHECK_EQ(names(p.get_available_configurations()), std::string("big any-two solo "));
+  p.on_task_deleted(t1);                                                               // tests.rs:1467-1627: the last task of a topology disables it
+  CHECK_EQ(names(p.get_available_configurations()), std::string("big "));
+  // get_task_topologies (mod.rs:1407-1421): what create_task refuses an empty answer of (api/routes/task.rs:68-75)
+  CHECK_EQ(get_task_topologies(t1).size(), size_t(2));
+  CHECK(get_task_topologies(task(3, 1, std::nullopt)).empty());
+}
+
+static void storage_route_file_name_through_the_read_surface() {
+  // api/routes/storage.rs:534-716: one node, a configuration of one — the upload's name carries the group id, size 1, index
+  // 0, the count after this upload and the file's index; :718-..: a node in no group gets the counts only, under "no-group"
+  NodeGroupConfiguration cfg{"test-config", 1, 1, std::nullopt};
+  GpuMatchPlugin p({cfg}, 0, nullptr);
+  p.sync_nodes({node(0), node(1, NodeStatus::Unhealthy)});
+  p.sync_tasks({task(1, 100, std::vector<std::string>{"test-config"})});
+  p.tick();
+  const std::optional<NodeGroup> group = p.get_node_group(addr(0).text);
+  CHECK(group.has_value());
+  if (!group) return;
+  const std::string tmpl = "model_xyz/dataset_1/${NODE_GROUP_ID}-${NODE_GROUP_SIZE}-${NODE_GROUP_INDEX}-${TOTAL_UPLOAD_COUNT_AFTER}-${CURRENT_FILE_INDEX}.parquet";
+  std::vector<std::string> asked;
+  uint64_t uploads = 1;
+  const auto count = [&](const std::string& a, const std::string& g) {
+    asked.push_back(a + ":" + g);
+    return uploads;
+  };
+  std::string gid;
+  CHECK_EQ(upload_file_name(p, tmpl, addr(0).text, count, &gid), "model_xyz/dataset_1/" + group->id + "-1-0-1-0.parquet");
+  CHECK_EQ(gid, group->id);
+  uploads = 2;   // (a second, different file: the route's key count went up)
+  CHECK_EQ(upload_file_name(p, tmpl, addr(0).text, count, &gid), "model_xyz/dataset_1/" + group->id + "-1-0-2-1.parquet");
+  CHECK_EQ(asked.back(), addr(0).text + ":" + group->id);
+  // the node outside any group: the group variables stay as they are, the counter is keyed "no-group"
+  uploads = 1;
+  CHECK_EQ(upload_file_name(p, "x/${NODE_GROUP_ID}/${TOTAL_UPLOAD_COUNT_AFTER}-${CURRENT_FILE_INDEX}", addr(1).text, count, &gid),
+           std::string("x/${NODE_GROUP_ID}/1-0"));
+  CHECK_EQ(gid, std::string());
+  CHECK_EQ(asked.back(), addr(1).text + ":no-group");
+}
+
+static void resync_keeps_groups_and_reports_the_dissolved_ones() {
+  // the resync after a failed interval must not drop the groups silently (no webhook, ids reused)
+  auto rec = std::make_shared<Recorder>();
+  GpuMatchPlugin p(two_configs(), 0, nullptr, {rec});
+  p.sync_nodes({node(0), node(1), node(2), node(3)});
+  p.sync_tasks({task(1, 100, std::vector<std::string>{"pair"})});
+  p.tick();                                      // pair(0,1), pair(2,3)
+  const std::vector<NodeGroup> before = p.get_all_groups();
+  CHECK_EQ(before.size(), size_t(2));
+  pm_mock_fail_appends(1);
+  bool threw = false;
+  try {
+    p.sync_nodes({node(0), node(1), node(2), node(6)});   // node 3 left (its pair must dissolve), node 6 is new: the append fails
+  } catch (const EngineError&) {
+    threw = true;
+  }
+  CHECK(threw);
+  {
+    std::lock_guard<std::mutex> lk(rec->mu);
+    rec->lines.clear();
+  }
+  p.sync_nodes({node(0), node(1), node(2), node(6)});     // the resync
+  const std::optional<NodeGroup> kept = p.get_node_group(addr(0).text);
+  CHECK(kept.has_value());
+  if (kept) CHECK(std::any_of(before.begin(), before.end(), [&](const NodeGroup& g) { return g == *kept; }));   // same id, same nodes, same stamp
+  CHECK(!p.get_node_group(addr(2).text).has_value());     // node 3's partner is free again
+  {
+    std::lock_guard<std::mutex> lk(rec->mu);
+    size_t destroyed = 0;
+    for (const std::string& l : rec->lines) destroyed += starts_with(l, "destroyed ");
+    CHECK(destroyed >= 1);                                // (the tombstone may have gone out with the failed interval already: then its webhook did too)
+  }
+  p.tick();                                               // pair(2, 6) forms with a NEW id
+  const std::optional<NodeGroup> fresh = p.get_node_group(addr(2).text);
+  CHECK(fresh.has_value());
+  if (fresh)
+    for (const NodeGroup& g : before) CHECK(fresh->id != g.id);
+}
+
 int main(int argc, char** argv) {
   struct { const char* name; void (*fn)(); } tests[] = {
       {"constructor_contract", constructor_contract},
@@ -558,6 +768,11 @@ int main(int argc, char** argv) {
       {"newest_task_plugin_picks_the_newest", newest_task_plugin_picks_the_newest},
       {"task_uid_is_the_uuids_low_half", task_uid_is_the_uuids_low_half},
       {"heartbeats_race_the_task_observers", heartbeats_race_the_task_observers},
+      {"read_surface_idx_in_group", read_surface_idx_in_group},
+      {"read_surface_groups_and_mappings", read_surface_groups_and_mappings},
+      {"read_surface_configurations", read_surface_configurations},
+      {"storage_route_file_name_through_the_read_surface", storage_route_file_name_through_the_read_surface},
+      {"resync_keeps_groups_and_reports_the_dissolved_ones", resync_keeps_groups_and_reports_the_dissolved_ones},
   };
   int ran = 0;
   for (const auto& t : tests) {

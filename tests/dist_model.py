@@ -6,12 +6,11 @@ protocol_amd.dist.ShardedEngine — the code under test — can run on CPU with 
 collectives:
 
   tick_begin       eligible list, first candidate list, the batch's seeds (live located slots below a limit)
-  carve_next       this rank computes the neighbour rows of the seeds it is dealt (seed i -> rank i % world) into
-                   its send segment; recv = [world][rows_pr][64]
-  carve_validate   the sequential chain of try_form_new_groups (mod.rs:505-610), replicated on every rank: a
-                   step is served from the seed's row (row minus dead entries — candidates only ever leave) when
-                   the row still holds enough live entries, else by the exact sort; re-prepares when the seed lies
-                   beyond the batch or half of the list is dead
+  carve_wait       the whole carve, REPLICATED on every rank (the engine's protocol since round 5; nothing is exchanged):
+                   per batch the neighbour rows of its seeds, then the sequential chain of try_form_new_groups
+                   (mod.rs:505-610) — a step is served from the seed's row (row minus dead entries — candidates only
+                   ever leave) when the row still holds enough live entries, else by the exact sort; re-prepares when
+                   the seed lies beyond the batch or half of the list is dead
   match_begin      topology filter + claim for the OWNED workers, rows packed into this rank's segment
   tick_end         scatter of the all-gathered segments into the full per-worker table
 
@@ -33,11 +32,7 @@ F64_MAX = 1.7976931348623157e308
 
 
 class ModelLocal:
-    def __init__(self, sw, *, group_id_seed=1, proximity=True, max_seeds=16384, min_cap=512, local_carve=False):
-        # local_carve: the engine's protocol since round 5 — every rank carves the whole pool itself (its rows are its own),
-        # carve_next reports no batch; False: a batch's rows are dealt over the ranks and all-gathered (what
-        # ShardedEngine's loop is for)
-        self.local_carve = local_carve
+    def __init__(self, sw, *, group_id_seed=1, proximity=True, max_seeds=16384, min_cap=512):
         self.sw = sw
         nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
         self.masks = orc.compat_masks(nodes, cfgs)
@@ -52,14 +47,12 @@ class ModelLocal:
         self.proximity = proximity
         self.max_seeds, self.min_cap = max_seeds, min_cap
         self.rank, self.world = 0, 1
-        self.c_rank, self.c_world = 0, 1
+        self.c_rank, self.c_world = 0, 1      # (who makes which row of a batch: this rank, all of them)
         self.batches = 0
-        self.rows_from_others = 0
 
     # ---------------------------------------------------------------- ownership
     def configure(self, rank, world, shard):
         self.rank, self.world = rank, world
-        self.c_rank, self.c_world = (0, 1) if self.local_carve else (rank, world)   # who makes which row of a batch
         self.shard = np.asarray(shard, dtype=np.int64)
         self.own = np.nonzero(self.shard == rank)[0]
         counts = np.bincount(self.shard, minlength=world)
@@ -126,15 +119,12 @@ class ModelLocal:
         d[has] = orc.distance_column(float(sw.lat[ws]), float(sw.lon[ws]), sw.lat[w[has]], sw.lon[w[has]])
         return idx[np.argsort(d, kind="stable")]
 
-    def carve_next(self):
-        if self.local_carve:   # the whole carve here and now: every batch's rows made and used by this rank
-            while not self.done:
-                more, send, recv = self._carve_next_batch()
-                if send is not None:
-                    recv.copy_(send)
-                self.carve_validate()
-            return False, None, None
-        return self._carve_next_batch()
+    def carve_wait(self):
+        while not self.done:   # every batch's rows made and used by this rank
+            _more, send, recv = self._carve_next_batch()
+            if send is not None:
+                recv.copy_(send)
+            self.carve_validate()
 
     def _carve_next_batch(self):
         if self.done:
@@ -174,9 +164,7 @@ class ModelLocal:
                     i = self.seed_no[seed]
                     r0 = ((i % self.c_world) * self.rows_pr + i // self.c_world) * ROW
                     row = recv[r0:r0 + ROW]
-                    assert row[ROW - 1] in (0, 1), "the row of another rank never arrived"
-                    if i % self.c_world != self.c_rank:
-                        self.rows_from_others += 1
+                    assert row[ROW - 1] in (0, 1), "the seed's row was never made"
                     ent = row[:ROW - 1]
                     ent = ent[ent >= 0]
                     alive_ent = ent[self.alive[ent]]

@@ -77,6 +77,17 @@ def plugin_lib(path: str | None = None) -> C.CDLL:
         sz = C.c_size_t
         L.pmx_get_task_for_node.argtypes = [vp, C.c_char_p, C.c_int64, C.c_char_p, sz, C.POINTER(sz)]
         L.pmx_take_webhooks.argtypes = [vp, C.c_char_p, sz, C.POINTER(sz)]
+        text = [C.c_char_p, sz, C.POINTER(sz)]
+        L.pmx_set_clock.argtypes = [vp, C.c_int64]
+        L.pmx_set_clock.restype = None
+        L.pmx_get_all_groups.argtypes = [vp] + text
+        L.pmx_get_group_by_id.argtypes = [vp, C.c_char_p] + text
+        L.pmx_get_node_group.argtypes = [vp, C.c_char_p] + text
+        L.pmx_get_node_groups_batch.argtypes = [vp, C.POINTER(C.c_char_p), u32] + text
+        L.pmx_get_all_node_group_mappings.argtypes = [vp] + text
+        L.pmx_get_configurations.argtypes = [vp, u32] + text
+        L.pmx_dissolve_group.argtypes = [vp, C.c_char_p]
+        L.pmx_upload_file_name.argtypes = [vp, C.c_char_p, C.c_char_p] + text
         _plib = L
     return _plib
 
@@ -151,7 +162,7 @@ class PluginCxx:
                        int(p["gpu_count"][node]), int(p["gpu_mem_mb"][node]), model, int(p["cpu_cores"][node]),
                        int(p["ram_mb"][node]), int(p["storage_gb"][node]), float(p["lat"][node]), float(p["lon"][node]))
 
-    def _task(self, mask: int, created: int, uid: int, keep: list) -> PmxTask:
+    def _task(self, mask: int, created: int, uid: int, keep: list, env=None, cmd=None, mounts=None) -> PmxTask:
         mask = int(mask) & ALL
         if mask == ALL:
             n_topo, names = -1, []
@@ -161,7 +172,14 @@ class PluginCxx:
         arr = (C.c_char_p * max(len(names), 1))(*names)
         ident = uuid_of(int(uid)).encode()
         keep += [arr, ident]
-        return PmxTask(ident, b"task", int(created), n_topo, arr, 0, None, None, -1, None, -1, None, None)
+        def strings(items):
+            a = (C.c_char_p * max(len(items), 1))(*[x.encode() for x in items])
+            keep.append(a)
+            return a
+        env = env or {}
+        return PmxTask(ident, b"task", int(created), n_topo, arr, len(env), strings(list(env.keys())), strings(list(env.values())),
+                       -1 if cmd is None else len(cmd), strings(cmd or []), -1 if mounts is None else len(mounts),
+                       strings([m[0] for m in (mounts or [])]), strings([m[1] for m in (mounts or [])]))
 
     def _take_webhooks(self):
         for line in _text(lambda o, c, n: self.L.pmx_take_webhooks(self._p, o, c, n)).splitlines():
@@ -186,11 +204,12 @@ class PluginCxx:
         _check(self.L.pmx_sync_nodes(self._p, nodes, len(snapshot)))
         self._take_webhooks()
 
-    def sync_tasks(self, masks, created, uid, enabled=None):
+    def sync_tasks(self, masks, created, uid, enabled=None, env=None, cmd=None, mounts=None):
+        """env / cmd / mounts: the same templates on every task ({key: value}, [arg], [(host, container)])"""
         keep: list = []
         tasks = (PmxTask * max(len(uid), 1))()
         for i in range(len(uid)):
-            tasks[i] = self._task(masks[i], created[i], uid[i], keep)
+            tasks[i] = self._task(masks[i], created[i], uid[i], keep, env, cmd, mounts)
         _check(self.L.pmx_sync_tasks(self._p, tasks, len(uid)))
         self.tasks = [int(u) for u in uid]
 
@@ -241,6 +260,65 @@ class PluginCxx:
         if len(args) == 2:
             return [] if uid is None else [uid]
         return uid
+
+    # ---- the read surface (what the API routes call on the plugin)
+    @staticmethod
+    def _group(fields):
+        """-> {"id", "config", "created_at", "nodes"} from the fields of a group line"""
+        return {"id": fields[0], "config": fields[1], "created_at": int(fields[2]), "nodes": fields[3:]}
+
+    def set_clock(self, now_ms: int):
+        self.L.pmx_set_clock(self._p, int(now_ms))
+
+    def set_upload_count(self, n: int):
+        self.L.pmx_set_upload_count(self._p, int(n))
+
+    def get_all_groups(self):
+        text = _text(lambda o, c, n: self.L.pmx_get_all_groups(self._p, o, c, n))
+        return [self._group([_unesc(x) for x in line.split("\t")]) for line in text.splitlines()]
+
+    def get_group_by_id(self, group_id: str):
+        text = _text(lambda o, c, n: self.L.pmx_get_group_by_id(self._p, group_id.encode(), o, c, n))
+        return self._group([_unesc(x) for x in text.splitlines()[0].split("\t")]) if text else None
+
+    def get_node_group(self, address: str):
+        """-> None or (get_idx_in_group, group)"""
+        text = _text(lambda o, c, n: self.L.pmx_get_node_group(self._p, address.encode(), o, c, n))
+        if not text:
+            return None
+        f = [_unesc(x) for x in text.splitlines()[0].split("\t")]
+        return int(f[0]), self._group(f[1:])
+
+    def get_node_groups_batch(self, addresses):
+        arr = (C.c_char_p * max(len(addresses), 1))(*[a.encode() for a in addresses])
+        text = _text(lambda o, c, n: self.L.pmx_get_node_groups_batch(self._p, arr, len(addresses), o, c, n))
+        out = {}
+        for line in text.splitlines():
+            f = [_unesc(x) for x in line.split("\t")]
+            out[f[0]] = None if f[1:] == ["-"] else self._group(f[1:])
+        return out
+
+    def get_all_node_group_mappings(self):
+        text = _text(lambda o, c, n: self.L.pmx_get_all_node_group_mappings(self._p, o, c, n))
+        return dict(tuple(_unesc(x) for x in line.split("\t")) for line in text.splitlines())
+
+    def get_configurations(self, available_only: bool):
+        text = _text(lambda o, c, n: self.L.pmx_get_configurations(self._p, int(available_only), o, c, n))
+        out = []
+        for line in text.splitlines():
+            name, mn, mx, req = [_unesc(x) for x in line.split("\t")]
+            out.append((name, int(mn), int(mx), None if req == "-" else req))
+        return out
+
+    def dissolve_group(self, group_id: str):
+        _check(self.L.pmx_dissolve_group(self._p, group_id.encode()))
+        self._take_webhooks()
+
+    def upload_file_name(self, file_name: str, address: str):
+        """-> (the rendered name, the group the route keys its upload counter by)"""
+        text = _text(lambda o, c, n: self.L.pmx_upload_file_name(self._p, file_name.encode(), address.encode(), o, c, n))
+        name, key = text.split("\n")[:2]
+        return _unesc(name), _unesc(key)
 
     @property
     def store_loads(self) -> int:

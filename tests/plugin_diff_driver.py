@@ -70,10 +70,37 @@ def main(lib_path: str, seeds=(3, 4, 5)) -> int:
         present = list(range(100))
         snap = np.array(present)
         r.shuffle(snap)
+        def read_surface(name):
+            """the read surface as a step of its own: the answers go where the heartbeats go"""
+            addr = sw.address_strings()
+            strip = lambda g: None if g is None else (g["id"], g["config"], g["created_at"], tuple(g["nodes"]))
+            groups = shim.get_all_groups()
+            ans = [("all", [strip(g) for g in groups]), ("map", sorted(shim.get_all_node_group_mappings().items()))]
+            for n in present[:30]:
+                r = shim.get_node_group(addr[n])
+                ans.append(("node", n, None if r is None else (r[0], strip(r[1]))))
+            batch = shim.get_node_groups_batch([addr[n] for n in present[:30]] + ["0xnobody"])
+            ans.append(("batch", sorted((a, strip(g)) for a, g in batch.items())))
+            for g in groups[:3]:
+                ans.append(("by id", strip(shim.get_group_by_id(g["id"]))))
+            ans.append(("by id", shim.get_group_by_id("0123"), shim.get_group_by_id("zz")))
+            if groups:
+                shim.dissolve_group(groups[len(groups) // 2]["id"])
+                shim.dissolve_group(groups[len(groups) // 2]["id"])      # the second time: no such group, Ok(())
+                shim.dissolve_group("not-an-id")
+                ans.append(("after dissolve", [strip(g) for g in shim.get_all_groups()]))
+            calls = L.pm_mock_calls().decode().splitlines()
+            L.pm_mock_reset_calls()
+            ev = list(shim.events)
+            shim.events.clear()
+            trace.append((name, calls, ans, ev))
+
+        shim.set_clock(1111)
         shim.sync_nodes(snap, healthy)
         step("sync_nodes A")
         shim.tick()
         step("tick 1", present)
+        read_surface("read surface 1")
         t_max = int(created.max())
         for k in range(3):
             src = int(r.integers(0, len(masks)))
@@ -83,7 +110,7 @@ def main(lib_path: str, seeds=(3, 4, 5)) -> int:
             shim.on_task_created(new[0], new[1], new[2], enabled())
             step(f"on_task_created {k}", present[:20])
         # the task most heartbeats were answered with goes
-        answered = [b for b in trace[3][2] if b is not None]
+        answered = [b for b in next(t for t in trace if t[0] == "tick 1")[2] if b is not None]
         victim = max(set(answered), key=answered.count)
         cur = [t for t in cur if t[2] != victim]
         shim.on_task_deleted(victim, enabled())
@@ -105,8 +132,10 @@ def main(lib_path: str, seeds=(3, 4, 5)) -> int:
         r.shuffle(snap)
         shim.sync_nodes(snap, healthy)
         step("sync_nodes B", present)
+        shim.set_clock(2222)
         shim.tick()
         step("tick 2", present)
+        read_surface("read surface 2")
         shim.sync_nodes(snap, healthy)   # nothing changed
         step("sync_nodes B again")
         n_rows = len(shim.rows)
@@ -156,8 +185,8 @@ def main(lib_path: str, seeds=(3, 4, 5)) -> int:
                       next(((x, y) for x, y in zip(e1, e2) if x != y), None))
         totals[0] += len(py)
         totals[1] += sum(len(c) for _n, c, _b, _e in py)
-        totals[2] += sum(len(b) for _n, _c, b, _e in py)
-        totals[3] += sum(x is not None for _n, _c, b, _e in py for x in b)
+        totals[2] += sum(len(b) for n, _c, b, _e in py if not n.startswith("read surface"))
+        totals[3] += sum(x is not None for n, _c, b, _e in py for x in b if not n.startswith("read surface"))
         totals[4] += sum(len(e) for _n, _c, _b, e in py)
     print(f"seeds {len(seeds)}, steps {totals[0]}, C-ABI calls {totals[1]}, heartbeats {totals[2]} ({totals[3]} served), webhook events {totals[4]}")
     print("DIFF OK" if not bad else f"DIFF FAILED ({bad})")

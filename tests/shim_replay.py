@@ -11,6 +11,10 @@ protocol_amd.engine).  The "store" is a protocol_amd.swarm.Swarm; a node is a ro
                                          their current ranks), new rows (pm_append_workers + pm_set_addr_ranks), then
                                          the two-call pm_drain_group_events
   sync_tasks / on_task_created / on_task_deleted / handle_status_change / tick     as named
+  get_all_groups / get_group_by_id / get_node_group (+ get_idx_in_group) / get_node_groups_batch /
+  get_all_node_group_mappings / dissolve_group                                     the read surface the API routes call
+                                         (node_groups/mod.rs:324-434, :1002-1065): pm_get_groups, pm_get_group_by_id,
+                                         pm_get_group_of_worker, pm_dissolve_group_by_id + the drain
   Scheduler(store, [shim])               Scheduler::get_task_for_node with the INTEGRATION.md edit: a chain headed by
                                          the engine's plugin does not load the store's task list
 
@@ -86,6 +90,10 @@ class ShimReplay:
         self.sorted_rows: list = []                            # engine rows in address-string order (incremental ranks)
         self.sorted_keys: list = []
         self.events: list = []                                 # what send_group_created / _destroyed were called with
+        self.engine_rows_stale = False                         # NodeTable::engine_rows_stale
+        self.clock = lambda: 0                                 # chrono::Utc::now() (NodeGroup.created_at)
+        self.group_created_at: dict = {}                       # GpuMatchPlugin::group_created_at
+        self.addr_strings = sw.address_strings()
         self.tasks: list = []                                  # the shim's Vec<Task>: uids in list order
         empty = {f: np.zeros(0, dtype=self.packed_all[f].dtype) for f in _ROW_FIELDS}
         empty["addr_rank"] = np.zeros(0, dtype=np.uint32)
@@ -129,7 +137,14 @@ class ShimReplay:
 
     def _emit_group_webhooks(self):
         """emit_group_webhooks(): size query, then the drain (Engine.drain_group_events makes exactly these two calls)"""
-        self.events.extend(self.eng.drain_group_events())
+        ev = self.eng.drain_group_events()
+        now = self.clock()
+        for kind, gid, _cfg, _mem in ev:
+            if kind == E.GROUP_CREATED:
+                self.group_created_at[gid] = now
+            else:
+                self.group_created_at.pop(gid, None)
+        self.events.extend(ev)
 
     # ---- the plugin surface
     def sync_nodes(self, snapshot, healthy):
@@ -160,6 +175,24 @@ class ShimReplay:
                 self.sorted_keys.insert(k, key)
                 self.sorted_rows.insert(k, i)
                 appended.append(row)
+        if self.engine_rows_stale:                             # every row again, groups kept, then the deaths the engine missed
+            for i in range(len(seen)):
+                if not seen[i]:
+                    self.present[i] = False
+            gone, gone_flags = [], []
+            for i in range(len(self.rows)):
+                if not self.present[i]:
+                    self.rows[i]["flags"] = np.uint32(int(self.rows[i]["flags"]) & ~E.W_HEALTHY)
+                    gone.append(i)
+                    gone_flags.append(int(self.rows[i]["flags"]))
+            self._push_model_table()
+            self.eng.upload_workers(self._columns(self.rows, self._ranks()), keep_groups=True)
+            if gone:
+                self.eng.on_worker_status_many(np.array(gone), np.array(gone_flags, dtype=np.uint32), np.ones(len(gone), dtype=np.uint32))
+            self.engine_rows_stale = False
+            self._emit_group_webhooks()
+            return
+        self.engine_rows_stale = True                          # (cleared behind the last engine call below)
         if new_model:
             self._push_model_table()
         gone, gone_flags = [], []
@@ -179,8 +212,10 @@ class ShimReplay:
             self.eng.update_workers(np.array(upd_idx), self._columns(updated, ranks_known[np.array(upd_idx)]))
         if appended:
             first = self.eng.append_workers(self._columns(appended, np.zeros(len(appended), dtype=np.uint32)))
-            assert first == len(seen)
+            if first != len(seen):
+                raise RuntimeError("the engine's worker table and the plugin's row map disagree")
             self.eng.set_addr_ranks(self._ranks())
+        self.engine_rows_stale = False
         self._emit_group_webhooks()
 
     def _push_enabled(self):
@@ -258,6 +293,79 @@ class ShimReplay:
         if as_list:
             return [] if uid is None else [uid]
         return uid
+
+    # ---- the read surface (same record as tests/plugin_cxx.PluginCxx: {"id", "config", "created_at", "nodes"})
+    def _make_group(self, gid: int, cfg: int, members) -> dict:
+        return {"id": "%x" % gid, "config": self.sw.configs[cfg][0],
+                "created_at": self.group_created_at.get(gid, self.clock()),
+                "nodes": [self.addr_strings[self.node_of_row[int(w)]] for w in members]}
+
+    @staticmethod
+    def _parse_group_id(text: str):
+        if not text or len(text) > 16 or (len(text) > 1 and text[0] == "0") or any(c not in "0123456789abcdef" for c in text):
+            return None
+        return int(text, 16)
+
+    def _row_of_address_text(self, text: str):
+        node = next((n for n in self.index if self.addr_strings[n] == text), None)   # (the Rust: a binary search)
+        return None if node is None else self.index[node]
+
+    def get_all_groups(self):
+        _gow, groups, members = self.eng.get_groups()
+        out = [self._make_group(int(g["id"]), int(g["config"]), members[int(g["member_begin"]):int(g["member_begin"]) + int(g["n_members"])])
+               for g in groups]
+        return sorted(out, key=lambda g: g["id"])                                     # mod.rs:1040
+
+    def get_group_by_id(self, group_id: str):
+        gid = self._parse_group_id(group_id)
+        if gid is None:
+            return None
+        g = self.eng.get_group_by_id(gid)
+        return None if g is None else self._make_group(g["id"], g["config"], g["members"])
+
+    def get_node_group(self, address: str):
+        """-> None or (get_idx_in_group, group)"""
+        row = self._row_of_address_text(address)
+        if row is None:
+            return None
+        try:
+            g = self.eng.get_group_of_worker(row)
+        except E.EngineError as ex:
+            if ex.code == E.PM_ERANGE:                                                # a row the engine was never sent
+                return None
+            raise
+        if g is None:
+            return None
+        group = self._make_group(g["id"], g["config"], g["members"])
+        return group["nodes"].index(address), group
+
+    def get_node_groups_batch(self, addresses):
+        if not addresses:
+            return {}
+        gow, groups, members = self.eng.get_groups()
+        out = {}
+        for a in addresses:
+            row = self._row_of_address_text(a)
+            gi = -1 if row is None or row >= len(gow) else int(gow[row])
+            if gi < 0:
+                out[a] = None
+            else:
+                g = groups[gi]
+                out[a] = self._make_group(int(g["id"]), int(g["config"]), members[int(g["member_begin"]):int(g["member_begin"]) + int(g["n_members"])])
+        return out
+
+    def get_all_node_group_mappings(self):
+        return {n: g["id"] for g in self.get_all_groups() for n in g["nodes"]}
+
+    def dissolve_group(self, group_id: str):
+        gid = self._parse_group_id(group_id)
+        if gid is None:
+            return
+        if self.eng.dissolve_group_by_id(gid):
+            self._emit_group_webhooks()
+
+    def set_clock(self, now_ms: int):
+        self.clock = lambda: int(now_ms)
 
     def close(self):
         self.eng.close()

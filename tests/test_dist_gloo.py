@@ -32,23 +32,23 @@ def _free_port() -> int:
     return port
 
 
-def _run_rank(sw, local_carve=False):
-    model = ModelLocal(sw, group_id_seed=SEED, min_cap=64, local_carve=local_carve)   # small batches: several per configuration
+def _run_rank(sw):
+    model = ModelLocal(sw, group_id_seed=SEED, min_cap=64)   # small batches: several per configuration
     se = ShardedEngine(model, sw.address)
     best0, count0 = se.match_per_task()                         # before the carve: every eligible worker bids
     se.tick()
     best1, count1 = se.match_per_task()                         # after: only the leftovers bid (mod.rs:492-497)
     return dict(groups=model.groups_sorted_members(), table=model.table.copy(), best0=best0, count0=count0,
                 best1=best1, count1=count1, exchanges=se.exchanges, batches=model.batches,
-                rows_from_others=model.rows_from_others, own=len(model.own) if se.world > 1 else sw.W, local_carve=local_carve)
+                own=len(model.own) if se.world > 1 else sw.W)
 
 
-def _worker(rank: int, world: int, port: int, out_dir: str, local_carve: bool = False):
+def _worker(rank: int, world: int, port: int, out_dir: str):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _run_rank(make_swarm(SEED, T, W), local_carve)
+        res = _run_rank(make_swarm(SEED, T, W))
         with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
             pickle.dump(res, f)
     finally:
@@ -93,19 +93,14 @@ def _check_rank(res, sw, st, b0, b1, rows, world):
             assert (task, idx, size, nx) == (NONE if t < 0 else t, gi, gs, nxt), w
     assert np.array_equal(res["best0"], b0[0]) and np.array_equal(res["count0"], b0[1])
     assert np.array_equal(res["best1"], b1[0]) and np.array_equal(res["count1"], b1[1])
-    if world > 1 and res["local_carve"]:
-        assert res["exchanges"] == 1 and res["rows_from_others"] == 0   # the table; every row of the carve was made here
-        assert 0 < res["own"] < sw.W
-    elif world > 1:
-        assert res["batches"] > 3 and res["exchanges"] == res["batches"] + 1 + 0   # one per batch + the table
-        assert res["rows_from_others"] > 0, "no step was ever served from another rank's rows"
+    if world > 1:
+        assert res["batches"] > 3 and res["exchanges"] == 1   # the ONE exchange of a tick: the published rows (the carve is replicated)
         assert 0 < res["own"] < sw.W
 
 
-@pytest.mark.parametrize("local_carve", [True, False])   # the engine's protocol (replicated carve) / rows dealt over the ranks
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_tick_equals_the_unsharded_oracle(world, local_carve, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), local_carve), nprocs=world, join=True)
+def test_sharded_tick_equals_the_unsharded_oracle(world, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sw = make_swarm(SEED, T, W)
     st, b0, b1, rows = _oracle_reference(sw)
     for r in range(world):

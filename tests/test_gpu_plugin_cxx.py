@@ -21,6 +21,58 @@ pytestmark = pytest.mark.gpu
 NONE = 0xFFFFFFFF
 
 
+def _check_read_surface(shim, st, first_seen, sw, stamps, clock_now):
+    """The plugin's read surface (what the API routes call, node_groups/mod.rs:324-434, :1002-1065) against the oracle's
+    group state: get_all_groups (sorted by id text), get_group_by_id, get_node_group + get_idx_in_group for every known
+    node, get_node_groups_batch, get_all_node_group_mappings, and the storage route's upload name rendered through them."""
+    addr = sw.address_strings()
+    names = shim.config_names
+    og = st.groups()
+    want = sorted((("%x" % gid, names[cfg], [addr[first_seen[i]] for i in mem]) for (_s, gid, cfg, mem, _t) in og),
+                  key=lambda g: g[0])                                                # mod.rs:1040: by id TEXT
+    got = shim.get_all_groups()
+    assert [(g["id"], g["config"], g["nodes"]) for g in got] == want
+    for g in got:   # created_at: a group keeps the stamp of the interval that formed it
+        assert stamps.setdefault(g["id"], clock_now) == g["created_at"], g
+    by_slot = {s: ("%x" % gid, names[cfg], [addr[first_seen[i]] for i in mem]) for (s, gid, cfg, mem, _t) in og}
+    n2g = st.node_to_group
+    known = list(first_seen[:len(shim.rows)])
+    want_map, per_node = {}, {}
+    for i, node in enumerate(known):
+        r = shim.get_node_group(addr[node])
+        if n2g[i] < 0:
+            assert r is None, (i, r)
+            per_node[addr[node]] = None
+            continue
+        gid, cfg, nodes = by_slot[int(n2g[i])]
+        _t, gi, gs, _nxt = st.filter_tasks(i)                                        # the oracle's GROUP_INDEX / GROUP_SIZE
+        assert r is not None and r[0] == gi == nodes.index(addr[node]) and len(nodes) == gs
+        assert (r[1]["id"], r[1]["config"], r[1]["nodes"]) == (gid, cfg, nodes)
+        want_map[addr[node]] = gid
+        per_node[addr[node]] = (gid, cfg, nodes)
+    assert shim.get_all_node_group_mappings() == want_map
+    asked = [addr[n] for n in known] + ["0x" + "9" * 40]                             # + an address nobody has
+    batch = shim.get_node_groups_batch(asked)
+    assert set(batch) == set(asked) and batch[asked[-1]] is None
+    for a in asked[:-1]:
+        b = batch[a]
+        assert (None if b is None else (b["id"], b["config"], b["nodes"])) == per_node[a], a
+    for gid, cfg, nodes in list(by_slot.values())[:40]:
+        g = shim.get_group_by_id(gid)
+        assert g is not None and (g["id"], g["config"], g["nodes"]) == (gid, cfg, nodes)
+    assert shim.get_group_by_id("f" * 16 if "f" * 16 not in stamps else "e" * 16) is None
+    # the storage route (api/routes/storage.rs:147-207): the upload's name through get_node_group + get_idx_in_group
+    tmpl = "m/${NODE_GROUP_ID}-${NODE_GROUP_SIZE}-${NODE_GROUP_INDEX}-${TOTAL_UPLOAD_COUNT_AFTER}-${CURRENT_FILE_INDEX}.parquet"
+    shim.set_upload_count(3)
+    for a in asked[:60]:
+        name, key = shim.upload_file_name(tmpl, a)
+        g = per_node[a]
+        if g is None:
+            assert (name, key) == (orc.upload_name_vars(tmpl, None, 0, 0, 3), "no-group")
+        else:
+            assert (name, key) == (orc.upload_name_vars(tmpl, g[0], len(g[2]), g[2].index(a), 3), g[0])
+
+
 def test_cxx_plugin_call_sequence_tracks_the_oracle():
     """tests/test_gpu_shim_replay.py::test_shim_call_sequence_tracks_the_oracle with the COMPILED host side in the shim's
     place: five management intervals (snapshots in a new order each, new / rewritten / departed nodes), task observers,
@@ -72,7 +124,10 @@ def test_cxx_plugin_call_sequence_tracks_the_oracle():
     next_uid = 1 << 42
     t_max = int(created.max())
     n_created = n_destroyed = 0
+    stamps: dict = {}
+    assert [c[0] for c in shim.get_configurations(False)] == [shim.config_names[c] for c in host.config_order(host.pack_configs(sw.configs)[0], (1 << len(sw.configs)) - 1)]
     for k in range(ticks):
+        shim.set_clock(1000 * (k + 1))
         # ---- discovery rewrote some rows (specs, location) since the last interval
         for node in rewritten[k]:
             for f in _WORKER_FIELDS:
@@ -140,6 +195,81 @@ def test_cxx_plugin_call_sequence_tracks_the_oracle():
         n_created += sum(e[0] == E.GROUP_CREATED for e in ev)
         n_destroyed += sum(e[0] == E.GROUP_DESTROYED for e in ev)
         shim.events.clear()
+        _check_read_surface(shim, st, first_seen, sw, stamps, 1000 * (k + 1))
+        # ---- the admin route: DELETE /groups/{id} (api/routes/groups.rs:126) on three groups, by id text
+        victims = st.groups()[1::max(len(st.groups()) // 3, 1)][:3]
+        for (slot, gid, _cfg, _mem, _t) in victims:
+            shim.dissolve_group("%x" % gid)
+            st.dissolve_group(slot)
+        shim.dissolve_group("%x" % victims[0][1])                      # already gone: Ok(()), nothing happens
+        assert shim.events == st.drain_events() and len(shim.events) == len(victims)
+        n_destroyed += len(victims)
+        shim.events.clear()
+        assert sorted(oracle_groups(st)) == sorted(engine_groups(shim.eng))
+        for (_slot, gid, _cfg, mem, _t) in victims:
+            assert shim.get_group_by_id("%x" % gid) is None
+            assert shim.get_node_group(sw.address_strings()[first_seen[mem[0]]]) is None
+            assert shim.filter_tasks(first_seen[mem[0]]) is None     # the heartbeat of a freed node: no group, no task
+    avail = [c[0] for c in shim.get_configurations(True)]
+    assert avail and set(avail) <= set(shim.config_names)
     assert n_created > 100 and n_destroyed > 20 and len(shim.rows) == len(first_seen)
     assert shim.store_loads == 0, "a chain headed by the engine's plugin must not load the store's task list per heartbeat"
+    shim.close()
+
+
+def test_cxx_scheduler_renders_the_task_every_worker_receives():
+    """SURVEY 8(f)3 end to end on the GPU path: the task a worker is handed by Scheduler::get_task_for_node on the real
+    engine — env values, cmd arguments and volume mounts with ${GROUP_INDEX} ${GROUP_SIZE} ${NEXT_P2P_ADDRESS} ${GROUP_ID}
+    ${TOTAL_UPLOAD_COUNT} ${LAST_FILE_IDX} (scheduler_impl.rs:112-205), then ${TASK_ID} ${NODE_ADDRESS} ${TIMESTAMP}
+    (scheduler/mod.rs:34-70, shared/models/task.rs:75-98) — string for string against the oracle's orc_group_vars /
+    orc_volume_vars fed with the oracle's own filter_tasks numbers, for every worker of a 1,600-node swarm, over two
+    intervals with deaths in between."""
+    W, T = 1600, 300
+    sw = make_swarm(41, T, W)
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False)
+    shim = PluginCxx(sw)
+    env = {"IDX": "${GROUP_INDEX}/${GROUP_SIZE}", "NEXT": "peer=${NEXT_P2P_ADDRESS}", "WHO": "${TASK_ID}@${NODE_ADDRESS}",
+           "GID": "${GROUP_ID}-${GROUP_ID}", "UP": "${TOTAL_UPLOAD_COUNT}:${LAST_FILE_IDX}", "PLAIN": "no variables", "GROUP_INDEX": "overwritten"}
+    cmd = ["--rank=${GROUP_INDEX}", "--world=${GROUP_SIZE}", "--next", "${NEXT_P2P_ADDRESS}", "--out=/data/${GROUP_ID}/${TASK_ID}/${LAST_FILE_IDX}",
+           "--node=${NODE_ADDRESS}", "${GROUP_SIZE}${GROUP_SIZE}"]
+    mounts = [("/host/${GROUP_ID}/${TASK_ID}", "/mnt/${NODE_ADDRESS}/${TIMESTAMP}"), ("/scratch/${GROUP_INDEX}", "/g/${GROUP_ID}")]
+    shim.sync_tasks(sw.task_masks(), sw.created_at.copy(), sw.task_uid.copy(), sw.enabled_mask(), env=env, cmd=cmd, mounts=mounts)
+    shim.set_upload_count(7)
+    healthy = {n for n in range(W) if sw.status[n] == 2}
+    addr = sw.address_strings()
+    from plugin_cxx import uuid_of
+    rng = np.random.default_rng(7)
+    served = 0
+    for interval in range(2):
+        shim.sync_nodes(np.arange(W), healthy)
+        shim.tick()
+        st.try_form_new_groups()
+        st.try_merge_solo_groups()
+        gid_of_slot = {s: "%x" % gid for (s, gid, _c, _m, _t) in st.groups()}
+        now = 1_700_000_000 + interval
+        for w in range(W):
+            t, gi, gs, nxt = st.filter_tasks(w)                                     # (the oracle claims on this call)
+            got = shim.task_for_node(w, now=now)
+            if t < 0:
+                assert got is None, w
+                continue
+            served += 1
+            gid = gid_of_slot[int(st.node_to_group[w])]
+            tid = uuid_of(int(sw.task_uid[t]))
+            assert got["id"] == tid
+            gv = lambda s: orc.group_vars(s, gi, gs, "p2p-%d" % nxt, gid, "7")      # scheduler_impl.rs:160-183
+            sv = lambda s: s.replace("${TASK_ID}", tid).replace("${NODE_ADDRESS}", addr[w])   # scheduler/mod.rs:38-54
+            want_env = dict(env)
+            want_env["GROUP_INDEX"] = str(gi)                                        # scheduler_impl.rs:161: inserted, THEN expanded
+            assert got["env"] == {k: sv(gv(v)) for k, v in want_env.items()}, w
+            assert got["cmd"] == [sv(gv(a)) for a in cmd], w
+            assert got["mounts"] == [tuple(sv(orc.volume_vars(p, gid)).replace("${TIMESTAMP}", str(now)) for p in m) for m in mounts], w
+        if interval == 0:   # a few deaths: their groups dissolve, the second interval re-forms from the leftovers
+            for w in rng.choice(sorted(healthy), size=40, replace=False):
+                healthy.discard(int(w))
+                shim.handle_status_change(int(w), healthy=False, dead=True)
+                st.set_node_status(int(w), orc.ST_DEAD)
+    assert served > 1500
+    assert shim.store_loads == 0
     shim.close()

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in pm_engine.h but not exported"
     assert declared == set(E.EXPORTS)
-    assert L.pm_abi_version() == 2
+    assert L.pm_abi_version() == 3
 
 
 def test_library_exports_every_debug_hook():
@@ -84,7 +84,7 @@ def test_rust_shim_binds_the_header_as_declared():
         assert name in protos, f"{name} is bound by the Rust shim but not declared in pm_engine.h"
         assert protos[name] == n, f"{name}: {n} parameters in the Rust shim, {protos[name]} in pm_engine.h"
     called = set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", rs[rs.index("\n}\n", rs.index('extern "C" {')):]))
-    called -= {"pm_engine_config", "pm_worker_soa", "pm_task_soa", "pm_stats", "pm_group_event", "pm_assignment"}
+    called -= {"pm_engine_config", "pm_worker_soa", "pm_task_soa", "pm_stats", "pm_group_event", "pm_assignment", "pm_group"}
     assert called <= set(bound), f"called but not bound: {sorted(called - set(bound))}"
     # struct layouts: field names in order
     def c_fields(name):
@@ -106,8 +106,13 @@ def test_rust_shim_binds_the_header_as_declared():
         return re.findall(r"pub (\w+)\s*:", body)
 
     for name in ("pm_engine_config", "pm_worker_soa", "pm_task_soa", "pm_config_row", "pm_gpu_alt_row", "pm_assignment",
-                 "pm_group_event", "pm_stats"):
+                 "pm_group_event", "pm_stats", "pm_group", "pm_dist_xfer", "pm_group_vars"):
         assert rs_fields(name) == c_fields(name), name
+    # the read surface the API routes call (node_groups/mod.rs:324-434, :1002-1065), with the reference's names
+    for method in ("get_all_groups", "get_group_by_id", "get_all_node_group_mappings", "get_node_group", "get_node_groups_batch",
+                   "get_idx_in_group", "get_available_configurations", "get_all_configuration_templates", "dissolve_group"):
+        assert re.search(r"pub(?:\(crate\))? (?:async )?fn " + method + r"\(&self", rs), method
+        assert re.search(r"\b" + method + r"\(", open(os.path.join(ROOT, "protocol_amd", "plugin", "gpu_match_plugin.hpp")).read()), method
 
 
 _C_BASE = {"uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "float": "f32",

@@ -36,8 +36,8 @@ def test_plugin_against_the_mock_engine(tmp_path):
     assert exe, err
     out = _run(exe)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "12 tests, 0 failed checks" in out.stdout
-    assert out.stdout.count("ok  ") == 12
+    assert "17 tests, 0 failed checks" in out.stdout
+    assert out.stdout.count("ok  ") == 17
 
 
 def test_plugin_under_thread_sanitizer(tmp_path):
@@ -101,8 +101,10 @@ def test_product_plugin_library_binds_the_header():
                                                                     "pm_gpu_alt_row"}
     # (the C++ parses the requirement STRING with the library's parser where the Rust projects serde's parsed struct)
     assert rust_calls <= undefined | {"pm_host_parse_requirements"}, sorted(rust_calls - undefined)
-    # (... and pm_tick_many, which the Rust declares for the K-pool loop of INTEGRATION.md and the C++ wraps as tick_many)
-    assert undefined - rust_calls <= {"pm_host_parse_requirements", "pm_tick_many"}, sorted(undefined - rust_calls)
+    # (... and pm_tick_many, which the Rust declares for the K-pool loop of INTEGRATION.md and the C++ wraps as tick_many;
+    # pm_host_upload_name_vars: upload_file_name() is the storage ROUTE's code (api/routes/storage.rs:147-207), which stays
+    # as it is in the reference and is restated in C++ only so that the read surface can be tested through its caller)
+    assert undefined - rust_calls <= {"pm_host_parse_requirements", "pm_tick_many", "pm_host_upload_name_vars"}, sorted(undefined - rust_calls)
 
 
 def test_cxx_plugin_and_python_replay_make_the_same_calls(tmp_path):
