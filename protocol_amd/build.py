@@ -54,7 +54,12 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
 PLUGIN_DIR = os.path.join(HERE, "plugin")
 PLUGIN_LIB = os.path.join(HERE, "libpm_plugin.so")
 PLUGIN_SOURCES = ["gpu_match_plugin.cpp", "pm_plugin_c.cpp"]
-PLUGIN_HEADERS = ["gpu_match_plugin.hpp", "pm_plugin_c.h"]
+PLUGIN_HEADERS = ["gpu_match_plugin.hpp", "pm_plugin_c.h", "pm_plugin_c_internal.hpp"]
+# the communicators of GpuMatchPlugin::tick_dist (RCCL over xGMI; in-process ranks) + their C face: links librccl, libamdhip64
+PLUGIN_DIST_LIB = os.path.join(HERE, "libpm_plugin_dist.so")
+PLUGIN_DIST_SOURCES = ["rccl_all_gather.cpp", "pm_plugin_dist_c.cpp"]
+PLUGIN_DIST_HEADERS = ["rccl_all_gather.hpp", "pm_plugin_dist_c.h"]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
 def _cxx() -> str:
@@ -87,6 +92,35 @@ def build_plugin(force: bool = False, verbose: bool = False) -> str:
     return PLUGIN_LIB
 
 
+def plugin_dist_needs_build() -> bool:
+    if not os.path.exists(PLUGIN_DIST_LIB):
+        return True
+    t = os.path.getmtime(PLUGIN_DIST_LIB)
+    deps = [os.path.join(PLUGIN_DIST_DIR, f) for f in PLUGIN_DIST_SOURCES + PLUGIN_DIST_HEADERS + PLUGIN_HEADERS] + [PLUGIN_LIB]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+PLUGIN_DIST_DIR = PLUGIN_DIR
+
+
+def build_plugin_dist(force: bool = False, verbose: bool = False) -> str:
+    """libpm_plugin_dist.so: RcclAllGather / LocalAllGather + pmx_tick_dist & co.; plain host C++ (g++) against the HIP
+    runtime's and RCCL's C APIs."""
+    build_plugin()
+    if not force and not plugin_dist_needs_build():
+        return PLUGIN_DIST_LIB
+    cmd = [_cxx(), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I", INCLUDE, "-I", PLUGIN_DIR,
+           "-isystem", os.path.join(ROCM, "include"), *[os.path.join(PLUGIN_DIR, s) for s in PLUGIN_DIST_SOURCES],
+           "-L", HERE, "-lpm_plugin", "-lpm_engine", "-L", os.path.join(ROCM, "lib"), "-lrccl", "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-o", PLUGIN_DIST_LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(PLUGIN_DIST_LIB + ".tmp", PLUGIN_DIST_LIB)
+    return PLUGIN_DIST_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_plugin(force=True, verbose=True))
+    print(build_plugin_dist(force=True, verbose=True))

@@ -536,6 +536,57 @@ std::vector<pm_stats> GpuMatchPlugin::tick_many(const std::vector<GpuMatchPlugin
   return stats;
 }
 
+uint32_t shard_of(const Address& a, uint32_t world) {
+  // the low 8 bytes of the 20-byte address = the last sixteen hex digits of its text, big-endian
+  uint64_t v = 0;
+  int digits = 0;
+  for (size_t i = a.text.size(); i-- > 0 && digits < 16;) {
+    const char c = a.text[i];
+    uint64_t d;
+    if (c >= '0' && c <= '9') d = uint64_t(c - '0');
+    else if (c >= 'a' && c <= 'f') d = uint64_t(c - 'a' + 10);
+    else if (c >= 'A' && c <= 'F') d = uint64_t(c - 'A' + 10);
+    else break;  // 'x'
+    v |= d << (4 * digits);
+    ++digits;
+  }
+  uint64_t z = v + 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return world ? uint32_t(z % world) : 0u;
+}
+
+pm_stats GpuMatchPlugin::tick_dist(AllGather& comm) {
+  const uint32_t rank = comm.rank(), world = comm.world();
+  if (world == 0 || rank >= world) throw std::invalid_argument("tick_dist: rank outside the communicator");
+  {
+    std::shared_lock<std::shared_mutex> lk(nodes_mu_);
+    if (dist_stream_ != comm.stream()) {
+      check(pm_set_stream(engine_, comm.stream()));  // the engine's kernels and the collective on one stream: no host wait between them
+      dist_stream_ = comm.stream();
+    }
+    if (rank != dist_rank_.load() || world != dist_world_ || nodes_.rows.size() != dist_rows_) {
+      // ownership is per row and every rank computes the same: a hash of the address, nothing is negotiated
+      std::vector<uint8_t> shard(nodes_.rows.size());
+      for (size_t i = 0; i < shard.size(); ++i) shard[i] = uint8_t(shard_of(nodes_.addresses[i], world));
+      check(pm_dist_configure(engine_, rank, world, shard.empty() ? nullptr : shard.data()));
+      dist_rank_.store(rank), dist_world_ = world;
+      dist_rows_ = engine_rows_stale_ ? size_t(-1) : nodes_.rows.size();  // (the engine is behind the row map: configure again next time)
+    }
+  }
+  pm_stats s{};
+  pm_dist_xfer x{};
+  check(pm_dist_tick_begin(engine_));   // compat sweep; the whole carve is started (replicated: every rank runs it)
+  check(pm_dist_carve_wait(engine_));   // waits for it; near-ties settled on the host, identically everywhere
+  check(pm_dist_match_begin(engine_, &x));  // solo merge, pair sweep + claim of the OWNED workers
+  if (x.bytes_per_rank)                 // the ONE exchange of a tick: the published rows
+    comm.all_gather(reinterpret_cast<const void*>(uintptr_t(x.send_ptr)), reinterpret_cast<void*>(uintptr_t(x.recv_ptr)), size_t(x.bytes_per_rank));
+  check(pm_dist_tick_end(engine_, &s));  // scatter into the full table, publish
+  emit_group_webhooks();
+  return s;
+}
+
 // Drains the engine's group life-cycle feed into send_group_created / send_group_destroyed, in the order the
 // reference emits them.  Runs after everything that can create or dissolve groups.
 void GpuMatchPlugin::emit_group_webhooks() {
@@ -564,7 +615,7 @@ void GpuMatchPlugin::emit_group_webhooks() {
       else group_created_at_.erase(events[k].group_id);
     }
   }
-  if (webhook_plugins_.empty()) return;
+  if (webhook_plugins_.empty() || dist_rank_.load() != 0) return;  // (a rank > 0 of a multi-GPU pool: rank 0 reports)
   // (the address strings are copied under the lock and the deliveries made without it: a slow webhook endpoint must not
   // hold handle_status_change and sync_nodes up)
   std::vector<std::vector<std::string>> nodes_of(ne);

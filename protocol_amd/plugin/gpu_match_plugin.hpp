@@ -168,6 +168,25 @@ class NewestTaskPlugin : public SchedulerPlugin {
   std::vector<Task> filter_tasks(const std::vector<Task>& tasks, const Address&) override;
 };
 
+// The collective of the multi-GPU tick (include/pm_engine.h "multi-GPU"): one process per GPU, every rank holds
+// the whole swarm and runs the whole carve (replicated), the pair sweep + claim run for the OWNED workers, and the published
+// rows are all-gathered ONCE per tick.  The plugin is handed the communicator; it owns none.
+//   RcclAllGather (rccl_all_gather.hpp)   ncclAllGather over xGMI on the stream the engine's kernels run on
+//   LocalAllGather (same header)          ranks that live in one process (tests; several ranks sharing a GPU)
+class AllGather {
+ public:
+  virtual ~AllGather() = default;
+  virtual uint32_t rank() const = 0;
+  virtual uint32_t world() const = 0;
+  // the hipStream_t the engine's kernels and the collective share (ordered without a host wait); nullptr = the engine's own
+  virtual void* stream() const = 0;
+  // device pointers; recv = [world][bytes_per_rank], send = this rank's segment (it may alias recv's own slot): enqueue on stream()
+  virtual void all_gather(const void* send, void* recv, size_t bytes_per_rank) = 0;
+};
+
+// owner rank of a node: splitmix64 finaliser of the low 8 bytes of the address, mod world
+uint32_t shard_of(const Address& a, uint32_t world);
+
 // The third variant.  Thread-safe like the reference's Arc<NodeGroupsPlugin>: heartbeats (filter_tasks) from any
 // thread beside the management loop (sync_nodes / tick), the status updater (handle_status_change) and the task
 // store's observers (on_task_created / on_task_deleted).
@@ -201,6 +220,15 @@ class GpuMatchPlugin : public SchedulerPlugin {
   // every pool's carve started before the first is waited for — then each pool's webhooks.  pools[i]->tick() K times
   // in a row matches one pool after the other.
   static std::vector<pm_stats> tick_many(const std::vector<GpuMatchPlugin*>& pools);
+  // The management interval of ONE pool matched by several GPUs, one process (or thread) per GPU: this plugin is rank
+  // comm.rank() of comm.world().  Every rank is fed every store event (sync_nodes, the task observers, status changes —
+  // replicated calls) and calls tick_dist at the same point of its loop; every rank ends with the identical groups and
+  // the full published table (any rank answers any heartbeat).  The five calls of INTEGRATION.md "Multi-GPU":
+  // pm_dist_tick_begin, pm_dist_carve_wait, pm_dist_match_begin, the ONE all-gather, pm_dist_tick_end.  From its first
+  // tick_dist on a plugin of rank > 0 delivers no webhooks (every rank sees every creation and dissolution: rank 0 reports
+  // them; the others drain their feed and keep the created_at stamps).  Called by the management loop's thread only
+  // (like tick); ownership is recomputed when the node table grew.
+  pm_stats tick_dist(AllGather& comm);
   // SchedulerPlugin::filter_tasks: `tasks` is ignored (the plugin serves from its own list)
   std::vector<Task> filter_tasks(const std::vector<Task>& tasks, const Address& node_address) override;
   bool serves_from_own_task_list() const override { return true; }
@@ -294,6 +322,11 @@ class GpuMatchPlugin : public SchedulerPlugin {
   mutable std::shared_mutex nodes_mu_;
   NodeTable nodes_;
   bool engine_rows_stale_ = false;   // an engine call of sync_nodes failed half-way: the next one re-sends every row
+  // tick_dist's (the management loop's thread only): what pm_dist_configure was last told
+  std::atomic<uint32_t> dist_rank_{0};   // (read by emit_group_webhooks on any thread)
+  uint32_t dist_world_ = 1;
+  size_t dist_rows_ = size_t(-1);
+  void* dist_stream_ = nullptr;
   mutable std::shared_mutex tasks_mu_;
   std::vector<Task> tasks_;               // get_all_tasks order: the engine reports positions in this list
   UploadCounter upload_counter_;

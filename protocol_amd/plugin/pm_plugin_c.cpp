@@ -6,45 +6,15 @@
 #include <string>
 
 #include "gpu_match_plugin.hpp"
+#include "pm_plugin_c_internal.hpp"
 
 using namespace orchestrator;
+using pmx_detail::ListStore;
+using pmx_detail::RecordingWebhook;
 
 namespace {
 
 thread_local std::string g_error;
-
-struct RecordingWebhook : WebhookPlugin {
-  std::mutex mu;
-  std::string text;
-  void line(const char* what, const std::string& id, const std::string& name, const std::vector<std::string>& nodes) {
-    std::lock_guard<std::mutex> lk(mu);
-    text += what;
-    text += '\t' + id + '\t' + name;
-    for (const std::string& n : nodes) text += '\t' + n;
-    text += '\n';
-  }
-  void send_group_created(const std::string& id, const std::string& name, const std::vector<std::string>& nodes) override {
-    line("created", id, name, nodes);
-  }
-  void send_group_destroyed(const std::string& id, const std::string& name, const std::vector<std::string>& nodes) override {
-    line("destroyed", id, name, nodes);
-  }
-};
-
-struct ListStore : TaskStore {
-  std::mutex mu;
-  std::vector<Task> tasks;
-  uint32_t loads = 0;
-  std::vector<Task> get_all_tasks() override {
-    std::lock_guard<std::mutex> lk(mu);
-    ++loads;
-    return tasks;
-  }
-  std::vector<Task> snapshot() {
-    std::lock_guard<std::mutex> lk(mu);
-    return tasks;
-  }
-};
 
 std::string esc(const std::string& s) {
   std::string o;
@@ -128,15 +98,6 @@ std::string group_line(const NodeGroup& g) {
 }
 
 }  // namespace
-
-struct pmx_plugin {
-  std::atomic<int64_t> now_ms{0};
-  std::shared_ptr<RecordingWebhook> hook = std::make_shared<RecordingWebhook>();
-  std::shared_ptr<ListStore> store = std::make_shared<ListStore>();
-  std::shared_ptr<GpuMatchPlugin> plugin;
-  std::unique_ptr<Scheduler> scheduler;
-  std::atomic<uint64_t> upload_count{0};
-};
 
 #define PMX_TRY(...)                  \
   try {                               \

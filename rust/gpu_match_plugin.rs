@@ -27,7 +27,7 @@
 use std::collections::{BTreeSet, HashMap};
 use std::ffi::{c_char, CStr, CString};
 use std::os::raw::c_void;
-use std::sync::atomic::{AtomicU64, Ordering};
+use std::sync::atomic::{AtomicU32, AtomicU64, Ordering};
 
 use alloy::primitives::Address;
 use anyhow::{anyhow, Error, Result};
@@ -218,6 +218,60 @@ extern "C" {
     fn pm_dist_tick_end(e: *mut c_void, stats: *mut pm_stats) -> i32;
 }
 
+/// RCCL (librccl.so, rccl/rccl.h): the one collective the multi-GPU tick issues
+#[link(name = "rccl")]
+extern "C" {
+    fn ncclAllGather(sendbuff: *const c_void, recvbuff: *mut c_void, sendcount: usize, datatype: i32,
+                     comm: *mut c_void, stream: *mut c_void) -> i32;
+    fn ncclGetErrorString(result: i32) -> *const c_char;
+}
+const NCCL_UINT8: i32 = 1;      // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
+/// The collective of the multi-GPU tick (include/pm_engine.h "multi-GPU"): one process per GPU, every rank holds
+/// the whole swarm and runs the whole carve (replicated), the pair sweep + claim run for the OWNED workers, and the
+/// published rows are all-gathered ONCE per tick.  The plugin is handed the communicator; it owns none.
+pub trait AllGather: Send + Sync {
+    fn rank(&self) -> u32;
+    fn world(&self) -> u32;
+    /// the hipStream_t the engine's kernels and the collective share (ordered without a host wait); null = the engine's own
+    fn stream(&self) -> *mut c_void;
+    /// device pointers; recv = [world][bytes_per_rank], send = this rank's slot of it: enqueue on stream()
+    fn all_gather(&self, send: *const c_void, recv: *mut c_void, bytes_per_rank: usize) -> Result<()>;
+}
+
+/// ncclAllGather over xGMI on a communicator and a stream the host owns (`ncclComm_t`, `hipStream_t`: created by
+/// `main()` with ncclCommInitRank after the launcher's rendezvous — protocol_amd/plugin/rccl_all_gather.cpp shows one
+/// through an id file).  The tick's one collective moves world x cap x 32 bytes (8 ranks x 100k workers: 3.2 MB landed
+/// per GPU): latency-bound, a single call on the compute stream.
+pub struct RcclAllGather { pub comm: *mut c_void, pub stream: *mut c_void, pub rank: u32, pub world: u32 }
+unsafe impl Send for RcclAllGather {}
+unsafe impl Sync for RcclAllGather {}
+impl AllGather for RcclAllGather {
+    fn rank(&self) -> u32 { self.rank }
+    fn world(&self) -> u32 { self.world }
+    fn stream(&self) -> *mut c_void { self.stream }
+    fn all_gather(&self, send: *const c_void, recv: *mut c_void, bytes_per_rank: usize) -> Result<()> {
+        // (send is this rank's slot of recv: RCCL's in-place form, no staging copy)
+        let rc = unsafe { ncclAllGather(send, recv, bytes_per_rank, NCCL_UINT8, self.comm, self.stream) };
+        if rc == 0 { return Ok(()); }
+        Err(anyhow!("ncclAllGather: {}", unsafe { CStr::from_ptr(ncclGetErrorString(rc)) }.to_string_lossy()))
+    }
+}
+
+/// owner rank of a node: splitmix64 finaliser of the low 8 bytes of the address, mod world
+pub fn shard_of(a: &Address, world: u32) -> u32 {
+    let mut low = [0u8; 8];
+    low.copy_from_slice(&a.as_slice()[12..20]);
+    let mut z = u64::from_be_bytes(low).wrapping_add(0x9E37_79B9_7F4A_7C15);
+    z = (z ^ (z >> 30)).wrapping_mul(0xBF58_476D_1CE4_E5B9);
+    z = (z ^ (z >> 27)).wrapping_mul(0x94D0_49BB_1331_11EB);
+    z ^= z >> 31;
+    if world == 0 { 0 } else { (z % world as u64) as u32 }
+}
+
+/// what pm_dist_configure was last told (tick_dist's; the management loop's thread only)
+struct DistState { world: u32, rows: usize, stream: *mut c_void }
+
 // worker flag bits (include/pm_engine.h)
 const W_HAS_SPECS: u32 = 1 << 0; const W_HAS_GPU: u32 = 1 << 1; const W_GPU_COUNT: u32 = 1 << 2;
 const W_GPU_MEM: u32 = 1 << 3; const W_GPU_MODEL: u32 = 1 << 4; const W_HAS_CPU: u32 = 1 << 5;
@@ -287,6 +341,8 @@ pub struct GpuMatchPlugin {
     /// NodeGroup.created_at (mod.rs:575: Utc::now() when the group forms): stamped when the creation is reported by the
     /// life-cycle feed, dropped with the group.  A LEAF lock: never held across an engine call or another lock.
     group_created_at: parking_lot::Mutex<HashMap<u64, chrono::DateTime<chrono::Utc>>>,
+    dist: parking_lot::Mutex<DistState>,
+    dist_rank: AtomicU32,                       // (read by emit_group_webhooks on any thread: rank 0 reports)
     config_names: Vec<String>,
     req_models: Vec<CString>,       // requirement model strings, one per pm_gpu_alt_row.model_row
     nodes: parking_lot::RwLock<NodeTable>,
@@ -301,6 +357,7 @@ pub struct GpuMatchPlugin {
     pub republish_on_insert: bool,
 }
 
+unsafe impl Send for DistState {}
 unsafe impl Send for GpuMatchPlugin {}
 unsafe impl Sync for GpuMatchPlugin {}
 
@@ -335,6 +392,8 @@ impl GpuMatchPlugin {
         }
         let mut this = Self { engine, templates: templates.clone(), config_rows: Vec::new(), enabled_mask: AtomicU64::new(0),
                               group_created_at: Default::default(),
+                              dist: parking_lot::Mutex::new(DistState { world: 1, rows: usize::MAX, stream: std::ptr::null_mut() }),
+                              dist_rank: AtomicU32::new(0),
                               config_names: templates.iter().map(|t| t.name.clone()).collect(),
                               req_models: Vec::new(), nodes: Default::default(), tasks: Default::default(),
                               upload_counter, webhook_plugins, republish_on_insert: false };
@@ -640,6 +699,43 @@ impl GpuMatchPlugin {
         Ok(s)
     }
 
+    /// The management interval of ONE pool matched by several GPUs, one process per GPU: this plugin is rank comm.rank()
+    /// of comm.world().  Every rank is fed every store event (sync_nodes, the task observers, status changes — replicated
+    /// calls) and calls tick_dist at the same point of its loop; every rank ends with the identical groups and the full
+    /// published table (any rank answers any heartbeat).  The five calls of INTEGRATION.md "Multi-GPU" around ONE
+    /// all-gather.  From its first tick_dist on a plugin of rank > 0 delivers no webhooks (rank 0 reports them).
+    pub fn tick_dist(&self, comm: &dyn AllGather) -> Result<pm_stats> {
+        let (rank, world) = (comm.rank(), comm.world());
+        if world == 0 || rank >= world { return Err(anyhow!("tick_dist: rank outside the communicator")); }
+        {
+            let t = self.nodes.read();
+            let mut d = self.dist.lock();
+            if d.stream != comm.stream() {
+                // the engine's kernels and the collective on one stream: no host wait between them
+                check(unsafe { pm_set_stream(self.engine, comm.stream()) })?;
+                d.stream = comm.stream();
+            }
+            if rank != self.dist_rank.load(Ordering::Acquire) || world != d.world || t.rows.len() != d.rows {
+                // ownership is per row and every rank computes the same: a hash of the address, nothing is negotiated
+                let shard: Vec<u8> = t.addresses.iter().map(|a| shard_of(a, world) as u8).collect();
+                check(unsafe { pm_dist_configure(self.engine, rank, world, if shard.is_empty() { std::ptr::null() } else { shard.as_ptr() }) })?;
+                self.dist_rank.store(rank, Ordering::Release);
+                d.world = world;
+                d.rows = if t.engine_rows_stale { usize::MAX } else { t.rows.len() };  // (the engine is behind the row map: configure again next time)
+            }
+        }
+        let (mut s, mut x) = (pm_stats::default(), pm_dist_xfer::default());
+        check(unsafe { pm_dist_tick_begin(self.engine) })?;      // compat sweep; the whole carve is started (replicated)
+        check(unsafe { pm_dist_carve_wait(self.engine) })?;      // waits for it; near-ties settled on the host, identically everywhere
+        check(unsafe { pm_dist_match_begin(self.engine, &mut x) })?;   // solo merge, pair sweep + claim of the OWNED workers
+        if x.bytes_per_rank != 0 {                               // the ONE exchange of a tick: the published rows
+            comm.all_gather(x.send_ptr as usize as *const c_void, x.recv_ptr as usize as *mut c_void, x.bytes_per_rank as usize)?;
+        }
+        check(unsafe { pm_dist_tick_end(self.engine, &mut s) })?;   // scatter into the full table, publish
+        self.emit_group_webhooks()?;
+        Ok(s)
+    }
+
     /// Drains the engine's group life-cycle feed into send_group_created / send_group_destroyed, in the order the
     /// reference emits them.  Runs after everything that can create or dissolve groups: tick, handle_status_change,
     /// on_task_deleted, sync_nodes (tombstones).  (pm_enable_group_events(1) in `new`.)
@@ -667,6 +763,7 @@ impl GpuMatchPlugin {
             }
         }
         let Some(plugins) = &self.webhook_plugins else { return Ok(()) };
+        if self.dist_rank.load(Ordering::Acquire) != 0 { return Ok(()); }     // a rank > 0 of a multi-GPU pool: rank 0 reports
         let t = self.nodes.read();
         for ev in &events[..ne as usize] {
             let id = format!("{:x}", ev.group_id);                                   // generate_group_id, mod.rs:1489-1493

@@ -55,6 +55,14 @@ struct pm_engine {
   bool events_on = false;
   std::vector<pm_group_event> ev;
   std::vector<uint32_t> ev_members;
+  // the stepwise multi-GPU tick: ownership, the exchange buffer ("device" memory is host memory here), the gathered table
+  uint32_t dist_rank = 0, dist_world = 1, dist_cap = 0;
+  int dist_phase = 0;
+  uint32_t dist_formed = 0;
+  std::vector<uint8_t> shard;
+  std::vector<uint32_t> xrow;              // shard * cap + index within the shard
+  std::vector<pm_assignment> xbuf, table;  // [world][cap] / per worker, as gathered
+  bool table_valid = false;
 };
 
 static std::mutex g_log_mu;
@@ -89,6 +97,7 @@ static void log_event(pm_engine* e, uint32_t kind, const MockGroup& g) {
 }
 
 static void dissolve(pm_engine* e, size_t slot) {
+  e->table_valid = false;  // (the real engine patches the published rows in place; the toy falls back to computing them)
   log_event(e, PM_GROUP_DESTROYED, e->groups[slot]);
   e->groups.erase(e->groups.begin() + long(slot));
   std::fill(e->group_of.begin(), e->group_of.end(), -1);
@@ -405,9 +414,27 @@ int32_t pm_dissolve_group_by_id(pm_engine* e, uint64_t id, uint32_t* dissolved) 
   return PM_OK;
 }
 
+static uint32_t form_groups_locked(pm_engine* e);
+static void row_of_worker(pm_engine* e, uint32_t w, pm_assignment* out);
+
 int32_t pm_tick(pm_engine* e, pm_stats* stats) {
   if (!e) return pm::set_error(PM_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  const uint32_t formed = form_groups_locked(e);
+  offer_tasks(e);
+  e->published = true;
+  e->table_valid = false;
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->n_groups = uint32_t(e->groups.size());
+    stats->n_formed = formed;
+    stats->pair_evals = uint64_t(e->tasks.size()) * e->flags.size();
+  }
+  logf("tick formed=" + std::to_string(formed));
+  return PM_OK;
+}
+
+static uint32_t form_groups_locked(pm_engine* e) {
   std::vector<uint32_t> order;
   pm::available_order(e->cfgs.data(), uint32_t(e->cfgs.size()), e->enabled, &order);
   uint32_t formed = 0;
@@ -435,15 +462,90 @@ int32_t pm_tick(pm_engine* e, pm_stats* stats) {
       progress = true;
     }
   }
+  return formed;
+}
+
+// ---- the stepwise multi-GPU tick: the carve replicated, the published rows of the OWNED workers exchanged.  Look-ups of a
+// rank in a world > 1 are served from the GATHERED table only: rows another rank never sent read as garbage (0xFF).
+int32_t pm_set_stream(pm_engine* e, void* s) {
+  if (!e) return pm::set_error(PM_EINVAL, "null argument");
+  logf(std::string("set_stream ") + (s ? "caller's" : "own"));
+  return PM_OK;
+}
+int32_t pm_dist_configure(pm_engine* e, uint32_t rank, uint32_t world, const uint8_t* shard) {
+  if (!e || world == 0 || rank >= world) return pm::set_error(PM_EINVAL, "rank / world out of range");
+  std::lock_guard<std::mutex> lk(e->mu);
+  const uint32_t W = uint32_t(e->flags.size());
+  if (world > 1 && W && !shard) return pm::set_error(PM_EINVAL, "null shard column");
+  e->dist_rank = rank;
+  e->dist_world = world;
+  e->shard.assign(shard ? shard : nullptr, shard ? shard + W : nullptr);
+  std::vector<uint32_t> count(world, 0);
+  e->xrow.assign(W, 0);
+  for (uint32_t w = 0; w < W && world > 1; ++w) {
+    if (shard[w] >= world) return pm::set_error(PM_ERANGE, "shard index outside the world");
+    e->xrow[w] = count[shard[w]]++;
+  }
+  e->dist_cap = std::max<uint32_t>(*std::max_element(count.begin(), count.end()), 1u);
+  for (uint32_t w = 0; w < W && world > 1; ++w) e->xrow[w] += uint32_t(shard[w]) * e->dist_cap;
+  e->xbuf.assign(size_t(world) * e->dist_cap, pm_assignment{});
+  std::memset(e->xbuf.data(), 0xFF, e->xbuf.size() * sizeof(pm_assignment));
+  logf("dist_configure rank=" + std::to_string(rank) + " world=" + std::to_string(world) + " rows=" + std::to_string(W));
+  return PM_OK;
+}
+int32_t pm_dist_tick_begin(pm_engine* e) {
+  if (!e) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_world > 1 && e->shard.size() != e->flags.size())
+    return pm::set_error(PM_ESTATE, "the worker table changed size: call pm_dist_configure again");
+  e->dist_phase = 1;
+  logf("dist_tick_begin");
+  return PM_OK;
+}
+int32_t pm_dist_carve_wait(pm_engine* e) {
+  if (!e) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 1) return pm::set_error(PM_ESTATE, "pm_dist_tick_begin first");
+  e->dist_formed = form_groups_locked(e);  // replicated: every rank forms the same groups with the same ids
+  e->dist_phase = 2;
+  logf("dist_carve_wait");
+  return PM_OK;
+}
+int32_t pm_dist_match_begin(pm_engine* e, pm_dist_xfer* x) {
+  if (!e || !x) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 2) return pm::set_error(PM_ESTATE, "the carve is not finished (pm_dist_carve_wait first)");
+  std::memset(x, 0, sizeof(*x));
   offer_tasks(e);
   e->published = true;
+  if (e->dist_world > 1) {
+    std::memset(e->xbuf.data(), 0xFF, e->xbuf.size() * sizeof(pm_assignment));
+    for (uint32_t w = 0; w < e->flags.size(); ++w)
+      if (e->shard[w] == e->dist_rank) row_of_worker(e, w, &e->xbuf[e->xrow[w]]);  // the OWNED workers only
+    x->recv_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->xbuf.data()));
+    x->send_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->xbuf.data() + size_t(e->dist_rank) * e->dist_cap));
+    x->bytes_per_rank = uint64_t(e->dist_cap) * sizeof(pm_assignment);
+  }
+  e->dist_phase = 3;
+  logf("dist_match_begin bytes_per_rank=" + std::to_string(x->bytes_per_rank));
+  return PM_OK;
+}
+int32_t pm_dist_tick_end(pm_engine* e, pm_stats* stats) {
+  if (!e) return pm::set_error(PM_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->dist_phase != 3) return pm::set_error(PM_ESTATE, "pm_dist_match_begin first");
+  e->dist_phase = 0;
+  if (e->dist_world > 1) {
+    e->table.resize(e->flags.size());
+    for (uint32_t w = 0; w < e->flags.size(); ++w) e->table[w] = e->xbuf[e->xrow[w]];
+    e->table_valid = true;
+  }
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->n_groups = uint32_t(e->groups.size());
-    stats->n_formed = formed;
-    stats->pair_evals = uint64_t(e->tasks.size()) * e->flags.size();
+    stats->n_formed = e->dist_formed;
   }
-  logf("tick formed=" + std::to_string(formed));
+  logf("dist_tick_end formed=" + std::to_string(e->dist_formed));
   return PM_OK;
 }
 
@@ -462,9 +564,17 @@ int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t w, pm_assignment* out) 
   std::lock_guard<std::mutex> lk(e->mu);
   if (!e->published) return pm::set_error(PM_ESTATE, "no assignment table published yet");
   if (w >= e->flags.size()) return pm::set_error(PM_ERANGE, "worker index out of range");
+  if (e->table_valid && w < e->table.size()) {  // a rank of a world > 1: what the all-gather brought
+    *out = e->table[w];
+    return PM_OK;
+  }
+  row_of_worker(e, w, out);
+  return PM_OK;
+}
+static void row_of_worker(pm_engine* e, uint32_t w, pm_assignment* out) {
   std::memset(out, 0, sizeof(*out));
   out->task = out->group_slot = out->next_worker = PM_NONE;
-  if (e->group_of[w] < 0) return PM_OK;
+  if (e->group_of[w] < 0) return;
   const MockGroup& g = e->groups[size_t(e->group_of[w])];
   const size_t k = size_t(std::find(g.members.begin(), g.members.end(), w) - g.members.begin());
   out->group_slot = uint32_t(e->group_of[w]);
@@ -475,7 +585,6 @@ int32_t pm_lookup_task_for_worker(pm_engine* e, uint32_t w, pm_assignment* out) 
   if (g.task_uid)
     for (size_t i = 0; i < e->tasks.size(); ++i)
       if (e->tasks[i].uid == g.task_uid) out->task = uint32_t(i);
-  return PM_OK;
 }
 
 // ---- what only the mock has

@@ -13,6 +13,8 @@
 // The matching itself is NOT tested here (the mock's is a toy): that is tests/test_gpu_*.py against the oracle.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -754,6 +756,152 @@ static void resync_keeps_groups_and_reports_the_dissolved_ones() {
     for (const NodeGroup& g : before) CHECK(fresh->id != g.id);
 }
 
+// ------------------------------------------------------------------------------------------------ the multi-GPU tick
+
+// N ranks in one process: all_gather = every rank copies every rank's segment, between two barriers (the fake communicator
+// of the review: the memory the mock calls "device" is host memory)
+struct FakeWorld {
+  explicit FakeWorld(uint32_t n) : n(n), send(n, nullptr) {}
+  const uint32_t n;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint32_t waiting = 0, generation = 0;
+  std::vector<const void*> send;
+  std::atomic<int> gathers{0};
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint32_t gen = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+struct FakeGather : AllGather {
+  FakeGather(FakeWorld* w, uint32_t r) : w(w), r(r) {}
+  FakeWorld* w;
+  uint32_t r;
+  uint32_t rank() const override { return r; }
+  uint32_t world() const override { return w->n; }
+  void* stream() const override { return nullptr; }
+  void all_gather(const void* s, void* recv, size_t bytes) override {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->send[r] = s;
+    }
+    w->barrier();
+    for (uint32_t k = 0; k < w->n; ++k)
+      if (k != r) std::memcpy(static_cast<char*>(recv) + size_t(k) * bytes, w->send[k], bytes);
+    ++w->gathers;
+    w->barrier();  // nobody rewrites its segment before everyone has read it
+  }
+};
+
+static void tick_dist_over_a_fake_communicator() {
+  // one pool on three ranks: every rank is fed the same store events and must end with the answers of a single plugin
+  const uint32_t N = 3;
+  const auto feed = [](GpuMatchPlugin& p, int n_nodes) {
+    std::vector<OrchestratorNode> snap;
+    for (int k = 0; k < n_nodes; ++k) snap.push_back(node(k));
+    p.sync_nodes(snap);
+  };
+  const std::vector<Task> tasks = {task(1, 100, std::vector<std::string>{"pair"}), task(2, 90, std::vector<std::string>{"solo"})};
+  auto rec1 = std::make_shared<Recorder>();
+  GpuMatchPlugin single(two_configs(), 0, nullptr, {rec1});
+  feed(single, 9);
+  single.sync_tasks(tasks);
+  single.tick();
+  std::vector<std::shared_ptr<Recorder>> recs;
+  std::vector<std::unique_ptr<GpuMatchPlugin>> ranks;
+  for (uint32_t r = 0; r < N; ++r) {
+    recs.push_back(std::make_shared<Recorder>());
+    ranks.emplace_back(new GpuMatchPlugin(two_configs(), 0, nullptr, {recs[r]}));
+    feed(*ranks[r], 9);
+    ranks[r]->sync_tasks(tasks);
+  }
+  uint32_t owned[3] = {0, 0, 0};
+  for (int k = 0; k < 9; ++k) owned[shard_of(addr(k), N)]++;
+  CHECK(owned[0] + owned[1] + owned[2] == 9);
+  FakeWorld world(N);
+  const auto tick_all = [&] {
+    std::vector<std::thread> th;
+    std::atomic<int> failed{0};
+    for (uint32_t r = 0; r < N; ++r)
+      th.emplace_back([&, r] {
+        try {
+          FakeGather comm(&world, r);
+          ranks[r]->tick_dist(comm);
+        } catch (const std::exception& e) {
+          std::fprintf(stderr, "  rank %u: %s\n", r, e.what());
+          ++failed;
+        }
+      });
+    for (std::thread& t : th) t.join();
+    CHECK_EQ(failed.load(), 0);
+  };
+  pm_mock_reset_calls();
+  tick_all();
+  CHECK_EQ(world.gathers.load(), int(N));                            // ONE exchange per tick and rank
+  for (const char* c : {"dist_configure", "dist_tick_begin", "dist_carve_wait", "dist_match_begin", "dist_tick_end"})
+    CHECK_EQ(calls_named(c).size(), size_t(N));
+  CHECK(calls_named("tick").empty());
+  const auto same_answers = [&](int n_nodes) {
+    for (uint32_t r = 0; r < N; ++r)
+      for (int k = 0; k < n_nodes; ++k) {
+        const std::vector<Task> a = single.filter_tasks({}, addr(k)), b = ranks[r]->filter_tasks({}, addr(k));
+        CHECK_EQ(a.size(), b.size());
+        if (a.size() == 1 && b.size() == 1) CHECK(a[0] == b[0]);    // the templated task: GROUP_INDEX, NEXT_P2P_ADDRESS, GROUP_ID ...
+      }
+  };
+  same_answers(9);
+  for (uint32_t r = 0; r < N; ++r) {                                 // every rank holds every group
+    const std::vector<NodeGroup> a = single.get_all_groups(), b = ranks[r]->get_all_groups();
+    CHECK_EQ(a.size(), b.size());
+    for (size_t i = 0; i < a.size() && i < b.size(); ++i) CHECK(a[i].id == b[i].id && a[i].nodes == b[i].nodes);
+  }
+  {  // webhooks: rank 0 delivers, the others only drain
+    std::lock_guard<std::mutex> l0(recs[0]->mu), l1(rec1->mu);
+    CHECK(!rec1->lines.empty());
+    CHECK(recs[0]->lines == rec1->lines);
+  }
+  for (uint32_t r = 1; r < N; ++r) {
+    std::lock_guard<std::mutex> lk(recs[r]->mu);
+    CHECK(recs[r]->lines.empty());
+  }
+  // the pool grows: ownership is recomputed (the engine refuses a tick with a stale shard column), deaths are replicated calls
+  feed(single, 12);
+  single.handle_status_change(node(1, NodeStatus::Dead));
+  single.tick();
+  for (uint32_t r = 0; r < N; ++r) {
+    feed(*ranks[r], 12);
+    ranks[r]->handle_status_change(node(1, NodeStatus::Dead));
+  }
+  pm_mock_reset_calls();
+  tick_all();
+  CHECK_EQ(calls_named("dist_configure").size(), size_t(N));
+  same_answers(12);
+  pm_mock_reset_calls();
+  tick_all();                                                        // nothing changed: no reconfiguration
+  CHECK(calls_named("dist_configure").empty());
+  same_answers(12);
+  // a world of one: the same five calls, nothing to exchange
+  FakeWorld alone(1);
+  FakeGather comm(&alone, 0);
+  GpuMatchPlugin one(two_configs(), 0, nullptr);
+  feed(one, 9);
+  one.sync_tasks(tasks);
+  one.tick_dist(comm);
+  CHECK_EQ(alone.gathers.load(), 0);
+  GpuMatchPlugin plain(two_configs(), 0, nullptr);
+  feed(plain, 9);
+  plain.sync_tasks(tasks);
+  plain.tick();
+  for (int k = 0; k < 9; ++k) CHECK(one.filter_tasks({}, addr(k)) == plain.filter_tasks({}, addr(k)));
+}
+
 int main(int argc, char** argv) {
   struct { const char* name; void (*fn)(); } tests[] = {
       {"constructor_contract", constructor_contract},
@@ -773,6 +921,7 @@ int main(int argc, char** argv) {
       {"read_surface_configurations", read_surface_configurations},
       {"storage_route_file_name_through_the_read_surface", storage_route_file_name_through_the_read_surface},
       {"resync_keeps_groups_and_reports_the_dissolved_ones", resync_keeps_groups_and_reports_the_dissolved_ones},
+      {"tick_dist_over_a_fake_communicator", tick_dist_over_a_fake_communicator},
   };
   int ran = 0;
   for (const auto& t : tests) {

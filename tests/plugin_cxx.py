@@ -92,6 +92,53 @@ def plugin_lib(path: str | None = None) -> C.CDLL:
     return _plib
 
 
+_dlib = None
+
+
+class PmxCommError(RuntimeError):
+    pass
+
+
+def dist_lib() -> C.CDLL:
+    """libpm_plugin_dist.so: GpuMatchPlugin::tick_dist's communicators (protocol_amd/plugin/pm_plugin_dist_c.h)"""
+    global _dlib
+    if _dlib is None:
+        plugin_lib()
+        L = C.CDLL(_build.build_plugin_dist())
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.pmx_last_error_dist.restype = C.c_char_p
+        L.pmx_rccl_create.argtypes = [u32, u32, C.c_int32, C.c_char_p, C.POINTER(vp)]
+        L.pmx_local_world_create.argtypes = [u32, C.c_int32, C.POINTER(vp)]
+        L.pmx_comm_destroy.argtypes = [vp]
+        L.pmx_comm_destroy.restype = None
+        L.pmx_tick_dist.argtypes = [vp, vp, C.POINTER(E.Stats)]
+        L.pmx_rccl_self_test.argtypes = [C.c_int32, u32, C.c_char_p]
+        _dlib = L
+    return _dlib
+
+
+def _check_dist(rc: int):
+    if rc != 0:
+        raise PmxCommError("pm_plugin_dist: " + dist_lib().pmx_last_error_dist().decode(errors="replace"))
+
+
+def local_world(n: int, device: int = 0) -> list:
+    """n communicator handles of ranks that share this process (one thread each)"""
+    out = (C.c_void_p * n)()
+    _check_dist(dist_lib().pmx_local_world_create(n, device, out))
+    return [C.c_void_p(out[i]) for i in range(n)]
+
+
+def rccl_comm(rank: int, world: int, device: int, id_file: str):
+    out = C.c_void_p()
+    _check_dist(dist_lib().pmx_rccl_create(rank, world, device, id_file.encode(), C.byref(out)))
+    return out
+
+
+def comm_destroy(comm):
+    dist_lib().pmx_comm_destroy(comm)
+
+
 def _check(rc: int):
     if rc != 0:
         raise RuntimeError("pm_plugin: " + plugin_lib().pmx_last_error().decode(errors="replace"))
@@ -231,6 +278,13 @@ class PluginCxx:
     def tick(self):
         s = E.Stats()
         _check(self.L.pmx_tick(self._p, C.byref(s)))
+        self._take_webhooks()
+        return s.as_dict()
+
+    def tick_dist(self, comm):
+        """GpuMatchPlugin::tick_dist(comm): every rank calls it at the same point (its own thread or process)"""
+        s = E.Stats()
+        _check_dist(dist_lib().pmx_tick_dist(self._p, comm, C.byref(s)))
         self._take_webhooks()
         return s.as_dict()
 

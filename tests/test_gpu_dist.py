@@ -72,7 +72,8 @@ class _InProcExchanger:
         self.g.barrier.wait()                            # nobody rewrites its segment before everyone has read it
 
 
-def _run_in_process(sw, world, ticks=1, between=None, **kw):
+def _run_in_process(sw, world, ticks=1, between=None, finish=None, per_task=True, **kw):
+    """finish(eng, stats, exchanges) -> what out[r] holds instead of the groups and the table themselves (big swarms)"""
     grp = _InProcGroup(world)
     out = [None] * world
     errs = []
@@ -83,13 +84,13 @@ def _run_in_process(sw, world, ticks=1, between=None, **kw):
             host.load_swarm(eng, sw)
             se = ShardedEngine(EngineLocal(eng, torch.device("cuda", 0)), sw.address,
                                exchanger=_InProcExchanger(grp, r))
-            per_task = se.match_per_task()
+            bids = se.match_per_task() if per_task else None
             stats = None
             for k in range(ticks):
                 if between and k:
                     between(eng, k)
                 stats = se.tick()
-            out[r] = (engine_groups(eng), _table(eng, sw.W), stats, per_task, se.exchanges)
+            out[r] = finish(eng, stats, se.exchanges) if finish else (engine_groups(eng), _table(eng, sw.W), stats, bids, se.exchanges)
             eng.close()
         except Exception as ex:  # a dead rank must not leave the others at the barrier
             errs.append((r, repr(ex)))
@@ -132,6 +133,37 @@ def test_in_process_ranks_equal_the_single_gpu_engine_and_the_oracle(world):
         assert s["host_resolved_steps"] == 0 and s["n_groups"] == s1["n_groups"]
         assert np.array_equal(best, best1) and np.array_equal(count, count1), f"rank {r}: folded bids"
         assert n_x == 1                                # ONE exchange per tick: the published rows (the carve is replicated)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_in_process_ranks_config2_against_the_digest(world):
+    """BASELINE configs[3]: the 1M-task x 100k-worker swarm of configs[2] hash-sharded over N ranks (in-process here: N
+    engines on the one GPU, the exchange as device copies) — every rank's groups and full published table against the
+    ORACLE's committed digests (tests/golden/scale_digests.json cfg2_seed1: group list, per-worker task, GROUP_INDEX /
+    SIZE / NEXT), with exactly one exchange in the tick."""
+    import json
+    from test_gpu_scale import _engine_digests, _sha
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scale_digests.json")))["cfg2_seed1"]
+    sw = baseline_config(gold["config"], seed=gold["seed"])
+    assert (sw.W, sw.T) == (gold["W"], gold["T"]) == (100000, 1000000)
+
+    def finish(eng, stats, exchanges):
+        got = engine_groups(eng)
+        gsha, tbl = _engine_digests(sw, eng)
+        return dict(stats=stats, exchanges=exchanges, n_groups=len(got), first=[[g[0], g[1], g[2]] for g in got[:1000]],
+                    last=[[g[0], g[1], g[2]] for g in got[-1000:]], groups_sha=gsha,
+                    task_sha=_sha(tbl["task"].astype(np.uint32)),
+                    table_sha=_sha(tbl["group_index"].astype(np.uint32), tbl["group_size"].astype(np.uint32), tbl["next_worker"].astype(np.uint32)))
+
+    res = _run_in_process(sw, world, finish=finish, per_task=False, group_id_seed=gold["seed"])
+    for r, got in enumerate(res):
+        assert got["exchanges"] == 1, f"rank {r}"
+        assert got["stats"]["n_formed"] == gold["n_formed"] and got["stats"]["n_merged"] == gold["n_merged"], f"rank {r}"
+        assert got["n_groups"] == gold["n_groups"] and got["first"] == gold["first_groups"] and got["last"] == gold["last_groups"], f"rank {r}"
+        assert got["groups_sha"] == gold["groups_sha256"], f"rank {r}: group list differs from the oracle"
+        assert got["task_sha"] == gold["task_sha256"], f"rank {r}: per-worker task column differs from the oracle"
+        assert got["table_sha"] == gold["table_sha256"], f"rank {r}: GROUP_INDEX / SIZE / NEXT differ from the oracle"
+        assert got["stats"]["host_resolved_steps"] == 0
 
 
 def test_in_process_ranks_big_lists_and_forced_host_resolves():

@@ -36,8 +36,8 @@ def test_plugin_against_the_mock_engine(tmp_path):
     assert exe, err
     out = _run(exe)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "17 tests, 0 failed checks" in out.stdout
-    assert out.stdout.count("ok  ") == 17
+    assert "18 tests, 0 failed checks" in out.stdout
+    assert out.stdout.count("ok  ") == 18
 
 
 def test_plugin_under_thread_sanitizer(tmp_path):
