@@ -22,12 +22,16 @@ N = 1   BASELINE.json configs[1]: 100k tasks x 10k workers, mixed gpu/mem/storag
                      and, because the carve is a dependent chain, `chain`: achieved time per step against a floor
           cpu_baseline  the C oracle (a port of the reference path) on this box's host cores: reference-shaped on
                      one thread, the pair sweep on all cores, and a best-effort CPU variant
-N > 1   BASELINE.json configs[3]: the SAME 1M x 100k swarm on every rank (strong scaling).  Workers are owned by
-        hash(address) % N; the validation chain is replicated, the proposal sweeps and the pair sweep are sharded,
-        two kinds of RCCL all-gather per tick (protocol_amd/dist.py).  Every rank ends with identical groups.
-        Beside it: dist.one_gpu_same_workload (the same swarm on one unsharded engine), dist.replicated_ms /
-        sharded_ms / exchange_ms (the Amdahl split), and dist.replicas — N independent pools, one configs[1] swarm per
-        rank, no collective: the weak-scaling counterpart of the N = 1 line.
+N > 1   REPLICAS (weak scaling): one configs[1] pool per rank (seed + rank), the loop of the N = 1 line on every GPU, no
+        data-path collective — value = N x T x W x K / (max-over-ranks time between barriers).  The reference runs one
+        pool per orchestrator process and its carve is a chain of dependent steps that N GPUs do not divide (DESIGN.md
+        section 7: "replicas only" for the dependent stream), so N GPUs serve N pools.
+        Beside it, `dist.one_pool_sharded`: BASELINE configs[3] — ONE 1M x 100k pool matched by all N ranks (strong
+        scaling): workers owned by hash(address) % N, the carve REPLICATED (one streaming launch per rank, nothing
+        exchanged), the pair sweep + claim over the owned workers, ONE RCCL all-gather of the published rows per tick
+        (protocol_amd/dist.py; the compiled hosts: GpuMatchPlugin::tick_dist).  Every rank ends with identical groups
+        (checked by digest).  With it: one_gpu_same_workload (the same swarm on one unsharded engine) and the
+        replicated / sharded / exchange split (the Amdahl bound of that design, ~1.1x by construction).
 """
 from __future__ import annotations
 
@@ -469,6 +473,80 @@ def run_extra_churn(E, host, seed, ticks=6):
                      "and prints single ticks, so the two differ by the delta calls (0.4 - 0.5 ms) and by what a median hides")}
 
 
+def run_one_pool_sharded(E, host, torch, dist, args, rank, world, local_rank, dev, coll_dev, backend, steps=5, warmup=2):
+    """BASELINE configs[3]: ONE 1M x 100k pool matched by all ranks (strong scaling).  The carve is replicated (every rank
+    runs the whole streaming launch), the pair sweep + claim run over the owned workers, one all-gather of the published
+    rows per tick.  Returns the sub-object of the line (every rank takes part; rank 0's numbers are reported)."""
+    import hashlib
+    from protocol_amd.dist import EngineLocal, ShardedEngine
+    from protocol_amd.swarm import baseline_config
+    sw = baseline_config(3, seed=args.seed)                  # the SAME swarm on every rank
+    eng = E.Engine(device=local_rank, group_id_seed=args.seed)
+    host.load_swarm(eng, sw)
+    sharded = ShardedEngine(EngineLocal(eng, dev), sw.address)
+    sharded.time_exchanges = True
+
+    def step():
+        eng.reset_groups()
+        return sharded.tick()
+
+    for _ in range(warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(steps)]
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # every rank must hold the same groups and the same full table: compare a digest across the ranks
+    _, groups, members = eng.get_groups()
+    h = hashlib.sha256(groups.tobytes() + members.tobytes()).digest()[:8]
+    mine = torch.tensor([int.from_bytes(h, "little") >> 1, len(groups)], dtype=torch.int64, device=coll_dev)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    assert all(bool((v == mine).all()) for v in allv), "ranks disagree on the groups they formed"
+    n_ticks = steps + warmup
+    exch_ms = sharded.exchange_ms / n_ticks
+    sharded_ms = med(stats, "ms_sweep")
+    T, W = sw.T, sw.W
+    out = {"workload": ("BASELINE configs[3]: 1M tasks x 100k workers, Zipf-skewed topologies, ONE pool, worker ownership "
+                        "hash-sharded across the ranks, one all-gather of the published rows per tick"),
+           "scaling": "strong", "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+           "value": float(T) * float(W) * steps / elapsed, "unit": "pair-evals/s",
+           "sharding": "ownership = splitmix64(address) % n_gpus; carve replicated, pair sweep + claim over the owned workers",
+           "workers_owned_by_rank0": int((sharded.shard == rank).sum()), "exchanges_per_tick": sharded.exchanges / n_ticks,
+           "backend": backend, "identical_groups_on_all_ranks": True, "groups": int(stats[-1]["n_groups"]),
+           "exchange_ms": exch_ms, "sharded_ms": sharded_ms,
+           "replicated_ms": max(1e3 * elapsed / steps - sharded_ms - exch_ms, 0.0),
+           "split_note": ("per tick on rank 0: exchange = device time inside the ONE all-gather of a tick (the published rows of "
+                          "the owned workers; events around it); sharded = this rank's pair sweep + claim over the workers it "
+                          "owns; replicated = the rest of the tick — compat sweep, the carve (one streaming launch, the same on "
+                          "every rank: a chain of dependent steps that N GPUs do not divide), publish")}
+    if rank == 0:
+        # the SAME swarm on one GPU, unsharded (a second engine on rank 0's device): the honest one-GPU reference of this
+        # sub-object's strong scaling
+        solo = E.Engine(device=local_rank, group_id_seed=args.seed)
+        host.load_swarm(solo, sw)
+        ts = []
+        for _k in range(4):
+            solo.reset_groups()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            solo.tick()
+            ts.append(time.perf_counter() - t1)
+        solo.close()
+        one = statistics.median(ts[1:])
+        out["one_gpu_same_workload"] = {"ms_per_step": 1e3 * one, "value": float(T) * float(W) / one,
+                                        "note": "rank 0, unsharded engine, p50 of 3 cold matches"}
+        out["speedup_vs_one_gpu"] = one / (elapsed / steps)
+    dist.barrier()   # (rank 0 may still be measuring its one-GPU reference)
+    eng.close()
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -518,28 +596,24 @@ def main() -> int:
     from protocol_amd import engine as E, host
     from protocol_amd.swarm import baseline_config, make_swarm
 
-    cfg_index = args.config if args.config is not None else (1 if world == 1 else 3)
-    sw = baseline_config(cfg_index, seed=args.seed)          # the SAME swarm on every rank (strong scaling for N > 1)
+    # N = 1: configs[1].  N > 1: REPLICAS — the same configuration, one independent pool per rank (seed + rank), no
+    # data-path collective (weak scaling); the one-pool sharded tick of configs[3] is measured behind it (dist.one_pool_sharded)
+    cfg_index = args.config if args.config is not None else 1
+    seed_r = args.seed + (rank if world > 1 else 0)
+    sw = baseline_config(cfg_index, seed=seed_r)
     names = {1: "100k tasks x 10000 workers, mixed gpu/mem/storage/cpu constraints (BASELINE configs[1])",
-             2: "1M tasks x 100k workers, Zipf-skewed topologies (BASELINE configs[2])",
-             3: ("1M tasks x 100k workers, Zipf-skewed topologies, worker ownership hash-sharded across the ranks with RCCL "
-                 "all-gathers (BASELINE configs[3])")}
+             2: "1M tasks x 100k workers, Zipf-skewed topologies (BASELINE configs[2])"}
     workload = names.get(cfg_index, f"BASELINE configs[{cfg_index}]")
+    if world > 1:
+        workload += f" — one such pool per rank (seed + rank), {world} independent engines"
 
     eng = E.Engine(device=local_rank, sweep_variant=args.sweep_variant, carve_variant=args.carve_variant,
-                   group_id_seed=args.seed)
+                   group_id_seed=seed_r)
     host.load_swarm(eng, sw)
-    sharded = None
-    if world > 1:
-        from protocol_amd.dist import EngineLocal, ShardedEngine
-        sharded = ShardedEngine(EngineLocal(eng, dev), sw.address)
-
-    if sharded is not None:
-        sharded.time_exchanges = True
 
     def step():
         eng.reset_groups()
-        return sharded.tick() if sharded else eng.tick()
+        return eng.tick()
 
     for _ in range(args.warmup):
         step()
@@ -554,25 +628,17 @@ def main() -> int:
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ranks_seen, own = 1, sw.W
+    ranks_seen = 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # every rank must hold the same groups and the same full table: compare a digest across the ranks
-        import hashlib
-        _, groups, members = eng.get_groups()
-        h = hashlib.sha256(groups.tobytes() + members.tobytes()).digest()[:8]
-        mine = torch.tensor([int.from_bytes(h, "little") >> 1, len(groups)],
-                            dtype=torch.int64, device=coll_dev)
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        assert all(bool((v == mine).all()) for v in allv), "ranks disagree on the groups they formed"
-        ranks_seen = len(allv)
-        own = int((sharded.shard == rank).sum())
+        t = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=coll_dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        ranks_seen = int(round(float(t[1].item())))
 
     T, W = sw.T, sw.W
-    value = float(T) * float(W) * args.steps / elapsed
+    value = world * float(T) * float(W) * args.steps / elapsed   # whole job: every rank matched its own pool K times
     ms = [s["ms_total"] for s in stats]
     prop = proposer_split(E, host, sw, args.seed) if (world == 1 and not args.no_extras) else \
         {"ms": 0.0, "proposals": med(stats, "proposals"), "keys": med(stats, "propose_keys"),
@@ -583,12 +649,13 @@ def main() -> int:
     out = {
         "metric": "task x worker pair-evals/sec (full-swarm match)", "value": value, "unit": "pair-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u64",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": workload, "tasks": T, "workers": W, "workers_total": W, "configs": len(sw.configs),
+        "config": {"workload": workload, "tasks": T, "workers": W, "workers_total": W * world, "configs": len(sw.configs),
                    "seed": args.seed,
-                   "sharding": ("none" if world == 1 else
-                                "ownership = splitmix64(address) % n_gpus; proposals + pair sweep sharded, chain replicated"),
+                   "parallelism": ("one pool on one GPU" if world == 1 else
+                                   f"{world} replicas: one independent pool per GPU, no data-path collective (the one-pool sharded "
+                                   f"tick of configs[3] is in dist.one_pool_sharded)"),
                    "sweep_variant": args.sweep_variant, "carve_variant": args.carve_variant},
         "p50_match_latency_ms": statistics.median(ms),
         "match_latency_ms": {"min": min(ms), "p50": statistics.median(ms), "max": max(ms)},
@@ -613,66 +680,10 @@ def main() -> int:
     }
     if world > 1:
         out["ranks_seen"] = ranks_seen
-        n_ticks = args.steps + args.warmup
-        exch_ms = sharded.exchange_ms / n_ticks
-        # what the N GPUs share out (the pair sweep + claim: owned rows) against what every rank repeats (the carve: a
-        # chain of dependent steps, replicated — one streaming launch per rank) — the Amdahl split of this design
-        sharded_ms = med(stats, "ms_sweep")
-        out["dist"] = {"workers_owned_by_rank0": own, "exchanges_per_tick": sharded.exchanges / n_ticks,
-                       "backend": backend, "identical_groups_on_all_ranks": True,
-                       "exchange_ms": exch_ms, "sharded_ms": sharded_ms,
-                       "replicated_ms": max(1e3 * elapsed / args.steps - sharded_ms - exch_ms, 0.0),
-                       "split_note": ("per tick on rank 0: exchange = device time inside the ONE all-gather of a tick (the "
-                                      "published rows of the owned workers; events around it); sharded = this rank's pair "
-                                      "sweep + claim over the workers it owns; replicated = the rest of the tick — compat "
-                                      "sweep, the carve (one streaming launch, the same on every rank: a chain of "
-                                      "dependent steps that N GPUs do not divide), publish")}
-        if rank == 0:
-            # the SAME swarm on one GPU, unsharded (a second engine on rank 0's device, after the timed region): the
-            # N = 1 line of the default command is a different workload (configs[1]), so the honest one-GPU
-            # reference for this line's strong scaling is measured here
-            solo = E.Engine(device=local_rank, group_id_seed=args.seed)
-            host.load_swarm(solo, sw)
-            ts = []
-            for k in range(4):
-                solo.reset_groups()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                solo.tick()
-                ts.append(time.perf_counter() - t1)
-            solo.close()
-            one = statistics.median(ts[1:])
-            out["dist"]["one_gpu_same_workload"] = {"ms_per_step": 1e3 * one, "value": float(T) * float(W) / one,
-                                                    "note": "rank 0, unsharded engine, p50 of 3 cold matches"}
-            out["dist"]["speedup_vs_one_gpu"] = one / (elapsed / args.steps)
-    if world > 1:
-        # N independent pools: every rank carves its OWN configs[1] swarm (seed + rank) with the loop of the N = 1
-        # line — no data-path collective.  This is how a deployment with several orchestrator pools uses N GPUs, and
-        # the weak-scaling counterpart of the N = 1 line (the sharded tick above is strong scaling of one big pool).
-        sw_r = baseline_config(1, seed=args.seed + rank)
-        eng_r = E.Engine(device=local_rank, group_id_seed=args.seed + rank)
-        host.load_swarm(eng_r, sw_r)
-        k_rep = 10
-        for _ in range(2):
-            eng_r.reset_groups()
-            eng_r.tick()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(k_rep):
-            eng_r.reset_groups()
-            eng_r.tick()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t_rep = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t_rep, op=dist.ReduceOp.MAX)
-        eng_r.close()
-        el = float(t_rep.item())
-        out["dist"]["replicas"] = {
-            "workload": "one BASELINE configs[1] swarm per rank (seed + rank), independent engines, no collective",
-            "scaling": "weak", "steps": k_rep, "ms_per_step": 1e3 * el / k_rep,
-            "value": world * float(sw_r.T) * float(sw_r.W) * k_rep / el, "unit": "pair-evals/s",
-            "note": "aggregate over the ranks, max-over-ranks time between barriers; compare with the N = 1 line's value"}
+        try:
+            out["dist"] = {"one_pool_sharded": run_one_pool_sharded(E, host, torch, dist, args, rank, world, local_rank, dev, coll_dev, backend)}
+        except Exception as ex:   # never lose the line over the secondary measurement
+            out["dist"] = {"one_pool_sharded": {"error": repr(ex)}}
     single = rank == 0 and world == 1
     if single and not args.no_extras:
         try:
@@ -709,7 +720,7 @@ def main() -> int:
     if args.check and rank == 0:
         from oracle import oracle_ffi as orc
         nodes, cfgs, tasks, enabled = orc.from_swarm(sw)
-        st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False, group_id_seed=args.seed)
+        st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False, group_id_seed=seed_r)
         st.try_form_new_groups()
         st.try_merge_solo_groups()
         _, groups, members = eng.get_groups()

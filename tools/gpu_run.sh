@@ -9,6 +9,8 @@
 #   suite[:q16][:<pytest args>]  pytest tests -m gpu -x (q16: under PM_TEST_HW_QUEUES=16)
 #   tests:<file>[,<file>]    the named test files only (tests/ is implied), e.g. tests:test_gpu_plugin_cxx.py
 #   bench[:<bench.py args>]  the default bench line -> bench.json (+ one-line digest)
+#   benchn:<N>[:<bench.py args>]  bench.py --gpus N as the driver launches it, but on ONE GPU: N ranks over gloo sharing device 0
+#                            (PM_BENCH_BACKEND=gloo PM_BENCH_SHARE_DEVICE=1) — the plumbing of the N > 1 line, not its numbers
 #   timing[:<rounds>]        cold matches of configs[1] and [2] (tools/variant_bench.py) + 8 churn ticks, <rounds> times (2)
 #   variants:<a>,<b>         the same timings for prebuilt protocol_amd/variants/libpm_engine_<name>.so (tools/build_variants.py),
 #                            product library first and last
@@ -59,6 +61,21 @@ try:
     for k in ("churn", "configs2", "merge", "dist"):
         if k in d:
             print(" ", k, {a: b for a, b in d[k].items() if not isinstance(b, (list, dict))})
+except Exception as ex:
+    print("no bench line:", ex)
+PY
+      ;;
+    benchn)
+      nr=${arg%%:*}; rest=""; [ "$arg" != "$nr" ] && rest=${arg#*:}
+      PM_BENCH_BACKEND=gloo PM_BENCH_SHARE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$nr" \
+        --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus "$nr" --steps 5 --warmup 2 $rest > "$out/bench_n${nr}_gloo.json" 2> "$out/bench_n${nr}.err"
+      echo "benchn rc=$?"; tail -3 "$out/bench_n${nr}.err"
+      python - "$out/bench_n${nr}_gloo.json" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    print("n_gpus", d["n_gpus"], "scaling", d["scaling"], "ms_per_step", d["ms_per_step"], "value", d["value"], "ranks_seen", d.get("ranks_seen"))
+    print("  one_pool_sharded", {a: b for a, b in d["dist"]["one_pool_sharded"].items() if not isinstance(b, (str, dict))})
 except Exception as ex:
     print("no bench line:", ex)
 PY
