@@ -39,7 +39,8 @@ extern "C" {
 
 #define PM_ABI_VERSION 3 /* 3 (round 6): + the by-id / by-worker group calls of the plugin's read surface; the stepwise tick's
                             carve_next / carve_validate pair became pm_dist_carve_wait; pm_upload_workers(keep_groups = 1)
-                            accepts new rows behind the known ones; carve_variant 2 / 4 are PM_EINVAL (since round 5) */
+                            accepts new rows behind the known ones; + pm_host_to_lowercase (the model rule is Unicode now); carve_variant 2 / 4
+                            are PM_EINVAL (since round 5) */
 
 enum {
   PM_OK = 0,
@@ -459,8 +460,14 @@ int32_t pm_match_per_task_device(pm_engine*, uint64_t* best_ptr, uint64_t* count
  * NUL-terminated copy.  Returns PM_OK, PM_EPARSE, PM_EPANIC or PM_ERANGE. */
 int32_t pm_host_parse_requirements(const char* s, pm_config_row* cfg, pm_gpu_alt_row* alts,
                                    uint32_t alt_cap, char* models_out, size_t models_cap);
-/* GpuSpecs::meets model rule (shared/src/models/node.rs:463-484) for one string pair. */
+/* GpuSpecs::meets model rule (shared/src/models/node.rs:463-484) for one string pair: both sides through
+ * `str::to_lowercase` — the full Unicode mapping (pm_host_to_lowercase), not ASCII — then ' ' -> '_', the requirement split
+ * at ',' and every part trimmed of Unicode white space, four `contains` with and without '_'. */
 int32_t pm_host_model_matches(const char* spec_model, const char* req_model);
+/* str::to_lowercase (UTF-8 in, UTF-8 out): every code point through char::to_lowercase (up to three code points for one:
+ * U+0130), a capital sigma that ends a word as the final form.  Tables: Unicode 13.0 (tools/make_unicode_tables.py).
+ * *needed = strlen(result) + 1; out may be NULL with cap 0 to size the buffer; PM_ERANGE when cap is too small. */
+int32_t pm_host_to_lowercase(const char* in, char* out, size_t cap, size_t* needed);
 /* Bit table for pm_set_model_table: req_models[n_rows] x spec_models[n_classes]. */
 int32_t pm_host_build_model_table(const char* const* req_models, uint32_t n_rows,
                                   const char* const* spec_models, uint32_t n_classes, uint32_t* bits_out);

@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         L.orc_meets.restype = C.c_int
         L.orc_model_matches.argtypes = [C.c_char_p, C.c_char_p]
         L.orc_model_matches.restype = C.c_int
+        L.orc_to_lowercase_str.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.orc_to_lowercase_str.restype = None
         L.orc_is_node_compatible_with_config.argtypes = [vp, vp]
         L.orc_is_node_compatible_with_config.restype = C.c_int
         L.orc_calculate_distance.argtypes = [C.c_double] * 4
@@ -197,6 +199,14 @@ def meets(specs: np.ndarray, req) -> bool:
 
 def model_matches(spec_model: str, req_model: str) -> bool:
     return bool(lib().orc_model_matches(spec_model.encode(), req_model.encode()))
+
+
+def to_lowercase(text: str) -> str:
+    """str::to_lowercase as the oracle restates it"""
+    raw = text.encode()
+    buf = C.create_string_buffer(4 * len(raw) + 8)
+    lib().orc_to_lowercase_str(raw, buf, len(buf))
+    return buf.value.decode()
 
 
 def calculate_distance(lat1, lon1, lat2, lon2) -> float:

@@ -31,15 +31,135 @@ static uint64_t mix64(uint64_t x) {
   return orc_splitmix64(&s);
 }
 
-static int is_ws(char c) {
-  /* ASCII subset of Rust's char::is_whitespace used by str::trim */
-  return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r';
+#include "orc_unicode_lower.inc" /* GENERATED (tools/make_unicode_tables.py): orc_uc_lower_map, orc_uc_cased_ranges, orc_uc_case_ignorable_ranges */
+
+/* One code point of UTF-8 text in [p, e); a byte that starts no well-formed sequence counts as a code point of its own
+ * (0x110000 + byte): Rust strings are valid UTF-8, the C boundary does not promise it. */
+static uint32_t utf8_next(const char* p, const char* e, size_t* len) {
+  const unsigned char* u = (const unsigned char*)p;
+  size_t left = (size_t)(e - p);
+  uint32_t c = u[0];
+  *len = 1;
+  if (c < 0x80u) return c;
+  if (c >= 0xC2u && c <= 0xDFu && left >= 2 && (u[1] & 0xC0u) == 0x80u) {
+    *len = 2;
+    return ((c & 0x1Fu) << 6) | (u[1] & 0x3Fu);
+  }
+  if (c >= 0xE0u && c <= 0xEFu && left >= 3 && (u[1] & 0xC0u) == 0x80u && (u[2] & 0xC0u) == 0x80u) {
+    uint32_t v = ((c & 0x0Fu) << 12) | ((uint32_t)(u[1] & 0x3Fu) << 6) | (u[2] & 0x3Fu);
+    if (v >= 0x800u && !(v >= 0xD800u && v <= 0xDFFFu)) {
+      *len = 3;
+      return v;
+    }
+  }
+  if (c >= 0xF0u && c <= 0xF4u && left >= 4 && (u[1] & 0xC0u) == 0x80u && (u[2] & 0xC0u) == 0x80u && (u[3] & 0xC0u) == 0x80u) {
+    uint32_t v = ((c & 0x07u) << 18) | ((uint32_t)(u[1] & 0x3Fu) << 12) | ((uint32_t)(u[2] & 0x3Fu) << 6) | (u[3] & 0x3Fu);
+    if (v >= 0x10000u && v <= 0x10FFFFu) {
+      *len = 4;
+      return v;
+    }
+  }
+  return 0x110000u + c;
+}
+/* the code point that ENDS at e (p < e): its start */
+static const char* utf8_prev(const char* b, const char* e, uint32_t* cp) {
+  const char* k = e - 1;
+  size_t n;
+  while (k > b && ((unsigned char)*k & 0xC0u) == 0x80u && e - k < 4) --k;
+  *cp = utf8_next(k, e, &n);
+  if (k + n != e) { /* a stray continuation byte */
+    k = e - 1;
+    *cp = utf8_next(k, e, &n);
+  }
+  return k;
+}
+static size_t utf8_put(uint32_t v, char* o) {
+  if (v < 0x80u) { o[0] = (char)v; return 1; }
+  if (v < 0x800u) { o[0] = (char)(0xC0u | (v >> 6)); o[1] = (char)(0x80u | (v & 0x3Fu)); return 2; }
+  if (v < 0x10000u) { o[0] = (char)(0xE0u | (v >> 12)); o[1] = (char)(0x80u | ((v >> 6) & 0x3Fu)); o[2] = (char)(0x80u | (v & 0x3Fu)); return 3; }
+  o[0] = (char)(0xF0u | (v >> 18)); o[1] = (char)(0x80u | ((v >> 12) & 0x3Fu)); o[2] = (char)(0x80u | ((v >> 6) & 0x3Fu)); o[3] = (char)(0x80u | (v & 0x3Fu));
+  return 4;
 }
 
-/* trim [b,e) in place */
+/* Rust's char::is_whitespace (White_Space): what str::trim strips */
+static int is_ws_cp(uint32_t c) {
+  return (c >= 0x09u && c <= 0x0Du) || c == 0x20u || c == 0x85u || c == 0xA0u || c == 0x1680u || (c >= 0x2000u && c <= 0x200Au) ||
+         c == 0x2028u || c == 0x2029u || c == 0x202Fu || c == 0x205Fu || c == 0x3000u;
+}
+
+/* trim [b,e) in place (str::trim) */
 static void trim(const char** b, const char** e) {
-  while (*b < *e && is_ws(**b)) (*b)++;
-  while (*e > *b && is_ws(*(*e - 1))) (*e)--;
+  while (*b < *e) {
+    size_t n;
+    if (!is_ws_cp(utf8_next(*b, *e, &n))) break;
+    *b += n;
+  }
+  while (*e > *b) {
+    uint32_t c;
+    const char* k = utf8_prev(*b, *e, &c);
+    if (!is_ws_cp(c)) break;
+    *e = k;
+  }
+}
+
+static int in_ranges(const uint32_t (*r)[2], size_t n, uint32_t c) {
+  size_t lo = 0, hi = n;
+  while (lo < hi) {
+    size_t mid = (lo + hi) / 2;
+    if (c > r[mid][1]) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo < n && c >= r[lo][0];
+}
+#define ORC_CASED(c) in_ranges(orc_uc_cased_ranges, sizeof(orc_uc_cased_ranges) / sizeof(orc_uc_cased_ranges[0]), (c))
+#define ORC_IGNORABLE(c) in_ranges(orc_uc_case_ignorable_ranges, sizeof(orc_uc_case_ignorable_ranges) / sizeof(orc_uc_case_ignorable_ranges[0]), (c))
+
+/* str::to_lowercase (alloc::str): char::to_lowercase per code point; 'Σ' is 'ς' when it ends a word — preceded by a cased
+ * letter and not followed by one, case-ignorable code points skipped on both sides (map_uppercase_sigma).  Writes at most
+ * cap - 1 bytes + NUL (input that does not fit is cut at a code point boundary: the oracle's strings are short). */
+static void orc_to_lowercase(const char* b, const char* e, char* out, size_t cap) {
+  size_t n = 0;
+  for (const char* p = b; p < e;) {
+    size_t len;
+    uint32_t c = utf8_next(p, e, &len);
+    char tmp[16];
+    size_t m = 0;
+    if (c < 0x80u) {
+      tmp[m++] = (c >= 'A' && c <= 'Z') ? (char)(c - 'A' + 'a') : (char)c;
+    } else if (c == 0x3A3u) {
+      int before = 0, after = 0;
+      for (const char* q = p; q > b;) { /* backwards over the ignorables */
+        uint32_t d;
+        q = utf8_prev(b, q, &d);
+        if (!ORC_IGNORABLE(d)) { before = ORC_CASED(d); break; }
+      }
+      for (const char* q = p + len; q < e;) {
+        size_t l2;
+        uint32_t d = utf8_next(q, e, &l2);
+        if (!ORC_IGNORABLE(d)) { after = ORC_CASED(d); break; }
+        q += l2;
+      }
+      m = utf8_put((before && !after) ? 0x3C2u : 0x3C3u, tmp);
+    } else {
+      size_t lo = 0, hi = sizeof(orc_uc_lower_map) / sizeof(orc_uc_lower_map[0]), N = hi;
+      while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if (orc_uc_lower_map[mid].cp < c) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < N && orc_uc_lower_map[lo].cp == c) {
+        for (uint32_t k = 0; k < orc_uc_lower_map[lo].n; ++k) m += utf8_put(orc_uc_lower_map[lo].out[k], tmp + m);
+      } else {
+        memcpy(tmp, p, len);
+        m = len;
+      }
+    }
+    if (n + m + 1 > cap) break;
+    memcpy(out + n, tmp, m);
+    n += m;
+    p += len;
+  }
+  out[n] = 0;
 }
 
 /* Rust <u32 as FromStr>::from_str: optional '+', >=1 ASCII digit, no overflow. */
@@ -255,16 +375,11 @@ int orc_parse_requirements(const char* s, orc_requirements* out, char* err, size
 /* ------------------------------------------------------------------ predicate
  * shared/src/models/node.rs:377-541 */
 
-/* to_lowercase().replace(' ', "_") — ASCII only (documented restriction) */
+/* to_lowercase().replace(' ', "_") (:465, :470); out holds ORC_MODEL_LEN * 2 bytes */
 static void norm_model(const char* b, const char* e, char* out) {
-  size_t n = 0;
-  for (const char* p = b; p < e && n < ORC_MODEL_LEN * 2 - 1; ++p) {
-    char c = *p;
-    if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
-    if (c == ' ') c = '_';
-    out[n++] = c;
-  }
-  out[n] = 0;
+  orc_to_lowercase(b, e, out, ORC_MODEL_LEN * 2);
+  for (char* p = out; *p; ++p)
+    if (*p == ' ') *p = '_';
 }
 static void strip_underscore(const char* in, char* out) {
   size_t n = 0;
@@ -272,6 +387,8 @@ static void strip_underscore(const char* in, char* out) {
     if (*in != '_') out[n++] = *in;
   out[n] = 0;
 }
+
+void orc_to_lowercase_str(const char* in, char* out, size_t cap) { orc_to_lowercase(in, in + strlen(in), out, cap); }
 
 int orc_model_matches(const char* spec_model, const char* req_model) { /* :463-484 */
   char ns[ORC_MODEL_LEN * 2], ns_nu[ORC_MODEL_LEN * 2];

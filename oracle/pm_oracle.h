@@ -148,8 +148,10 @@ int orc_parse_requirements(const char* s, orc_requirements* out, char* err, size
 /* shared/src/models/node.rs:377-541  ComputeSpecs::meets (+ GpuSpecs::meets, CpuSpecs::meets). */
 int orc_meets(const orc_specs* specs, const orc_requirements* req);
 
-/* shared/src/models/node.rs:463-484  the model-string rule alone (ASCII to_lowercase). */
+/* shared/src/models/node.rs:463-484  the model-string rule alone (Unicode to_lowercase, Unicode trim). */
 int orc_model_matches(const char* spec_model, const char* req_model);
+/* str::to_lowercase (Unicode: char::to_lowercase per code point + the final-sigma rule), at most cap - 1 bytes + NUL */
+void orc_to_lowercase_str(const char* in, char* out, size_t cap);
 
 /* orchestrator/src/plugins/node_groups/mod.rs:206-215 */
 int orc_is_node_compatible_with_config(const orc_config* cfg, const orc_node* node);

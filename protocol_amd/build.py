@@ -17,7 +17,7 @@ HEADERS = ["pm_device.h", "pm_internal.h", "pm_members.h", "pm_validate.inc", "p
            "pm_carve_kernel.inc", "pm_stream.inc", "pm_launch.inc",
            "pm_engine_types.inc", "pm_engine_state.inc", "pm_engine_groups.inc", "pm_engine_carve.inc", "pm_engine_match.inc",
            "pm_engine_merge.inc", "pm_engine_workers.inc", "pm_engine_tasks.inc", "pm_engine_api.inc", "pm_engine_tick.inc",
-           "pm_engine_dist.inc", "pm_engine_debug.inc"]
+           "pm_engine_dist.inc", "pm_engine_debug.inc", "pm_unicode_lower.inc"]
 
 
 def _hipcc() -> str:

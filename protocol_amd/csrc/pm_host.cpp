@@ -17,14 +17,138 @@ namespace pm {
 
 namespace {
 
-constexpr std::string_view kWs = " \t\n\v\f\r";  // ASCII subset of char::is_whitespace (str::trim)
+#include "pm_unicode_lower.inc"  // GENERATED (tools/make_unicode_tables.py): pm_uc_lower_map, pm_uc_cased_ranges, pm_uc_case_ignorable_ranges
 
-std::string_view trim(std::string_view s) {
-  const size_t b = s.find_first_not_of(kWs);
-  if (b == std::string_view::npos) return {};
-  const size_t e = s.find_last_not_of(kWs);
-  return s.substr(b, e - b + 1);
+// One code point of a UTF-8 string (Rust strings are valid UTF-8; a byte that is not the start of a well-formed sequence is
+// passed through as itself: *len = 1, value = 0x110000 + byte, which no table knows).
+uint32_t decode_utf8(std::string_view s, size_t i, size_t* len) {
+  const auto b = [&](size_t k) { return uint32_t(static_cast<unsigned char>(s[k])); };
+  const uint32_t c = b(i);
+  *len = 1;
+  if (c < 0x80u) return c;
+  const auto cont = [&](size_t k) { return k < s.size() && (b(k) & 0xC0u) == 0x80u; };
+  if (c >= 0xC2u && c <= 0xDFu && cont(i + 1)) {
+    *len = 2;
+    return ((c & 0x1Fu) << 6) | (b(i + 1) & 0x3Fu);
+  }
+  if (c >= 0xE0u && c <= 0xEFu && cont(i + 1) && cont(i + 2)) {
+    const uint32_t v = ((c & 0x0Fu) << 12) | ((b(i + 1) & 0x3Fu) << 6) | (b(i + 2) & 0x3Fu);
+    if (v >= 0x800u && !(v >= 0xD800u && v <= 0xDFFFu)) {
+      *len = 3;
+      return v;
+    }
+  }
+  if (c >= 0xF0u && c <= 0xF4u && cont(i + 1) && cont(i + 2) && cont(i + 3)) {
+    const uint32_t v = ((c & 0x07u) << 18) | ((b(i + 1) & 0x3Fu) << 12) | ((b(i + 2) & 0x3Fu) << 6) | (b(i + 3) & 0x3Fu);
+    if (v >= 0x10000u && v <= 0x10FFFFu) {
+      *len = 4;
+      return v;
+    }
+  }
+  return 0x110000u + c;
 }
+void encode_utf8(uint32_t v, std::string* o) {
+  if (v < 0x80u) o->push_back(char(v));
+  else if (v < 0x800u) { o->push_back(char(0xC0u | (v >> 6))); o->push_back(char(0x80u | (v & 0x3Fu))); }
+  else if (v < 0x10000u) { o->push_back(char(0xE0u | (v >> 12))); o->push_back(char(0x80u | ((v >> 6) & 0x3Fu))); o->push_back(char(0x80u | (v & 0x3Fu))); }
+  else { o->push_back(char(0xF0u | (v >> 18))); o->push_back(char(0x80u | ((v >> 12) & 0x3Fu))); o->push_back(char(0x80u | ((v >> 6) & 0x3Fu))); o->push_back(char(0x80u | (v & 0x3Fu))); }
+}
+
+// char::is_whitespace (the White_Space property): what str::trim strips
+bool is_whitespace(uint32_t c) {
+  return (c >= 0x09u && c <= 0x0Du) || c == 0x20u || c == 0x85u || c == 0xA0u || c == 0x1680u || (c >= 0x2000u && c <= 0x200Au) ||
+         c == 0x2028u || c == 0x2029u || c == 0x202Fu || c == 0x205Fu || c == 0x3000u;
+}
+
+template <size_t N>
+bool in_ranges(const uint32_t (&r)[N][2], uint32_t c) {
+  size_t lo = 0, hi = N;
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (c > r[mid][1]) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo < N && c >= r[lo][0];
+}
+
+std::string_view trim(std::string_view s) {  // str::trim
+  size_t b = 0, e = s.size();
+  while (b < e) {
+    size_t n;
+    if (!is_whitespace(decode_utf8(s, b, &n))) break;
+    b += n;
+  }
+  while (e > b) {  // (the last code point: step back over continuation bytes)
+    size_t k = e - 1;
+    while (k > b && (static_cast<unsigned char>(s[k]) & 0xC0u) == 0x80u && e - k < 4) --k;
+    size_t n;
+    const uint32_t c = decode_utf8(s, k, &n);
+    if (k + n != e || !is_whitespace(c)) break;
+    e = k;
+  }
+  return s.substr(b, e - b);
+}
+
+// alloc::str: case_ignorable_then_cased over the code points of s[from..to) (forwards) or backwards from `from`
+bool cased_after_ignorables_fwd(std::string_view s, size_t i) {
+  while (i < s.size()) {
+    size_t n;
+    const uint32_t c = decode_utf8(s, i, &n);
+    if (!in_ranges(pm_uc_case_ignorable_ranges, c)) return in_ranges(pm_uc_cased_ranges, c);
+    i += n;
+  }
+  return false;
+}
+bool cased_after_ignorables_back(std::string_view s, size_t i) {
+  while (i > 0) {
+    size_t k = i - 1;
+    while (k > 0 && (static_cast<unsigned char>(s[k]) & 0xC0u) == 0x80u && i - k < 4) --k;
+    size_t n;
+    uint32_t c = decode_utf8(s, k, &n);
+    if (k + n != i) {  // (a stray continuation byte: a code point of its own)
+      k = i - 1;
+      c = decode_utf8(s, k, &n);
+    }
+    if (!in_ranges(pm_uc_case_ignorable_ranges, c)) return in_ranges(pm_uc_cased_ranges, c);
+    i = k;
+  }
+  return false;
+}
+
+}  // namespace
+
+// str::to_lowercase (node.rs:465, :470): every code point through char::to_lowercase — which may give up to three — and
+// a capital sigma at the end of a word as the final form (alloc::str::to_lowercase, map_uppercase_sigma)
+std::string to_lowercase(std::string_view s) {
+  std::string o;
+  o.reserve(s.size());
+  for (size_t i = 0; i < s.size();) {
+    size_t n;
+    const uint32_t c = decode_utf8(s, i, &n);
+    if (c < 0x80u) {
+      o.push_back(c >= 'A' && c <= 'Z' ? char(c - 'A' + 'a') : char(c));
+    } else if (c == 0x3A3u) {
+      const bool word_final = cased_after_ignorables_back(s, i) && !cased_after_ignorables_fwd(s, i + n);
+      encode_utf8(word_final ? 0x3C2u : 0x3C3u, &o);
+    } else {
+      constexpr size_t N = sizeof(pm_uc_lower_map) / sizeof(pm_uc_lower_map[0]);
+      size_t lo = 0, hi = N;
+      while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (pm_uc_lower_map[mid].cp < c) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < N && pm_uc_lower_map[lo].cp == c)
+        for (uint32_t k = 0; k < pm_uc_lower_map[lo].n; ++k) encode_utf8(pm_uc_lower_map[lo].out[k], &o);
+      else
+        o.append(s.substr(i, n));
+    }
+    i += n;
+  }
+  return o;
+}
+
+namespace {
 
 // <u32 as FromStr>: optional '+', at least one ASCII digit, no overflow.
 bool parse_u32(std::string_view s, uint32_t* out) {
@@ -40,12 +164,10 @@ bool parse_u32(std::string_view s, uint32_t* out) {
   return true;
 }
 
-std::string normalize_model(std::string_view s) {  // to_lowercase().replace(' ', "_"), ASCII
-  std::string o(s);
-  for (char& c : o) {
-    if (c >= 'A' && c <= 'Z') c = char(c - 'A' + 'a');
+std::string normalize_model(std::string_view s) {  // to_lowercase().replace(' ', "_")
+  std::string o = to_lowercase(s);
+  for (char& c : o)
     if (c == ' ') c = '_';
-  }
   return o;
 }
 std::string drop_underscores(const std::string& s) {
@@ -237,6 +359,16 @@ int32_t pm_host_parse_requirements(const char* s, pm_config_row* cfg, pm_gpu_alt
 int32_t pm_host_model_matches(const char* spec_model, const char* req_model) {
   if (!spec_model || !req_model) return pm::set_error(PM_EINVAL, "null argument");
   return pm::model_matches(spec_model, req_model) ? 1 : 0;
+}
+
+int32_t pm_host_to_lowercase(const char* in, char* out, size_t cap, size_t* needed) {
+  if (!in || !needed) return pm::set_error(PM_EINVAL, "null argument");
+  const std::string r = pm::to_lowercase(in);
+  *needed = r.size() + 1;
+  if (!out && cap == 0) return PM_OK;  // sizing call
+  if (!out || cap < r.size() + 1) return pm::set_error(PM_ERANGE, "output buffer too small");
+  std::memcpy(out, r.c_str(), r.size() + 1);
+  return PM_OK;
 }
 
 int32_t pm_host_build_model_table(const char* const* req_models, uint32_t n_rows, const char* const* spec_models,

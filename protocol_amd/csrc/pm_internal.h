@@ -24,6 +24,7 @@ struct ParsedRequirements {
 
 int32_t parse_requirements(std::string_view s, ParsedRequirements* out);
 bool model_matches(std::string_view spec_model, std::string_view req_model);
+std::string to_lowercase(std::string_view s);  // str::to_lowercase (Unicode; pm_host.cpp)
 void template_order(const pm_config_row* cfgs, uint32_t n, std::vector<uint32_t>* order);
 void available_order(const pm_config_row* cfgs, uint32_t n, uint64_t enabled, std::vector<uint32_t>* out);
 

@@ -98,7 +98,7 @@ EXPORTS = [
     "pm_host_upload_name_vars", "pm_host_last_file_idx", "pm_abi_version",
     "pm_append_workers", "pm_set_addr_ranks", "pm_tasks_insert_front", "pm_tasks_insert_front_ex", "pm_tasks_delete", "pm_set_stream", "pm_set_carve_workgroups", "pm_tick_many", "pm_dist_configure", "pm_dist_tick_begin", "pm_dist_carve_wait",
     "pm_dist_match_begin", "pm_dist_tick_end", "pm_match_per_task_device",
-    "pm_dissolve_group_by_id", "pm_get_group_by_id", "pm_get_group_of_worker",
+    "pm_dissolve_group_by_id", "pm_get_group_by_id", "pm_get_group_of_worker", "pm_host_to_lowercase",
 ]
 
 _lib = None
@@ -173,6 +173,7 @@ def lib() -> C.CDLL:
         L.pm_host_group_vars.argtypes = [C.c_char_p, C.POINTER(GroupVars), C.c_char_p, sz, C.POINTER(sz)]
         L.pm_host_volume_vars.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
         L.pm_host_upload_name_vars.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, C.c_char_p, sz, C.POINTER(sz)]
+        L.pm_host_to_lowercase.argtypes = [C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
         L.pm_host_last_file_idx.argtypes = [C.c_char_p]
         L.pm_host_last_file_idx.restype = u32
         for name in EXPORTS:

@@ -75,6 +75,16 @@ def build_model_table(req_models: list, spec_models: list) -> np.ndarray:
     return bits[:n_rows * words]
 
 
+def to_lowercase(text: str) -> str:
+    """str::to_lowercase as the product evaluates it (pm_host_to_lowercase)"""
+    raw = text.encode()
+    need = C.c_size_t(0)
+    E.check(E.lib().pm_host_to_lowercase(raw, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    E.check(E.lib().pm_host_to_lowercase(raw, buf, len(buf), C.byref(need)))
+    return buf.value.decode()
+
+
 def config_order(cfg_rows: np.ndarray, enabled: int) -> list:
     out = np.zeros(max(len(cfg_rows), 1), dtype=np.uint32)
     n = C.c_uint32(0)
