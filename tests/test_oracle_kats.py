@@ -137,3 +137,21 @@ def test_config_sort_rules():
     assert orc.sort_configs(dup)[0] == 2
     bad = orc.make_config("x", 3, 2, None)
     assert orc.sort_configs(bad)[0] == 2
+
+
+def test_fixture_is_the_references_test_module_structurally():
+    """tests/golden/check_kats_against_reference.py parses the reference's own test module — every create_compute_specs call
+    and ComputeSpecs literal, every requirement string through the `let` that names it, every assert!(..meets..) with its
+    polarity, every from_str(..).is_err() — and compares the triples with the fixture (container-only: needs /root/reference)."""
+    import importlib.util
+    import os
+    if not os.path.exists("/root/reference/crates/shared/src/models/node.rs"):
+        pytest.skip("the reference is not present on this box")
+    path = os.path.join(os.path.dirname(__file__), "golden", "check_kats_against_reference.py")
+    spec = importlib.util.spec_from_file_location("check_kats", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
+    vectors = mod.reference_vectors(open(mod.REF).read())
+    assert sum(1 for vs in vectors.values() for v in vs if v[0] == "meets") == 29
+    assert sum(1 for vs in vectors.values() for v in vs if v[0] == "meets" and not v[3]) >= 9     # the negative assertions are seen as such
