@@ -205,9 +205,10 @@ def kernel_table(sw, stats, T, W, prop):
         "pair_sweep": {"ms": sweep_ms, "alg_bytes": sweep_bytes, "GB/s": gbs(sweep_bytes, sweep_ms),
                        "pair_evals_per_s": pair_rate,
                        "valu_ceiling_pair_evals_per_s": VALU_LANE_OPS / OPS_PER_PAIR_EVAL,
-                       "valu_frac": pair_rate / (VALU_LANE_OPS / OPS_PER_PAIR_EVAL) if pair_rate else None,
-                       "note": ("bit-sliced: one 64-bit op evaluates 64 pairs, so the fraction of the one-pair-per-lane-op "
-                                "ceiling (SURVEY 8d: CUs x lanes x clk / 20 ops) can exceed 1")},
+                       "x_one_pair_per_op_ceiling": pair_rate / (VALU_LANE_OPS / OPS_PER_PAIR_EVAL) if pair_rate else None,
+                       "note": ("x_one_pair_per_op_ceiling is a RATIO, not a fraction of a peak: the kernel is bit-sliced (one "
+                                "64-bit op evaluates 64 pairs), so it runs tens of times above SURVEY 8d's one-pair-per-lane-op "
+                                "ceiling (CUs x lanes x clk / 20 ops); as a share of the bit-sliced ceiling (x 64) it is that / 64")},
         "carve": {"ms": carve_ms, "alg_bytes": carve_bytes, "GB/s": gbs(carve_bytes, carve_ms),
                   "steps": steps, "fast_steps": med(stats, "carve_fast_steps"), "us_per_step": 1e3 * carve_ms / steps,
                   "launches": med(stats, "carve_launches")},
@@ -238,7 +239,10 @@ def chain_model(steps, carve_ms, prop_ms):
                       "(carve_variant 0): ONE launch, the rows are made by the other workgroups while the chain runs, so "
                       "what is left on the chain besides the steps is waiting for rows at the start of a configuration; "
                       "batch pipeline (variant 3): the preparation and proposer launches between the validation "
-                      "launches are on the chain too"),
+                      "launches are on the chain too.  What a step costs beyond the floor (round 6, priced in situ with padded "
+                      "builds, profiles/r06_chain_loop_isa.txt): the chain wave's own 43 instructions are worth ~210 cycles; the "
+                      "rest is the rate at which the parkers land rows (0.87 blocks of 16 tickets per us), i.e. the row "
+                      "pipeline's look-ahead window — the chain takes entries as they arrive"),
             "steps": steps, "floor_us_per_step": floor_us, "achieved_us_per_step": 1e3 * carve_ms / max(steps, 1),
             "validate_only_us_per_step": 1e3 * val_ms / max(steps, 1),
             "frac": floor_us / (1e3 * carve_ms / max(steps, 1)) if carve_ms > 0 else None}

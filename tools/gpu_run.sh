@@ -109,8 +109,9 @@ PY
       done
       cat "$out/${n}_kstat.txt" ;;
     anatomy)
-      PM_PROF_NO_BUILD=1 timeout 200 python tools/stream_prof.py 100000 10000 > "$out/stream_anatomy_10k.txt" 2>&1
-      PM_PROF_NO_BUILD=1 timeout 200 python tools/stream_prof.py 1000000 100000 > "$out/stream_anatomy_100k.txt" 2>&1
+      P=protocol_amd/variants/libpm_engine_prof.so   # (tools/build_variants.py prof=PM_CARVE_PROF, built where there is no GPU)
+      PM_PROF_LIB=$P PM_PROF_NO_BUILD=1 timeout 200 python tools/stream_prof.py 100000 10000 > "$out/stream_anatomy_10k.txt" 2>&1
+      PM_PROF_LIB=$P PM_PROF_NO_BUILD=1 timeout 200 python tools/stream_prof.py 1000000 100000 > "$out/stream_anatomy_100k.txt" 2>&1
       grep "T=\|a row\|proposer rows\|chain anatomy\|compute\|networks\|bitmap sweeps" "$out/stream_anatomy_10k.txt" "$out/stream_anatomy_100k.txt" ;;
     timeline)
       L=protocol_amd/variants/libpm_engine_rowrec.so
