@@ -51,6 +51,9 @@ print(f"  wave 0 (us): chain {us(o[0]):.1f} over {o[1]} calls, {o[2]} commits ({
       f"wave 0 in total {us(o[11]):.1f}; exact steps {us(o[22]):.1f}")
 print(f"  chain anatomy (us): waiting for rows {us(o[16]):.1f} ({o[24]} waits), steps {us(o[18]):.1f}, stopping the other waves {us(o[17]):.1f}; "
       f"{o[19]} batches of steps, {o[23]} seeds dead at their turn")
+if os.environ.get("PM_CHAIN_FINE") == "1":   # (a -DPM_CARVE_PROF,PM_CHAIN_FINE build: the chain's counters in the parkers' slots)
+    print(f"  the steps' time (us): batch heads {us(o[5]):.1f} ({us(o[5]) / max(o[19], 1):.3f} a batch), plain steps {us(o[6]):.1f} "
+          f"({us(o[6]) / max(o[2], 1):.3f} a commit), steps that needed attention {us(o[7]):.1f} ({o[8]} of them), batch tails {us(o[18]):.1f}")
 print(f"  the parkers together (us): waiting for tickets {us(o[5]):.1f}, for room {us(o[6]):.1f}, for rows {us(o[7]):.1f} "
       f"({o[26]} polls, {o[27]} of {o[28]} rows late at the first look), digesting {us(o[8]):.1f}, idle between runs {us(o[9]):.1f}")
 row = lambda t, n: f"{n} rows, {us(t) / max(n, 1):.2f} us each" if n else "none"
