@@ -240,7 +240,8 @@ def chain_model(steps, carve_ms, prop_ms):
                       "what is left on the chain besides the steps is waiting for rows at the start of a configuration; "
                       "batch pipeline (variant 3): the preparation and proposer launches between the validation "
                       "launches are on the chain too.  What a step costs beyond the floor (round 6, priced in situ with padded "
-                      "builds, profiles/r06_chain_loop_isa.txt): the chain wave's own 43 instructions are worth ~210 cycles; the "
+                      "builds and s_memtime marks, profiles/r06_chain_loop_isa.txt, r06_chain_fine_anatomy.txt): the chain wave's "
+                      "own plain step is 37 instructions, 0.149 us (~360 cycles) per commit; the "
                       "rest is the rate at which the parkers land rows (0.87 blocks of 16 tickets per us), i.e. the row "
                       "pipeline's look-ahead window — the chain takes entries as they arrive"),
             "steps": steps, "floor_us_per_step": floor_us, "achieved_us_per_step": 1e3 * carve_ms / max(steps, 1),
