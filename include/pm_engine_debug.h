@@ -54,11 +54,19 @@ int32_t pm_debug_prune_mode(pm_engine* e, uint32_t mode);
  * bench.py cites beside the roofline's 8 TB/s. */
 int32_t pm_debug_hbm_triad(pm_engine* e, uint64_t n_doubles, uint32_t reps, double* gb_per_s);
 
-/* A measuring build's (-DPM_ROW_REC) record of the last streaming launch's rows: eight words per ticket — s_memtime when the
- * ticket was seen, when the first pass of the sweep was packed, when the first batch's keys were there, when the candidates
+/* A measuring build's (-DPM_ROW_REC) record of the last streaming launch's rows: eight words per ticket — the real-time
+ * counter (100 MHz, one clock for all CUs; the validator's events of such a build carry the same) when the ticket was seen, when the first pass of the sweep was packed, when the first batch's keys were there, when the candidates
  * were through, when the row was finished, when it was stored; candidates evaluated | mode << 32; hardware id.  n_rows = 0 from
  * a product build. */
 int32_t pm_debug_row_records(pm_engine* e, unsigned long long* out, uint32_t cap_rows, uint32_t* n_rows);
+/* ... and the batches of steps its chain took up: four words each — the clock at the top of the chain's loop; first entry |
+ * entries << 24 | live ones << 32 | commits so far << 40; the clock when the entries had been looked at; the clock behind the steps.
+ * n = 0 from a product build. */
+int32_t pm_debug_chain_batches(pm_engine* e, unsigned long long* out, uint32_t cap, uint32_t* n);
+/* ... and the blocks of sixteen tickets its parkers took up, eight words each, indexed by first ticket / 16: first ticket | tickets
+ * whose rows were asked for << 32 | tickets in the block << 48 | 1 << 63; clock at that moment; when the rows were all there; when the
+ * block had its turn; when it had room in the ring; when it was parked; first entry | tickets parked << 32 | block of the run << 48. */
+int32_t pm_debug_park_records(pm_engine* e, unsigned long long* out, uint32_t cap_blocks, uint32_t* n_blocks);
 
 /* Neighbour rows two ways from the same keys (keys[n_waves * n_per_wave], ~0 = no candidate; the low slot_bits of a key index
  * sites[1 << slot_bits]; n_waves a multiple of four): the serial insertion, and four strides at a time through the sorting networks for the first `upto`

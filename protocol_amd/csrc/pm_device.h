@@ -79,7 +79,8 @@ enum { SC_CLAIM = 0,    // next ticket a proposer wave takes (atomicAdd)
        SC_GAVE_UP = 49, // proposer waves that left because nothing was asked of them for too long
        SC_FINISH = 50,  // the carve launch ran (carve_finish_kernel has records to finish)
        SC_FINISH_TICKET = 52,  // carve_finish_kernel: blocks through (the last one mirrors the status to the host)
-       SC_TRACE = 51    // PM_CARVE_PROF builds: events written to the trace buffer
+       SC_TRACE = 51,   // PM_CARVE_PROF builds: events written to the trace buffer
+       SC_BATCHES = 54  // PM_ROW_REC builds: batches of steps the chain has recorded
 };
 static constexpr uint32_t PM_STREAM_TRACE_CAP = 1u << 17;  // events (two u64 each) of a PM_CARVE_PROF build's timeline
 // how the rows of a ticket are made (bits 24..25 of the ticket's payload)

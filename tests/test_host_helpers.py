@@ -39,7 +39,7 @@ def test_library_exports_every_debug_hook():
     protos = _c_prototypes(hdr)
     assert set(protos) == {"pm_debug_carve_prof", "pm_debug_stream_trace", "pm_debug_mem_lists_above", "pm_debug_prune_mode",
                            "pm_debug_hbm_triad", "pm_debug_stream_abort_after", "pm_debug_merge_streamed", "pm_debug_delta_pushes",
-                           "pm_debug_row_networks", "pm_debug_row_records"}
+                           "pm_debug_row_networks", "pm_debug_row_records", "pm_debug_chain_batches", "pm_debug_park_records"}
     L = E.lib()
     for name in protos:
         assert hasattr(L, name), f"{name} declared in pm_engine_debug.h but not exported"

@@ -18,6 +18,7 @@
 #   kstat[:<variant>,...]    rocprofv3 --kernel-trace --stats of 20 matches -> average duration of the carve's kernels
 #   anatomy                  streaming carve taken apart with the prebuilt PM_CARVE_PROF library (tools/stream_prof.py), 10k / 100k
 #   timeline                 product-like timelines (prebuilt PM_ROW_REC library, tools/stream_trace.py): 10k, 100k, churn
+#   pipeline[:<args>]        a ticket's way through the streaming carve on one clock (prebuilt PM_ROW_REC library, tools/pipeline_probe.py)
 #   host                     PM_TRACE_HOST marks of a cold match and of churn ticks + the rocprofv3 kernel timeline of a match
 #   profiles:<rNN>           tools/collect_profiles.py <rNN>: kernel statistics, PMC passes, bench line -> gpurun_out/<rNN>/
 #   fuzz[:<swarms>[:<seed>]] tools/parity_fuzz.py (engine against oracle on random swarms)
@@ -119,6 +120,9 @@ PY
       PM_PROF_LIB=$L PM_PROF_NO_BUILD=1 timeout 200 python tools/stream_trace.py 1000000 100000 > "$out/stream_timeline_100k.txt" 2>&1
       PM_PROF_LIB=$L PM_PROF_NO_BUILD=1 timeout 200 python tools/stream_trace.py churn > "$out/stream_timeline_churn.txt" 2>&1
       head -30 "$out/stream_timeline_10k.txt"; grep "chain waits\|totals" "$out/stream_timeline_100k.txt"; head -12 "$out/stream_timeline_churn.txt" ;;
+    pipeline)
+      PM_EXP_LIB=protocol_amd/variants/libpm_engine_rowrec.so timeout 300 python tools/pipeline_probe.py $arg > "$out/${n}_pipeline.txt" 2>&1
+      echo "pipeline rc=$?"; head -150 "$out/${n}_pipeline.txt" | cut -c1-200 ;;
     host)
       PM_TRACE_HOST=1 timeout 120 python tools/host_trace.py 1 2>&1 | tail -16 > "$out/host_marks_match.txt"
       PM_TRACE_HOST=1 timeout 120 python tools/churn_probe.py 8 2>&1 | tail -40 > "$out/host_marks_churn.txt"

@@ -35,7 +35,7 @@ r = r[r[:, 0] != 0]
 if not len(r):
     raise SystemExit("no records (not a PM_ROW_REC build)")
 MODE_BITMAP, MODE_WALK = 1, 2  # (SROW_BITMAP, SROW_WALK: pm_device.h)
-tick = 2375.0  # s_memtime ticks per microsecond on this part (tools/stream_trace.py calibrates it against the launch's hipEvent time)
+tick = 100.0  # the PM_ROW_REC build stamps with the real-time counter (100 MHz, one clock for all CUs)
 print(f"T={T} W={W}: carve kernel {s['ms_carve_kernel']:.3f} ms, {len(r)} rows recorded")
 d = lambda a, b: (r[:, b].astype(np.int64) - r[:, a].astype(np.int64)) / tick
 mode = (r[:, 6] >> np.uint64(32)).astype(np.int64)
