@@ -14,6 +14,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 template <int VARIANT>
 __device__ __forceinline__ void run_batch(uint32_t rab0, uint32_t tail0, uint32_t n_steps, uint32_t group_n, uint32_t& commits) {
+  const uint32_t lane_ = threadIdx.x & 63u;
   const uint32_t want = group_n - 1u;
   uint32_t lm = n_steps >= 32u ? 0xFFFFFFFFu : ((1u << n_steps) - 1u);
   const uint32_t guard = 1u << n_steps;
@@ -540,6 +541,143 @@ __device__ __forceinline__ void run_batch(uint32_t rab0, uint32_t tail0, uint32_
         : [gn] "s"(group_n), [want] "s"(want), [rabT] "v"(rabT)
         : "vcc", "scc", "memory");
 #undef STEP_BODY7
+  } else if constexpr (VARIANT == 15) {  // variant 5 with the row after next asked for right behind the look, and a wait for the look only
+    const uint32_t rabT = rab0 + ((tail0 & (R - 1u)) << 9);
+    uint32_t sc = s, vk, sn2;
+    lm = n_steps >= 32u ? 0xFFFFFFFEu : (((1u << n_steps) - 1u) & ~1u);  // behind the current one (offset 0)
+    s_n = lm ? (uint32_t)__builtin_ctz(lm) : 0xFFFFFFFFu;
+    // per step, in the shadow of the look that is on its way: the offset and the address of the entry after next (they depend on the live
+    // mask only); behind the kill: the next look, at once the row after next into the set the kill has freed, then the collector's word
+#define STEP_BODY7(XRA, XNRB, XADR, XADR2, YRA, LBL_ATT, LBL_LAST)                                                    \
+        "s_mov_b32 m0, %[sc]\n\t"                                                                                    \
+        "s_bitset0_b32 %[lm], %[sn]\n\t"           /* lm: the live entries behind the NEXT one */                     \
+        "s_ff1_i32_b32 %[sn2], %[lm]\n\t"          /* the entry after next (-1: none) */                              \
+        "v_lshl_add_u32 %[" XADR2 "], %[sn2], 9, %[rabT]\n\t"                                                        \
+        "s_waitcnt lgkmcnt(2)\n\t"                 /* the look is back; the two behind it stay on their way */          \
+        "v_bfi_b32 %[vt], %[" XNRB "], 0, %[w]\n\t"                                                                  \
+        "v_cmp_ne_u32_e32 vcc, 0, %[vt]\n\t"                                                                         \
+        "s_nop 0\n\t"                                                                                                \
+        "v_mbcnt_lo_u32_b32 %[vt], vcc_lo, 0\n\t"                                                                    \
+        "v_mbcnt_hi_u32_b32 %[vt], vcc_hi, %[vt]\n\t"                                                                \
+        "v_cmp_ge_u32_e64 %[sx], %[want], %[vt]\n\t"                                                                 \
+        "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                             \
+        "s_bfe_i32 %[su], vcc_lo, 0x10000\n\t"                                                                       \
+        "v_cndmask_b32_e64 %[vk], -1, %[" XNRB "], %[sx]\n\t"                                                        \
+        "s_and_b32 %[st], %[st], %[su]\n\t"                                                                          \
+        "s_cmp_lt_u32 %[st], %[gn]\n\t"                                                                              \
+        "s_cbranch_scc1 " LBL_ATT "\n\t"                                                                             \
+        "ds_and_b32 %[" XRA "], %[vk]\n\t"                                                                           \
+        "s_cmp_eq_u32 %[sn], -1\n\t"               /* no next entry: this was the batch's last live one */            \
+        "s_cbranch_scc1 " LBL_LAST "\n\t"                                                                            \
+        "s_waitcnt lgkmcnt(1)\n\t"                 /* (the next row's address: asked for a step ago) */               \
+        "ds_read_b32 %[w], %[" YRA "]\n\t"                                                                           \
+        "ds_read_b32 %[" XRA "], %[" XADR2 "]\n\t"                                                                   \
+        "ds_read_b32 %[" XNRB "], %[" XADR2 "] offset:4\n\t"                                                         \
+        "v_writelane_b32 %[acl], vcc_lo, m0\n\t"                                                                  \
+        "v_writelane_b32 %[ach], vcc_hi, m0\n\t"                                                                  \
+        "v_mov_b32 %[" XADR "], %[" XADR2 "]\n\t"                                                                    \
+        "s_add_u32 %[cm], %[cm], 1\n\t"                                                                              \
+        "s_mov_b32 %[sc], %[sn]\n\t"                                                                                 \
+        "s_mov_b32 %[sn], %[sn2]\n\t"
+    uint32_t adr2, acl = 0u, ach = 0u;
+    asm volatile(
+        "ds_read_b32 %[w], %[ra]\n\t"
+        "s_nop 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "1:\n\t"
+        STEP_BODY7("ra", "nrb", "adr", "adr2", "ran", "3f", "2f")
+        STEP_BODY7("ran", "nrbn", "adrn", "adr2", "ra", "5f", "6f")
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "v_writelane_b32 %[acl], vcc_lo, m0\n\t"
+        "v_writelane_b32 %[ach], vcc_hi, m0\n\t"
+        "s_add_u32 %[cm], %[cm], 1\n\t"
+        "s_mov_b32 %[status], 0\n\t"
+        "s_branch 4f\n\t"
+        "6:\n\t"
+        "v_writelane_b32 %[acl], vcc_lo, m0\n\t"
+        "v_writelane_b32 %[ach], vcc_hi, m0\n\t"
+        "s_add_u32 %[cm], %[cm], 1\n\t"
+        "s_mov_b32 %[status], 0\n\t"
+        "s_branch 4f\n\t"
+        "3:\n\t"
+        "s_mov_b32 %[status], 1\n\t"
+        "s_branch 4f\n\t"
+        "5:\n\t"
+        "s_mov_b32 %[status], 3\n\t"
+        "4:\n\t"
+        "s_mov_b64 %[a], vcc\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [w] "=&v"(w), [vt] "=&v"(vt), [va] "=&v"(va), [vk] "=&v"(vk), [adr2] "=&v"(adr2), [st] "=&s"(st), [su] "=&s"(su), [sx] "=&s"(sx),
+          [a] "=&s"(a), [sn2] "=&s"(sn2), [status] "=&s"(status), [acl] "+v"(acl), [ach] "+v"(ach), [ra] "+v"(ra), [nrb] "+v"(nrb), [adr] "+v"(adr), [ran] "+v"(ra_n),
+          [nrbn] "+v"(nrb_n), [adrn] "+v"(adr_n), [lm] "+s"(lm), [sc] "+s"(sc), [sn] "+s"(s_n), [cm] "+s"(commits)
+        : [gn] "s"(group_n), [want] "s"(want), [rabT] "v"(rabT)
+        : "vcc", "scc", "m0", "memory");
+#undef STEP_BODY7
+    if (lane_ < n_steps) *(__attribute__((address_space(3))) unsigned long long*)(uintptr_t)(rabT - lane_ * 8u + (lane_ << 9)) = ((unsigned long long)ach << 32) | acl;  // (lane j: entry j's word into its lane-0 slot)
+  } else if constexpr (VARIANT == 16) {  // 15 with a row in ONE read (address and bit: a register pair by its numbers)
+    const uint32_t rabT = rab0 + ((tail0 & (R - 1u)) << 9);
+    uint32_t sc = s, vk, sn2, adr2, acl = 0u, ach = 0u;
+    lm = n_steps >= 32u ? 0xFFFFFFFEu : (((1u << n_steps) - 1u) & ~1u);
+    s_n = lm ? (uint32_t)__builtin_ctz(lm) : 0xFFFFFFFFu;
+#define STEP_BODY16(XRA, XNRB, XPAIR, YRA, LBL_ATT, LBL_LAST)                                                         \
+        "s_mov_b32 m0, %[sc]\n\t"                                                                                    \
+        "s_bitset0_b32 %[lm], %[sn]\n\t"                                                                             \
+        "s_ff1_i32_b32 %[sn2], %[lm]\n\t"                                                                            \
+        "v_lshl_add_u32 %[adr2], %[sn2], 9, %[rabT]\n\t"                                                             \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                   \
+        "v_bfi_b32 %[vt], " XNRB ", 0, %[w]\n\t"                                                                     \
+        "v_cmp_ne_u32_e32 vcc, 0, %[vt]\n\t"                                                                         \
+        "s_nop 0\n\t"                                                                                                \
+        "v_mbcnt_lo_u32_b32 %[vt], vcc_lo, 0\n\t"                                                                    \
+        "v_mbcnt_hi_u32_b32 %[vt], vcc_hi, %[vt]\n\t"                                                                \
+        "v_cmp_ge_u32_e64 %[sx], %[want], %[vt]\n\t"                                                                 \
+        "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                             \
+        "s_bfe_i32 %[su], vcc_lo, 0x10000\n\t"                                                                       \
+        "v_cndmask_b32_e64 %[vk], -1, " XNRB ", %[sx]\n\t"                                                           \
+        "s_and_b32 %[st], %[st], %[su]\n\t"                                                                          \
+        "s_cmp_lt_u32 %[st], %[gn]\n\t"                                                                              \
+        "s_cbranch_scc1 " LBL_ATT "\n\t"                                                                             \
+        "ds_and_b32 " XRA ", %[vk]\n\t"                                                                              \
+        "s_cmp_eq_u32 %[sn], -1\n\t"                                                                                 \
+        "s_cbranch_scc1 " LBL_LAST "\n\t"                                                                            \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                   \
+        "ds_read_b32 %[w], " YRA "\n\t"                                                                              \
+        "ds_read_b64 " XPAIR ", %[adr2]\n\t"                                                                         \
+        "v_writelane_b32 %[acl], vcc_lo, m0\n\t"                                                                     \
+        "v_writelane_b32 %[ach], vcc_hi, m0\n\t"                                                                     \
+        "s_add_u32 %[cm], %[cm], 1\n\t"                                                                              \
+        "s_mov_b32 %[sc], %[sn]\n\t"                                                                                 \
+        "s_mov_b32 %[sn], %[sn2]\n\t"
+    asm volatile(
+        "ds_read_b32 %[w], v20\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "1:\n\t"
+        STEP_BODY16("v20", "v21", "v[20:21]", "v22", "3f", "2f")
+        STEP_BODY16("v22", "v23", "v[22:23]", "v20", "5f", "6f")
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "6:\n\t"
+        "v_writelane_b32 %[acl], vcc_lo, m0\n\t"
+        "v_writelane_b32 %[ach], vcc_hi, m0\n\t"
+        "s_add_u32 %[cm], %[cm], 1\n\t"
+        "s_mov_b32 %[status], 0\n\t"
+        "s_branch 4f\n\t"
+        "3:\n\t"
+        "s_mov_b32 %[status], 1\n\t"
+        "s_branch 4f\n\t"
+        "5:\n\t"
+        "s_mov_b32 %[status], 3\n\t"
+        "4:\n\t"
+        "s_mov_b64 %[a], vcc\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [w] "=&v"(w), [vt] "=&v"(vt), [vk] "=&v"(vk), [adr2] "=&v"(adr2), [st] "=&s"(st), [su] "=&s"(su), [sx] "=&s"(sx),
+          [a] "=&s"(a), [sn2] "=&s"(sn2), [status] "=&s"(status), [acl] "+v"(acl), [ach] "+v"(ach), "+{v20}"(ra), "+{v21}"(nrb),
+          "+{v22}"(ra_n), "+{v23}"(nrb_n), [lm] "+s"(lm), [sc] "+s"(sc), [sn] "+s"(s_n), [cm] "+s"(commits)
+        : [gn] "s"(group_n), [want] "s"(want), [rabT] "v"(rabT)
+        : "vcc", "scc", "m0", "memory");
+#undef STEP_BODY16
+    if (lane_ < n_steps) *(__attribute__((address_space(3))) unsigned long long*)(uintptr_t)(rabT - lane_ * 8u + (lane_ << 9)) = ((unsigned long long)ach << 32) | acl;
   } else if constexpr (VARIANT == 10) {  // variant 5 with the row after next asked for right behind the look, and a wait for the look only
     const uint32_t rabT = rab0 + ((tail0 & (R - 1u)) << 9);
     uint32_t sc = s, vk, sn2;
@@ -927,6 +1065,8 @@ extern "C" int chain_step_run(int variant, uint32_t n_batches, uint32_t batch_n,
     case 12: chain_step_kernel<12><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
     case 13: chain_step_kernel<13><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
     case 14: chain_step_kernel<14><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
+    case 15: chain_step_kernel<15><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
+    case 16: chain_step_kernel<16><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
     case 7: chain_step_kernel<7><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
     case 5: chain_step_kernel<5><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
     default: chain_step_kernel<4><<<1, 512, lds, 0>>>(d, n_batches, batch_n, group_n, pollers, thin); break;
