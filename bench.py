@@ -240,10 +240,12 @@ def chain_model(steps, carve_ms, prop_ms):
                       "what is left on the chain besides the steps is waiting for rows at the start of a configuration; "
                       "batch pipeline (variant 3): the preparation and proposer launches between the validation "
                       "launches are on the chain too.  What a step costs beyond the floor (round 6, priced in situ with padded "
-                      "builds and s_memtime marks, profiles/r06_chain_loop_isa.txt, r06_chain_fine_anatomy.txt): the chain wave's "
-                      "own plain step is 37 instructions, 0.149 us (~360 cycles) per commit; the "
-                      "rest is the rate at which the parkers land rows (0.87 blocks of 16 tickets per us), i.e. the row "
-                      "pipeline's look-ahead window — the chain takes entries as they arrive"),
+                      "builds, s_memtime marks, and alone on a CU: profiles/r06_chain_step_microbench.txt): the chain wave's own plain step is "
+                      "168 cycles alone (75 of them the look at the bitmap), 0.117 us per commit inside the kernel, 0.2 - 0.25 under the "
+                      "load of the seven waves beside it; two thirds of a configs[1] launch are not chain runs but the first rows and the "
+                      "ends of its twelve configurations (profiles/r06_pipeline_experiments.txt: which wave is on the critical path) — "
+                      "the chain takes entries as they arrive, the collector frees their slots, the parkers refill them; "
+                      "round 6 rewrote the chain's run and the collector"),
             "steps": steps, "floor_us_per_step": floor_us, "achieved_us_per_step": 1e3 * carve_ms / max(steps, 1),
             "validate_only_us_per_step": 1e3 * val_ms / max(steps, 1),
             "frac": floor_us / (1e3 * carve_ms / max(steps, 1)) if carve_ms > 0 else None}
