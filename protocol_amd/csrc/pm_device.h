@@ -307,7 +307,7 @@ void launch_geo(const double* lat, const double* lon, double* coslat, double* ux
                 hipStream_t s);
 void launch_triad(const double* b, const double* c, double* a, size_t n, hipStream_t s);
 #ifdef PM_ROW_BENCH
-hipError_t launch_row_bench(const CarveArgs* d_args, uint32_t seed, uint32_t ci, uint32_t reps, unsigned long long* d_out, hipStream_t s);
+hipError_t launch_row_bench(const CarveArgs* d_args, uint32_t seed, uint32_t ci, uint32_t reps, uint32_t mode, unsigned long long* d_out, hipStream_t s);
 #endif
 void launch_row_network_test(const uint64_t* keys, const uint32_t* sites, uint32_t n_waves, uint32_t n_per_wave, uint32_t slot_bits,
                              uint64_t ulps, uint32_t upto, uint64_t* rows_out, uint32_t* mismatches, hipStream_t s);

@@ -53,7 +53,8 @@ def test_library_exports_every_debug_hook():
         for fn in os.listdir(os.path.join(ROOT, sub)):
             if fn.endswith(".py"):
                 used |= set(re.findall(r"\.(pm_debug_[a-z_]+)\b", open(os.path.join(ROOT, sub, fn)).read()))
-    assert used - {"pm_debug_batch_log"} <= set(protos), used - set(protos)   # (batch_log: -DPM_BATCH_LOG builds only)
+    # (batch_log: -DPM_BATCH_LOG builds only; row_bench: -DPM_ROW_BENCH builds only, tools/row_bench.py)
+    assert used - {"pm_debug_batch_log", "pm_debug_row_bench"} <= set(protos), used - set(protos)
 
 
 def _c_prototypes(text):
