@@ -271,7 +271,7 @@ def run_extra_configs2(E, host, seed):
            "carve_launches": med(stats, "carve_launches"),
            "sweep_ms": med(stats, "ms_sweep"), "compat_ms": med(stats, "ms_compat"), "publish_ms": med(stats, "ms_publish"),
            "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
-           "roofline": {"bound": "latency-chain", "kernel": "carve_stream_kernel (the dominant kernel of this match)",
+           "roofline": {"bound": "hbm", "binds": "latency-chain", "kernel": "carve_stream_kernel (the dominant kernel of this match)",
                         "achieved": kt["carve"]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (kt["carve"]["GB/s"] or 0.0) / HBM_PEAK_GBS,
                         "traffic": pmc_traffic("configs2_carve")[0],
@@ -668,14 +668,15 @@ def main() -> int:
         "match_latency_ms": {"min": min(ms), "p50": statistics.median(ms), "max": max(ms)},
         "phase_ms_p50": {k: med(stats, k) for k in ("ms_compat", "ms_carve", "ms_merge", "ms_sweep", "ms_publish")},
         "groups": int(stats[-1]["n_groups"]), "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
-        "roofline": {"bound": "latency-chain",
+        "roofline": {"bound": "hbm", "binds": "latency-chain",
                      "kernel": ("carve_stream_kernel (+ its list preparation and carve_finish_kernel: one launch sequence, "
                                 "one hipEvent pair)" if args.carve_variant == 0 else
                                 "carve (preparation + carve_propose_kernel + carve_kernel launch sequence)"),
                      "achieved": carve["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (carve["GB/s"] or 0.0) / HBM_PEAK_GBS,
-                     "bound_note": ("achieved / peak / frac are the contract's HBM accounting (algorithmic bytes over the "
-                                    "launch sequence's duration) and are NOT what binds the sequence: it is a chain of "
+                     "bound_note": ("bound / achieved / peak / frac are the contract's HBM accounting (algorithmic bytes over "
+                                    "the launch sequence's duration: of the contract's two roofs, hbm is the one this byte / integer "
+                                    "path belongs under) and are NOT what binds the sequence — `binds`: it is a chain of "
                                     "dependent steps, priced in `chain` (floor per step vs achieved)"),
                      "traffic": traffic, "traffic_source": (f"profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                             f"of this command, a committed constant — not measured in this run")
@@ -687,10 +688,39 @@ def main() -> int:
     }
     if world > 1:
         out["ranks_seen"] = ranks_seen
+        out["cpu_baseline"] = None
+        # The secondary measurement is a sequence of collectives: an exception on ONE rank leaves the others inside a
+        # collective it never joins, and RCCL has not met this path on N > 1 GPUs before the driver's run.  A watchdog
+        # thread (the main thread may be inside a collective, which releases the GIL) prints the headline as it stands —
+        # it is complete at this point — and ends the process when the leg has not returned in time: never lose the line.
+        import threading
+        done = threading.Event()
+        limit_s = float(os.environ.get("PM_BENCH_DIST_TIMEOUT", "240"))
+
+        def watchdog():
+            if done.wait(limit_s):
+                return
+            if rank == 0:
+                out["dist"] = {"one_pool_sharded": {"error": f"no result within {limit_s:.0f} s (a rank failed or a collective hung): "
+                                                             f"the headline above is unaffected"}}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        wd = threading.Thread(target=watchdog, daemon=True)
+        wd.start()
         try:
             out["dist"] = {"one_pool_sharded": run_one_pool_sharded(E, host, torch, dist, args, rank, world, local_rank, dev, coll_dev, backend)}
         except Exception as ex:   # never lose the line over the secondary measurement
             out["dist"] = {"one_pool_sharded": {"error": repr(ex)}}
+            if rank == 0:   # (the other ranks may be inside a collective this one left: do not wait for them)
+                done.set()
+                print(json.dumps(out), flush=True)
+                os._exit(0)
+            # (another rank: stay — a peer that disappears can take rank 0's communicator down with it before the line is out;
+            # the watchdog ends this process when rank 0's has printed)
+            time.sleep(limit_s + 30.0)
+            os._exit(0)
+        done.set()
     single = rank == 0 and world == 1
     if single and not args.no_extras:
         try:
