@@ -191,7 +191,7 @@ void pm_engine_destroy(pm_engine* e) {
   e->d_sel.release(); e->d_wplanes.release(); e->d_sel_perm.release();
   e->d_first.release(); e->d_count.release(); e->d_rank.release(); e->d_chosen.release(); e->d_perm.release();
   e->d_table.release(); e->d_task_col.release(); e->d_shard.release(); e->d_own_rows.release(); e->d_xrow.release();
-  e->d_sel_own.release(); e->d_table_x.release(); e->d_row_stage.release(); if (e->h_row_pin) (void)hipHostFree(e->h_row_pin); e->d_nb_idx.release(); e->d_nb_val.release();
+  e->d_sel_own.release(); e->d_table_x.release(); e->d_row_stage.release(); if (e->h_row_pin) (void)hipHostFree(e->h_row_pin); if (e->ev_row_stage) (void)hipEventDestroy(e->ev_row_stage); e->d_nb_idx.release(); e->d_nb_val.release();
   if (e->h_gstage) (void)hipHostFree(e->h_gstage);
   if (e->h_status) (void)hipHostFree(e->h_status);
   for (int k = 0; k < 2; ++k) {
