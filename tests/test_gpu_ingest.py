@@ -147,6 +147,79 @@ def test_appended_and_rewritten_rows_track_the_oracle():
     eng.close()
 
 
+def test_status_changes_then_rewrites_of_the_same_rows_then_new_rows_in_one_interval():
+    """The order a busy interval has: status reports first (deaths, and dead nodes that come back), THEN the discovery sync
+    rewrites known rows — some of them the very rows whose status has just changed — THEN brand-new rows join; one tick
+    behind all of it.  pm_update_workers / pm_append_workers leave the pending status changes pending (they go up before the
+    next kernel that reads the flags: what goes up is the host column's value at that time), so a row that is in both must end
+    with what the LAST call said.  Groups and every worker's task against the oracle after every tick
+    (status_update_impl.rs:8-39, discovery/monitor.rs:236-420, node_groups/mod.rs:487-497)."""
+    rng = np.random.default_rng(23)
+    W0, add, ticks = 2000, 150, 3
+    sw_all = make_swarm(52, 1200, W0 + add * ticks)
+    donor = make_swarm(53, 10, W0 + add * ticks)
+    packed_all = host.pack_workers(sw_all)
+    packed_join = {k: v.copy() for k, v in packed_all.items()}
+    nodes, cfgs, tasks, enabled = orc.from_swarm(sw_all)
+    status_all = nodes["status"].copy()
+    nodes["status"][W0:] = 0
+    st = orc.State(nodes, cfgs, enabled=enabled, tasks=tasks, reference_shaped=False)
+    eng = E.Engine()
+    host.load_swarm(eng, _take(sw_all, np.arange(W0)))
+    eng.upload_workers(_rows(packed_all, np.arange(W0)))
+    W = W0
+
+    def check(tag):
+        eng.tick()
+        st.try_form_new_groups()
+        st.try_merge_solo_groups()
+        assert _tasks_of(eng, W) == [st.get_task_for_node(w) for w in range(W)], tag
+        assert sorted(oracle_groups(st)) == sorted(engine_groups(eng)), tag
+
+    check("initial")
+    gone = np.zeros(0, dtype=np.int64)
+    for k in range(ticks):
+        # ---- status reports: deaths (the group dissolves), and last interval's dead reporting healthy again
+        alive = np.nonzero(st.nodes["status"][:W] == 2)[0]
+        victims = rng.choice(alive, size=40, replace=False)
+        ws = np.concatenate([victims, gone])
+        fl = np.concatenate([packed_all["flags"][victims] & ~np.uint32(E.W_HEALTHY), packed_all["flags"][gone] | np.uint32(E.W_HEALTHY)])
+        dead = np.concatenate([np.ones(len(victims)), np.zeros(len(gone))]).astype(np.uint32)
+        eng.on_worker_status_many(ws, fl.astype(np.uint32), dead)
+        for w in victims:
+            st.set_node_status(int(w), 4)
+        for w in gone:
+            st.set_node_status(int(w), 2)
+        packed_all["flags"][victims] &= ~np.uint32(E.W_HEALTHY)
+        packed_all["flags"][gone] |= np.uint32(E.W_HEALTHY)
+        # ---- the discovery sync rewrites known rows: half of the rows whose status has just changed among them
+        idx_upd = np.unique(np.concatenate([rng.choice(W, size=50, replace=False), victims[:20], gone[:10]])).astype(np.int64)
+        for f in _WORKER_FIELDS:
+            if f not in ("address", "status"):
+                getattr(sw_all, f)[idx_upd] = getattr(donor, f)[idx_upd]
+        packed_new = host.pack_workers(sw_all)
+        cur_status = st.nodes["status"].copy()
+        packed_new["flags"] = np.where(cur_status == 2, packed_new["flags"] | E.W_HEALTHY,
+                                       packed_new["flags"] & ~np.uint32(E.W_HEALTHY)).astype(np.uint32)
+        packed_all = packed_new
+        eng.update_workers(idx_upd, _rows(packed_all, idx_upd))
+        fresh = orc.from_swarm(sw_all)[0]
+        for w in idx_upd:
+            keep = int(st.nodes["status"][w])
+            st.nodes[w] = fresh[w]
+            st.nodes["status"][w] = keep
+        # ---- brand-new rows behind both
+        idx_new = np.arange(W, W + add)
+        assert eng.append_workers(_rows(packed_join, idx_new)) == W
+        for w in idx_new:
+            st.set_node_status(int(w), int(status_all[w]))
+        W += add
+        packed_all["flags"][idx_new] = packed_join["flags"][idx_new]
+        gone = victims
+        check(f"tick {k}")
+    eng.close()
+
+
 def test_status_changes_in_one_call_equal_the_single_calls():
     """pm_on_worker_status_many == the same events through pm_on_worker_status, one by one (status_update_impl.rs:8-39:
     a death dissolves the whole group; the survivors re-group on the next tick)."""
