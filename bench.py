@@ -695,7 +695,7 @@ def main() -> int:
         # it is complete at this point — and ends the process when the leg has not returned in time: never lose the line.
         import threading
         done = threading.Event()
-        limit_s = float(os.environ.get("PM_BENCH_DIST_TIMEOUT", "240"))
+        limit_s = float(os.environ.get("PM_BENCH_DIST_TIMEOUT", "120"))
 
         def watchdog():
             if done.wait(limit_s):
