@@ -695,15 +695,19 @@ def main() -> int:
         # it is complete at this point — and ends the process when the leg has not returned in time: never lose the line.
         import threading
         done = threading.Event()
+        once = threading.Lock()   # whoever takes it first — the watchdog or the main thread — is the one that prints the line
         limit_s = float(os.environ.get("PM_BENCH_DIST_TIMEOUT", "120"))
 
         def watchdog():
             if done.wait(limit_s):
                 return
+            if not once.acquire(blocking=False):
+                return   # (the main thread is through and printing)
             if rank == 0:
-                out["dist"] = {"one_pool_sharded": {"error": f"no result within {limit_s:.0f} s (a rank failed or a collective hung): "
-                                                             f"the headline above is unaffected"}}
-                print(json.dumps(out), flush=True)
+                line = dict(out)
+                line["dist"] = {"one_pool_sharded": {"error": f"no result within {limit_s:.0f} s (a rank failed or a collective hung): "
+                                                              f"the headline above is unaffected"}}
+                print(json.dumps(line), flush=True)
             os._exit(0)
 
         wd = threading.Thread(target=watchdog, daemon=True)
@@ -714,13 +718,17 @@ def main() -> int:
             out["dist"] = {"one_pool_sharded": {"error": repr(ex)}}
             if rank == 0:   # (the other ranks may be inside a collective this one left: do not wait for them)
                 done.set()
-                print(json.dumps(out), flush=True)
+                if once.acquire(blocking=False):
+                    print(json.dumps(out), flush=True)
                 os._exit(0)
             # (another rank: stay — a peer that disappears can take rank 0's communicator down with it before the line is out;
             # the watchdog ends this process when rank 0's has printed)
             time.sleep(limit_s + 30.0)
             os._exit(0)
         done.set()
+        if not once.acquire(blocking=False):   # (the watchdog has the line: it prints and ends the process)
+            time.sleep(60.0)
+            os._exit(0)
     single = rank == 0 and world == 1
     if single and not args.no_extras:
         try:
@@ -773,8 +781,12 @@ def main() -> int:
             except Exception as ex:
                 out[key] = {"error": repr(ex)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        # (the line is out: a rank that left the secondary leg early must not keep the others — and the driver's clock — waiting
+        # in this barrier for the collective's own time-out)
+        import threading
+        threading.Thread(target=lambda: (time.sleep(30.0), os._exit(0)), daemon=True).start()
         dist.barrier()  # (rank 0 may still be measuring its one-GPU reference)
         dist.destroy_process_group()
     return 0
