@@ -109,6 +109,25 @@ struct ClaimArgs {
   const uint32_t* t_prefix;
   pm_assignment* table;  // per worker; with `rows`: per row (this rank's segment of the exchange buffer)
   uint32_t* task_col;    // compact per-worker task column (device-side consumers; not written with `rows`)
+  // The snapshot buffer the look-ups will read (pinned host memory, the one that is not current) and the groups' task words
+  // beside it: written by the claim itself — a row is 32 bytes of a coalesced store over PCIe — instead of by two copies
+  // queued behind it (each a launch of the runtime's copy kernel with a 12 us gap in front).  nullptr: the caller copies.
+  pm_assignment* h_table;
+  uint32_t* h_gtask;     // [groups]: written by the group's member of rank 0
+};
+
+// Behind the carve, in front of the pair sweep (one engine, every worker a row): what is per worker or per group and needs
+// no pair — the worker's selector, the sweep's outputs at their neutral values, GROUP_INDEX and the members by rank, the
+// groups' task words carried over — in ONE launch where there were three kernels and a copy (each 4 - 5 us with 5 - 6 us of an
+// idle GPU in front: profiles/r06_timeline.txt).
+struct MatchPrepArgs {
+  uint32_t W, G;
+  const int32_t* group_of;
+  const uint32_t *g_cfg, *g_n, *g_off, *members, *addr_rank, *g_task;
+  uint64_t* sel;                      // [W]
+  uint32_t *first, *count;            // [W]: PM_NONE / 0
+  uint32_t *rank_in_group, *by_rank;  // group_rank_kernel's outputs
+  uint32_t* g_task_next;              // [G] <- g_task
 };
 
 // pm_update_workers / pm_append_workers: n packed rows (one H2D copy) scattered into the worker columns
@@ -326,11 +345,12 @@ void launch_group_rank(const int32_t* group_of, const uint32_t* g_n, const uint3
                        const uint32_t* addr_rank, uint32_t W, uint32_t* rank_in_group, uint32_t* by_rank,
                        hipStream_t s);
 void launch_claim_publish(const ClaimArgs& a, hipStream_t s);
+void launch_match_prep(const MatchPrepArgs& a, hipStream_t s);
 void launch_build_planes(const uint64_t* col_mask, uint32_t n_cols, uint32_t c_begin, uint32_t c_end, uint32_t stride,
                          uint32_t n_planes, uint64_t* planes, hipStream_t s);
 void launch_pair_sweep(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
                        const uint64_t* planes, uint32_t c_begin, uint32_t c_end, uint32_t stride, uint32_t n_planes,
-                       uint32_t* first, uint32_t* count, hipStream_t s);
+                       uint32_t* first, uint32_t* count, hipStream_t s, bool inited = false);
 void launch_pair_select(int variant, const uint64_t* row_sel, uint32_t R, const uint64_t* col_mask,
                         const uint64_t* planes, uint32_t c_begin, uint32_t c_end, uint32_t stride, uint32_t n_planes,
                         const uint32_t* rank, uint32_t* out, hipStream_t s);
@@ -355,7 +375,8 @@ hipError_t launch_carve(const CarveArgs* d_args, uint32_t flags, uint32_t start_
 uint32_t launch_carve_prep(const CarveArgs* d_args, uint32_t W, hipStream_t s);  // count + place
 // eligible list [+ spatial index]; returns the launches.  fresh: the status block is initialised by the first kernel
 // (state RUNNING, n_groups0 groups, n_members0 member slots, everything else zero) instead of by a copy in front of it
-uint32_t launch_carve_elig(const CarveArgs* d_args, uint32_t W, uint32_t n_bound, uint32_t index_min, uint32_t start_ci,
+hipError_t launch_carve_args_put(const CarveArgs& a, CarveArgs* d_args, hipStream_t s);
+uint32_t launch_carve_elig(CarveArgs* d_args, const CarveArgs* put, uint32_t W, uint32_t n_bound, uint32_t index_min, uint32_t start_ci,
                            bool fresh, uint32_t n_groups0, uint32_t n_members0, hipStream_t s);
 void launch_carve_apply(const CarveArgs* d_args, uint32_t W, hipStream_t s);
 void launch_carve_propose(const CarveArgs* d_args, uint32_t W, hipStream_t s);

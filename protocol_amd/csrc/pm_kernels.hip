@@ -591,6 +591,28 @@ __global__ __launch_bounds__(256) void group_rank_kernel(const int32_t* __restri
   by_rank[off + idx] = w;
 }
 
+// worker_selector_kernel + pair_init_kernel + group_rank_kernel + the copy of the groups' task words, for the match of one
+// engine over all its workers (MatchPrepArgs)
+__global__ __launch_bounds__(256) void match_prep_kernel(MatchPrepArgs p) {
+  const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+  if (w < p.G) p.g_task_next[w] = p.g_task[w];
+  if (w >= p.W) return;
+  const int32_t g = p.group_of[w];
+  p.first[w] = PM_NONE;
+  p.count[w] = 0u;
+  if (g < 0) {
+    p.sel[w] = 0ull;
+    p.rank_in_group[w] = 0;
+    return;
+  }
+  p.sel[w] = 1ull << p.g_cfg[g];
+  const uint32_t n = p.g_n[g], off = p.g_off[g], my = p.addr_rank[w];
+  uint32_t idx = 0;
+  for (uint32_t k = 0; k < n; ++k) idx += p.addr_rank[p.members[off + k]] < my;
+  p.rank_in_group[w] = idx;
+  p.by_rank[off + idx] = w;
+}
+
 __device__ __forceinline__ uint32_t task_position(const uint64_t* __restrict__ live, const uint32_t* __restrict__ prefix,
                                                   uint32_t u) {
   return prefix[u >> 6] + (uint32_t)__popcll(live[u >> 6] & ((1ull << (u & 63u)) - 1ull));
@@ -600,9 +622,10 @@ __device__ __forceinline__ uint32_t task_position(const uint64_t* __restrict__ l
 // computed the same choice, so the group's task word is written with the same value by all.
 __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  if (r >= p.R) return;
-  const uint32_t w = p.rows ? p.rows[r] : r;
-  const int32_t g = p.group_of[w];
+  const bool in = r < p.R;
+  if (!in && !p.h_table) return;  // (with the host's buffer to write, every thread of the workgroup goes to the barrier below)
+  const uint32_t w = !in ? 0u : p.rows ? p.rows[r] : r;
+  const int32_t g = in ? p.group_of[w] : -1;
   pm_assignment a;
   a.task = PM_NONE;
   a.group_slot = PM_NONE;
@@ -610,8 +633,9 @@ __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
   a.group_size = 0;
   a.next_worker = PM_NONE;
   a.group_id = 0;
+  uint32_t t = PM_NONE;
   if (g >= 0) {
-    uint32_t t = p.g_task[g];  // get_current_group_task (scheduler_impl.rs:33)
+    t = p.g_task[g];  // get_current_group_task (scheduler_impl.rs:33)
     if (t == PM_NONE) {
       t = p.chosen[r];
       if (t != PM_NONE) p.g_task_next[g] = t;  // same value from every member
@@ -629,9 +653,26 @@ __global__ __launch_bounds__(256) void claim_publish_kernel(ClaimArgs p) {
   }
   if (p.rows) {  // multi-GPU: this rank's rows, packed, into its segment of the exchange buffer
     p.table[r] = a;
-  } else {
+    return;
+  }
+  if (in) {
     p.table[w] = a;
     p.task_col[w] = a.task;
+  }
+  if (p.h_table) {
+    // The host's snapshot buffer and the groups' task words, straight from here.  The rows cross PCIe: a thread that stores
+    // its own 32-byte row leaves every 64-byte line to be completed by a second instruction (19 GB/s measured); staged in
+    // LDS and stored 16 contiguous bytes a lane, an instruction writes whole lines.
+    static_assert(sizeof(pm_assignment) == 32, "a row is two 16-byte pieces");
+    __shared__ uint4 s_rows[512];
+    s_rows[2u * threadIdx.x] = make_uint4(a.task, a.group_slot, a.group_index, a.group_size);
+    s_rows[2u * threadIdx.x + 1u] = make_uint4(a.next_worker, 0u, (uint32_t)a.group_id, (uint32_t)(a.group_id >> 32));
+    if (g >= 0 && a.group_index == 0u) p.h_gtask[g] = t;  // (one member of every group has rank 0)
+    __syncthreads();
+    const uint32_t row0 = blockIdx.x * 256u;
+    const uint32_t n16 = 2u * (p.R - row0 < 256u ? p.R - row0 : 256u);
+    uint4* const dst = reinterpret_cast<uint4*>(p.h_table + row0);
+    for (uint32_t k = threadIdx.x; k < n16; k += 256u) dst[k] = s_rows[k];
   }
 }
 

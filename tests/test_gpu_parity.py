@@ -415,19 +415,21 @@ def test_lookups_from_other_threads_during_ticks():
         t.start()
     rng = np.random.default_rng(5)
     healthy = np.nonzero(sw.status == 2)[0]
-    for tick in range(60):
-        victims = rng.choice(healthy, size=6, replace=False)        # a death dissolves the whole group ...
-        for w in victims:
-            eng.on_worker_status(int(w), int(flags[w] & ~E.W_HEALTHY), True)
-        eng.tick()
-        snapshot()
-        for w in victims:                                           # ... and the rejoin re-carves the leftovers
-            eng.on_worker_status(int(w), int(flags[w]), False)
-        eng.tick()
-        snapshot()
-    stop.set()
-    for t in threads:
-        t.join()
+    try:
+        for tick in range(60):
+            victims = rng.choice(healthy, size=6, replace=False)        # a death dissolves the whole group ...
+            for w in victims:
+                eng.on_worker_status(int(w), int(flags[w] & ~E.W_HEALTHY), True)
+            eng.tick()
+            snapshot()
+            for w in victims:                                           # ... and the rejoin re-carves the leftovers
+                eng.on_worker_status(int(w), int(flags[w]), False)
+            eng.tick()
+            snapshot()
+    finally:   # (a tick that fails must not leave the readers running: the suite would never end)
+        stop.set()
+        for t in threads:
+            t.join()
     n_reads = sum(len(s) for s in seen)
     assert n_reads > 10000
     # (a death between two ticks republishes the rows of the dissolved group's members as rows of workers in no group)
