@@ -340,21 +340,24 @@ __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* 
         // every row of this wave selects at most one plane (the reference orientation: a group's configuration
         // bit; a task of one topology, or of all of them): one LDS read per word, no selector loop; four words per
         // step keep the reads in flight
+        // (a word costs its read and two popcounts: the first hit is where the count leaves zero — looked for once a row, not
+        // asked about every word — and a row without a selector counts like the others and is zeroed behind the sweep)
         const uint64_t* pl = s_pl + my_plane[k] * lds_stride;
         uint32_t j = 0;
         for (; j + 4u <= nj; j += 4u) {
-          const uint64_t h0 = pl[j] & keep[k], h1 = pl[j + 1u] & keep[k], h2 = pl[j + 2u] & keep[k], h3 = pl[j + 3u] & keep[k];
+          const uint64_t h0 = pl[j], h1 = pl[j + 1u], h2 = pl[j + 2u], h3 = pl[j + 3u];
+          const uint32_t before = cnt[k];
           cnt[k] += __popcll(h0) + __popcll(h1) + __popcll(h2) + __popcll(h3);
-          if (first[k] == PM_NONE && (h0 | h1 | h2 | h3)) {
+          if (before == 0u && cnt[k] != 0u) {
             const uint32_t u = h0 ? 0u : (h1 ? 1u : (h2 ? 2u : 3u));
             const uint64_t h = h0 ? h0 : (h1 ? h1 : (h2 ? h2 : h3));
             first[k] = (j0 + j + u) * 64u + __builtin_ctzll(h);
           }
         }
         for (; j < nj; ++j) {
-          const uint64_t h = pl[j] & keep[k];
+          const uint64_t h = pl[j];
+          if (h && cnt[k] == 0u) first[k] = (j0 + j) * 64u + __builtin_ctzll(h);
           cnt[k] += __popcll(h);
-          if (h && first[k] == PM_NONE) first[k] = (j0 + j) * 64u + __builtin_ctzll(h);
         }
       } else {
         for (uint32_t j = 0; j < nj; ++j) {
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(256) void pair_sweep_planes_kernel(const uint64_t* 
 #pragma unroll
   for (uint32_t k = 0; k < RPT; ++k) {
     const uint32_t r = r0 + k * 256u;
+    if (!keep[k]) {  // (rows without a selector hit nothing)
+      first[k] = PM_NONE;
+      cnt[k] = 0u;
+    }
     if (r < R) pair_fold(first_out, count_out, r, first[k], cnt[k], atomic != 0u);
   }
 }
