@@ -184,6 +184,7 @@ def proposer_split(E, host, sw, seed, steps=3):
     cc = eng.debug_carve_counters()
     eng.close()
     return {"ms": med(st, "ms_propose_kernel"), "proposals": med(st, "proposals"), "keys": med(st, "propose_keys"),
+            "ms_sweep_kernel": med(st, "ms_sweep_kernel"),   # (this engine brackets the sweep's kernel too: the headline's does not)
             "ms_carve_kernel_with_events": med(st, "ms_carve_kernel"),
             "index": {"grid": cc["cell_g"], "indexed_positions": cc["n_indexed"], "batches": cc["batches"],
                       "batches_walked": cc["pruned_batches"], "walks_given_up": cc["prune_fallbacks"]}}
@@ -195,7 +196,8 @@ def kernel_table(sw, stats, T, W, prop):
     carve_bytes = 20.0 * med(stats, "carve_cand_sum") + 8.0 * med(stats, "carve_steps")
     compat_bytes = W * 32 + n_cfgs * 32 + n_alts * 32 + W * 8
     sweep_bytes = T * 16 + W * 16 + W * 8          # per-worker orientation: (16T + 24W)
-    compat_ms, sweep_ms = med(stats, "ms_compat_kernel"), med(stats, "ms_sweep_kernel")
+    # (the sweep kernel's own events are two barrier packets in a match: only the time_proposer engine of proposer_split records them)
+    compat_ms, sweep_ms = med(stats, "ms_compat_kernel"), (prop.get("ms_sweep_kernel") or med(stats, "ms_sweep_kernel"))
     prop_ms, keys = prop["ms"], prop["keys"]
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else None
     pair_rate = T * W / (sweep_ms * 1e-3) if sweep_ms > 0 else None

@@ -166,7 +166,8 @@ typedef struct {
                                     Anything else is PM_EINVAL (2: single-wave validation, 4: two batches in flight —
                                     both measured slower in rounds 2 / 3 and removed in round 5; their numbers are in
                                     profiles/r03_*) */
-  uint32_t time_proposer;        /* bench: hipEvents around every proposer launch (pm_stats.ms_propose_kernel) */
+  uint32_t time_proposer;        /* bench: hipEvents around every proposer launch (pm_stats.ms_propose_kernel) and around the
+                                    pair sweep's kernel (pm_stats.ms_sweep_kernel) */
 } pm_engine_config;
 
 void pm_engine_config_default(pm_engine_config*);
@@ -331,9 +332,12 @@ int32_t pm_match_per_task(pm_engine*, uint32_t* best_worker, uint32_t* candidate
 int32_t pm_newest_task(pm_engine*, uint32_t* task_idx);
 
 typedef struct {
-  /* GPU time per phase of the last pm_tick, from hipEvents on the engine's stream (ms) */
+  /* GPU time per phase of the last pm_tick, from hipEvents on the engine's stream (ms).  ms_publish is 0 where the claim
+     writes the snapshot buffer itself (pm_tick, pm_tick_many: the sweep phase ends with it); ms_total is the tick as its
+     caller sees it: there the host's clock from the tick's begin to its end, elsewhere first event to last */
   float ms_compat, ms_carve, ms_merge, ms_sweep, ms_publish, ms_total;
-  /* kernel-only durations (hipEvents recorded immediately around the launches, summed over relaunches) */
+  /* kernel-only durations (hipEvents recorded immediately around the launches, summed over relaunches); ms_sweep_kernel is
+     measured — two more events, each a barrier packet on the stream — only by an engine created with time_proposer, else 0 */
   float ms_compat_kernel, ms_carve_kernel, ms_sweep_kernel;
   uint32_t n_groups, n_formed, n_merged;
   uint32_t carve_steps;         /* groups carved + merge selections done on the GPU */

@@ -15,7 +15,7 @@ from protocol_amd.swarm import baseline_config
 ci = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 sw = baseline_config(ci, seed=1)
-eng = E.Engine()
+eng = E.Engine(time_proposer=True)   # (the sweep kernel's own events)
 host.load_swarm(eng, sw)
 eng.tick()
 rows = []
