@@ -356,7 +356,7 @@ def run_extra_pools(E, host, seed, ks=(2, 4, 8), steps=8):
     # library: no Python between the calls)
     try:
         tm = {"note": ("pm_tick_many(engines, K): per round K x pm_reset_groups + ONE call; x_one_pool = aggregate rate / the "
-                       "one-pool rate above; match_ms = per pool, device time from the start of its tick to its published "
+                       "one-pool rate above; match_ms = per pool, the host's clock from the start of its tick to its published "
                        "table (pm_stats.ms_total); `staged` = one host thread walks the engines (start every carve, then "
                        "finish each, then publish each), `threads` = a host thread per engine inside the library"),
               "by_k": {}}
@@ -668,7 +668,11 @@ def main() -> int:
                    "sweep_variant": args.sweep_variant, "carve_variant": args.carve_variant},
         "p50_match_latency_ms": statistics.median(ms),
         "match_latency_ms": {"min": min(ms), "p50": statistics.median(ms), "max": max(ms)},
+        "match_latency_note": ("pm_stats.ms_total of the timed ticks: the host's clock from the tick's begin to its end (the claim "
+                               "kernel writes the host's snapshot buffer itself, the tick's last event is queued behind it)"),
         "phase_ms_p50": {k: med(stats, k) for k in ("ms_compat", "ms_carve", "ms_merge", "ms_sweep", "ms_publish")},
+        "phase_note": ("GPU time between hipEvents on the engine's stream; ms_sweep = match_prep + pair sweep + the claim that publishes "
+                       "(rows straight into pinned host memory): ms_publish is 0 on this path"),
         "groups": int(stats[-1]["n_groups"]), "host_resolved_steps": int(stats[-1]["host_resolved_steps"]),
         "roofline": {"bound": "hbm", "binds": "latency-chain",
                      "kernel": ("carve_stream_kernel (+ its list preparation and carve_finish_kernel: one launch sequence, "
