@@ -40,7 +40,8 @@ extern "C" {
 #define PM_ABI_VERSION 3 /* 3 (round 6): + the by-id / by-worker group calls of the plugin's read surface; the stepwise tick's
                             carve_next / carve_validate pair became pm_dist_carve_wait; pm_upload_workers(keep_groups = 1)
                             accepts new rows behind the known ones; + pm_host_to_lowercase (the model rule is Unicode now); carve_variant 2 / 4
-                            are PM_EINVAL (since round 5) */
+                            are PM_EINVAL (since round 5); pm_stats of a pm_tick / pm_tick_many: ms_publish is 0 (the claim publishes),
+                            ms_total is the host's clock over the call, ms_sweep_kernel is measured by a time_proposer engine only */
 
 enum {
   PM_OK = 0,
