@@ -118,14 +118,27 @@ __device__ __forceinline__ bool gpu_alt_meets(uint32_t wf, uint32_t wcount, uint
   return true;
 }
 
-__global__ __launch_bounds__(256) void compat_kernel(CompatArgs p) {
-  const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-  if (w >= p.W) return;
-  const uint32_t wf = p.flags[w];
-  const uint32_t wcount = p.gpu_count[w], wmem = p.gpu_mem[w], wcls = p.gpu_cls[w];
-  const uint32_t wcores = p.cpu_cores[w], wram = p.ram[w], wsto = p.storage[w];
+// One worker per lane and the configurations one after the other: the sweep of one worker x one configuration is a hundred
+// dependent instructions, and a wave that has its SIMD to itself gets through one every five cycles or so — at 10,000 workers
+// (160 waves on 1,024 SIMDs) the kernel is that chain, 14 us.  While the workers are few a workgroup takes 64 of them and its
+// four waves a QUARTER of the configurations each, ORed through LDS (compat_sliced_kernel); from 65,536 workers on every
+// SIMD has its waves and the plain form does the same work without the barrier.
+template <bool SLICED>
+__device__ __forceinline__ void compat_body(const CompatArgs& p) {
+  __shared__ uint64_t s_part[SLICED ? 256 : 1];
+  const uint32_t lane = threadIdx.x & 63u, slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the rows stay scalar loads)
+  const uint32_t w = SLICED ? blockIdx.x * 64u + lane : blockIdx.x * 256u + threadIdx.x;
+  const bool in = w < p.W;
+  if (!SLICED && !in) return;
+  const uint32_t per = SLICED ? (p.n_cfgs + 3u) / 4u : p.n_cfgs;
+  const uint32_t c_begin = SLICED ? (slice * per < p.n_cfgs ? slice * per : p.n_cfgs) : 0u;
+  const uint32_t c_end = SLICED ? (c_begin + per < p.n_cfgs ? c_begin + per : p.n_cfgs) : p.n_cfgs;
+  const uint32_t wr = in ? w : 0u;
+  const uint32_t wf = p.flags[wr];
+  const uint32_t wcount = p.gpu_count[wr], wmem = p.gpu_mem[wr], wcls = p.gpu_cls[wr];
+  const uint32_t wcores = p.cpu_cores[wr], wram = p.ram[wr], wsto = p.storage[wr];
   uint64_t mask = 0;
-  for (uint32_t c = 0; c < p.n_cfgs; ++c) {
+  for (uint32_t c = c_begin; c < c_end; ++c) {
     const pm_config_row cfg = p.cfgs[c];  // uniform -> SGPRs
     bool ok;
     if (!(cfg.flags & PM_R_HAS_REQ)) {
@@ -150,8 +163,16 @@ __global__ __launch_bounds__(256) void compat_kernel(CompatArgs p) {
     }
     mask |= (uint64_t)ok << c;
   }
-  p.compat[w] = mask;
+  if (!SLICED) {
+    p.compat[w] = mask;
+    return;
+  }
+  s_part[threadIdx.x] = mask;
+  __syncthreads();
+  if (slice == 0u && in) p.compat[w] = s_part[lane] | s_part[64u + lane] | s_part[128u + lane] | s_part[192u + lane];
 }
+__global__ __launch_bounds__(256) void compat_kernel(CompatArgs p) { compat_body<false>(p); }
+__global__ __launch_bounds__(256) void compat_sliced_kernel(CompatArgs p) { compat_body<true>(p); }
 
 // stream triad a = b + 3 c over f64 (3 x 8 bytes per element): the measured HBM rate bench.py cites next to the
 // nominal 8 TB/s

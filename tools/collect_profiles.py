@@ -85,8 +85,8 @@ def main():
             print("pmc pass failed:", counter, ex)
             sums[counter] = {}
     groups = {"carve": ("carve_",),  # validator, proposer, eligible-list and list-preparation kernels
-              "pair_sweep": ("pair_sweep", "pair_init", "build_planes"),
-              "compat_kernel": ("compat_kernel",)}
+              "pair_sweep": ("pair_sweep", "pair_init", "build_planes", "match_prep"),
+              "compat_kernel": ("compat_kernel", "compat_sliced_kernel")}
     traffic = {}
     for g, pats in groups.items():
         f = sum(t for k, (t, _n) in sums.get("FETCH_SIZE", {}).items() if any(p in k for p in pats))

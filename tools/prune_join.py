@@ -15,7 +15,7 @@ def launches(dbp):
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol") or (t.startswith("rocpd_") and "kernel_symbol" in t)][0]
     names = dict(cur.execute(f"select id, kernel_name from {ks}"))
     seq = [(names[k], s, e) for k, s, e in cur.execute(f"select kernel_id,start,end from {kt} order by start")]
-    idx = max(i for i, (n, _, _) in enumerate(seq) if "compat_kernel" in n)
+    idx = max(i for i, (n, _, _) in enumerate(seq) if "compat_kernel" in n or "compat_sliced_kernel" in n)
     last = seq[idx:]
     prop = [(e - s) / 1000 for n, s, e in last if "carve_propose" in n]
     build = sum((e - s) / 1000 for n, s, e in last if "cell_" in n)

@@ -14,7 +14,7 @@ def main():
     names = dict(cur.execute(f"select id, kernel_name from {ks}"))
     rows = list(cur.execute(f"select kernel_id,start,end from {kt} order by start"))
     seq = [(names[k], s, e) for k, s, e in rows]
-    idx = max(i for i, (n, _, _) in enumerate(seq) if "compat_kernel" in n)
+    idx = max(i for i, (n, _, _) in enumerate(seq) if "compat_kernel" in n or "compat_sliced_kernel" in n)
     t0 = seq[idx][1]
     prev_end = None
     busy = 0
